@@ -1,0 +1,107 @@
+"""ctypes binding of libchore_hip.so (include/chore_hip.h).
+
+This is the only place Python touches the native library.  There is deliberately NO fallback:
+if the shared object is missing the import raises, and `check()` turns every non-zero return code
+into a RuntimeError carrying chore_last_error().
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint8, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class WeightDesc(ctypes.Structure):
+    _fields_ = [("name", c_char_p), ("ptr", c_void_p), ("numel", c_int64)]
+
+
+class EncoderCfg(ctypes.Structure):
+    _fields_ = [("in_channels", c_int), ("num_stack", c_int), ("num_hourglass", c_int),
+                ("hourglass_dim", c_int)]
+
+
+# every exported symbol of include/chore_hip.h with its signature (restype, argtypes)
+SIGNATURES = {
+    "chore_version": (c_int, []),
+    "chore_create": (c_int, [POINTER(c_void_p), c_int]),
+    "chore_destroy": (c_int, [c_void_p]),
+    "chore_last_error": (c_char_p, [c_void_p]),
+    "chore_heads_arena_bytes": (c_size_t, [c_int]),
+    "chore_heads_pack": (c_int, [c_void_p, POINTER(WeightDesc), c_int, c_int, c_void_p, c_void_p]),
+    "chore_query_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p]),
+    "chore_sample_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                      POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_query_bwd_points": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                       c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p]),
+    "chore_encoder_arena_bytes": (c_size_t, [POINTER(EncoderCfg), c_int]),
+    "chore_encoder_pack": (c_int, [c_void_p, POINTER(EncoderCfg), POINTER(WeightDesc), c_int, c_int,
+                                   c_void_p, c_void_p]),
+    "chore_encoder_workspace_bytes": (c_size_t, [POINTER(EncoderCfg), c_int, c_int, c_int, c_int]),
+    "chore_encode_fwd": (c_int, [c_void_p, POINTER(EncoderCfg), c_void_p, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p,
+                                 c_void_p, c_void_p]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: build it with `python -m chore_amd.build` "
+            "(hipcc --offload-arch=gfx950). chore_amd has no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = load_library()
+
+
+class ChoreError(RuntimeError):
+    pass
+
+
+_handles = {}
+
+
+def handle(device_index: int) -> c_void_p:
+    """one chore_handle per (process, device)"""
+    h = _handles.get(device_index)
+    if h is None:
+        h = c_void_p()
+        rc = lib.chore_create(ctypes.byref(h), device_index)
+        if rc != 0:
+            raise ChoreError(f"chore_create(device={device_index}) failed with {rc}: "
+                             f"{lib.chore_last_error(None).decode()}")
+        _handles[device_index] = h
+    return h
+
+
+def check(rc: int, h: c_void_p, what: str):
+    if rc != 0:
+        msg = lib.chore_last_error(h)
+        raise ChoreError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+
+def make_descs(named_tensors):
+    """[(name, fp32 contiguous device tensor)] -> (ctypes array, keepalive list)"""
+    arr = (WeightDesc * len(named_tensors))()
+    keep = []
+    for i, (name, t) in enumerate(named_tensors):
+        bname = name.encode()
+        keep.append((bname, t))
+        arr[i].name = bname
+        arr[i].ptr = t.data_ptr()
+        arr[i].numel = t.numel()
+    return arr, keep

@@ -1,0 +1,144 @@
+// capi.hip -- extern "C" entry points of libchore_hip.so (see include/chore_hip.h).
+#include "common.h"
+#include <cstring>
+
+int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s);
+
+static thread_local std::string g_noh_err;
+
+static const void* find_desc(const chore_weight_desc* d, int n, const std::string& name, int64_t numel,
+                             std::string& err) {
+    for (int i = 0; i < n; ++i) {
+        if (d[i].name && name == d[i].name) {
+            if (d[i].numel != numel) {
+                err = "tensor '" + name + "' has " + std::to_string(d[i].numel) + " elements, expected " +
+                      std::to_string(numel);
+                return nullptr;
+            }
+            return d[i].ptr;
+        }
+    }
+    err = "tensor '" + name + "' missing from weight descriptors";
+    return nullptr;
+}
+
+extern "C" {
+
+int chore_version(void) { return 100; }
+
+int chore_create(chore_handle** out, int device_ordinal) {
+    if (!out) return CHORE_EINVAL;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device_ordinal < 0 || device_ordinal >= count) {
+        g_noh_err = "chore_create: no such HIP device";
+        return CHORE_EHIP;
+    }
+    chore_handle* h = new chore_handle();
+    h->device = device_ordinal;
+    *out = h;
+    return CHORE_OK;
+}
+
+void chore_encoder_cache_free(chore_handle* h);
+
+int chore_destroy(chore_handle* h) {
+    if (!h) return CHORE_EINVAL;
+    chore_encoder_cache_free(h);
+    delete h;
+    return CHORE_OK;
+}
+
+const char* chore_last_error(const chore_handle* h) { return h ? h->err.c_str() : g_noh_err.c_str(); }
+
+size_t chore_heads_arena_bytes(int dtype) {
+    (void)dtype;  // the exact-fp32 heads use the same arena for fp32 and bf16 feature maps
+    return QF_TOTAL_FLOATS * sizeof(float);
+}
+
+int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_descs, int dtype, void* arena,
+                     chore_stream_t stream) {
+    if (!h || !descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_pack: null argument");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_pack: bad dtype");
+    static const char* names[HEAD_NUM] = {"df", "part_predictor", "pca_predictor", "center_predictor"};
+    HeadsRaw raw;
+    std::string err;
+    for (int hd = 0; hd < HEAD_NUM; ++hd) {
+        for (int l = 0; l < 4; ++l) {
+            const int in = (l == 0) ? HEAD_IN : HEAD_HID;
+            const int out = (l == 3) ? head_out_dim(hd) : HEAD_HID;
+            const std::string base = std::string(names[hd]) + "." + std::to_string(2 * l);
+            raw.w[hd][l] = (const float*)find_desc(descs, n_descs, base + ".weight", (int64_t)in * out, err);
+            if (!raw.w[hd][l]) CHORE_FAIL(h, CHORE_ESTATE, "chore_heads_pack: %s", err.c_str());
+            raw.b[hd][l] = (const float*)find_desc(descs, n_descs, base + ".bias", out, err);
+            if (!raw.b[hd][l]) CHORE_FAIL(h, CHORE_ESTATE, "chore_heads_pack: %s", err.c_str());
+        }
+    }
+    return launch_heads_pack_f32(h, raw, (float*)arena, (hipStream_t)stream);
+}
+
+static int fill_query_args(chore_handle* h, QueryArgs& a, const float* points, const float* crop_center, int B,
+                           int N, const void* feat, int FH, int FW, const void* tmpx, int TH, int TW,
+                           int dtype, const void* arena, const float* cam) {
+    if (!points || !crop_center || !feat || !tmpx || !arena || !cam)
+        CHORE_FAIL(h, CHORE_EINVAL, "query: null argument");
+    if (B <= 0 || N <= 0 || FH < 2 || FW < 2 || TH < 2 || TW < 2) CHORE_FAIL(h, CHORE_EINVAL, "query: bad shape");
+    if (B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "query: B > 65535");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "query: bad dtype");
+    memset(&a, 0, sizeof(a));
+    a.points = points; a.crop_center = crop_center; a.B = B; a.N = N;
+    a.feat = feat; a.FH = FH; a.FW = FW; a.tmpx = tmpx; a.TH = TH; a.TW = TW;
+    a.arena = arena;
+    a.fx = cam[0]; a.fy = cam[1]; a.cx = cam[2]; a.cy = cam[3]; a.half_crop = cam[4]; a.crop = cam[5];
+    return CHORE_OK;
+}
+
+int chore_query_fwd(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                    const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                    const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
+                    float* centers, uint8_t* in_img, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!df || !pca || !parts || !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: null output");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
+                             cam6_host);
+    if (rc) return rc;
+    a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
+    a.in_img = in_img;
+    return dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream)
+                              : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream);
+}
+
+int chore_sample_features(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                          const float* cam6_host, float* features, float* nxy, uint8_t* in_img,
+                          chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!features) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: null output");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, feat /*unused*/,
+                             cam6_host);
+    if (rc) return rc;
+    a.in_img = in_img;
+    return launch_sample_features(h, dtype, a, features, nxy, (hipStream_t)stream);
+}
+
+int chore_query_bwd_points(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                           const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                           const void* heads_arena, const float* cam6_host, const float* g_df,
+                           const float* g_pca, const float* g_parts, const float* g_centers, float* dpoints,
+                           chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!dpoints) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_points: null dpoints");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
+                             cam6_host);
+    if (rc) return rc;
+    a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
+    a.dpoints = dpoints;
+    return dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream)
+                              : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);
+}
+
+}  // extern "C"

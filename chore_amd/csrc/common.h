@@ -1,0 +1,113 @@
+// common.h -- shared declarations of libchore_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include <unordered_map>
+#include "../../include/chore_hip.h"
+
+struct chore_handle {
+    int device = 0;
+    std::string err;
+    // cached encoder programs keyed by shape (see encoder.cpp)
+    void* enc_cache = nullptr;
+};
+
+#define CHORE_FAIL(h, code, ...)                         \
+    do {                                                 \
+        char _b[512];                                    \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);           \
+        if (h) (h)->err = _b;                            \
+        return (code);                                   \
+    } while (0)
+
+#define CHORE_HIP_CHECK(h, expr)                                                        \
+    do {                                                                                \
+        hipError_t _e = (expr);                                                         \
+        if (_e != hipSuccess)                                                           \
+            CHORE_FAIL(h, CHORE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                       __FILE__, __LINE__);                                             \
+    } while (0)
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using bf16x8 = __attribute__((ext_vector_type(8))) short;  // 8 bf16 in 4 VGPRs
+using u16x4 = __attribute__((ext_vector_type(4))) unsigned short;
+using u16x8 = __attribute__((ext_vector_type(8))) unsigned short;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+// bf16 helpers (round-to-nearest-even, like torch's float->bfloat16)
+__host__ __device__ inline unsigned short f2bf(float f) {
+    union { float f; unsigned int u; } v;
+    v.f = f;
+    if ((v.u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((v.u >> 16) | 0x40);  // NaN
+    unsigned int r = 0x7fffu + ((v.u >> 16) & 1u);
+    return (unsigned short)((v.u + r) >> 16);
+}
+__host__ __device__ inline float bf2f(unsigned short b) {
+    union { float f; unsigned int u; } v;
+    v.u = ((unsigned int)b) << 16;
+    return v.f;
+}
+
+// D-fragment row of the 32x32 MFMA family: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+__host__ __device__ inline int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+// ----- heads (query) constants -----
+constexpr int HEAD_NUM = 4;        // df, parts, pca, centers (kernel wave order)
+constexpr int HEAD_HID = 128;
+constexpr int FEAT_C = 256;        // hourglass_dim
+constexpr int TMPX_C = 64;
+constexpr int HEAD_IN = FEAT_C + 3 + TMPX_C;  // 323
+// fp32 arena layout (floats)
+constexpr int QF_KPAD = 328;                  // 323 padded to a multiple of 8
+constexpr int QF_KG = QF_KPAD / 8;            // 41 k-groups
+constexpr size_t QF_L1_FLOATS = (size_t)HEAD_NUM * QF_KG * 4 * 64 * 4;
+constexpr size_t QF_L23_FLOATS = (size_t)HEAD_NUM * 2 * 16 * 4 * 64 * 4;
+constexpr size_t QF_L4_FLOATS = (size_t)HEAD_NUM * 16 * 64 * 4;
+constexpr size_t QF_BIAS_FLOATS = (size_t)HEAD_NUM * 4 * 4 * 2 * 16;
+constexpr size_t QF_OFF_L1 = 0;
+constexpr size_t QF_OFF_L23 = QF_OFF_L1 + QF_L1_FLOATS;
+constexpr size_t QF_OFF_L4 = QF_OFF_L23 + QF_L23_FLOATS;
+constexpr size_t QF_OFF_BIAS = QF_OFF_L4 + QF_L4_FLOATS;
+constexpr size_t QF_FWD_FLOATS = QF_OFF_BIAS + QF_BIAS_FLOATS;
+// transposed (backward-to-points) fragments, appended to the same arena
+constexpr int QB_RB1 = 11;                    // 328 input features -> 11 row blocks of 32 (352)
+constexpr size_t QB_L4T_FLOATS = (size_t)HEAD_NUM * 4 * 4 * 64 * 4;
+constexpr size_t QB_L32T_FLOATS = (size_t)HEAD_NUM * 2 * 16 * 4 * 64 * 4;
+constexpr size_t QB_L1T_FLOATS = (size_t)HEAD_NUM * 16 * QB_RB1 * 64 * 4;
+constexpr size_t QB_OFF_L4T = QF_FWD_FLOATS;
+constexpr size_t QB_OFF_L32T = QB_OFF_L4T + QB_L4T_FLOATS;
+constexpr size_t QB_OFF_L1T = QB_OFF_L32T + QB_L32T_FLOATS;
+constexpr size_t QF_TOTAL_FLOATS = QB_OFF_L1T + QB_L1T_FLOATS;
+
+__host__ __device__ inline int head_out_dim(int h) { return h == 0 ? 2 : (h == 1 ? 14 : (h == 2 ? 9 : 6)); }
+
+// raw (reference-layout) weights of the heads, device pointers
+struct HeadsRaw {
+    const float* w[HEAD_NUM][4];
+    const float* b[HEAD_NUM][4];
+};
+
+struct QueryArgs {
+    const float* points;
+    const float* crop_center;
+    int B, N;
+    const void* feat;
+    int FH, FW;
+    const void* tmpx;
+    int TH, TW;
+    const void* arena;
+    float fx, fy, cx, cy, half_crop, crop;
+    float* out[HEAD_NUM];  // df, parts, pca, centers
+    uint8_t* in_img;
+    // backward only
+    const float* g[HEAD_NUM];
+    float* dpoints;
+};
+
+// launchers implemented in the .hip files
+int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s);
+int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);

@@ -1,0 +1,51 @@
+// enc_common.h -- kernel argument blocks and launchers of the stacked-hourglass encoder.
+//
+// Activations are NHWC, element type T = float (CHORE_F32) or bf16 stored as unsigned short
+// (CHORE_BF16).  A "view" is (pointer, channel stride of the buffer, channel offset, channels):
+// ConvBlock's concat (model/net_util.py:388) is never materialised -- each conv writes its slice.
+#pragma once
+#include "common.h"
+
+typedef unsigned short bf16_t;
+
+struct View {
+    void* p = nullptr;
+    int cs = 0;   // channel stride (channels of the underlying buffer)
+    int co = 0;   // channel offset of this view
+    int C = 0;    // channels in the view
+};
+
+constexpr int GN_GROUPS = 32;
+constexpr int GN_SPLITS_MAX = 64;
+
+struct ConvArgs {
+    View in;            // input activations
+    const float* ss;    // [B][Cin][2] GroupNorm scale/shift fused with ReLU into the operand load, or null
+    const void* wpk;    // fragment-ordered weights (pack_conv_weights)
+    const float* bias;  // [Cout] or null
+    View out;           // acc + bias + res + res2
+    View raw;           // optional: acc + bias
+    View res, res2;     // optional residuals (may alias out)
+    int B, H, W, Cout;
+};
+
+int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
+size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
+int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w /*(O,C,k,k)*/,
+                     void* dst, hipStream_t s);
+
+// --- misc kernels (enc_misc.hip) ---
+int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W,
+                const float* wk /*[Cin*49][64]*/, const float* bias, void* out /*(B,H/2,W/2,64)*/, hipStream_t s);
+int launch_pack_stem(chore_handle* h, int Cin, const float* w /*(64,Cin,7,7)*/, float* dst, hipStream_t s);
+int gn_splits(int HW);
+int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, float* partial, hipStream_t s);
+int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
+                       const float* beta, float* ss, hipStream_t s);
+int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const float* ss, const View& y, int B,
+                         int HW, hipStream_t s);
+int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, hipStream_t s);
+// y = a + bicubic_up2(low)   (low is (B,H,W,C), a and y are (B,2H,2W,C); y may alias a)
+int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
+                 hipStream_t s);
+int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s);

@@ -1,0 +1,155 @@
+// heads_f32.h -- LDS feature tile gather + exact-fp32 MFMA MLP heads, shared by the forward and
+// the backward-to-points query kernels.  See query_fwd.hip for the design notes.
+#pragma once
+#include "query_common.h"
+
+constexpr int XS = 332;  // LDS row stride of the X tile in floats (332/4 odd -> conflict-free b128)
+
+template <typename T>
+__device__ __forceinline__ void gather_tile(float* X, const PtTable& tab, const T* feat_b,
+                                            const T* tmpx_b, int wid, int lane) {
+    using L = MapLoad<T>;
+#pragma unroll 1
+    for (int i = 0; i < QT_PTS / 4; i += 4) {
+        f32x4 fv[4][4];
+        float tv[4][4];
+        float fw[4][4], tw[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pt = wid * (QT_PTS / 4) + i + u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fo = tab.foff[k][pt];
+                const int to = tab.toff[k][pt];
+                fw[u][k] = tab.fw[k][pt];
+                tw[u][k] = tab.tw[k][pt];
+                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                fv[u][k] = (fo >= 0) ? L::load4(feat_b + fo + lane * 4) : z4;
+                tv[u][k] = (to >= 0) ? L::load1(tmpx_b + to + lane) : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pt = wid * (QT_PTS / 4) + i + u;
+            f32x4 r;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                r[c] = interp4(fv[u][0][c], fv[u][1][c], fv[u][2][c], fv[u][3][c], fw[u]);
+            float* row = X + pt * XS;
+            *(f32x4*)(row + lane * 4) = r;
+            row[FEAT_C + 3 + lane] = interp4(tv[u][0], tv[u][1], tv[u][2], tv[u][3], tw[u]);
+            if (lane < 3) row[FEAT_C + lane] = tab.xyz[lane][pt];
+            if (lane >= 3 && lane < 3 + (QF_KPAD - HEAD_IN)) row[HEAD_IN + lane - 3] = 0.f;
+        }
+    }
+}
+
+__device__ __forceinline__ float relu(float v) { return v > 0.f ? v : 0.f; }
+
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// load the bias fragment (accumulator initialiser) of layer `layer`, row block rb
+__device__ __forceinline__ f32x16 load_bias_frag(const float* arena, int head, int layer, int rb, int half) {
+    const float* p = arena + QF_OFF_BIAS + ((((size_t)head * 4 + layer) * 4 + rb) * 2 + half) * 16;
+    f32x16 r;
+    const f32x4* p4 = (const f32x4*)p;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = p4[q];
+        r[q * 4 + 0] = v[0]; r[q * 4 + 1] = v[1]; r[q * 4 + 2] = v[2]; r[q * 4 + 3] = v[3];
+    }
+    return r;
+}
+
+// hidden layer 1: acc[rb][cb] = b1 + W1 * X^T     (K = 328 in 41 groups of 8)
+__device__ __forceinline__ void heads_layer1(f32x16 (&acc)[4][2], const float* X, const float* arena,
+                                             int head, int lane) {
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const f32x16 bf = load_bias_frag(arena, head, 0, rb, half);
+        acc[rb][0] = bf;
+        acc[rb][1] = bf;
+    }
+    const f32x4* A = (const f32x4*)(arena + QF_OFF_L1) + ((size_t)head * QF_KG * 4) * 64 + lane;
+    const float* x0 = X + col * XS + 4 * half;
+    const float* x1 = X + (32 + col) * XS + 4 * half;
+    f32x4 a_cur[4];
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) a_cur[rb] = A[rb * 64];
+#pragma unroll 1
+    for (int q = 0; q < QF_KG; ++q) {
+        f32x4 a_nxt[4];
+        const int qn = (q + 1 < QF_KG) ? q + 1 : q;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a_nxt[rb] = A[(qn * 4 + rb) * 64];
+        const f32x4 xb0 = *(const f32x4*)(x0 + q * 8);
+        const f32x4 xb1 = *(const f32x4*)(x1 + q * 8);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                acc[rb][0] = MFMA_F32(a_cur[rb][i], xb0[i], acc[rb][0]);
+                acc[rb][1] = MFMA_F32(a_cur[rb][i], xb1[i], acc[rb][1]);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) a_cur[rb] = a_nxt[rb];
+    }
+}
+
+// hidden layers 2 and 3: out = b + W * relu(in), activations stay in registers
+__device__ __forceinline__ void heads_layer_hid(f32x16 (&out)[4][2], const f32x16 (&in)[4][2],
+                                                const float* arena, int head, int layer /*1|2*/, int lane) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const f32x16 bf = load_bias_frag(arena, head, layer, rb, half);
+        out[rb][0] = bf;
+        out[rb][1] = bf;
+    }
+    const f32x4* A = (const f32x4*)(arena + QF_OFF_L23) +
+                     (((size_t)head * 2 + (layer - 1)) * 16 * 4) * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 a[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) a[rb] = A[((kb * 4 + rg) * 4 + rb) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float b0 = relu(in[kb][0][rg * 4 + i]);
+                const float b1 = relu(in[kb][1][rg * 4 + i]);
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    out[rb][0] = MFMA_F32(a[rb][i], b0, out[rb][0]);
+                    out[rb][1] = MFMA_F32(a[rb][i], b1, out[rb][1]);
+                }
+            }
+        }
+    }
+}
+
+// output layer: out[cb] = b4 + W4 * relu(in)   (rows >= out_dim are zero padding)
+__device__ __forceinline__ void heads_layer_out(f32x16 (&out)[2], const f32x16 (&in)[4][2],
+                                                const float* arena, int head, int lane) {
+    const int half = lane >> 5;
+    const f32x16 bf = load_bias_frag(arena, head, 3, 0, half);
+    out[0] = bf;
+    out[1] = bf;
+    const f32x4* A = (const f32x4*)(arena + QF_OFF_L4) + ((size_t)head * 16) * 64 + lane;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 a = A[(kb * 4 + rg) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                out[0] = MFMA_F32(a[i], relu(in[kb][0][rg * 4 + i]), out[0]);
+                out[1] = MFMA_F32(a[i], relu(in[kb][1][rg * 4 + i]), out[1]);
+            }
+        }
+    }
+}
+

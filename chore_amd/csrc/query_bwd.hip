@@ -1,0 +1,262 @@
+// query_bwd.hip -- backward of the fused query with respect to the POINTS (gfx950, exact fp32).
+//
+// What recon/generator.py:62-77 (`df.sum().backward()` w.r.t. the samples) and every fitting loss
+// of recon/recon_fit_base.py need: parameters and feature maps are frozen, gradients flow
+//   dOut -> heads (W^T GEMMs, ReLU masks) -> d(323-vector) -> { xyz channels directly,
+//   bilinear taps -> d(ix,iy) -> projection Jacobian (model/camera.py:64-78) } -> dpoints.
+// Nothing is saved by the forward: this kernel recomputes gather + hidden layers (keeping only the
+// ReLU sign bits, 12 registers) and then runs the transposed chain with the same register-resident
+// MFMA scheme (D fragment of one GEMM = B fragment of the next).  The four heads' contributions to
+// d(323-vector) are reduced through LDS in a fixed order, so the result is deterministic.
+#include "heads_f32.h"
+
+struct QueryBwdSmem {
+    float X[QT_PTS * XS];          // forward: feature tile; backward: d(feature) tile
+    float P[HEAD_NUM][32 * QT_PTS];  // per-head partial of one 32-row block, [row][pt]
+    PtTable tab;
+};
+
+__device__ __forceinline__ unsigned sign_mask(const f32x16& c0, const f32x16& c1) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        m |= (c0[r] > 0.f ? 1u : 0u) << r;
+        m |= (c1[r] > 0.f ? 1u : 0u) << (16 + r);
+    }
+    return m;
+}
+__device__ __forceinline__ void apply_mask(f32x16 (&d)[4][2], const unsigned (&m)[4]) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            d[rb][0][r] = ((m[rb] >> r) & 1u) ? d[rb][0][r] : 0.f;
+            d[rb][1][r] = ((m[rb] >> (16 + r)) & 1u) ? d[rb][1][r] : 0.f;
+        }
+    }
+}
+
+// d_prev = W^T * d_cur for a 128x128 layer; `which` = 0 -> W3 (3rd conv), 1 -> W2
+__device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][2], const f32x16 (&in)[4][2], const float* arena,
+                                        int head, int which, int lane) {
+    const f32x4* A = (const f32x4*)(arena + QB_OFF_L32T) + (((size_t)head * 2 + which) * 16 * 4) * 64 + lane;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { out[rb][0][r] = 0.f; out[rb][1][r] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            f32x4 a[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) a[rb] = A[((kb * 4 + rg) * 4 + rb) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float b0 = in[kb][0][rg * 4 + i];
+                const float b1 = in[kb][1][rg * 4 + i];
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    out[rb][0] = MFMA_F32(a[rb][i], b0, out[rb][0]);
+                    out[rb][1] = MFMA_F32(a[rb][i], b1, out[rb][1]);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    QueryBwdSmem& sm = *reinterpret_cast<QueryBwdSmem*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+
+    if (tid < QT_PTS)
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW,
+                      nullptr);
+    __syncthreads();
+    const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
+    const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
+    gather_tile<T>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    __syncthreads();
+
+    const float* arena = (const float*)a.arena;
+    const int head = wid;
+    const int odim = head_out_dim(head);
+
+    // ---- forward recompute, keep ReLU sign bits only ----
+    unsigned m1[4], m2[4], m3[4];
+    f32x16 u[4][2], v[4][2];
+    heads_layer1(u, sm.X, arena, head, lane);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask(u[rb][0], u[rb][1]);
+    heads_layer_hid(v, u, arena, head, 1, lane);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask(v[rb][0], v[rb][1]);
+    heads_layer_hid(u, v, arena, head, 2, lane);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask(u[rb][0], u[rb][1]);
+
+    // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
+    {
+        const float* g = a.g[head];
+        float gb[2][16];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int pt = cb * 32 + col;
+            const int n = n0 + pt;
+            const bool live = (g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = 2 * s + half;
+                gb[cb][s] = (live && k < odim) ? g[((size_t)b * odim + k) * a.N + n] : 0.f;
+            }
+        }
+        const f32x4* A = (const f32x4*)(arena + QB_OFF_L4T) + ((size_t)head * 16) * 64 + lane;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { v[rb][0][r] = 0.f; v[rb][1][r] = 0.f; }
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            f32x4 aw[4];
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) aw[rb] = A[(sg * 4 + rb) * 64];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int rb = 0; rb < 4; ++rb) {
+                    v[rb][0] = MFMA_F32(aw[rb][i], gb[0][sg * 4 + i], v[rb][0]);
+                    v[rb][1] = MFMA_F32(aw[rb][i], gb[1][sg * 4 + i], v[rb][1]);
+                }
+            }
+        }
+    }
+    apply_mask(v, m3);
+    bwd_hid(u, v, arena, head, 0, lane);  // d2 = W3^T d3
+    apply_mask(u, m2);
+    bwd_hid(v, u, arena, head, 1, lane);  // d1 = W2^T d2
+    apply_mask(v, m1);
+
+    // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
+    __syncthreads();  // every wave is done reading X as the forward tile
+    const f32x4* A1 = (const f32x4*)(arena + QB_OFF_L1T) + ((size_t)head * 16 * QB_RB1) * 64 + lane;
+#pragma unroll 1
+    for (int rb = 0; rb < QB_RB1; ++rb) {
+        f32x16 dx0, dx1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dx0[r] = 0.f; dx1[r] = 0.f; }
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 aw = A1[((kb * 4 + rg) * QB_RB1 + rb) * 64];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dx0 = MFMA_F32(aw[i], v[kb][0][rg * 4 + i], dx0);
+                    dx1 = MFMA_F32(aw[i], v[kb][1][rg * 4 + i], dx1);
+                }
+            }
+        }
+        float* P = sm.P[head];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma32_row(r, half);
+            P[row * QT_PTS + col] = dx0[r];
+            P[row * QT_PTS + 32 + col] = dx1[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < (32 * QT_PTS) / 256; ++e) {
+            const int idx = e * 256 + tid;  // row-major [row][pt]
+            const int row = idx / QT_PTS, pt = idx % QT_PTS;
+            const float s = ((sm.P[0][idx] + sm.P[1][idx]) + sm.P[2][idx]) + sm.P[3][idx];
+            const int k = rb * 32 + row;
+            if (k < QF_KPAD) sm.X[pt * XS + k] = s;
+        }
+        __syncthreads();
+    }
+
+    // ---- taps again: d(value)/d(ix,iy), then the projection Jacobian ----
+    using L = MapLoad<T>;
+#pragma unroll 1
+    for (int i = 0; i < QT_PTS / 4; ++i) {
+        const int pt = wid * (QT_PTS / 4) + i;
+        const float* drow = sm.X + pt * XS;
+        float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
+        {
+            const f32x4 g = *(const f32x4*)(drow + lane * 4);
+            f32x4 tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int fo = sm.tab.foff[k][pt];
+                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                tv[k] = (fo >= 0) ? L::load4(feat_b + fo + lane * 4) : z4;
+            }
+            const float w = sm.tab.ffrac[0][pt], n = sm.tab.ffrac[1][pt];
+            const float e = 1.f - w, s = 1.f - n;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                gix_f += g[c] * ((tv[1][c] - tv[0][c]) * s + (tv[3][c] - tv[2][c]) * n);
+                giy_f += g[c] * ((tv[2][c] - tv[0][c]) * e + (tv[3][c] - tv[1][c]) * w);
+            }
+        }
+        {
+            const float g = drow[FEAT_C + 3 + lane];
+            float tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int to = sm.tab.toff[k][pt];
+                tv[k] = (to >= 0) ? L::load1(tmpx_b + to + lane) : 0.f;
+            }
+            const float w = sm.tab.tfrac[0][pt], n = sm.tab.tfrac[1][pt];
+            const float e = 1.f - w, s = 1.f - n;
+            gix_t = g * ((tv[1] - tv[0]) * s + (tv[3] - tv[2]) * n);
+            giy_t = g * ((tv[2] - tv[0]) * e + (tv[3] - tv[1]) * w);
+        }
+        float gnx = gix_f * ((float)(a.FW - 1) * 0.5f) + gix_t * ((float)(a.TW - 1) * 0.5f);
+        float gny = giy_f * ((float)(a.FH - 1) * 0.5f) + giy_t * ((float)(a.TH - 1) * 0.5f);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            gnx += __shfl_xor(gnx, o, 64);
+            gny += __shfl_xor(gny, o, 64);
+        }
+        if (lane == 0 && sm.tab.valid[pt]) {
+            const float x = sm.tab.xyz[0][pt], y = sm.tab.xyz[1][pt], z = sm.tab.zraw[pt];
+            const float k = 2.0f / cam.crop;
+            const float gpx = gnx * k, gpy = gny * k;  // d/d(px), d/d(py)
+            const float iz = 1.0f / z;
+            const float dx = drow[FEAT_C + 0] + gpx * cam.fx * iz;
+            const float dy = drow[FEAT_C + 1] + gpy * cam.fy * iz;
+            const float dz = drow[FEAT_C + 2] - (gpx * cam.fx * x + gpy * cam.fy * y) * iz * iz;
+            float* o = a.dpoints + ((size_t)b * a.N + n0 + pt) * 3;
+            o[0] = dx; o[1] = dy; o[2] = dz;
+        }
+    }
+}
+
+template <typename T>
+static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryBwdSmem);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
+    hipLaunchKernelGGL(query_bwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
+    CHORE_HIP_CHECK(h, hipGetLastError());
+    return CHORE_OK;
+}
+
+int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_bwd_t<float>(h, a, s);
+}
+int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_bwd_t<unsigned short>(h, a, s);
+}

@@ -1,0 +1,131 @@
+// query_common.h -- projection, tap set-up and the pixel-aligned gather shared by the fused query
+// kernels (forward and backward-to-points).
+//
+// Arithmetic follows, operation by operation and WITHOUT fused multiply-add:
+//   model/camera.py:64-65,75-78   (pinhole projection, crop shift, normalisation to [-1,1])
+//   model/chore.py:128-130        (z_feat = [x, y, z-2.2], in_img mask)
+//   ATen grid_sampler_2d (bilinear, zeros padding, align_corners=True) as called from
+//   model/geometry.py:12: ix = (nx+1)*((W-1)/2); w = ix-floor(ix); e = 1-w; taps outside the
+//   map contribute 0; value = fma(se,w*n, fma(sw,e*n, fma(ne,w*s, nw*(e*s)))).
+// The __f*_rn intrinsics pin IEEE single operations so hipcc cannot contract them.
+#pragma once
+#include "common.h"
+
+constexpr int QT_PTS = 64;  // points per workgroup tile
+
+struct Cam {
+    float fx, fy, cx, cy, half_crop, crop;
+};
+
+__device__ __forceinline__ void project_point(float x, float y, float z, float ccx, float ccy,
+                                              const Cam& c, float& nx, float& ny) {
+    float px = __fadd_rn(__fdiv_rn(__fmul_rn(c.fx, x), z), c.cx);
+    float py = __fadd_rn(__fdiv_rn(__fmul_rn(c.fy, y), z), c.cy);
+    px = __fsub_rn(__fadd_rn(c.half_crop, px), ccx);
+    py = __fsub_rn(__fadd_rn(c.half_crop, py), ccy);
+    nx = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, px), c.crop), 1.0f);
+    ny = __fsub_rn(__fdiv_rn(__fmul_rn(2.0f, py), c.crop), 1.0f);
+}
+
+// Bilinear tap description of one point in one map: element offsets of the 4 taps (nw, ne, sw,
+// se; -1 = outside the map) and their weights.  Offsets are in elements of a (H,W,C) NHWC map.
+struct Taps {
+    int off[4];
+    float w[4];
+    float wx, wy;  // fractional parts (w, n) -- needed by the backward pass
+};
+
+__device__ __forceinline__ Taps make_taps(float nx, float ny, int H, int W, int C) {
+    Taps t;
+    const float ix = __fmul_rn(__fadd_rn(nx, 1.0f), (float)(W - 1) / 2);
+    const float iy = __fmul_rn(__fadd_rn(ny, 1.0f), (float)(H - 1) / 2);
+    const bool sane = (ix > -2.0f) && (ix < (float)W + 1.0f) && (iy > -2.0f) && (iy < (float)H + 1.0f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float w = __fsub_rn(ix, x0f), e = __fsub_rn(1.0f, w);
+    const float n = __fsub_rn(iy, y0f), s = __fsub_rn(1.0f, n);
+    t.wx = w;
+    t.wy = n;
+    t.w[0] = __fmul_rn(e, s);
+    t.w[1] = __fmul_rn(w, s);
+    t.w[2] = __fmul_rn(e, n);
+    t.w[3] = __fmul_rn(w, n);
+    const int x0 = sane ? (int)x0f : -4, y0 = sane ? (int)y0f : -4;
+    const bool xv0 = (x0 >= 0) && (x0 < W), xv1 = (x0 + 1 >= 0) && (x0 + 1 < W);
+    const bool yv0 = (y0 >= 0) && (y0 < H), yv1 = (y0 + 1 >= 0) && (y0 + 1 < H);
+    const int base = (y0 * W + x0) * C;
+    t.off[0] = (xv0 && yv0) ? base : -1;
+    t.off[1] = (xv1 && yv0) ? base + C : -1;
+    t.off[2] = (xv0 && yv1) ? base + W * C : -1;
+    t.off[3] = (xv1 && yv1) ? base + W * C + C : -1;
+    return t;
+}
+
+// ---- typed loads of NHWC feature rows ----
+template <typename T> struct MapLoad;
+template <> struct MapLoad<float> {
+    static __device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ float load1(const float* p) { return *p; }
+};
+template <> struct MapLoad<unsigned short> {  // bf16 storage
+    static __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
+        const u16x4 v = *(const u16x4*)p;
+        f32x4 r;
+        r[0] = bf2f(v[0]); r[1] = bf2f(v[1]); r[2] = bf2f(v[2]); r[3] = bf2f(v[3]);
+        return r;
+    }
+    static __device__ __forceinline__ float load1(const unsigned short* p) { return bf2f(*p); }
+};
+
+__device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
+    // fma(se,w3, fma(sw,w2, fma(ne,w1, nw*w0))): the chain ATen's CPU grid_sampler executes
+    // (pinned bit for bit by tests/golden/query_index.npz)
+    return fmaf(d, w[3], fmaf(c, w[2], fmaf(b, w[1], __fmul_rn(a, w[0]))));
+}
+
+// Per-tile point table kept in LDS (structure of arrays, QT_PTS entries each).
+struct PtTable {
+    float xyz[3][QT_PTS];   // x, y, z-2.2
+    int foff[4][QT_PTS];
+    float fw[4][QT_PTS];
+    int toff[4][QT_PTS];
+    float tw[4][QT_PTS];
+    int in_img[QT_PTS];
+    int valid[QT_PTS];
+    // backward only: fractional tap coordinates (w, n) of both maps and the raw depth
+    float ffrac[2][QT_PTS];
+    float tfrac[2][QT_PTS];
+    float zraw[QT_PTS];
+};
+
+// thread `t` (< QT_PTS) fills entry t of the table
+__device__ __forceinline__ void fill_pt_table(PtTable& tab, int t, const float* points,
+                                              const float* crop_center, int b, int n, int N,
+                                              const Cam& cam, int FH, int FW, int TH, int TW,
+                                              float* nxy_out /* optional [2] */) {
+    const bool valid = n < N;
+    const int nn = valid ? n : (N - 1);
+    const float* p = points + ((size_t)b * N + nn) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    float nx, ny;
+    project_point(x, y, z, crop_center[b * 2 + 0], crop_center[b * 2 + 1], cam, nx, ny);
+    if (nxy_out) { nxy_out[0] = nx; nxy_out[1] = ny; }
+    tab.xyz[0][t] = x;
+    tab.xyz[1][t] = y;
+    tab.xyz[2][t] = __fsub_rn(z, 2.2f);
+    tab.in_img[t] = (nx >= -1.0f) && (nx <= 1.0f) && (ny >= -1.0f) && (ny <= 1.0f);
+    tab.valid[t] = valid;
+    tab.zraw[t] = z;
+    const Taps tf = make_taps(nx, ny, FH, FW, FEAT_C);
+    const Taps tt = make_taps(nx, ny, TH, TW, TMPX_C);
+    tab.ffrac[0][t] = tf.wx;
+    tab.ffrac[1][t] = tf.wy;
+    tab.tfrac[0][t] = tt.wx;
+    tab.tfrac[1][t] = tt.wy;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        tab.foff[k][t] = tf.off[k];
+        tab.fw[k][t] = tf.w[k];
+        tab.toff[k][t] = tt.off[k];
+        tab.tw[k][t] = tt.w[k];
+    }
+}

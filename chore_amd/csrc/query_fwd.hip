@@ -1,0 +1,235 @@
+// query_fwd.hip -- fused CHORE.query forward for gfx950, exact-fp32 heads.
+//
+// One workgroup = 64 query points of one image, 4 waves.  Phase 1: 64 lanes project their point
+// (bit-exact restatement of model/camera.py:44-88) and build the bilinear tap table.  Phase 2: each
+// wave gathers 16 points: the 4 taps of a point are contiguous 1 KB (feat, 256 ch) / 256 B (tmpx,
+// 64 ch) rows of the NHWC maps, so every load is a fully coalesced wave access; the 323-vector
+// [feat | x y z-2.2 | tmpx] (model/chore.py:139-143) lands in an LDS tile X[64][332].  Phase 3: wave
+// w runs the complete MLP of head w (model/chore.py:74-85,156-167) on the matrix cores with
+// v_mfma_f32_32x32x2_f32 in the transposed form H^T = W * X^T: the D fragment of one layer
+// (row = channel, col = point) is already the B fragment of the next layer, so the activations
+// never leave registers; weights stream from the L2-resident fragment-ordered arena written by
+// heads_pack.  Phase 4: masked (df[~in_img] = 5.0, model/chore.py:147-150) coalesced stores in the
+// (B,C,N) layout the reference API returns.
+#include "heads_f32.h"
+
+struct QueryFwdSmem {
+    float X[QT_PTS * XS];
+    PtTable tab;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    QueryFwdSmem& sm = *reinterpret_cast<QueryFwdSmem*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+
+    if (tid < QT_PTS) {
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH,
+                      a.TW, nullptr);
+        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
+    }
+    __syncthreads();
+    const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
+    const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
+    gather_tile<T>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    __syncthreads();
+
+    const float* arena = (const float*)a.arena;
+    const int head = wid;
+    f32x16 h1[4][2], h2[4][2];
+    heads_layer1(h1, sm.X, arena, head, lane);
+    heads_layer_hid(h2, h1, arena, head, 1, lane);
+    heads_layer_hid(h1, h2, arena, head, 2, lane);
+    f32x16 o[2];
+    heads_layer_out(o, h1, arena, head, lane);
+
+    const int odim = head_out_dim(head);
+    float* outp = a.out[head] + (size_t)b * odim * a.N;
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int pt = cb * 32 + col;
+        const int n = n0 + pt;
+        const bool inside = sm.tab.in_img[pt] != 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = mfma32_row(r, half);
+            if (ch < odim && n < a.N) {
+                float v = o[cb][r];
+                if (head == 0 && !inside) v = 5.0f;
+                outp[(size_t)ch * a.N + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pixel-aligned feature sample only (projection + 2x index + z_feat, no heads): the 323-vector per
+// point, point-major.  Same phase 1/2 code as the fused kernel, so it doubles as its probe.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sample_features_kernel(QueryArgs a, float* features, float* nxy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    QueryFwdSmem& sm = *reinterpret_cast<QueryFwdSmem*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+    if (tid < QT_PTS) {
+        float nn[2];
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW, nn);
+        if (nxy && n0 + tid < a.N) {
+            nxy[((size_t)b * a.N + n0 + tid) * 2 + 0] = nn[0];
+            nxy[((size_t)b * a.N + n0 + tid) * 2 + 1] = nn[1];
+        }
+        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
+    }
+    __syncthreads();
+    const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
+    const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
+    gather_tile<T>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    __syncthreads();
+    for (int i = tid; i < QT_PTS * HEAD_IN; i += 256) {
+        const int pt = i / HEAD_IN, k = i % HEAD_IN;
+        if (n0 + pt < a.N) features[((size_t)b * a.N + n0 + pt) * HEAD_IN + k] = sm.X[pt * XS + k];
+    }
+}
+
+template <typename T>
+static int launch_sample_features_t(chore_handle* h, const QueryArgs& a, float* features, float* nxy, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryFwdSmem);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)sample_features_kernel<T>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
+    hipLaunchKernelGGL(sample_features_kernel<T>, grid, dim3(256), smem, s, a, features, nxy);
+    CHORE_HIP_CHECK(h, hipGetLastError());
+    return CHORE_OK;
+}
+int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s) {
+    return dtype == CHORE_F32 ? launch_sample_features_t<float>(h, a, features, nxy, s)
+                              : launch_sample_features_t<unsigned short>(h, a, features, nxy, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: reference Conv1d layouts -> MFMA fragment order (see common.h for the layout)
+// ------------------------------------------------------------------------------------------------
+__global__ void heads_pack_f32_kernel(HeadsRaw raw, float* arena) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= QF_TOTAL_FLOATS) return;
+    float v = 0.f;
+    if (idx < QF_OFF_L23) {  // layer 1: [h][q][rb][lane][4]
+        size_t t = idx - QF_OFF_L1;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int q = (int)(t % QF_KG);
+        const int h = (int)(t / QF_KG);
+        const int row = rb * 32 + (lane & 31);
+        const int k = q * 8 + 4 * (lane >> 5) + i;
+        if (k < HEAD_IN) v = raw.w[h][0][(size_t)row * HEAD_IN + k];
+    } else if (idx < QF_OFF_L4) {  // layers 2,3: [h][l][kb][rg][rb][lane][4]
+        size_t t = idx - QF_OFF_L23;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int rg = t & 3; t >>= 2;
+        const int kb = t & 3; t >>= 2;
+        const int l = t & 1; t >>= 1;
+        const int h = (int)t;
+        const int row = rb * 32 + (lane & 31);
+        const int k = kb * 32 + mfma32_row(rg * 4 + i, lane >> 5);
+        v = raw.w[h][1 + l][(size_t)row * HEAD_HID + k];
+    } else if (idx < QF_OFF_BIAS) {  // layer 4: [h][kb][rg][lane][4]
+        size_t t = idx - QF_OFF_L4;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rg = t & 3; t >>= 2;
+        const int kb = t & 3; t >>= 2;
+        const int h = (int)t;
+        const int row = lane & 31;
+        const int k = kb * 32 + mfma32_row(rg * 4 + i, lane >> 5);
+        if (row < head_out_dim(h)) v = raw.w[h][3][(size_t)row * HEAD_HID + k];
+    } else if (idx < QB_OFF_L4T) {  // bias fragments: [h][layer][rb][half][16]
+        size_t t = idx - QF_OFF_BIAS;
+        const int r = t & 15; t >>= 4;
+        const int half = t & 1; t >>= 1;
+        const int rb = t & 3; t >>= 2;
+        const int layer = t & 3; t >>= 2;
+        const int h = (int)t;
+        const int ch = rb * 32 + mfma32_row(r, half);
+        const int dim = (layer == 3) ? head_out_dim(h) : HEAD_HID;
+        if (ch < dim) v = raw.b[h][layer][ch];
+    } else if (idx < QB_OFF_L32T) {  // W4^T: [h][sg][rb][lane][4], k = 2*(sg*4+i) + half
+        size_t t = idx - QB_OFF_L4T;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int sg = t & 3; t >>= 2;
+        const int h = (int)t;
+        const int k = 2 * (sg * 4 + i) + (lane >> 5);
+        const int in = rb * 32 + (lane & 31);
+        if (k < head_out_dim(h)) v = raw.w[h][3][(size_t)k * HEAD_HID + in];
+    } else if (idx < QB_OFF_L1T) {  // W3^T (j=0), W2^T (j=1): [h][j][kb][rg][rb][lane][4]
+        size_t t = idx - QB_OFF_L32T;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int rg = t & 3; t >>= 2;
+        const int kb = t & 3; t >>= 2;
+        const int j = t & 1; t >>= 1;
+        const int h = (int)t;
+        const int k = kb * 32 + mfma32_row(rg * 4 + i, lane >> 5);
+        const int in = rb * 32 + (lane & 31);
+        v = raw.w[h][2 - j][(size_t)k * HEAD_HID + in];
+    } else {  // W1^T: [h][kb][rg][rb(11)][lane][4]
+        size_t t = idx - QB_OFF_L1T;
+        const int i = t & 3; t >>= 2;
+        const int lane = t & 63; t >>= 6;
+        const int rb = (int)(t % QB_RB1); t /= QB_RB1;
+        const int rg = t & 3; t >>= 2;
+        const int kb = t & 3; t >>= 2;
+        const int h = (int)t;
+        const int k = kb * 32 + mfma32_row(rg * 4 + i, lane >> 5);
+        const int in = rb * 32 + (lane & 31);
+        if (in < HEAD_IN) v = raw.w[h][0][(size_t)k * HEAD_IN + in];
+    }
+    arena[idx] = v;
+}
+
+int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s) {
+    const int threads = 256;
+    const int blocks = (int)((QF_TOTAL_FLOATS + threads - 1) / threads);
+    hipLaunchKernelGGL(heads_pack_f32_kernel, dim3(blocks), dim3(threads), 0, s, raw, arena);
+    CHORE_HIP_CHECK(h, hipGetLastError());
+    return CHORE_OK;
+}
+
+template <typename T>
+static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryFwdSmem);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
+    hipLaunchKernelGGL(query_fwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
+    CHORE_HIP_CHECK(h, hipGetLastError());
+    return CHORE_OK;
+}
+
+int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_fwd_t<float>(h, a, s);
+}
+int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_fwd_t<unsigned short>(h, a, s);
+}

@@ -1,0 +1,266 @@
+"""`CHORE` -- the field network with the reference's Python surface, computed by HIP kernels.
+
+Drop-in for /root/reference/model/chore.py:10-257 on the hot path:
+  filter(images)                  -> chore_encode_fwd           (HGFilter, model/HGFilters.py:144-185)
+  query(points, crop_center)      -> chore_query_fwd            (model/chore.py:107-154)
+  autograd to `points`            -> chore_query_bwd_points     (recon/generator.py:62-77)
+Same constructor signature, same sub-module / parameter names (state_dict contract), same
+attributes (`im_feat_list, tmpx, normx, intermediate_preds_list, preds, camera, OUT_DIST,
+loss_weights, error_buffer`).  Everything runs on the GPU through libchore_hip.so; CPU tensors are
+rejected (no fallback).
+
+Precision: `compute_dtype` "fp32" (exact-fp32 matrix-core path, parity mode) or "bf16"
+(bf16 feature maps / MFMA operands with fp32 accumulation; heads stay fp32).  Selected by
+`opt.compute_dtype`, else the CHORE_AMD_DTYPE environment variable, else "fp32".
+"""
+import ctypes
+import os
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _lib
+from .camera import KinectColorCamera
+from .hgfilter import HGFilter
+
+_DT = {"fp32": _lib.F32, "bf16": _lib.BF16}
+
+
+def _nhwc_ptr(t, C):
+    """(B,C,H,W) channels-last view (or plain NHWC tensor) -> (data_ptr, H, W); validates layout"""
+    if t.dim() != 4 or t.shape[1] != C:
+        raise ValueError(f"expected a (B,{C},H,W) feature map, got {tuple(t.shape)}")
+    B, _, H, W = t.shape
+    if t.stride() != (H * W * C, 1, W * C, C):
+        raise ValueError("feature maps must be NHWC in memory (as produced by CHORE.filter)")
+    return t.data_ptr(), H, W
+
+
+class _QueryFn(torch.autograd.Function):
+    """chore_query_fwd / chore_query_bwd_points as one autograd node (gradient w.r.t. points)."""
+
+    @staticmethod
+    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype):
+        B, N, _ = points.shape
+        dev = points.device
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(feat, 256)
+        tp, TH, TW = _nhwc_ptr(tmpx, 64)
+        df = torch.empty(B, 2, N, device=dev, dtype=torch.float32)
+        pca = torch.empty(B, 9, N, device=dev, dtype=torch.float32)
+        parts = torch.empty(B, 14, N, device=dev, dtype=torch.float32)
+        centers = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_query_fwd(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
+                                            tp, TH, TW, dtype, arena.data_ptr(), cam6, df.data_ptr(),
+                                            pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), None,
+                                            stream), h, "chore_query_fwd")
+        ctx.save_for_backward(points, crop_center, feat, tmpx, arena)
+        ctx.cam6, ctx.dtype = cam6, dtype
+        return df, pca, parts, centers
+
+    @staticmethod
+    def backward(ctx, g_df, g_pca, g_parts, g_centers):
+        points, crop_center, feat, tmpx, arena = ctx.saved_tensors
+        B, N, _ = points.shape
+        dev = points.device
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(feat, 256)
+        tp, TH, TW = _nhwc_ptr(tmpx, 64)
+
+        def prep(g):
+            return None if g is None else g.contiguous().float()
+
+        gs = [prep(g) for g in (g_df, g_pca, g_parts, g_centers)]
+        dpoints = torch.empty_like(points)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        ptr = [None if g is None else g.data_ptr() for g in gs]
+        _lib.check(_lib.lib.chore_query_bwd_points(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH,
+                                                   FW, tp, TH, TW, ctx.dtype, arena.data_ptr(), ctx.cam6,
+                                                   ptr[0], ptr[1], ptr[2], ptr[3], dpoints.data_ptr(),
+                                                   stream), h, "chore_query_bwd_points")
+        return dpoints, None, None, None, None, None, None
+
+
+def _mlp(input_sz, output_sz, hidden_sz):
+    # parameter container with the reference's Sequential indices 0,2,4,6 (model/chore.py:74-85)
+    return nn.Sequential(nn.Conv1d(input_sz, hidden_sz, 1), nn.ReLU(),
+                         nn.Conv1d(hidden_sz, hidden_sz, 1), nn.ReLU(),
+                         nn.Conv1d(hidden_sz, hidden_sz, 1), nn.ReLU(),
+                         nn.Conv1d(hidden_sz, output_sz, 1))
+
+
+class CHORE(nn.Module):
+    def __init__(self, opt, projection_mode="perspective", error_term=nn.MSELoss(), rank=-1, num_parts=14,
+                 hidden_dim=128):
+        super().__init__()
+        self.name = "chore"
+        self.opt = opt
+        self.error_term = error_term
+        self.device = torch.device("cuda", opt.gpu_id) if isinstance(opt.gpu_id, int) else torch.device(opt.gpu_id)
+        if opt.z_feat != "xyz" or opt.projection_mode != "perspective" or not opt.skip_hourglass:
+            raise ValueError("chore_amd implements z_feat='xyz', projection_mode='perspective', skip_hourglass=True")
+        if num_parts != 14 or hidden_dim != 128:
+            raise ValueError("the HIP heads are specialised for num_parts=14, hidden_dim=128")
+        self.z_feat = opt.z_feat
+        self.image_filter = HGFilter(opt)
+        feature_size = 256 + 3 + 256 // 4
+        self.df = _mlp(feature_size, 2, hidden_dim)
+        self.part_predictor = _mlp(feature_size, num_parts, hidden_dim)
+        self.pca_predictor = _mlp(feature_size, 9, hidden_dim)
+        self.center_predictor = _mlp(feature_size, 6, hidden_dim)
+        self.rank = rank
+        self.dfloss_func = nn.L1Loss(reduction="none")
+        self.part_loss_func = nn.CrossEntropyLoss(reduction="none")
+        self.loss_weights = [1.0, 1.0, 0.006, 500, 1000, 1000]
+        self.camera = KinectColorCamera(opt.loadSize)
+        self.OUT_DIST = 5.0
+        self._init_weights()
+
+        self.im_feat_list = []
+        self.tmpx = None
+        self.normx = None
+        self.intermediate_preds_list = []
+        self.preds = None
+        self.labels = None
+        self.points = None
+        self.crop_center = None
+        self.error_buffer = None
+        dt = getattr(opt, "compute_dtype", None) or os.environ.get("CHORE_AMD_DTYPE", "fp32")
+        if dt not in _DT:
+            raise ValueError(f"compute_dtype must be one of {list(_DT)}")
+        self.compute_dtype = dt
+        self._heads_packed = None  # (version key, arena)
+        self._cam6 = (ctypes.c_float * 6)(*self.camera.kernel_constants())
+
+    def _init_weights(self, gain=0.02):
+        # same distribution as net_util.init_weights('normal', 0.02): N(0, gain) conv weights,
+        # zero conv biases, GroupNorm left at (1, 0)   (/root/reference/model/net_util.py:218-251)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                nn.init.normal_(m.weight.data, 0.0, gain)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias.data, 0.0)
+
+    # ---- packed weights ---------------------------------------------------------------------
+    def _head_modules(self):
+        return (("df", self.df), ("part_predictor", self.part_predictor), ("pca_predictor", self.pca_predictor),
+                ("center_predictor", self.center_predictor))
+
+    def _heads_arena(self, device):
+        params = [p for _, m in self._head_modules() for p in m.parameters()]
+        key = (str(device), sum(p._version for p in params), params[0].data_ptr())
+        if self._heads_packed is not None and self._heads_packed[0] == key:
+            return self._heads_packed[1]
+        dtype = _DT[self.compute_dtype]
+        h = _lib.handle(device.index or 0)
+        arena = torch.empty(_lib.lib.chore_heads_arena_bytes(dtype), dtype=torch.uint8, device=device)
+        named = []
+        for name, m in self._head_modules():
+            for k, p in m.state_dict(keep_vars=True).items():
+                t = p.detach()
+                if not t.is_cuda:
+                    raise RuntimeError("CHORE parameters must live on the GPU: call .to(device) first")
+                named.append((f"{name}.{k}", t.float().contiguous()))
+        descs, keep = _lib.make_descs(named)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.lib.chore_heads_pack(h, descs, len(named), dtype, arena.data_ptr(), stream), h,
+                   "chore_heads_pack")
+        self._heads_packed = (key, arena)
+        return arena
+
+    # ---- reference API ----------------------------------------------------------------------
+    def filter(self, images):
+        """encode images (B,5,H,W); keeps all stacks in training, the last one in eval
+        (/root/reference/model/chore.py:87-96)"""
+        n_out = self.image_filter.num_modules if self.training else 1
+        feats, self.tmpx, self.normx = self.image_filter(images, _DT[self.compute_dtype], n_out)
+        self.im_feat_list = feats
+
+    def project_points(self, points, offsets):
+        """(B,N,3),(B,2) -> (B,3,N) normalised image coordinates + depth, op for op as
+        /root/reference/model/camera.py:44-88 (host-side helper; the query kernel projects itself)"""
+        c = self.camera
+        x, y, z = points[:, :, 0:1], points[:, :, 1:2], points[:, :, 2:3]
+        px = c.fx_px * x / z + c.cx_px
+        py = c.fy_px * y / z + c.cy_px
+        px = c.crop_size / 2 + px - offsets[:, 0].unsqueeze(1).unsqueeze(1)
+        py = c.crop_size / 2 + py - offsets[:, 1].unsqueeze(1).unsqueeze(1)
+        nx = 2 * px / c.crop_size - 1
+        ny = 2 * py / c.crop_size - 1
+        return torch.cat([nx, ny, z], -1).transpose(1, 2)
+
+    def query(self, points, crop_center=None, **kwargs):
+        if crop_center is None:
+            raise ValueError("crop_center is required (the reference asserts it in camera.normalize)")
+        if not points.is_cuda:
+            raise RuntimeError("chore_amd.CHORE.query needs device tensors (no CPU path)")
+        if not self.im_feat_list:
+            raise RuntimeError("call filter(images) before query()")
+        self.points = points
+        self.crop_center = crop_center
+        pts = points if (points.dtype == torch.float32 and points.is_contiguous()) else points.float().contiguous()
+        cc = crop_center.to(device=points.device, dtype=torch.float32).contiguous()
+        if pts.dim() != 3 or pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
+            raise ValueError("points must be (B,N,3) and crop_center (B,2)")
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "gradients w.r.t. network parameters are not implemented yet (training backward); "
+                "freeze the parameters (as recon/generator.py:41-42 does) or use torch.no_grad()")
+        arena = self._heads_arena(points.device)
+        dtype = _DT[self.compute_dtype]
+        self.intermediate_preds_list = []
+        for feat in self.im_feat_list:
+            df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype)
+            B, _, N = df.shape
+            self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
+        self.preds = self.intermediate_preds_list[-1]
+
+    def get_preds(self):
+        return self.preds
+
+    def get_im_feat(self):
+        return self.im_feat_list[-1]
+
+    def get_error(self):
+        return self.error_term(self.preds, self.labels)
+
+    def forward(self, images, points, df_h, df_o, parts_gt, pca_gt, body_center=None, max_dist=5.0,
+                obj_center=None, crop_center=None, **kwargs):
+        self.filter(images)
+        self.query(points=points, crop_center=crop_center, **kwargs)
+        return self.get_errors(df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs)
+
+    def get_errors(self, df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs):
+        """training loss of /root/reference/model/chore.py:192-237, averaged over the stacks"""
+        w = self.loss_weights
+        error, losses_all = 0.0, 0.0
+        for df_pred, pca_pred, parts_pred, centers in self.intermediate_preds_list:
+            loss_h = self.get_df_loss(df_h, df_pred[:, 0], max_dist) * w[0]
+            loss_o = self.get_df_loss(df_o, df_pred[:, 1], max_dist) * w[1]
+            loss_parts = (self.part_loss_func(parts_pred, parts_gt) * w[2]).sum(-1).mean()
+            mask = (df_o < 0.05).unsqueeze(1).unsqueeze(1)
+            loss_pca = ((F.mse_loss(pca_pred, pca_gt, reduction="none") * mask) * w[3]).mean()
+            loss_obj = (F.mse_loss(centers[:, 3:, :], obj_center, reduction="none") * mask).mean() * w[4]
+            mask = (df_h < 0.05).unsqueeze(1)
+            N = mask.shape[2]
+            loss_smpl = (F.mse_loss(centers[:, :3, :], body_center.unsqueeze(-1).repeat(1, 1, N),
+                                    reduction="none") * mask).mean() * w[5]
+            error = error + loss_h + loss_o + loss_parts + loss_pca + loss_smpl + loss_obj
+            losses_all = losses_all + torch.stack([loss_h, loss_o, loss_parts, loss_pca, loss_smpl, loss_obj]).detach()
+        n = len(self.intermediate_preds_list)
+        error = error / n
+        losses_all = (losses_all / n).cpu()
+        self.error_buffer = losses_all
+        return error, losses_all
+
+    def get_df_loss(self, df_gt, df_pred, max_dist):
+        return self.dfloss_func(torch.clamp(df_pred, max=max_dist), torch.clamp(df_gt, max=max_dist)).sum(-1).mean()
+
+    def format_sep_losses(self, losses_all):
+        return dict(zip(["df_h", "df_o", "parts", "pca", "smpl", "obj"], losses_all))
+
+    def print_errors(self, errors):
+        names = ["df_h", "df_o", "parts", "pca", "smpl", "obj", "grad_h", "grad_o"]
+        print(", ".join(f"{n}:{v}" for n, v in zip(names, errors)))

@@ -1,0 +1,170 @@
+"""Parameter tree of the stacked-hourglass encoder.
+
+Holds the encoder's parameters under exactly the names and shapes of the reference
+(`image_filter.*` entries of the state_dict contract, SURVEY.md Appendix D;
+/root/reference/model/HGFilters.py:57-142, /root/reference/model/net_util.py:346-372) so released
+checkpoints load unchanged and `optim.Adam(model.parameters())` / DDP see the same tensors.
+The modules here are containers only -- they are never called.  The forward pass is the HIP
+program behind `chore_encode_fwd` (csrc/encoder.hip), launched from `HGFilter.forward`.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class _Params(nn.Module):
+    """a module that only owns parameters; calling it is a bug"""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the computation lives in libchore_hip.so")
+
+
+def _conv(cin, cout, k, bias):
+    return nn.Conv2d(cin, cout, kernel_size=k, bias=bias)
+
+
+class ConvBlock(_Params):
+    """GN-ReLU-conv3x3 x3 with channel split (out/2, out/4, out/4), concat, residual.
+
+    `bn4` exists even when in==out (reference quirk, net_util.py:357-362): it then never receives a
+    gradient, which is why the reference needs find_unused_parameters=True.  When in!=out the
+    residual branch is `downsample` = [bn4 (shared module), ReLU, conv1x1] so the state dict
+    carries both `bn4.*` and `downsample.0.*` for the same tensors.
+    """
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.cin, self.cout = cin, cout
+        self.conv1 = _conv(cin, cout // 2, 3, False)
+        self.conv2 = _conv(cout // 2, cout // 4, 3, False)
+        self.conv3 = _conv(cout // 4, cout // 4, 3, False)
+        self.bn1 = nn.GroupNorm(32, cin)
+        self.bn2 = nn.GroupNorm(32, cout // 2)
+        self.bn3 = nn.GroupNorm(32, cout // 4)
+        self.bn4 = nn.GroupNorm(32, cin)
+        if cin != cout:
+            self.downsample = nn.Sequential(self.bn4, nn.ReLU(True), _conv(cin, cout, 1, False))
+        else:
+            self.downsample = None
+
+
+class HourGlass(_Params):
+    def __init__(self, depth, feat):
+        super().__init__()
+        self.depth = depth
+
+        def grow(level):  # registration order fixes the state_dict order
+            self.add_module(f"b1_{level}", ConvBlock(feat, feat))
+            self.add_module(f"b2_{level}", ConvBlock(feat, feat))
+            if level > 1:
+                grow(level - 1)
+            else:
+                self.add_module(f"b2_plus_{level}", ConvBlock(feat, feat))
+            self.add_module(f"b3_{level}", ConvBlock(feat, feat))
+
+        grow(depth)
+
+
+_INPUT_CHANNELS = {"RGB": 3, "RGBD": 4, "RGBN": 5, "RGBM2": 5, "RGBM3": 5, "RGBM4": 5, "RGBMD": 6,
+                   "RGBMD2": 6, "RGBM": 4, "RGBMN": 8}
+
+
+class HGFilter(_Params):
+    def __init__(self, opt):
+        super().__init__()
+        self.opt = opt
+        if opt.norm != "group" or opt.hg_down != "ave_pool":
+            raise ValueError("chore_amd implements the chore-release encoder: norm='group', hg_down='ave_pool'")
+        if opt.input_type not in _INPUT_CHANNELS:
+            raise ValueError(f"invalid input specification: {opt.input_type}")
+        self.input_channel = _INPUT_CHANNELS[opt.input_type]
+        self.num_modules = opt.num_stack
+        hd = opt.hourglass_dim
+        if hd != 256:
+            raise ValueError("the HIP encoder is specialised for hourglass_dim=256")
+        self.conv1 = nn.Conv2d(self.input_channel, 64, kernel_size=7, stride=2, padding=3)
+        self.bn1 = nn.GroupNorm(32, 64)
+        self.conv2 = ConvBlock(64, 128)
+        self.conv3 = ConvBlock(128, 128)
+        self.conv4 = ConvBlock(128, 256)
+        for i in range(self.num_modules):
+            self.add_module(f"m{i}", HourGlass(opt.num_hourglass, 256))
+            self.add_module(f"top_m_{i}", ConvBlock(256, 256))
+            self.add_module(f"conv_last{i}", _conv(256, 256, 1, True))
+            self.add_module(f"bn_end{i}", nn.GroupNorm(32, 256))
+            self.add_module(f"l{i}", _conv(256, hd, 1, True))
+            if i < self.num_modules - 1:
+                self.add_module(f"bl{i}", _conv(256, 256, 1, True))
+                self.add_module(f"al{i}", _conv(hd, 256, 1, True))
+        self._packed = {}  # dtype -> (version key, arena tensor)
+        self._work = {}    # (B,H,W,dtype) -> workspace tensor
+
+    # ---------------------------------------------------------------------------------------
+    def cfg(self):
+        return _lib.EncoderCfg(self.input_channel, self.num_modules, self.opt.num_hourglass,
+                               self.opt.hourglass_dim)
+
+    def _version_key(self, device):
+        return (str(device), sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in (self.conv1.weight,)))
+
+    def packed_arena(self, dtype, device):
+        key = self._version_key(device)
+        hit = self._packed.get(dtype)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        cfg = self.cfg()
+        h = _lib.handle(device.index or 0)
+        nbytes = _lib.lib.chore_encoder_arena_bytes(ctypes.byref(cfg), dtype)
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        named = []
+        seen = set()
+        for name, p in self.state_dict(keep_vars=True).items():
+            if p.data_ptr() in seen and "downsample.0" in name:
+                continue  # alias of bn4
+            seen.add(p.data_ptr())
+            t = p.detach()
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                t = t.float().contiguous()
+            named.append(("image_filter." + name, t))
+        descs, keep = _lib.make_descs(named)
+        stream = torch.cuda.current_stream(device).cuda_stream
+        _lib.check(_lib.lib.chore_encoder_pack(h, ctypes.byref(cfg), descs, len(named), dtype,
+                                               arena.data_ptr(), stream), h, "chore_encoder_pack")
+        self._packed[dtype] = (key, arena)
+        return arena
+
+    def forward(self, images, dtype=_lib.F32, n_stack_out=None):
+        """images (B,C,H,W) fp32 on the GPU -> (outputs, tmpx, normx) like
+        /root/reference/model/HGFilters.py:144-185; tensors are NHWC in memory and returned as
+        (B,C,H,W)-shaped channels-last views."""
+        if not images.is_cuda:
+            raise RuntimeError("chore_amd.HGFilter needs device tensors (no CPU path)")
+        B, C, H, W = images.shape
+        if C != self.input_channel or H % 16 or W % 16:
+            raise ValueError(f"images must be (B,{self.input_channel},H,W) with H,W multiples of 16")
+        dev = images.device
+        images = images.contiguous().float()
+        n_out = self.num_modules if n_stack_out is None else n_stack_out
+        tdt = torch.float32 if dtype == _lib.F32 else torch.bfloat16
+        arena = self.packed_arena(dtype, dev)
+        cfg = self.cfg()
+        h = _lib.handle(dev.index or 0)
+        wkey = (B, H, W, dtype, str(dev))
+        work = self._work.get(wkey)
+        if work is None:
+            nbytes = _lib.lib.chore_encoder_workspace_bytes(ctypes.byref(cfg), B, H, W, dtype)
+            work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self._work = {wkey: work}
+        feats = [torch.empty(B, H // 4, W // 4, 256, dtype=tdt, device=dev) for _ in range(n_out)]
+        tmpx = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
+        normx = torch.empty(B, H // 4, W // 4, 128, dtype=tdt, device=dev)
+        fptrs = (ctypes.c_void_p * n_out)(*[f.data_ptr() for f in feats])
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_encode_fwd(h, ctypes.byref(cfg), images.data_ptr(), B, H, W, dtype,
+                                             arena.data_ptr(), work.data_ptr(), work.numel(), fptrs,
+                                             n_out, tmpx.data_ptr(), normx.data_ptr(), stream),
+                   h, "chore_encode_fwd")
+        return [f.permute(0, 3, 1, 2) for f in feats], tmpx.permute(0, 3, 1, 2), normx.permute(0, 3, 1, 2)

@@ -1,0 +1,144 @@
+/*
+ * chore_hip.h -- C ABI of libchore_hip.so, the MI355X (gfx950) implementation of CHORE's
+ * implicit-field query + fitting hot path.
+ *
+ * The reference (xiexh20/CHORE) has no FFI seam of its own for this path: the hot path is pure
+ * ATen called from Python (model/chore.py:87-167).  The only C boundary in the reference tree is
+ * the vendored rasterizer's pybind module (external/neural_renderer/neural_renderer/cuda/
+ * rasterize_cuda.cpp:201-207), whose conventions we mirror: the CALLER allocates every buffer
+ * (inputs, outputs, workspaces), functions fill them and return; work is enqueued on the caller's
+ * stream; no hidden synchronisation, no internal threads.  Each entry point below cites the
+ * reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless stated otherwise
+ *   - return 0 (CHORE_OK) on success, negative CHORE_E* otherwise; chore_last_error() gives text
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream
+ *   - nothing here calls hipMalloc/hipFree/hipDeviceSynchronize on the hot path, so every call is
+ *     hipGraph-capturable
+ *   - one handle per (process, device); a handle is not thread-safe
+ */
+#ifndef CHORE_HIP_H
+#define CHORE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct chore_handle chore_handle;
+typedef void* chore_stream_t;
+
+enum {
+    CHORE_OK = 0,
+    CHORE_EINVAL = -1, /* bad argument (shape, dtype, null pointer)   */
+    CHORE_EHIP = -2,   /* a HIP runtime call failed                    */
+    CHORE_ESTATE = -3, /* missing weights / wrong call order           */
+    CHORE_ENOMEM = -4  /* caller workspace too small                   */
+};
+
+/* storage / MFMA-operand type of feature maps and packed weights */
+enum { CHORE_F32 = 0, CHORE_BF16 = 1 };
+
+/* one tensor of a reference state_dict (Appendix D of SURVEY.md): name, device pointer to its
+ * contiguous fp32 data in the reference layout, element count */
+typedef struct {
+    const char* name;
+    const void* ptr;
+    int64_t numel;
+} chore_weight_desc;
+
+/* encoder topology = the fields of config/chore-release.json the hot path reads
+ * (model/HGFilters.py:57-142) */
+typedef struct {
+    int in_channels;   /* 5 for input_type RGBM3                         */
+    int num_stack;     /* 5                                              */
+    int num_hourglass; /* 2 (recursion depth of one hourglass)           */
+    int hourglass_dim; /* 256                                            */
+} chore_encoder_cfg;
+
+int chore_version(void);
+int chore_create(chore_handle** out, int device_ordinal);
+int chore_destroy(chore_handle* h);
+const char* chore_last_error(const chore_handle* h);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-point MLP heads + fused query  (replaces CHORE.query, model/chore.py:107-154:
+ * camera.project_points model/camera.py:44-88, index()/grid_sample model/geometry.py:4-14 twice,
+ * torch.cat, CHORE.decode model/chore.py:156-167, the df[~in_img]=OUT_DIST fill :147-150)
+ * ------------------------------------------------------------------------------------------- */
+
+/* bytes of the packed (MFMA-fragment-ordered) weight arena of the four heads */
+size_t chore_heads_arena_bytes(int dtype);
+
+/* Repack the four decoders' Conv1d weights into the arena.  `descs` must contain
+ * {df,part_predictor,pca_predictor,center_predictor}.{0,2,4,6}.{weight,bias} (fp32, reference
+ * layout (out,in,1)).  model/chore.py:49-55,74-85. */
+int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_descs, int dtype,
+                     void* arena, chore_stream_t stream);
+
+/* Camera constants in the order (fx_px, fy_px, cx_px, cy_px, crop/2, crop) -- HOST pointer to 6
+ * floats, values as computed in model/camera.py:26-42. */
+
+/* Fused forward query.
+ *   points      (B,N,3) fp32 camera-space      crop_center (B,2) fp32
+ *   feat        (B,FH,FW,256) NHWC `dtype`     tmpx (B,TH,TW,64) NHWC `dtype`
+ *   df (B,2,N)  pca (B,9,N)  parts (B,14,N)  centers (B,6,N)  fp32;  in_img (B,N) uint8 (may be NULL)
+ * df is written with OUT_DIST (5.0) where the projected point falls outside [-1,1]^2. */
+int chore_query_fwd(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                    const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                    const void* heads_arena, const float* cam6_host, float* df, float* pca,
+                    float* parts, float* centers, uint8_t* in_img, chore_stream_t stream);
+
+/* Pixel-aligned feature sample without the heads: BasePIFuNet.index (model/BasePIFuNet.py:23 ->
+ * model/geometry.py:4-14) on both maps plus z_feat, concatenated as in model/chore.py:139-143.
+ *   features (B,N,323) fp32 point-major [feat 0..255 | x y z-2.2 | tmpx 0..63]
+ *   nxy (B,N,2) normalised image coordinates of model/camera.py:44-88 (may be NULL)
+ *   in_img (B,N) uint8 (may be NULL) */
+int chore_sample_features(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                          const float* cam6_host, float* features, float* nxy, uint8_t* in_img,
+                          chore_stream_t stream);
+
+/* Backward of chore_query_fwd with respect to the POINTS only (what
+ * recon/generator.py:62-77 `df_target.sum().backward()` and every fitting loss need):
+ * g_* are the upstream gradients of the four outputs (any may be NULL = zero); the forward is
+ * recomputed inside the kernel, nothing is saved.  Gradients of df at out-of-image points are
+ * dropped (the in-place fill of model/chore.py:149 cuts the graph there).
+ *   dpoints (B,N,3) fp32, overwritten. */
+int chore_query_bwd_points(chore_handle* h, const float* points, const float* crop_center, int B,
+                           int N, const void* feat, int FH, int FW, const void* tmpx, int TH,
+                           int TW, int dtype, const void* heads_arena, const float* cam6_host,
+                           const float* g_df, const float* g_pca, const float* g_parts,
+                           const float* g_centers, float* dpoints, chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stacked-hourglass encoder  (replaces HGFilter.forward model/HGFilters.py:144-185,
+ * HourGlass._forward :26-50, ConvBlock.forward model/net_util.py:374-396)
+ * ------------------------------------------------------------------------------------------- */
+
+/* bytes of the packed encoder weight arena */
+size_t chore_encoder_arena_bytes(const chore_encoder_cfg* cfg, int dtype);
+
+/* Repack `image_filter.*` tensors of the state_dict (fp32, reference layouts) into the arena. */
+int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg,
+                       const chore_weight_desc* descs, int n_descs, int dtype, void* arena,
+                       chore_stream_t stream);
+
+/* caller-allocated scratch needed by chore_encode_fwd for this shape */
+size_t chore_encoder_workspace_bytes(const chore_encoder_cfg* cfg, int B, int H, int W, int dtype);
+
+/* images (B,C,H,W) fp32 NCHW in [0,1] as data/test_data.py:107-125 delivers them.
+ * feat_out[i] (B,H/4,W/4,256) NHWC `dtype` for the last `n_stack_out` stacks (eval: 1, training:
+ * num_stack; model/chore.py:93-96), tmpx (B,H/2,W/2,64), normx (B,H/4,W/4,128) (may be NULL). */
+int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float* images, int B,
+                     int H, int W, int dtype, const void* arena, void* workspace,
+                     size_t workspace_bytes, void* const* feat_out, int n_stack_out, void* tmpx,
+                     void* normx, chore_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CHORE_HIP_H */

@@ -1,0 +1,73 @@
+"""Developer probe (GPU box): prints error metrics and rough timings of each kernel family."""
+import argparse, json, os, sys, time
+import numpy as np, torch
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+from chore_amd.model import CHORE
+from chore_amd.utils import synth
+from oracle import query as oq, encoder as oe
+
+def opt_ns(dtype):
+    return argparse.Namespace(input_type="RGBM3", norm="group", num_stack=5, num_hourglass=2, hg_down="ave_pool",
+        hourglass_dim=256, skip_hourglass=True, z_feat="xyz", projection_mode="perspective", loadSize=1200,
+        net_img_size=[512, 512], gpu_id=0, compute_dtype=dtype)
+
+def nhwc(x, dtype=torch.float32):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda().to(dtype)
+    return t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+def main():
+    G = os.path.join(REPO, "tests", "golden")
+    spec = [(k, tuple(s)) for k, s in json.load(open(os.path.join(G, "state_dict_spec.json")))]
+    sd = synth.synth_state_dict(spec, 0)
+    print(torch.cuda.get_device_name(0), flush=True)
+    net = CHORE(opt_ns("fp32")).cuda().eval(); synth.load_synth_weights(net, 0)
+    for p in net.parameters(): p.requires_grad_(False)
+    # ---- query
+    g = np.load(os.path.join(G, "query_full.npz"))
+    net.im_feat_list = [nhwc(g["feat"])]; net.tmpx = nhwc(g["tmpx"])
+    pts = torch.from_numpy(g["points"]).cuda().requires_grad_(True)
+    net.query(pts, crop_center=torch.from_numpy(g["crop_center"]).cuda())
+    preds = net.get_preds()
+    for k, v in zip(("df", "pca", "parts", "centers"), preds):
+        print("query", k, "max abs err", np.abs(v.detach().cpu().numpy() - g[k]).max(), flush=True)
+    loss = sum((o * torch.from_numpy(g["w_" + k]).cuda()).sum() for k, o in zip(("df", "pca", "parts", "centers"), preds))
+    loss.backward()
+    gr = pts.grad.cpu().numpy()
+    print("bwd rel err", np.abs(gr - g["dpoints"]).max() / np.abs(g["dpoints"]).max(), flush=True)
+    # ---- encoder small
+    ge = np.load(os.path.join(G, "encoder_64x96.npz"))
+    for dt in ("fp32", "bf16"):
+        n2 = CHORE(opt_ns(dt)).cuda().eval(); synth.load_synth_weights(n2, 0)
+        n2.train(True)
+        with torch.no_grad(): n2.filter(torch.from_numpy(ge["images"]).cuda())
+        n2.train(False)
+        outs = [o.float().cpu().numpy() for o in n2.im_feat_list]
+        tm, nm = n2.tmpx.float().cpu().numpy(), n2.normx.float().cpu().numpy()
+        rm = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+        rl = lambda a, b: np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())
+        print(dt, "tmpx relmax", rm(tm, ge["tmpx"]), "normx", rm(nm, ge["normx"]), "out_last relmax", rm(outs[-1], ge["out_last"]),
+              "rel l2", rl(outs[-1], ge["out_last"]), "first crop", rm(outs[0][:, :, 4:8, 8:12], ge["out_first_crop"]), flush=True)
+        # timings at config-2 size
+        img = torch.from_numpy(synth.synth_images(4, 512, 512, 0)).cuda()
+        with torch.no_grad():
+            ms = timeit(lambda: n2.filter(img), n=5, warm=2)
+        print(dt, "encode B=4 512^2 ms", ms, "TFLOP/s", 4 * 258.25e9 / ms / 1e9, flush=True)
+        p = torch.from_numpy(synth.synth_points(4, 20000, 1)).cuda()
+        cc = torch.tensor([synth.CROP_CENTER] * 4).cuda()
+        with torch.no_grad():
+            ms = timeit(lambda: n2.query(p, crop_center=cc), n=20)
+        print(dt, "query 4x20000 ms", ms, "pts/s", 80000 / ms * 1e3, flush=True)
+        pg = p.clone().requires_grad_(True)
+        def fb():
+            pg.grad = None
+            n2.query(pg, crop_center=cc); n2.get_preds()[0][:, 0].clamp(max=2.0).sum().backward()
+        print(dt, "query fwd+bwd 4x20000 ms", timeit(fb, n=10), flush=True)
+        del n2
+main()

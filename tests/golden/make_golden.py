@@ -1,0 +1,167 @@
+"""Generate the golden vectors under tests/golden/ by importing THE REFERENCE ITSELF.
+
+Run in the build container only (needs /root/reference; it does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+The reference's hot path is pure PyTorch, so it runs here on CPU.  Its `model/net_util.py` imports
+PIFu leftovers (cv2, skimage) that are absent from the image and never used by CHORE; empty stub
+modules are inserted for the import only.  Weights are the deterministic synthetic ones of
+chore_amd/utils/synth.py (rebuilt from (name, shape, seed) by the tests), so the fixtures hold only
+inputs and the reference's outputs.
+"""
+import argparse
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+for m in ("cv2", "skimage", "skimage.measure"):
+    sys.modules.setdefault(m, types.ModuleType(m))
+sys.path.insert(0, REF)
+
+from chore_amd.utils import synth  # noqa: E402
+
+
+def ref_model(seed=0, train=False):
+    from model import CHORE  # the reference's model package
+    opt = argparse.Namespace(**json.load(open(os.path.join(REF, "config/chore-release.json"))))
+    net = CHORE(opt)
+    sd = net.state_dict()
+    with torch.no_grad():
+        for name, p in sd.items():
+            p.copy_(torch.from_numpy(synth.synth_tensor(name, p.shape, seed)))
+    net.train(train)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    return net
+
+
+def edge_points(rs, n):
+    """camera-space points incl. exact image borders, far outside, tiny depth"""
+    pts = synth.synth_points(1, n, seed=7)[0]
+    # points that project exactly onto nx = +-1 / ny = +-1 for crop centre (1008, 995) at z = 2.2
+    fx, fy, cx, cy = 979.7844, 979.840, 1018.952, 779.486
+    for i, (nx, ny) in enumerate([(-1, -1), (1, 1), (-1, 1), (1, -1), (0, 0), (1, 0), (0, -1)]):
+        px = (nx + 1) * 600.0 - 600.0 + 1008.0
+        py = (ny + 1) * 600.0 - 600.0 + 995.0
+        z = 2.2
+        pts[i] = [(px - cx) * z / fx, (py - cy) * z / fy, z]
+    pts[8] = [5.0, 5.0, 2.0]      # far outside
+    pts[9] = [-5.0, 0.1, 2.0]
+    pts[10] = [0.1, 0.2, 0.05]    # very close to the camera
+    pts[11] = [0.0, 0.0, 3.5]
+    pts[12:40, 2] = rs.uniform(0.3, 6.0, 28).astype(np.float32)
+    return pts.astype(np.float32)
+
+
+def gen_projection():
+    from model.camera import KinectColorCamera
+    rs = np.random.RandomState(11)
+    pts = np.stack([edge_points(rs, 2048), synth.synth_points(1, 2048, seed=8)[0]])
+    cc = np.array([[1008.0, 995.0], [960.5, 1010.25]], np.float32)
+    cam = KinectColorCamera(1200)
+    xyz = cam.project_points(torch.from_numpy(pts), torch.from_numpy(cc))  # (B,3,N)
+    nx, ny = xyz[:, 0].numpy(), xyz[:, 1].numpy()
+    in_img = (xyz[:, 0] >= -1.0) & (xyz[:, 0] <= 1.0) & (xyz[:, 1] >= -1.0) & (xyz[:, 1] <= 1.0)
+    np.savez_compressed(os.path.join(HERE, "query_proj.npz"), points=pts, crop_center=cc,
+                        nx_bits=nx.view(np.uint32), ny_bits=ny.view(np.uint32), in_img=in_img.numpy())
+    return pts, cc, nx, ny
+
+
+def gen_index(nx, ny):
+    from model.geometry import index
+    rs = np.random.RandomState(12)
+    feat = rs.standard_normal((2, 256, 16, 12)).astype(np.float32)   # H != W on purpose
+    tmpx = rs.standard_normal((2, 64, 32, 24)).astype(np.float32)
+    uv = torch.from_numpy(np.stack([nx, ny], 1))
+    s_feat = index(torch.from_numpy(feat), uv).numpy()
+    s_tmpx = index(torch.from_numpy(tmpx), uv).numpy()
+    np.savez_compressed(os.path.join(HERE, "query_index.npz"), feat=feat, tmpx=tmpx, nx=nx, ny=ny,
+                        s_feat=s_feat[:, :, :512], s_tmpx=s_tmpx[:, :, :512])
+
+
+def gen_heads(net):
+    rs = np.random.RandomState(13)
+    feats = rs.standard_normal((1, 323, 257)).astype(np.float32)
+    with torch.no_grad():
+        df, pca, parts, centers = net.decode(torch.from_numpy(feats))
+    np.savez_compressed(os.path.join(HERE, "query_heads.npz"), features=feats, df=df.numpy(), pca=pca.numpy(),
+                        parts=parts.numpy(), centers=centers.numpy())
+
+
+def gen_query(net):
+    """full CHORE.query on seeded maps + gradient of a random linear functional w.r.t. the points"""
+    rs = np.random.RandomState(14)
+    B, N = 2, 300
+    feat = rs.standard_normal((B, 256, 16, 12)).astype(np.float32)
+    tmpx = rs.standard_normal((B, 64, 32, 24)).astype(np.float32)
+    pts = synth.synth_points(B, N, seed=9)
+    pts[0, :40] = edge_points(rs, 64)[:40]
+    cc = np.array([[1008.0, 995.0], [990.0, 1001.5]], np.float32)
+    wts = {k: rs.standard_normal(s).astype(np.float32) for k, s in
+           dict(df=(B, 2, N), pca=(B, 3, 3, N), parts=(B, 14, N), centers=(B, 6, N)).items()}
+    net.im_feat_list = [torch.from_numpy(feat)]
+    net.tmpx = torch.from_numpy(tmpx)
+    p = torch.from_numpy(pts).clone().requires_grad_(True)
+    net.query(p, crop_center=torch.from_numpy(cc))
+    df, pca, parts, centers = net.get_preds()
+    loss = sum((o * torch.from_numpy(wts[k])).sum() for k, o in
+               (("df", df), ("pca", pca), ("parts", parts), ("centers", centers)))
+    loss.backward()
+    np.savez_compressed(os.path.join(HERE, "query_full.npz"), feat=feat, tmpx=tmpx, points=pts, crop_center=cc,
+                        df=df.detach().numpy(), pca=pca.detach().numpy(), parts=parts.detach().numpy(),
+                        centers=centers.detach().numpy(), dpoints=p.grad.numpy(),
+                        **{"w_" + k: v for k, v in wts.items()})
+
+
+def gen_encoder(net_eval):
+    img = synth.synth_images(1, 64, 96, seed=3)
+    with torch.no_grad():
+        net_eval.train(True)
+        net_eval.filter(torch.from_numpy(img))
+        outs = [o.numpy() for o in net_eval.im_feat_list]
+        tmpx, normx = net_eval.tmpx.numpy(), net_eval.normx.numpy()
+        net_eval.train(False)
+    np.savez_compressed(os.path.join(HERE, "encoder_64x96.npz"), images=img, out_last=outs[-1], tmpx=tmpx,
+                        normx=normx, out_means=np.stack([o.mean((0, 2, 3)) for o in outs]),
+                        out_absmeans=np.stack([np.abs(o).mean((0, 2, 3)) for o in outs]),
+                        out_first_crop=outs[0][:, :, 4:8, 8:12])
+    # full-size checksums (config sizes: 512x512)
+    img = synth.synth_images(1, 512, 512, seed=0)
+    with torch.no_grad():
+        net_eval.filter(torch.from_numpy(img))
+        out = net_eval.im_feat_list[-1].numpy()
+        tmpx = net_eval.tmpx.numpy()
+    np.savez_compressed(os.path.join(HERE, "encoder_512_checksum.npz"),
+                        out_mean=out.mean((0, 2, 3)), out_absmean=np.abs(out).mean((0, 2, 3)),
+                        out_crop=out[:, :, 60:68, 100:108], tmpx_mean=tmpx.mean((0, 2, 3)),
+                        tmpx_crop=tmpx[:, :, 128:132, 200:204])
+
+
+def main():
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    net = ref_model(seed=0)
+    # the state-dict contract the synthetic weights (and checkpoints) rely on
+    spec = [(k, list(v.shape)) for k, v in net.state_dict().items()]
+    json.dump(spec, open(os.path.join(HERE, "state_dict_spec.json"), "w"))
+    pts, cc, nx, ny = gen_projection()
+    gen_index(nx, ny)
+    gen_heads(net)
+    gen_query(net)
+    gen_encoder(net)
+    for f in sorted(os.listdir(HERE)):
+        print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

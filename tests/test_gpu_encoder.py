@@ -1,0 +1,131 @@
+"""GPU parity tests of the stacked-hourglass encoder (chore_encode_fwd) against the reference's
+outputs (tests/golden/encoder_*.npz) and the numpy oracle.
+
+Stated tolerances
+  fp32 mode (exact-fp32 MFMA):  max |err| <= 2e-4 * max|ref| per tensor (150 layers, different
+                                summation order than MKL/oneDNN).
+  bf16 mode (bf16 storage + bf16 MFMA operands, fp32 accumulate and GroupNorm statistics):
+                                relative L2 error <= 2e-2 per tensor, max |err| <= 8e-2 * max|ref|.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from oracle import encoder as oe
+
+pytestmark = pytest.mark.gpu
+
+
+def make_net(opt, dtype):
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    opt.compute_dtype = dtype
+    m = CHORE(opt).cuda().eval()
+    synth.load_synth_weights(m, seed=0)
+    for p in m.parameters():
+        p.requires_grad_(False)
+    return m
+
+
+def rel_max(a, b):
+    return np.abs(a - b).max() / np.abs(b).max()
+
+
+def rel_l2(a, b):
+    return np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel())
+
+
+@pytest.fixture(scope="module")
+def net32(opt):
+    return make_net(opt, "fp32")
+
+
+@pytest.fixture(scope="module")
+def net16(opt):
+    return make_net(opt, "bf16")
+
+
+def encode(net, images, train):
+    net.train(train)
+    try:
+        with torch.no_grad():
+            net.filter(torch.from_numpy(images).cuda())
+    finally:
+        net.train(False)
+    outs = [o.float().cpu().numpy() for o in net.im_feat_list]
+    return outs, net.tmpx.float().cpu().numpy(), net.normx.float().cpu().numpy()
+
+
+def test_encoder_fp32_matches_reference(net32, synth_sd):
+    g = golden("encoder_64x96.npz")
+    outs, tmpx, normx = encode(net32, g["images"], train=True)
+    assert len(outs) == 5 and outs[-1].shape == (1, 256, 16, 24) and tmpx.shape == (1, 64, 32, 48)
+    # feature maps are NHWC in memory behind the (B,C,H,W) view
+    assert net32.tmpx.stride() == (32 * 48 * 64, 1, 48 * 64, 64)
+    assert rel_max(tmpx, g["tmpx"]) < 2e-5
+    assert rel_max(normx, g["normx"]) < 1e-4
+    assert rel_max(outs[-1], g["out_last"]) < 2e-4
+    assert rel_max(outs[0][:, :, 4:8, 8:12], g["out_first_crop"]) < 2e-4
+    np.testing.assert_allclose(np.stack([o.mean((0, 2, 3)) for o in outs]), g["out_means"], rtol=1e-3, atol=1e-3)
+    # and the oracle agrees stage by stage
+    o_outs, o_tmpx, o_normx = oe.Encoder(synth_sd).forward(g["images"])
+    for a, b in zip(outs, o_outs):
+        assert rel_max(a, b) < 2e-4
+    # eval mode keeps only the last stack and gives the same tensor
+    outs_e, _, _ = encode(net32, g["images"], train=False)
+    assert len(outs_e) == 1 and np.array_equal(outs_e[0], outs[-1])
+
+
+def test_encoder_bf16_within_stated_tolerance(net16):
+    g = golden("encoder_64x96.npz")
+    outs, tmpx, normx = encode(net16, g["images"], train=True)
+    assert net16.tmpx.dtype == torch.bfloat16
+    for name, a, b in (("tmpx", tmpx, g["tmpx"]), ("normx", normx, g["normx"]), ("out_last", outs[-1], g["out_last"])):
+        assert rel_l2(a, b) < 2e-2, (name, rel_l2(a, b))
+        assert rel_max(a, b) < 8e-2, (name, rel_max(a, b))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_encoder_512_checksums(net32, net16, mode):
+    """BASELINE size (512x512) against per-channel statistics and crops of the reference output"""
+    from chore_amd.utils import synth
+    net = net32 if mode == "fp32" else net16
+    g = golden("encoder_512_checksum.npz")
+    outs, tmpx, _ = encode(net, synth.synth_images(1, 512, 512, seed=0), train=False)
+    out = outs[0]
+    assert out.shape == (1, 256, 128, 128)
+    tol_max, tol_mean = (3e-4, 2e-4) if mode == "fp32" else (1e-1, 1e-2)
+    assert rel_max(out[:, :, 60:68, 100:108], g["out_crop"]) < tol_max
+    assert rel_max(tmpx[:, :, 128:132, 200:204], g["tmpx_crop"]) < tol_max
+    s = np.abs(g["out_absmean"]).max()
+    assert np.abs(out.mean((0, 2, 3)) - g["out_mean"]).max() < tol_mean * s
+    assert np.abs(np.abs(out).mean((0, 2, 3)) - g["out_absmean"]).max() < tol_mean * s
+
+
+def test_encoder_batch_independence(net32):
+    """size-independent property: every image of a batch is encoded independently (GroupNorm is
+    per sample), so a batch of 2 different images equals the two single-image runs bit for bit"""
+    from chore_amd.utils import synth
+    imgs = synth.synth_images(2, 64, 64, seed=5)
+    both, tb, _ = encode(net32, imgs, train=False)
+    for i in range(2):
+        one, t1, _ = encode(net32, imgs[i:i + 1], train=False)
+        assert np.array_equal(one[0][0], both[0][i]) and np.array_equal(t1[0], tb[i])
+
+
+def test_end_to_end_filter_query_matches_oracle(net32, synth_sd):
+    """config 1 shape of work at reduced image size: encode + query through the public API"""
+    from chore_amd.utils import synth
+    from oracle import query as oq
+    img = synth.synth_images(1, 128, 128, seed=2)
+    pts = synth.synth_points(1, 2048, seed=3)
+    cc = np.array([synth.CROP_CENTER], np.float32)
+    with torch.no_grad():
+        net32.filter(torch.from_numpy(img).cuda())
+        net32.query(torch.from_numpy(pts).cuda(), crop_center=torch.from_numpy(cc).cuda())
+    df, pca, parts, centers = [t.cpu().numpy() for t in net32.get_preds()]
+    outs, tmpx, _ = oe.Encoder(synth_sd).forward(img)
+    o = oq.query(pts, cc, outs[-1], tmpx, synth_sd)
+    for k, v in dict(df=df, pca=pca, parts=parts, centers=centers).items():
+        assert np.abs(v - o[k]).max() < 1e-4 * max(1.0, np.abs(o[k]).max()), k
