@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <unordered_map>
@@ -28,6 +30,21 @@ struct chore_handle {
         if (_e != hipSuccess)                                                           \
             CHORE_FAIL(h, CHORE_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                        __FILE__, __LINE__);                                             \
+    } while (0)
+
+// after every kernel launch: pick up launch errors; with CHORE_DEBUG_SYNC set also wait for the kernel
+// so that a device fault is attributed to the launch that caused it
+inline bool chore_debug_sync() {
+    static const bool v = getenv("CHORE_DEBUG_SYNC") != nullptr;
+    return v;
+}
+#define CHORE_LAUNCH_CHECK(h, stream)                                                         \
+    do {                                                                                      \
+        CHORE_HIP_CHECK(h, hipGetLastError());                                                \
+        if (chore_debug_sync()) {                                                             \
+            fprintf(stderr, "[chore] launched at %s:%d\n", __FILE__, __LINE__);               \
+            CHORE_HIP_CHECK(h, hipStreamSynchronize(stream));                                 \
+        }                                                                                     \
     } while (0)
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;

@@ -223,7 +223,7 @@ static int launch_conv_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     const int tiles = ((a.W + CT - 1) / CT) * ((a.H + CT - 1) / CT);
     dim3 grid(tiles, a.Cout / NT, a.B);
     hipLaunchKernelGGL((conv_igemm_kernel<T, TAPS, NT>), grid, dim3(256), smem, s, a);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -289,6 +289,6 @@ int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, co
     else
         hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst,
                            nvec);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

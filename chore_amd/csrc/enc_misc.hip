@@ -96,7 +96,7 @@ __global__ void pack_stem_kernel(int Cin, const float* __restrict__ w, float* __
 int launch_pack_stem(chore_handle* h, int Cin, const float* w, float* dst, hipStream_t s) {
     const int n = Cin * 49 * 64;
     hipLaunchKernelGGL(pack_stem_kernel, dim3((n + 255) / 256), dim3(256), 0, s, Cin, w, dst);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -123,7 +123,7 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), smem, s, images, B, Cin, H, W, wk, bias,
                            (bf16_t*)out);
     }
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -188,7 +188,7 @@ int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, 
     else
         hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, x.C, HW,
                            S, partial);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -217,7 +217,7 @@ __global__ void gn_finalize_kernel(const float* __restrict__ partial, int S, int
 int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
                        const float* beta, float* ss, hipStream_t s) {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gn_splits(HW), HW, C, gamma, beta, ss);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -255,7 +255,7 @@ int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const float*
     else
         hipLaunchKernelGGL(gn_apply_relu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x.p, x.cs,
                            x.co, ss, (bf16_t*)y.p, y.cs, y.co, x.C, HW, total4);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -289,7 +289,7 @@ int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, in
     else
         hipLaunchKernelGGL(avgpool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co,
                            (bf16_t*)y.p, y.cs, y.co, x.C, H, W, total4);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -355,7 +355,7 @@ int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, con
     else
         hipLaunchKernelGGL(upadd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)a.p, a.cs, a.co,
                            (const bf16_t*)low.p, low.cs, low.co, (bf16_t*)y.p, y.cs, y.co, a.C, H, W, total4);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -365,6 +365,6 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
 }
 int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s) {
     hipLaunchKernelGGL(copy_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, dst, n);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

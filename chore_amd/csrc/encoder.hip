@@ -139,7 +139,10 @@ struct RunCtx {
     int rc = CHORE_OK;
 };
 
-using Step = std::function<void(RunCtx&)>;
+struct Step {
+    std::string label;
+    std::function<void(RunCtx&)> fn;
+};
 
 struct Program {
     chore_encoder_cfg cfg;
@@ -155,6 +158,7 @@ struct Builder {
     Pool pool;
     int B, dtype;
     size_t partial_off;
+    std::string cur_label = "?";
 
     explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) {
         partial_off = pool.alloc((size_t)B * GN_SPLITS_MAX * GN_GROUPS * 2 * 4);
@@ -209,17 +213,19 @@ struct Builder {
         if (two) { g2 = w(*gn2 + ".weight"); bt2 = w(*gn2 + ".bias"); }
         const size_t poff = partial_off;
         const int HW = x.H * x.W;
-        P.steps.push_back([=](RunCtx& r) {
+        cur_label = "gn_stats " + gn;
+        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
             float* partial = (float*)(r.ws + poff);
-            r.rc = launch_gn_partial(r.h, r.dtype, view(r, x, co, C), B, HW, partial, r.s);
+            r.rc = launch_gn_partial(r.h, r.dtype, view(r, x, co, C), Bn, HW, partial, r.s);
             if (r.rc) return;
-            r.rc = launch_gn_finalize(r.h, partial, B, HW, C, (const float*)(r.arena + g.off),
+            r.rc = launch_gn_finalize(r.h, partial, Bn, HW, C, (const float*)(r.arena + g.off),
                                       (const float*)(r.arena + bt.off), (float*)(r.ws + ss), r.s);
             if (r.rc || !two) return;
-            r.rc = launch_gn_finalize(r.h, partial, B, HW, C, (const float*)(r.arena + g2.off),
+            r.rc = launch_gn_finalize(r.h, partial, Bn, HW, C, (const float*)(r.arena + g2.off),
                                       (const float*)(r.arena + bt2.off), (float*)(r.ws + ss2), r.s);
-        });
+        }});
     }
 
     struct ConvSpec {
@@ -237,7 +243,10 @@ struct Builder {
         WEntry be{};
         if (c.bias) be = w(c.wname + ".bias");
         const ConvSpec cs = c;
-        P.steps.push_back([=](RunCtx& r) {
+        cur_label = "conv " + c.wname + " taps=" + std::to_string(c.taps) + " cin=" + std::to_string(c.in_C) +
+                    " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
+        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
             ConvArgs a{};
             a.in = view(r, cs.in, cs.in_co, cs.in_C);
@@ -248,9 +257,9 @@ struct Builder {
             if (cs.has_raw) a.raw = view(r, cs.raw, cs.raw_co, cs.cout);
             if (cs.has_res) a.res = view(r, cs.res, cs.res_co, cs.cout);
             if (cs.has_res2) a.res2 = view(r, cs.res2, cs.res2_co, cs.cout);
-            a.B = B; a.H = cs.in.H; a.W = cs.in.W; a.Cout = cs.cout;
+            a.B = Bn; a.H = cs.in.H; a.W = cs.in.W; a.Cout = cs.cout;
             r.rc = launch_conv(r.h, r.dtype, cs.taps, a, r.s);
-        });
+        }});
     }
 
     // ConvBlock (net_util.py:374-396): y = cat(o1,o2,o3) + residual.  `out` may be an external tensor.
@@ -302,17 +311,21 @@ struct Builder {
 
     Buf pool2(const Buf& x, const Buf* out_opt = nullptr) {
         Buf y = out_opt ? *out_opt : alloc(x.H / 2, x.W / 2, x.C);
-        P.steps.push_back([=](RunCtx& r) {
+        cur_label = "avgpool2";
+        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), B, x.H, x.W, r.s);
-        });
+            r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W, r.s);
+        }});
         return y;
     }
     void upadd(const Buf& a, const Buf& low) {  // a += bicubic_up2(low)
-        P.steps.push_back([=](RunCtx& r) {
+        cur_label = "upadd";
+        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_upadd(r.h, r.dtype, view(r, a), view(r, low), view(r, a), B, low.H, low.W, r.s);
-        });
+            r.rc = launch_upadd(r.h, r.dtype, view(r, a), view(r, low), view(r, a), Bn, low.H, low.W, r.s);
+        }});
     }
 
     // HourGlass._forward (HGFilters.py:26-50)
@@ -340,21 +353,25 @@ struct Builder {
         {
             const WEntry we = w(p + "conv1.weight"), be = w(p + "conv1.bias");
             const int Cin = cfg.in_channels, H = P.H, W = P.W;
-            P.steps.push_back([=](RunCtx& r) {
+            cur_label = "stem";
+            const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_stem(r.h, r.dtype, r.images, B, Cin, H, W, (const float*)(r.arena + we.off),
+                r.rc = launch_stem(r.h, r.dtype, r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
                                    (const float*)(r.arena + be.off), ptr(r, c1), r.s);
-            });
+            }});
         }
         Buf tmpx = external(100, H2, W2, 64);
         {
             const size_t ss = alloc_ss(64);
             gn_stats(c1, 0, 64, p + "bn1", ss);
-            P.steps.push_back([=](RunCtx& r) {
+            cur_label = "gn_apply_relu bn1";
+            const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
+            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1), (const float*)(r.ws + ss), view(r, tmpx), B,
+                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1), (const float*)(r.ws + ss), view(r, tmpx), Bn,
                                             H2 * W2, r.s);
-            });
+            }});
             release_ss(ss, 64);
         }
         release(c1);
@@ -524,9 +541,15 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     RunCtx r;
     r.h = h; r.dtype = dtype; r.s = (hipStream_t)stream; r.ws = (char*)workspace; r.arena = (const char*)arena;
     r.images = images; r.feats = feat_out; r.tmpx = tmpx; r.normx = normx;
+    static const bool debug_sync = getenv("CHORE_DEBUG_SYNC") != nullptr;
     for (auto& st : P->steps) {
-        st(r);
+        st.fn(r);
         if (r.rc) return r.rc;
+        if (debug_sync) {
+            fprintf(stderr, "[chore] step %s\n", st.label.c_str());
+            hipError_t e = hipStreamSynchronize(r.s);
+            if (e != hipSuccess) CHORE_FAIL(h, CHORE_EHIP, "step '%s' failed: %s", st.label.c_str(), hipGetErrorString(e));
+        }
     }
     return CHORE_OK;
 }

@@ -250,7 +250,7 @@ static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     }
     dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
     hipLaunchKernelGGL(query_bwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 

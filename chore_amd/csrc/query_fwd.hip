@@ -110,7 +110,7 @@ static int launch_sample_features_t(chore_handle* h, const QueryArgs& a, float* 
     }
     dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
     hipLaunchKernelGGL(sample_features_kernel<T>, grid, dim3(256), smem, s, a, features, nxy);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s) {
@@ -208,7 +208,7 @@ int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hi
     const int threads = 256;
     const int blocks = (int)((QF_TOTAL_FLOATS + threads - 1) / threads);
     hipLaunchKernelGGL(heads_pack_f32_kernel, dim3(blocks), dim3(threads), 0, s, raw, arena);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
@@ -223,7 +223,7 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     }
     dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
     hipLaunchKernelGGL(query_fwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
-    CHORE_HIP_CHECK(h, hipGetLastError());
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 

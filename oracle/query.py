@@ -108,6 +108,23 @@ def mlp(features, sd, name):
     return h.astype(F32)
 
 
+def relu_margin(features, sd):
+    """smallest |pre-activation| over every hidden unit of the four heads, per point (B,N).
+    A point whose margin is ~1e-6 sits on a ReLU kink: its GRADIENT legitimately depends on the
+    fp32 summation order, so gradient parity tests skip such points."""
+    margin = None
+    for name in HEAD_NAMES:
+        h = np.asarray(features, F32)
+        for li in (0, 2, 4):
+            W = np.asarray(sd[f"{name}.{li}.weight"], F32)[:, :, 0]
+            b = np.asarray(sd[f"{name}.{li}.bias"], F32)
+            pre = np.einsum("oc,bcn->bon", W, h, optimize=True).astype(F32) + b[None, :, None]
+            m = np.abs(pre).min(1)
+            margin = m if margin is None else np.minimum(margin, m)
+            h = np.maximum(pre, F32(0))
+    return margin
+
+
 def query(points, crop_center, feat, tmpx, sd):
     """Full CHORE.query for one feature map.  Returns df (B,2,N), pca (B,3,3,N), parts (B,14,N),
     centers (B,6,N), in_img (B,N) bool, features (B,323,N)."""

@@ -45,6 +45,7 @@ def main():
     ge = np.load(os.path.join(G, "encoder_64x96.npz"))
     for dt in ("fp32", "bf16"):
         n2 = CHORE(opt_ns(dt)).cuda().eval(); synth.load_synth_weights(n2, 0)
+        for p_ in n2.parameters(): p_.requires_grad_(False)
         n2.train(True)
         with torch.no_grad(): n2.filter(torch.from_numpy(ge["images"]).cuda())
         n2.train(False)
@@ -70,4 +71,5 @@ def main():
             n2.query(pg, crop_center=cc); n2.get_preds()[0][:, 0].clamp(max=2.0).sum().backward()
         print(dt, "query fwd+bwd 4x20000 ms", timeit(fb, n=10), flush=True)
         del n2
-main()
+if __name__ == "__main__":
+    main()
