@@ -49,6 +49,9 @@ SIGNATURES = {
     "chore_encode_fwd": (c_int, [c_void_p, POINTER(EncoderCfg), c_void_p, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p,
                                  c_void_p, c_void_p]),
+    "chore_profile_enable": (c_int, [c_void_p, c_int]),
+    "chore_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double),
+                                   POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),
 }
 
 
@@ -92,6 +95,22 @@ def check(rc: int, h: c_void_p, what: str):
     if rc != 0:
         msg = lib.chore_last_error(h)
         raise ChoreError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+
+def profile_enable(device_index: int, on: bool):
+    h = handle(device_index)
+    check(lib.chore_profile_enable(h, 1 if on else 0), h, "chore_profile_enable")
+
+
+def profile_read(device_index: int):
+    """-> {class: dict(ms, flops, bytes, launches)} accumulated since profile_enable"""
+    h = handle(device_index)
+    n = 16
+    names = (c_char_p * n)()
+    ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
+    la = (c_int64 * n)()
+    k = lib.chore_profile_read(h, n, names, ms, fl, by, la)
+    return {names[i].decode(): dict(ms=ms[i], flops=fl[i], bytes=by[i], launches=la[i]) for i in range(k)}
 
 
 def make_descs(named_tensors):

@@ -27,7 +27,16 @@ struct ConvArgs {
     View raw;           // optional: acc + bias
     View res, res2;     // optional residuals (may alias out)
     int B, H, W, Cout;
+    // optional fused GroupNorm statistics of what this launch stores: per (image, tile, channel)
+    // (sum, sum of squares) partials in [B][tiles][C][2] buffers -- st_raw for the `raw` view,
+    // st_out for the `out` view; *_C / *_co = channels of the normalised tensor / offset of this slice
+    // *_tiles = tile stride of the buffer (>= tiles of this launch)
+    float* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0, st_raw_tiles = 0;
+    float* st_out = nullptr; int st_out_C = 0, st_out_co = 0, st_out_tiles = 0;
 };
+
+struct ConvPlan { int nt, th, ntiles; };
+ConvPlan conv_plan(int B, int H, int W, int Cout);   // tile configuration launch_conv will use
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
@@ -42,6 +51,16 @@ int gn_splits(int HW);
 int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, float* partial, hipStream_t s);
 int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
                        const float* beta, float* ss, hipStream_t s);
+// statistics assembled from conv-epilogue tile partials: up to 3 channel slices, each written by a
+// launch with its own tile count
+struct TileStats {
+    const float* p = nullptr;   // [B][max_tiles][C][2]
+    int max_tiles = 0, nslices = 0;
+    int c_end[3] = {0, 0, 0};   // exclusive end channel of each slice
+    int ntiles[3] = {0, 0, 0};
+};
+int launch_gn_finalize_tiles(chore_handle* h, const TileStats& ts, int B, int HW, int C, const float* gamma,
+                             const float* beta, float* ss, hipStream_t s);
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const float* ss, const View& y, int B,
                          int HW, hipStream_t s);
 int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, hipStream_t s);

@@ -192,31 +192,88 @@ int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, 
     return CHORE_OK;
 }
 
-__global__ void gn_finalize_kernel(const float* __restrict__ partial, int S, int HW, int C,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float* __restrict__ ss) {
-    const int b = blockIdx.x, c = threadIdx.x;
-    if (c >= C) return;
-    const int gs = C / GN_GROUPS, g = c / gs;
-    double a = 0.0, q = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const float* p = partial + (((size_t)b * S + s) * GN_GROUPS + g) * 2;
-        a += (double)p[0];
-        q += (double)p[1];
+// block-wide fixed-order fp64 reduction of (a, q); result valid in thread 0
+__device__ __forceinline__ void block_reduce2(double& a, double& q, double (*sh)[256], int tid) {
+    sh[0][tid] = a;
+    sh[1][tid] = q;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) {
+            sh[0][tid] += sh[0][tid + o];
+            sh[1][tid] += sh[1][tid + o];
+        }
+        __syncthreads();
     }
+    a = sh[0][0];
+    q = sh[1][0];
+}
+
+__device__ __forceinline__ void write_scale_shift(double a, double q, int HW, int gs, int C, int b, int g,
+                                                  const float* gamma, const float* beta, float* ss, int tid) {
     const double n = (double)HW * gs;
     const double mean = a / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
-    const float scale = rstd * gamma[c];
-    ss[((size_t)b * C + c) * 2 + 0] = scale;
-    ss[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * scale;
+    if (tid < gs) {
+        const int c = g * gs + tid;
+        const float scale = rstd * gamma[c];
+        ss[((size_t)b * C + c) * 2 + 0] = scale;
+        ss[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * scale;
+    }
+}
+
+// one block per (group, image)
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int S, int HW, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ ss) {
+    __shared__ double sh[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int s = tid; s < S; s += 256) {
+        const float* p = partial + (((size_t)b * S + s) * GN_GROUPS + g) * 2;
+        a += (double)p[0];
+        q += (double)p[1];
+    }
+    block_reduce2(a, q, sh, tid);
+    write_scale_shift(a, q, HW, C / GN_GROUPS, C, b, g, gamma, beta, ss, tid);
 }
 
 int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
                        const float* beta, float* ss, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 0, s, partial, gn_splits(HW), HW, C, gamma, beta, ss);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, B), dim3(256), 0, s, partial, gn_splits(HW), HW, C, gamma,
+                       beta, ss);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// finalize from the tile partials the conv epilogues wrote (fixed summation order -> deterministic)
+__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(TileStats ts, int HW, int C,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ ss) {
+    __shared__ double sh[2][256];
+    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int gs = C / GN_GROUPS;
+    int sl = 0;   // a group never straddles two slices (slice widths are multiples of the group size)
+    while (sl + 1 < ts.nslices && g * gs >= ts.c_end[sl]) ++sl;
+    const int nt = ts.ntiles[sl];
+    const float* base = ts.p + ((size_t)b * ts.max_tiles * C + g * gs) * 2;
+    double a = 0.0, q = 0.0;
+    for (int i = tid; i < nt * gs; i += 256) {   // element i = (tile, channel-in-group)
+        const int t = i / gs, j = i % gs;
+        const float* p = base + ((size_t)t * C + j) * 2;
+        a += (double)p[0];
+        q += (double)p[1];
+    }
+    block_reduce2(a, q, sh, tid);
+    write_scale_shift(a, q, HW, gs, C, b, g, gamma, beta, ss, tid);
+}
+
+int launch_gn_finalize_tiles(chore_handle* h, const TileStats& ts, int B, int HW, int C, const float* gamma,
+                             const float* beta, float* ss, hipStream_t s) {
+    if (C > 256 || C % GN_GROUPS) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", C);
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(GN_GROUPS, B), dim3(256), 0, s, ts, HW, C, gamma, beta, ss);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -101,11 +101,21 @@ int check_cfg(chore_handle* h, const chore_encoder_cfg* cfg) {
 // ------------------------------------------------------------------------------------------------
 // program = list of closures; buffers are offsets into the workspace (or caller tensors)
 // ------------------------------------------------------------------------------------------------
+// GroupNorm tile partials attached to a buffer (written by the conv epilogues that produce it)
+struct StatInfo {
+    bool valid = false;    // storage attached
+    bool usable = true;    // false once the buffer has been modified after the producing convs
+    size_t off = 0, bytes = 0;
+    int max_tiles = 0, nslices = 0;
+    int c_end[3] = {0, 0, 0}, ntiles[3] = {0, 0, 0};
+};
+
 struct Buf {
     size_t off = 0;       // offset into workspace, or
     int ext = -1;         // index of an external (caller) tensor: 0..n_out-1 feats, 100 tmpx, 101 normx
     int H = 0, W = 0, C = 0;
     size_t bytes = 0;
+    StatInfo st;
 };
 
 struct Pool {
@@ -139,9 +149,23 @@ struct RunCtx {
     int rc = CHORE_OK;
 };
 
+enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_CONV3_128, K_CONV3_64, K_CONV3_32, K_CONV1, K_POOL, K_UPADD, K_NUM };
+const char* const kclass_names[K_NUM] = {"stem_conv7x7", "gn_stats", "gn_apply_relu", "conv3x3_n128", "conv3x3_n64",
+                                         "conv3x3_n32", "conv1x1", "avgpool2", "bicubic_upadd"};
+
 struct Step {
     std::string label;
     std::function<void(RunCtx&)> fn;
+    int klass = 0;
+    double flops = 0.0;  // algorithmic FLOPs of the launch (convolutions: 2*taps*Cin*Cout*B*H*W)
+    double bytes = 0.0;  // algorithmic HBM bytes of the launch (compulsory reads + writes)
+};
+
+struct Profile {
+    bool on = false;
+    double ms[K_NUM] = {0}, flops[K_NUM] = {0}, bytes[K_NUM] = {0};
+    long long launches[K_NUM] = {0};
+    std::vector<hipEvent_t> ev;
 };
 
 struct Program {
@@ -159,6 +183,9 @@ struct Builder {
     int B, dtype;
     size_t partial_off;
     std::string cur_label = "?";
+    int cur_class = 0;
+    double cur_flops = 0.0, cur_bytes = 0.0;
+    double es() const { return (double)esize(dtype); }
 
     explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) {
         partial_off = pool.alloc((size_t)B * GN_SPLITS_MAX * GN_GROUPS * 2 * 4);
@@ -178,6 +205,22 @@ struct Builder {
     }
     void release(const Buf& b) {
         if (b.ext < 0) pool.release(b.off, b.bytes);
+        if (b.st.valid) pool.release(b.st.off, b.st.bytes);
+    }
+    // attach tile-partial storage for the slices [0,c_end0), [c_end0,c_end1) ... each produced by a conv
+    // with `cout_i` output channels (which fixes its tile configuration)
+    void attach_stats(Buf& b, int nslices, const int* c_end, const int* couts) {
+        StatInfo& st = b.st;
+        st.valid = true;
+        st.nslices = nslices;
+        st.max_tiles = 0;
+        for (int i = 0; i < nslices; ++i) {
+            st.c_end[i] = c_end[i];
+            st.ntiles[i] = conv_plan(B, b.H, b.W, couts[i]).ntiles;
+            if (st.ntiles[i] > st.max_tiles) st.max_tiles = st.ntiles[i];
+        }
+        st.bytes = (size_t)B * st.max_tiles * b.C * 2 * 4;
+        st.off = pool.alloc(st.bytes);
     }
     size_t alloc_ss(int C) { return pool.alloc((size_t)B * C * 2 * 4); }
     void release_ss(size_t off, int C) { pool.release(off, (size_t)B * C * 2 * 4); }
@@ -213,7 +256,27 @@ struct Builder {
         if (two) { g2 = w(*gn2 + ".weight"); bt2 = w(*gn2 + ".bias"); }
         const size_t poff = partial_off;
         const int HW = x.H * x.W;
+        if (x.st.valid && x.st.usable && co == 0 && C == x.C) {   // statistics already produced by the conv epilogues
+            const StatInfo st = x.st;
+            cur_label = "gn_finalize_tiles " + gn;
+            cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * st.max_tiles * C * 8;
+            const int Bn = B;
+            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+                if (r.rc) return;
+                TileStats ts;
+                ts.p = (const float*)(r.ws + st.off);
+                ts.max_tiles = st.max_tiles; ts.nslices = st.nslices;
+                for (int i = 0; i < 3; ++i) { ts.c_end[i] = st.c_end[i]; ts.ntiles[i] = st.ntiles[i]; }
+                r.rc = launch_gn_finalize_tiles(r.h, ts, Bn, HW, C, (const float*)(r.arena + g.off),
+                                                (const float*)(r.arena + bt.off), (float*)(r.ws + ss), r.s);
+                if (r.rc || !two) return;
+                r.rc = launch_gn_finalize_tiles(r.h, ts, Bn, HW, C, (const float*)(r.arena + g2.off),
+                                                (const float*)(r.arena + bt2.off), (float*)(r.ws + ss2), r.s);
+            }, cur_class, cur_flops, cur_bytes});
+            return;
+        }
         cur_label = "gn_stats " + gn;
+        cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * HW * C * es();
         const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
         P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
@@ -225,7 +288,7 @@ struct Builder {
             if (r.rc || !two) return;
             r.rc = launch_gn_finalize(r.h, partial, Bn, HW, C, (const float*)(r.arena + g2.off),
                                       (const float*)(r.arena + bt2.off), (float*)(r.ws + ss2), r.s);
-        }});
+        }, cur_class, cur_flops, cur_bytes});
     }
 
     struct ConvSpec {
@@ -237,6 +300,7 @@ struct Builder {
         bool has_res = false; Buf res; int res_co = 0;
         bool has_res2 = false; Buf res2; int res2_co = 0;
         int taps = 9, cout = 0;
+        bool stat_raw = false, stat_out = false;   // emit GroupNorm tile partials into raw.st / out.st
     };
     void conv(const ConvSpec& c) {
         const WEntry we = w(c.wname + ".weight");
@@ -245,6 +309,12 @@ struct Builder {
         const ConvSpec cs = c;
         cur_label = "conv " + c.wname + " taps=" + std::to_string(c.taps) + " cin=" + std::to_string(c.in_C) +
                     " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
+        {
+            const double px = (double)B * c.in.H * c.in.W;
+            cur_class = c.taps == 1 ? K_CONV1 : (c.cout % 128 == 0 ? K_CONV3_128 : (c.cout == 64 ? K_CONV3_64 : K_CONV3_32));
+            cur_flops = 2.0 * c.taps * c.in_C * c.cout * px;
+            cur_bytes = px * es() * (c.in_C + c.cout * (1 + (c.has_raw ? 1 : 0) + (c.has_res ? 1 : 0) + (c.has_res2 ? 1 : 0)));
+        }
         const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
         P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
@@ -258,8 +328,16 @@ struct Builder {
             if (cs.has_res) a.res = view(r, cs.res, cs.res_co, cs.cout);
             if (cs.has_res2) a.res2 = view(r, cs.res2, cs.res2_co, cs.cout);
             a.B = Bn; a.H = cs.in.H; a.W = cs.in.W; a.Cout = cs.cout;
+            if (cs.stat_raw) {
+                a.st_raw = (float*)(r.ws + cs.raw.st.off); a.st_raw_C = cs.raw.C; a.st_raw_co = cs.raw_co;
+                a.st_raw_tiles = cs.raw.st.max_tiles;
+            }
+            if (cs.stat_out) {
+                a.st_out = (float*)(r.ws + cs.out.st.off); a.st_out_C = cs.out.C; a.st_out_co = cs.out_co;
+                a.st_out_tiles = cs.out.st.max_tiles;
+            }
             r.rc = launch_conv(r.h, r.dtype, cs.taps, a, r.s);
-        }});
+        }, cur_class, cur_flops, cur_bytes});
     }
 
     // ConvBlock (net_util.py:374-396): y = cat(o1,o2,o3) + residual.  `out` may be an external tensor.
@@ -267,6 +345,13 @@ struct Builder {
         const int H = x.H, W = x.W;
         Buf out = out_opt ? *out_opt : alloc(H, W, cout);
         Buf o1 = alloc(H, W, cout / 2), o2 = alloc(H, W, cout / 4);
+        {
+            const int ce_out[3] = {cout / 2, 3 * cout / 4, cout}, co_out[3] = {cout / 2, cout / 4, cout / 4};
+            attach_stats(out, 3, ce_out, co_out);
+            const int ce1[1] = {cout / 2}, co1[1] = {cout / 2}, ce2[1] = {cout / 4}, co2[1] = {cout / 4};
+            attach_stats(o1, 1, ce1, co1);
+            attach_stats(o2, 1, ce2, co2);
+        }
         const size_t ss1 = alloc_ss(cin);
         Buf res = x;
         if (cin != cout) {
@@ -285,7 +370,7 @@ struct Builder {
         ConvSpec c1;
         c1.in = x; c1.in_C = cin; c1.use_ss = true; c1.ss = ss1; c1.wname = n + ".conv1";
         c1.out = out; c1.out_co = 0; c1.has_raw = true; c1.raw = o1; c1.has_res = true; c1.res = res; c1.res_co = 0;
-        c1.cout = cout / 2;
+        c1.cout = cout / 2; c1.stat_raw = true; c1.stat_out = true;
         conv(c1);
         release_ss(ss1, cin);
         const size_t ss2 = alloc_ss(cout / 2);
@@ -293,7 +378,7 @@ struct Builder {
         ConvSpec c2;
         c2.in = o1; c2.in_C = cout / 2; c2.use_ss = true; c2.ss = ss2; c2.wname = n + ".conv2";
         c2.out = out; c2.out_co = cout / 2; c2.has_raw = true; c2.raw = o2; c2.has_res = true; c2.res = res;
-        c2.res_co = cout / 2; c2.cout = cout / 4;
+        c2.res_co = cout / 2; c2.cout = cout / 4; c2.stat_raw = true; c2.stat_out = true;
         conv(c2);
         release_ss(ss2, cout / 2);
         const size_t ss3 = alloc_ss(cout / 4);
@@ -301,7 +386,7 @@ struct Builder {
         ConvSpec c3;
         c3.in = o2; c3.in_C = cout / 4; c3.use_ss = true; c3.ss = ss3; c3.wname = n + ".conv3";
         c3.out = out; c3.out_co = 3 * cout / 4; c3.has_res = true; c3.res = res; c3.res_co = 3 * cout / 4;
-        c3.cout = cout / 4;
+        c3.cout = cout / 4; c3.stat_out = true;
         conv(c3);
         release_ss(ss3, cout / 4);
         release(o1);
@@ -312,20 +397,22 @@ struct Builder {
     Buf pool2(const Buf& x, const Buf* out_opt = nullptr) {
         Buf y = out_opt ? *out_opt : alloc(x.H / 2, x.W / 2, x.C);
         cur_label = "avgpool2";
+        cur_class = K_POOL; cur_flops = 0.0; cur_bytes = (double)B * x.H * x.W * x.C * es() * 1.25;
         const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
         P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
             r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W, r.s);
-        }});
+        }, cur_class, cur_flops, cur_bytes});
         return y;
     }
     void upadd(const Buf& a, const Buf& low) {  // a += bicubic_up2(low)
         cur_label = "upadd";
+        cur_class = K_UPADD; cur_flops = 0.0; cur_bytes = (double)B * low.H * low.W * low.C * es() * 9.0;
         const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
         P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
             if (r.rc) return;
             r.rc = launch_upadd(r.h, r.dtype, view(r, a), view(r, low), view(r, a), Bn, low.H, low.W, r.s);
-        }});
+        }, cur_class, cur_flops, cur_bytes});
     }
 
     // HourGlass._forward (HGFilters.py:26-50)
@@ -340,6 +427,7 @@ struct Builder {
         Buf low3 = conv_block(low2, n + ".b3_" + l, 256, 256);
         release(low2);
         upadd(up1, low3);
+        up1.st.usable = false;   // modified in place: the conv-epilogue statistics no longer describe it
         release(low3);
         return up1;
     }
@@ -354,24 +442,27 @@ struct Builder {
             const WEntry we = w(p + "conv1.weight"), be = w(p + "conv1.bias");
             const int Cin = cfg.in_channels, H = P.H, W = P.W;
             cur_label = "stem";
+            cur_class = K_STEM; cur_flops = 2.0 * 49 * Cin * 64 * (double)B * (H / 2) * (W / 2);
+            cur_bytes = (double)B * H * W * Cin * 4 + (double)B * (H / 2) * (W / 2) * 64 * es();
             const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
             P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
                 if (r.rc) return;
                 r.rc = launch_stem(r.h, r.dtype, r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
                                    (const float*)(r.arena + be.off), ptr(r, c1), r.s);
-            }});
+            }, cur_class, cur_flops, cur_bytes});
         }
         Buf tmpx = external(100, H2, W2, 64);
         {
             const size_t ss = alloc_ss(64);
             gn_stats(c1, 0, 64, p + "bn1", ss);
             cur_label = "gn_apply_relu bn1";
+            cur_class = K_GN_APPLY; cur_flops = 0.0; cur_bytes = 2.0 * B * H2 * W2 * 64 * es();
             const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
             P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
                 if (r.rc) return;
                 r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1), (const float*)(r.ws + ss), view(r, tmpx), Bn,
                                             H2 * W2, r.s);
-            }});
+            }, cur_class, cur_flops, cur_bytes});
             release_ss(ss, 64);
         }
         release(c1);
@@ -389,9 +480,13 @@ struct Builder {
             Buf t1 = conv_block(hg, p + "top_m_" + s, 256, 256);
             release(hg);
             Buf t2 = alloc(H4, W4, 256);
+            {
+                const int ce[1] = {256}, co[1] = {256};
+                attach_stats(t2, 1, ce, co);
+            }
             ConvSpec cl;
             cl.in = t1; cl.in_C = 256; cl.wname = p + "conv_last" + s; cl.bias = true; cl.out = t2; cl.taps = 1;
-            cl.cout = 256;
+            cl.cout = 256; cl.stat_out = true;
             conv(cl);
             release(t1);
             const size_t ss = alloc_ss(256);
@@ -404,13 +499,17 @@ struct Builder {
             conv(l);
             if (i < cfg.num_stack - 1) {
                 Buf nprev = alloc(H4, W4, 256);
+                {
+                    const int ce[1] = {256}, co[1] = {256};
+                    attach_stats(nprev, 1, ce, co);
+                }
                 ConvSpec bl;
                 bl.in = t2; bl.in_C = 256; bl.use_ss = true; bl.ss = ss; bl.wname = p + "bl" + s; bl.bias = true;
                 bl.out = nprev; bl.has_res = true; bl.res = previous; bl.taps = 1; bl.cout = 256;
                 conv(bl);
                 ConvSpec al;
                 al.in = out_i; al.in_C = 256; al.wname = p + "al" + s; al.bias = true; al.out = nprev;
-                al.has_res = true; al.res = nprev; al.taps = 1; al.cout = 256;
+                al.has_res = true; al.res = nprev; al.taps = 1; al.cout = 256; al.stat_out = true;
                 conv(al);
                 release(previous);
                 previous = nprev;
@@ -426,6 +525,7 @@ struct Builder {
 
 struct EncCache {
     std::vector<std::unique_ptr<Program>> progs;
+    Profile prof;
 };
 
 Program* get_program(chore_handle* h, const chore_encoder_cfg& cfg, int B, int H, int W, int dtype, int n_out,
@@ -542,6 +642,32 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     r.h = h; r.dtype = dtype; r.s = (hipStream_t)stream; r.ws = (char*)workspace; r.arena = (const char*)arena;
     r.images = images; r.feats = feat_out; r.tmpx = tmpx; r.normx = normx;
     static const bool debug_sync = getenv("CHORE_DEBUG_SYNC") != nullptr;
+    Profile& prof = ((EncCache*)h->enc_cache)->prof;
+    if (prof.on) {  // bench/roofline aid: bracket every step with events on the caller's stream
+        const size_t need = 2 * P->steps.size();
+        while (prof.ev.size() < need) {
+            hipEvent_t e;
+            CHORE_HIP_CHECK(h, hipEventCreate(&e));
+            prof.ev.push_back(e);
+        }
+        for (size_t i = 0; i < P->steps.size(); ++i) {
+            CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i], r.s));
+            P->steps[i].fn(r);
+            if (r.rc) return r.rc;
+            CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i + 1], r.s));
+        }
+        CHORE_HIP_CHECK(h, hipStreamSynchronize(r.s));
+        for (size_t i = 0; i < P->steps.size(); ++i) {
+            float ms = 0.f;
+            CHORE_HIP_CHECK(h, hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]));
+            const Step& st = P->steps[i];
+            prof.ms[st.klass] += ms;
+            prof.flops[st.klass] += st.flops;
+            prof.bytes[st.klass] += st.bytes;
+            prof.launches[st.klass] += 1;
+        }
+        return CHORE_OK;
+    }
     for (auto& st : P->steps) {
         st.fn(r);
         if (r.rc) return r.rc;
@@ -552,6 +678,28 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
         }
     }
     return CHORE_OK;
+}
+
+int chore_profile_enable(chore_handle* h, int on) {
+    if (!h) return CHORE_EINVAL;
+    if (!h->enc_cache) h->enc_cache = new EncCache();
+    Profile& p = ((EncCache*)h->enc_cache)->prof;
+    p.on = on != 0;
+    for (int k = 0; k < K_NUM; ++k) { p.ms[k] = p.flops[k] = p.bytes[k] = 0.0; p.launches[k] = 0; }
+    return CHORE_OK;
+}
+
+int chore_profile_read(chore_handle* h, int max_classes, const char** names, double* ms, double* flops,
+                       double* bytes, int64_t* launches) {
+    if (!h || !names || !ms || !flops || !bytes || !launches) return CHORE_EINVAL;
+    if (!h->enc_cache) return 0;
+    const Profile& p = ((EncCache*)h->enc_cache)->prof;
+    int n = 0;
+    for (int k = 0; k < K_NUM && n < max_classes; ++k, ++n) {
+        names[n] = kclass_names[k];
+        ms[n] = p.ms[k]; flops[n] = p.flops[k]; bytes[n] = p.bytes[k]; launches[n] = p.launches[k];
+    }
+    return n;
 }
 
 }  // extern "C"

@@ -138,6 +138,17 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
                      size_t workspace_bytes, void* const* feat_out, int n_stack_out, void* tmpx,
                      void* normx, chore_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch
+ * with hipEvents on the caller's stream, synchronises at the end of the call and accumulates, per
+ * kernel class, the elapsed milliseconds, the algorithmic FLOPs and bytes and the launch count.
+ * Enabling/disabling resets the counters.  Not for the timed region (it serialises the host).
+ * chore_profile_read fills HOST arrays and returns the number of classes written.
+ * ------------------------------------------------------------------------------------------- */
+int chore_profile_enable(chore_handle* h, int on);
+int chore_profile_read(chore_handle* h, int max_classes, const char** names, double* ms, double* flops,
+                       double* bytes, int64_t* launches);
+
 #ifdef __cplusplus
 }
 #endif
