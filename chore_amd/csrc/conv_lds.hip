@@ -1,0 +1,514 @@
+// conv_lds.hip -- 3x3 / 1x1 convolution as an implicit GEMM on the gfx950 matrix cores
+// (every conv of ConvBlock, model/net_util.py:346-396, and the 1x1 convs of the stack tail,
+// model/HGFilters.py:128-142,167-183), with GroupNorm-apply + ReLU fused into the operand staging and
+// bias / residuals / concat-slice / raw copy / GroupNorm statistics fused into the epilogue.
+//
+// GEMM view: M = output pixels, N = Cout, K = taps x Cin.  One workgroup (4 waves) owns a tile of
+// 8 rows x 32 pixels and NT output channels.
+//   * A operand: the tile + 1-pixel halo of one 64-byte channel chunk (32 bf16 / 16 fp32 channels)
+//     is staged ONCE in LDS ([340 rows][80 B]) and re-read at the 9 tap shifts -- no im2col.  While
+//     it is staged the prologue applies relu(x*scale+shift) (GroupNorm folded to a per-(image,channel)
+//     affine) and writes zeros for the halo outside the image (= conv2d's zero padding of the
+//     normalised tensor).  A 32-pixel tile row is one MFMA pixel block: its 32 LDS rows, 80 B apart,
+//     land on 16 distinct 16-byte slots per ds_read_b128 lane group -> conflict-free.
+//   * B operand: fragment-ordered weights ([tap][k-group][n-block][lane][16 B], written once by
+//     pack_conv_weights) stream through a 2-slot LDS ring, one K-step (= kernel row of 3 taps x 2
+//     k-groups) at a time: fetched by the whole workgroup into registers while the previous step's
+//     MFMAs run, parked in the other slot, read as fragments by all waves.
+//   * Each wave owns (MB pixel rows) x (NBW channel blocks of 32): 4x2 / 2x2 / 2x1 accumulators of
+//     v_mfma_f32_32x32x16_bf16 (T = bf16) or 4x v_mfma_f32_32x32x2_f32 (T = fp32, exact).
+//   * Workgroups start the K loop at different chunks (rotation by tile index) so the grid does not
+//     hammer the same weight bytes at once; the order is a function of the tile index only, so
+//     results are deterministic and independent of the batch composition.
+//   * Epilogue: accumulators are transposed through a wave-private LDS scratch so that every lane
+//     handles 8 consecutive channels of one pixel: residual loads and all stores are 16-byte
+//     vectors covering full 128-byte lines (the first version stored 2-byte elements and spent
+//     37 % of the convolution time there).  GroupNorm partial sums of the
+//     stored values are reduced in a fixed order.
+#include "enc_common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TH = 8, TW = 32;   // tile
+constexpr int ROWB = 80;         // LDS patch row: 64 B of channels + 16 B pad (5 slots: odd)
+constexpr int KGC = 2;           // k-groups per chunk
+constexpr int SCR_LD = 68;       // scratch row stride in floats (64 channels + 4: conflict-free b128 reads)
+
+template <typename T> struct CT;
+template <> struct CT<float> { static constexpr int VE = 4, KGE = 8; };
+template <> struct CT<bf16_t> { static constexpr int VE = 8, KGE = 16; };
+
+template <typename T>
+__device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* sh, bool use_gn) {
+    if (!use_gn) return raw;
+    u32x4 o;
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = fmaf(__uint_as_float(raw[j]), sc[j], sh[j]);
+            o[j] = __float_as_uint(t > 0.f ? t : 0.f);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(raw[j] << 16), hi = __uint_as_float(raw[j] & 0xffff0000u);
+            float x = fmaf(lo, sc[2 * j], sh[2 * j]), y = fmaf(hi, sc[2 * j + 1], sh[2 * j + 1]);
+            x = x > 0.f ? x : 0.f;
+            y = y > 0.f ? y : 0.f;
+            o[j] = (unsigned)f2bf(x) | ((unsigned)f2bf(y) << 16);
+        }
+    }
+    return o;
+}
+
+template <typename T>
+__device__ __forceinline__ void mfma(f32x16& acc, const u32x4& av, const u32x4& bw) {
+    if constexpr (sizeof(T) == 2) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
+                                                      __builtin_bit_cast(bf16x8_t, bw), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[i]), __uint_as_float(bw[i]), acc, 0, 0, 0);
+    }
+}
+
+// 8 consecutive channels <-> registers
+template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+}
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+    const u32x4 a = *(const u32x4*)p;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[2 * j] = __uint_as_float(a[j] << 16);
+        v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
+    }
+}
+// store 8 channels; v is replaced by the values as stored (rounded to T)
+template <typename T> __device__ __forceinline__ void store8(T* p, float (&v)[8]);
+template <> __device__ __forceinline__ void store8<float>(float* p, float (&v)[8]) {
+    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
+    *(f32x4*)p = a;
+    *(f32x4*)(p + 4) = b;
+}
+template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)[8]) {
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const unsigned lo = f2bf(v[2 * j]), hi = f2bf(v[2 * j + 1]);
+        o[j] = lo | (hi << 16);
+        v[2 * j] = __uint_as_float(lo << 16);
+        v[2 * j + 1] = __uint_as_float(hi << 16);
+    }
+    *(u32x4*)p = o;
+}
+
+template <int TAPS, int NT> struct Geo {
+    static constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    static constexpr int PW = TW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
+    static constexpr int TPS = (TAPS == 9) ? 3 : 1;                 // taps per K-step
+    static constexpr int SBYTES = TPS * KGC * (NT / 32) * 1024;     // weight bytes per K-step
+    static constexpr int NBW = NT >= 64 ? 2 : 1;
+    static constexpr int WAVES_N = (NT / 32) / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
+    static constexpr size_t main_bytes(int Cin) { return (size_t)ROWS * ROWB + 2 * SBYTES + (size_t)Cin * 8; }
+    static constexpr size_t epi_bytes() { return (size_t)4 * 32 * SCR_LD * 4 + (size_t)4 * WAVES_M * NT * 4; }
+    static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
+};
+
+template <typename T, int TAPS, int NT>
+__global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
+    using G = Geo<TAPS, NT>;
+    constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
+    constexpr int CC = KGC * KGE;                       // channels per chunk (32 bf16 / 16 fp32)
+    constexpr int PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, TPS = G::TPS, SBYTES = G::SBYTES;
+    constexpr int NBW = G::NBW, WAVES_N = G::WAVES_N, WAVES_M = G::WAVES_M, MB = G::MB;
+    constexpr int VPR = 4;                              // 16-byte vectors per patch row
+    constexpr int NVP = (ROWS * VPR + 255) / 256;       // patch vectors per thread
+    constexpr int SVEC = SBYTES / 16, SBV = (SVEC + 255) / 256;
+    constexpr int KROWS = TAPS / TPS;                   // K-steps per chunk (3 or 1)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                                  // [ROWS][ROWB]
+    char* bst = smem + ROWS * ROWB;                      // [2][SBYTES]
+    float* ss_lds = (float*)(bst + 2 * SBYTES);          // [Cin][2]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid % WAVES_N, wm = wid / WAVES_N;
+    const int tiles_x = (a.W + TW - 1) / TW;
+    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
+    const int n_tile = blockIdx.y, b = blockIdx.z;
+    const int Cin = a.in.C;
+    const bool use_gn = a.ss != nullptr;
+    const int NKG = Cin / KGE, NB = a.Cout / 32;
+    const int NCH = Cin / CC;
+    const int S = NCH * KROWS;
+
+    if (use_gn)
+        for (int i = tid; i < Cin * 2; i += 256) ss_lds[i] = a.ss[(size_t)b * Cin * 2 + i];
+
+    // ---- staging coordinates ----
+    const int v = tid & 3;
+    const T* in_b = (const T*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
+    int row_off[NVP];
+#pragma unroll
+    for (int j = 0; j < NVP; ++j) {
+        const int row = (tid + j * 256) >> 2;
+        const int y = ty0 + row / PW - PAD, x = tx0 + row % PW - PAD;
+        const bool ok = (row < ROWS) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+        row_off[j] = ok ? (y * a.W + x) * a.in.cs : -1;
+    }
+    u32x4 pre[NVP];
+    auto load_patch = [&](int c0) {
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) {
+            u32x4 z = {0u, 0u, 0u, 0u};
+            pre[j] = (row_off[j] >= 0) ? *(const u32x4*)(in_b + row_off[j] + c0 + v * VE) : z;
+        }
+    };
+    auto write_patch = [&](int c0) {
+        float sc[VE], sh[VE];
+#pragma unroll
+        for (int j = 0; j < VE; ++j) {
+            sc[j] = use_gn ? ss_lds[(c0 + v * VE + j) * 2] : 0.f;
+            sh[j] = use_gn ? ss_lds[(c0 + v * VE + j) * 2 + 1] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < NVP; ++j) {
+            const int idx = tid + j * 256;
+            if (idx < ROWS * VPR) {
+                u32x4 val = {0u, 0u, 0u, 0u};
+                if (row_off[j] >= 0) val = xform<T>(pre[j], sc, sh, use_gn);
+                *(u32x4*)(patch + (idx >> 2) * ROWB + v * 16) = val;
+            }
+        }
+    };
+    // weight slice of K-step (chunk c, kernel row krow): [t][kg][nb][lane] vectors
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)(n_tile * (NT / 32)) * 64;
+    const size_t wkg = (size_t)NB * 64;   // vectors between consecutive k-groups
+    u32x4 rb[SBV];
+    auto load_w = [&](int c, int krow) {
+#pragma unroll
+        for (int j = 0; j < SBV; ++j) {
+            const int i = tid + j * 256;
+            if (i < SVEC) {
+                constexpr int PER_KG = (NT / 32) * 64;
+                const int t = i / (KGC * PER_KG), kg = (i / PER_KG) % KGC, r = i % PER_KG;
+                rb[j] = wbase[((size_t)(krow * TPS + t) * NKG + c * KGC + kg) * wkg + r];
+            }
+        }
+    };
+    auto write_w = [&](int slot) {
+#pragma unroll
+        for (int j = 0; j < SBV; ++j) {
+            const int i = tid + j * 256;
+            if (i < SVEC) *(u32x4*)(bst + slot * SBYTES + i * 16) = rb[j];
+        }
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < NBW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    const int half = lane >> 5, px = lane & 31;
+    const char* a_ptr = patch + ((wm * MB) * PW + px) * ROWB + 16 * half;
+    const char* b_ptr = bst + (wn * NBW) * 1024 + lane * 16;
+
+    const int crot = (blockIdx.x * 5 + blockIdx.y * 3) % NCH;
+    auto chunk_of = [&](int ci) -> int { int x = ci + crot; return x >= NCH ? x - NCH : x; };
+
+    // ---- prologue: first chunk's patch and K-step 0 weights ----
+    load_patch(chunk_of(0) * CC);
+    load_w(chunk_of(0), 0);
+    __syncthreads();   // ss_lds visible
+    write_patch(chunk_of(0) * CC);
+    write_w(0);
+    __syncthreads();
+
+    int c = 0, krow = 0;   // c counts chunks in visiting order
+#pragma unroll 1
+    for (int s = 0; s < S; ++s) {
+        const bool last_row = (krow == KROWS - 1);
+        const bool more_chunks = (c + 1 < NCH);
+        // (a) prefetch the next K-step's weights (and the next chunk's patch) into registers; they have
+        //     the whole MFMA block below to land
+        if (s + 1 < S && !(a.dbg & 1)) load_w(chunk_of(last_row ? c + 1 : c), last_row ? 0 : krow + 1);
+        if (krow == 0 && more_chunks && !(a.dbg & 2)) load_patch(chunk_of(c + 1) * CC);
+
+        // (b) the MFMAs of this K-step
+        if (!(a.dbg & 4)) {
+            const char* bs = b_ptr + (s & 1) * SBYTES;
+            const char* ar = a_ptr + (krow * PW) * ROWB;
+#pragma unroll
+            for (int t = 0; t < TPS; ++t) {
+#pragma unroll
+                for (int kg = 0; kg < KGC; ++kg) {
+                    u32x4 af[MB], bf[NBW];
+#pragma unroll
+                    for (int q = 0; q < NBW; ++q)
+                        bf[q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+                        af[m] = *(const u32x4*)(ar + (m * PW + t) * ROWB + kg * 32);
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[m], bf[q]);
+                }
+            }
+        }
+
+        // (c) publish the next step's operands
+        if (s + 1 < S) write_w((s + 1) & 1);
+        if (last_row && more_chunks) {
+            __syncthreads();   // every wave has finished reading this chunk's patch
+            write_patch(chunk_of(c + 1) * CC);
+        }
+        __syncthreads();
+        if (last_row) { krow = 0; ++c; } else ++krow;
+    }
+    if (a.dbg & 8) return;
+
+    // ---- epilogue (the loop ended with a barrier: patch and ring are dead, reuse them) ----
+    float* scr = (float*)smem + wid * (32 * SCR_LD);          // wave-private [32 pixels][SCR_LD]
+    float* red = (float*)smem + 4 * 32 * SCR_LD;              // [4][WAVES_M][NT]
+    constexpr int CW = NBW * 32;                              // channels of this wave
+    constexpr int G8 = CW / 8;                                // 8-channel groups per pixel (8 or 4)
+    constexpr int NVE = 32 * G8 / 64;                         // vectors per lane per pixel row (4 or 2)
+    const int nw0 = (n_tile * (NT / 32) + wn * NBW) * 32;     // first channel of this wave
+    const int g8 = lane % G8;
+    const int nv = nw0 + g8 * 8;                              // this lane's 8 channels
+    float bias[NBW];
+#pragma unroll
+    for (int q = 0; q < NBW; ++q) bias[q] = a.bias ? a.bias[nw0 + q * 32 + px] : 0.f;
+    const size_t img = (size_t)b * a.H * a.W;
+    T* out_p = (T*)a.out.p + img * a.out.cs + a.out.co + nv;
+    T* raw_p = a.raw.p ? (T*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
+    const T* res_p = a.res.p ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    const T* res2_p = a.res2.p ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
+    const bool want_stats = a.st_raw || a.st_out;
+    float sr[8], qr[8], so[8], qo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
+
+#pragma clang loop unroll(full)
+    for (int m = 0; m < MB; ++m) {
+#pragma clang loop unroll(full)
+        for (int q = 0; q < NBW; ++q)
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 16; ++r)
+                scr[mfma32_row(r, half) * SCR_LD + q * 32 + px] = acc[m][q][r] + bias[q];
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int y = ty0 + wm * MB + m;
+#pragma clang loop unroll(full)
+        for (int j = 0; j < NVE; ++j) {
+            const int p = (lane + 64 * j) / G8;               // pixel of the row
+            const int x = tx0 + p;
+            float f[8];
+            {
+                const f32x4 lo = *(const f32x4*)(scr + p * SCR_LD + g8 * 8), hi = *(const f32x4*)(scr + p * SCR_LD + g8 * 8 + 4);
+                f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+            }
+            if (y < a.H && x < a.W) {
+                const size_t pix = (size_t)y * a.W + x;
+                if (raw_p) {
+                    float g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) g[e] = f[e];
+                    store8<T>(raw_p + pix * a.raw.cs, g);
+                    if (want_stats) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
+                    }
+                }
+                if (res_p) {
+                    float g[8];
+                    load8<T>(res_p + pix * a.res.cs, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                }
+                if (res2_p) {
+                    float g[8];
+                    load8<T>(res2_p + pix * a.res2.cs, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] += g[e];
+                }
+                store8<T>(out_p + pix * a.out.cs, f);
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { so[e] += f[e]; qo[e] += f[e] * f[e]; }
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+
+    if (want_stats) {   // uniform over the grid
+        // lanes with equal (lane % G8) hold the same 8 channels: fixed-order butterfly over the rest
+#pragma unroll
+        for (int o = G8; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sr[e] += __shfl_xor(sr[e], o, 64); qr[e] += __shfl_xor(qr[e], o, 64);
+                so[e] += __shfl_xor(so[e], o, 64); qo[e] += __shfl_xor(qo[e], o, 64);
+            }
+        }
+        __syncthreads();   // all waves are done with their scratch reads (red is disjoint, but keep it simple)
+        if (lane < G8) {
+            const int cl = wn * CW + lane * 8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(0 * WAVES_M + wm) * NT + cl + e] = sr[e];
+                red[(1 * WAVES_M + wm) * NT + cl + e] = qr[e];
+                red[(2 * WAVES_M + wm) * NT + cl + e] = so[e];
+                red[(3 * WAVES_M + wm) * NT + cl + e] = qo[e];
+            }
+        }
+        __syncthreads();
+        if (tid < NT) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
+            const int cg = n_tile * NT + tid;
+            if (a.st_raw) {
+                const size_t tile = (size_t)b * a.st_raw_tiles + blockIdx.x;
+                float* o = a.st_raw + (tile * a.st_raw_C + a.st_raw_co + cg) * 2;
+                o[0] = t[0];
+                o[1] = t[1];
+            }
+            if (a.st_out) {
+                const size_t tile = (size_t)b * a.st_out_tiles + blockIdx.x;
+                float* o = a.st_out + (tile * a.st_out_C + a.st_out_co + cg) * 2;
+                o[0] = t[2];
+                o[1] = t[3];
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, int NT>
+int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+    using G = Geo<TAPS, NT>;
+    const size_t smem = G::smem_bytes(a.in.C);
+    static bool attr = false;
+    if (!attr) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_lds_kernel<T, TAPS, NT>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr = true;
+    }
+    const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
+    dim3 grid(tiles, a.Cout / NT, a.B);
+    hipLaunchKernelGGL((conv_lds_kernel<T, TAPS, NT>), grid, dim3(256), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+template <typename T, int TAPS>
+int launch_nt(chore_handle* h, int nt, const ConvArgs& a, hipStream_t s) {
+    if (nt == 128) return launch_t<T, TAPS, 128>(h, a, s);
+    if (nt == 64) return launch_t<T, TAPS, 64>(h, a, s);
+    return launch_t<T, TAPS, 32>(h, a, s);
+}
+
+int tiles_of(int H, int W) { return ((W + TW - 1) / TW) * ((H + TH - 1) / TH); }
+
+// N-tile choice: the largest channel tile that still gives every CU about two workgroups
+int choose_nt(int B, int H, int W, int Cout) {
+    static const int nts[3] = {128, 64, 32};
+    int best = 32;
+    long best_wgs = -1;
+    for (int i = 0; i < 3; ++i) {
+        const int nt = nts[i];
+        if (Cout % nt) continue;
+        const long wgs = (long)B * tiles_of(H, W) * (Cout / nt);
+        if (wgs >= 448) return nt;
+        if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
+    }
+    return best;
+}
+
+}  // namespace
+
+ConvPlan conv_plan(int taps, int B, int H, int W, int Cout) {
+    (void)taps;
+    return ConvPlan{choose_nt(B, H, W, Cout), TH, tiles_of(H, W)};
+}
+
+int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipStream_t s) {
+    const int cc = dtype == CHORE_F32 ? 16 : 32;
+    if (a_in.in.C % cc || a_in.in.C > 256) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cin=%d", a_in.in.C);
+    if (a_in.Cout % 32) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cout=%d", a_in.Cout);
+    if (a_in.B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "conv: B too large");
+    if (taps != 1 && taps != 9) CHORE_FAIL(h, CHORE_EINVAL, "conv: taps must be 1 or 9");
+    static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
+    ConvArgs a = a_in;
+    a.dbg = dbg;
+    const int nt = choose_nt(a.B, a.H, a.W, a.Cout);
+    if (dtype == CHORE_F32)
+        return taps == 9 ? launch_nt<float, 9>(h, nt, a, s) : launch_nt<float, 1>(h, nt, a, s);
+    return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, a, s) : launch_nt<bf16_t, 1>(h, nt, a, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: (O,C,kh,kw) fp32 -> [tap][kg][nb][lane][16 B]
+//   bf16: lane l holds W[n = nb*32 + (l&31)][c = kg*16 + 8*(l>>5) + 0..7]
+//   fp32: lane l holds W[n][c = kg*8 + 4*(l>>5) + 0..3]
+// ------------------------------------------------------------------------------------------------
+size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout) {
+    const int kge = dtype == CHORE_F32 ? 8 : 16;
+    return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024;
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __restrict__ w, u32x4* __restrict__ dst,
+                                 size_t nvec) {
+    constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= nvec) return;
+    const int NKG = Cin / KGE, NB = Cout / 32;
+    const int lane = (int)(i & 63);
+    size_t t = i >> 6;
+    const int nb = (int)(t % NB); t /= NB;
+    const int kg = (int)(t % NKG);
+    const int tap = (int)(t / NKG);
+    const int n = nb * 32 + (lane & 31);
+    const int c0 = kg * KGE + VE * (lane >> 5);
+    float vals[VE];
+#pragma unroll
+    for (int j = 0; j < VE; ++j) vals[j] = w[((size_t)n * Cin + c0 + j) * taps + tap];
+    u32x4 o;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (unsigned)f2bf(vals[2 * j]) | ((unsigned)f2bf(vals[2 * j + 1]) << 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = __float_as_uint(vals[j]);
+    }
+    dst[i] = o;
+}
+
+int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w, void* dst,
+                     hipStream_t s) {
+    const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16;
+    const unsigned blocks = (unsigned)((nvec + 255) / 256);
+    if (dtype == CHORE_F32)
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec);
+    else
+        hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst,
+                           nvec);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}

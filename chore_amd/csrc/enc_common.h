@@ -33,10 +33,12 @@ struct ConvArgs {
     // *_tiles = tile stride of the buffer (>= tiles of this launch)
     float* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0, st_raw_tiles = 0;
     float* st_out = nullptr; int st_out_C = 0, st_out_co = 0, st_out_tiles = 0;
+    int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
+                   // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
 
 struct ConvPlan { int nt, th, ntiles; };
-ConvPlan conv_plan(int B, int H, int W, int Cout);   // tile configuration launch_conv will use
+ConvPlan conv_plan(int taps, int B, int H, int W, int Cout);   // tile configuration launch_conv will use
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);

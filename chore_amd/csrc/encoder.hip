@@ -209,14 +209,14 @@ struct Builder {
     }
     // attach tile-partial storage for the slices [0,c_end0), [c_end0,c_end1) ... each produced by a conv
     // with `cout_i` output channels (which fixes its tile configuration)
-    void attach_stats(Buf& b, int nslices, const int* c_end, const int* couts) {
+    void attach_stats(Buf& b, int taps, int nslices, const int* c_end, const int* couts) {
         StatInfo& st = b.st;
         st.valid = true;
         st.nslices = nslices;
         st.max_tiles = 0;
         for (int i = 0; i < nslices; ++i) {
             st.c_end[i] = c_end[i];
-            st.ntiles[i] = conv_plan(B, b.H, b.W, couts[i]).ntiles;
+            st.ntiles[i] = conv_plan(taps, B, b.H, b.W, couts[i]).ntiles;
             if (st.ntiles[i] > st.max_tiles) st.max_tiles = st.ntiles[i];
         }
         st.bytes = (size_t)B * st.max_tiles * b.C * 2 * 4;
@@ -347,10 +347,10 @@ struct Builder {
         Buf o1 = alloc(H, W, cout / 2), o2 = alloc(H, W, cout / 4);
         {
             const int ce_out[3] = {cout / 2, 3 * cout / 4, cout}, co_out[3] = {cout / 2, cout / 4, cout / 4};
-            attach_stats(out, 3, ce_out, co_out);
+            attach_stats(out, 9, 3, ce_out, co_out);
             const int ce1[1] = {cout / 2}, co1[1] = {cout / 2}, ce2[1] = {cout / 4}, co2[1] = {cout / 4};
-            attach_stats(o1, 1, ce1, co1);
-            attach_stats(o2, 1, ce2, co2);
+            attach_stats(o1, 9, 1, ce1, co1);
+            attach_stats(o2, 9, 1, ce2, co2);
         }
         const size_t ss1 = alloc_ss(cin);
         Buf res = x;
@@ -482,7 +482,7 @@ struct Builder {
             Buf t2 = alloc(H4, W4, 256);
             {
                 const int ce[1] = {256}, co[1] = {256};
-                attach_stats(t2, 1, ce, co);
+                attach_stats(t2, 1, 1, ce, co);
             }
             ConvSpec cl;
             cl.in = t1; cl.in_C = 256; cl.wname = p + "conv_last" + s; cl.bias = true; cl.out = t2; cl.taps = 1;
@@ -501,7 +501,7 @@ struct Builder {
                 Buf nprev = alloc(H4, W4, 256);
                 {
                     const int ce[1] = {256}, co[1] = {256};
-                    attach_stats(nprev, 1, ce, co);
+                    attach_stats(nprev, 1, 1, ce, co);
                 }
                 ConvSpec bl;
                 bl.in = t2; bl.in_C = 256; bl.use_ss = true; bl.ss = ss; bl.wname = p + "bl" + s; bl.bias = true;

@@ -3,7 +3,7 @@ import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Kernel_Name"])[:70]
+    name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]).split("(")[0][:70]
     key = (name, r["Grid_Size"], )
     agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 flt = sys.argv[2] if len(sys.argv) > 2 else ""

@@ -7,7 +7,7 @@ for r in rows:
     dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     grid = "x".join(r.get(k, "?") for k in ("Grid_Size_X", "Grid_Size_Y", "Grid_Size_Z"))
     wg = r.get("Workgroup_Size_X", "?")
-    name = re.sub(r"\(.*", "", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", name).split("(")[0]
     key = (name[:90], grid, wg)
     agg[key][0] += 1; agg[key][1] += dur
 tot = sum(v[1] for v in agg.values())
