@@ -144,13 +144,11 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
     const int n_tile = blockIdx.y, b = blockIdx.z;
     const int Cin = a.in.C;
-    const bool use_gn = a.ss != nullptr;
+    const bool use_gn = a.in_st != nullptr;
     const int NKG = Cin / KGE, NB = a.Cout / 32;
     const int NCH = Cin / CC;
     const int S = NCH * KROWS;
 
-    if (use_gn)
-        for (int i = tid; i < Cin * 2; i += 256) ss_lds[i] = a.ss[(size_t)b * Cin * 2 + i];
 
     // ---- staging coordinates ----
     const int v = tid & 3;
@@ -229,7 +227,33 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // ---- prologue: first chunk's patch and K-step 0 weights ----
     load_patch(chunk_of(0) * CC);
     load_w(chunk_of(0), 0);
-    __syncthreads();   // ss_lds visible
+    if (use_gn) {
+        // GroupNorm affine of this image's input channels from the producers' exact totals: one
+        // 32-byte load per channel (patch area as scratch: nothing has been staged yet), then a
+        // fixed-order sum over the channels of the group
+        double* dsum = (double*)smem;          // [Cin] sum, [Cin] sum of squares
+        for (int ci = tid; ci < Cin; ci += 256) {
+            const ChanStat st = a.in_st[(size_t)b * Cin + ci];
+            dsum[ci] = stat_read(st.sum);
+            dsum[Cin + ci] = stat_read(st.sq);
+        }
+        __syncthreads();
+        const int gs = Cin / GN_GROUPS;
+        const double n = (double)a.H * a.W * gs;
+        for (int ci = tid; ci < Cin; ci += 256) {
+            const int g0 = (ci / gs) * gs;
+            double sa = 0.0, sq = 0.0;
+            for (int j = 0; j < gs; ++j) { sa += dsum[g0 + j]; sq += dsum[Cin + g0 + j]; }
+            const double mean = sa / n;
+            double var = sq / n - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+            const float scale = rstd * a.gamma[ci];
+            ss_lds[2 * ci] = scale;
+            ss_lds[2 * ci + 1] = a.beta[ci] - (float)mean * scale;
+        }
+    }
+    __syncthreads();   // ss_lds visible, scratch free
     write_patch(chunk_of(0) * CC);
     write_w(0);
     __syncthreads();
@@ -384,16 +408,14 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
             const int cg = n_tile * NT + tid;
             if (a.st_raw) {
-                const size_t tile = (size_t)b * a.st_raw_tiles + blockIdx.x;
-                float* o = a.st_raw + (tile * a.st_raw_C + a.st_raw_co + cg) * 2;
-                o[0] = t[0];
-                o[1] = t[1];
+                ChanStat* o = a.st_raw + (size_t)b * a.st_raw_C + a.st_raw_co + cg;
+                stat_add(&o->sum, t[0]);
+                stat_add(&o->sq, t[1]);
             }
             if (a.st_out) {
-                const size_t tile = (size_t)b * a.st_out_tiles + blockIdx.x;
-                float* o = a.st_out + (tile * a.st_out_C + a.st_out_co + cg) * 2;
-                o[0] = t[2];
-                o[1] = t[3];
+                ChanStat* o = a.st_out + (size_t)b * a.st_out_C + a.st_out_co + cg;
+                stat_add(&o->sum, t[2]);
+                stat_add(&o->sq, t[3]);
             }
         }
     }

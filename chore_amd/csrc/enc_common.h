@@ -18,21 +18,69 @@ struct View {
 constexpr int GN_GROUPS = 32;
 constexpr int GN_SPLITS_MAX = 64;
 
+// ---- exact, order-independent GroupNorm statistics -------------------------------------------------
+// Every producer adds its per-channel partial sums into a 128-bit fixed-point accumulator (unit 2^-40)
+// with 64-bit integer atomics.  Integer addition is associative, so the totals -- and everything
+// derived from them -- are bit-identical whatever order the workgroups run in, across runs and batch
+// compositions; no finalize kernel and no per-tile partial buffers are needed.  A consumer turns the
+// totals into the per-(image,channel) affine  relu(x*scale+shift)  in its own prologue.
+struct StatCell { unsigned long long lo; long long hi; };
+struct ChanStat { StatCell sum, sq; };   // per (image, channel): sum and sum of squares of the stored values
+
+__device__ __forceinline__ void stat_add(StatCell* c, float x) {
+    const double d = (double)x * 0x1p40;             // exact (power-of-two scaling)
+    const double h = floor(d * 0x1p-64);             // exact split of the <= 53 significant bits
+    const long long hi = (long long)h;
+    const unsigned long long lo = (unsigned long long)(d - h * 0x1p64);
+    const unsigned long long old = atomicAdd(&c->lo, lo);
+    const long long carry = (old + lo < old) ? 1 : 0;
+    if (hi + carry != 0) atomicAdd((unsigned long long*)&c->hi, (unsigned long long)(hi + carry));
+}
+__device__ __forceinline__ double stat_read(const StatCell& c) {
+    unsigned long long lo = c.lo;
+    long long hi = c.hi;
+    const bool neg = hi < 0;
+    if (neg) {   // two's-complement negate so that small negative totals keep their low bits
+        lo = ~lo + 1ull;
+        hi = ~hi + (lo == 0ull ? 1 : 0);
+    }
+    const double v = ((double)hi * 0x1p64 + (double)lo) * 0x1p-40;
+    return neg ? -v : v;
+}
+// scale/shift of channel c of image b: GroupNorm(32 groups, eps 1e-5, biased variance) folded to an affine
+__device__ __forceinline__ void gn_scale_shift(const ChanStat* st, int b, int C, int c, int HW,
+                                               const float* gamma, const float* beta, float& scale, float& shift) {
+    const int gs = C / GN_GROUPS, g = c / gs;
+    double a = 0.0, q = 0.0;
+    for (int j = 0; j < gs; ++j) {
+        const ChanStat s = st[(size_t)b * C + g * gs + j];
+        a += stat_read(s.sum);
+        q += stat_read(s.sq);
+    }
+    const double n = (double)HW * gs;
+    const double mean = a / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+    scale = rstd * gamma[c];
+    shift = beta[c] - (float)mean * scale;
+}
+
 struct ConvArgs {
-    View in;            // input activations
-    const float* ss;    // [B][Cin][2] GroupNorm scale/shift fused with ReLU into the operand load, or null
-    const void* wpk;    // fragment-ordered weights (pack_conv_weights)
-    const float* bias;  // [Cout] or null
-    View out;           // acc + bias + res + res2
-    View raw;           // optional: acc + bias
-    View res, res2;     // optional residuals (may alias out)
+    View in;                 // input activations (a whole tensor when GroupNorm is fused: co = 0, C = cs)
+    const ChanStat* in_st;   // [B][Cin] statistics of the input, or null: no GroupNorm+ReLU prologue
+    const float* gamma;      // [Cin] GroupNorm affine of the fused prologue
+    const float* beta;
+    const void* wpk;         // fragment-ordered weights (launch_pack_conv)
+    const float* bias;       // [Cout] or null
+    View out;                // acc + bias + res + res2
+    View raw;                // optional: acc + bias
+    View res, res2;          // optional residuals (may alias out)
     int B, H, W, Cout;
-    // optional fused GroupNorm statistics of what this launch stores: per (image, tile, channel)
-    // (sum, sum of squares) partials in [B][tiles][C][2] buffers -- st_raw for the `raw` view,
-    // st_out for the `out` view; *_C / *_co = channels of the normalised tensor / offset of this slice
-    // *_tiles = tile stride of the buffer (>= tiles of this launch)
-    float* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0, st_raw_tiles = 0;
-    float* st_out = nullptr; int st_out_C = 0, st_out_co = 0, st_out_tiles = 0;
+    // optional statistics of what this launch stores (for the next GroupNorm): [B][C] accumulators of
+    // the tensor `raw` / `out` belong to; *_C = channels of that tensor, *_co = offset of this slice
+    ChanStat* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0;
+    ChanStat* st_out = nullptr; int st_out_C = 0, st_out_co = 0;
     int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
@@ -49,22 +97,11 @@ int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, co
 int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W,
                 const float* wk /*[Cin*49][64]*/, const float* bias, void* out /*(B,H/2,W/2,64)*/, hipStream_t s);
 int launch_pack_stem(chore_handle* h, int Cin, const float* w /*(64,Cin,7,7)*/, float* dst, hipStream_t s);
-int gn_splits(int HW);
-int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, float* partial, hipStream_t s);
-int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
-                       const float* beta, float* ss, hipStream_t s);
-// statistics assembled from conv-epilogue tile partials: up to 3 channel slices, each written by a
-// launch with its own tile count
-struct TileStats {
-    const float* p = nullptr;   // [B][max_tiles][C][2]
-    int max_tiles = 0, nslices = 0;
-    int c_end[3] = {0, 0, 0};   // exclusive end channel of each slice
-    int ntiles[3] = {0, 0, 0};
-};
-int launch_gn_finalize_tiles(chore_handle* h, const TileStats& ts, int B, int HW, int C, const float* gamma,
-                             const float* beta, float* ss, hipStream_t s);
-int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const float* ss, const View& y, int B,
-                         int HW, hipStream_t s);
+// statistics of a tensor no convolution produced (pooling / upsampling / stem outputs): one pass, atomics
+int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, ChanStat* st, hipStream_t s);
+// y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
+int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanStat* st, const float* gamma,
+                         const float* beta, const View& y, int B, int HW, hipStream_t s);
 int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, hipStream_t s);
 // y = a + bicubic_up2(low)   (low is (B,H,W,C), a and y are (B,2H,2W,C); y may alias a)
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,

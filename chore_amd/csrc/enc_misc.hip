@@ -128,9 +128,9 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
 }
 
 // ------------------------------------------------------------------------------------------------
-// GroupNorm statistics: deterministic two-stage reduction.
-//   partial[b][s][g] = (sum, sum of squares) over the s-th slice of pixels, fp32
-//   finalize: fp64 combine -> mean, rstd -> per-channel scale = rstd*gamma, shift = beta - mean*scale
+// GroupNorm statistics of a tensor that no convolution produced (pool / upsample / stem outputs):
+// one streaming pass, per-block per-channel fp32 partials, then exact 128-bit fixed-point atomics
+// (enc_common.h) -> order-independent totals.
 // ------------------------------------------------------------------------------------------------
 int gn_splits(int HW) {
     int s = HW / 64;  // >= 64 pixels per slice
@@ -140,10 +140,9 @@ int gn_splits(int HW) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, int cs, int co, int C, int HW,
-                                                         int S, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int cs, int co, int C, int HW,
+                                                       int S, ChanStat* __restrict__ st) {
     __shared__ float red[2][1024];
-    __shared__ float chs[2][256];
     const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int tpr = C / 4, P = 256 / tpr;
     const int cv = tid % tpr, pl = tid / tpr;
@@ -164,154 +163,67 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     if (tid < C) {
         float a = 0.f, q = 0.f;
         for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
-        chs[0][tid] = a;
-        chs[1][tid] = q;
-    }
-    __syncthreads();
-    if (tid < GN_GROUPS) {
-        const int gs = C / GN_GROUPS;
-        float a = 0.f, q = 0.f;
-        for (int i = 0; i < gs; ++i) { a += chs[0][tid * gs + i]; q += chs[1][tid * gs + i]; }
-        float* o = partial + (((size_t)b * S + s) * GN_GROUPS + tid) * 2;
-        o[0] = a;
-        o[1] = q;
+        ChanStat* o = st + (size_t)b * C + tid;
+        stat_add(&o->sum, a);
+        stat_add(&o->sq, q);
     }
 }
 
-int launch_gn_partial(chore_handle* h, int dtype, const View& x, int B, int HW, float* partial, hipStream_t s) {
+int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, ChanStat* st, hipStream_t s) {
     if (x.C % GN_GROUPS || x.C > 256 || x.C < 32) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
     const int S = gn_splits(HW);
     dim3 grid(S, B);
     if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(gn_partial_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, x.C, HW, S,
-                           partial);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, x.C, HW, S, st);
     else
-        hipLaunchKernelGGL(gn_partial_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, x.C, HW,
-                           S, partial);
-    CHORE_LAUNCH_CHECK(h, s);
-    return CHORE_OK;
-}
-
-// block-wide fixed-order fp64 reduction of (a, q); result valid in thread 0
-__device__ __forceinline__ void block_reduce2(double& a, double& q, double (*sh)[256], int tid) {
-    sh[0][tid] = a;
-    sh[1][tid] = q;
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) {
-            sh[0][tid] += sh[0][tid + o];
-            sh[1][tid] += sh[1][tid + o];
-        }
-        __syncthreads();
-    }
-    a = sh[0][0];
-    q = sh[1][0];
-}
-
-__device__ __forceinline__ void write_scale_shift(double a, double q, int HW, int gs, int C, int b, int g,
-                                                  const float* gamma, const float* beta, float* ss, int tid) {
-    const double n = (double)HW * gs;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
-    if (tid < gs) {
-        const int c = g * gs + tid;
-        const float scale = rstd * gamma[c];
-        ss[((size_t)b * C + c) * 2 + 0] = scale;
-        ss[((size_t)b * C + c) * 2 + 1] = beta[c] - (float)mean * scale;
-    }
-}
-
-// one block per (group, image)
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, int S, int HW, int C,
-                                                          const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float* __restrict__ ss) {
-    __shared__ double sh[2][256];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    double a = 0.0, q = 0.0;
-    for (int s = tid; s < S; s += 256) {
-        const float* p = partial + (((size_t)b * S + s) * GN_GROUPS + g) * 2;
-        a += (double)p[0];
-        q += (double)p[1];
-    }
-    block_reduce2(a, q, sh, tid);
-    write_scale_shift(a, q, HW, C / GN_GROUPS, C, b, g, gamma, beta, ss, tid);
-}
-
-int launch_gn_finalize(chore_handle* h, const float* partial, int B, int HW, int C, const float* gamma,
-                       const float* beta, float* ss, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, B), dim3(256), 0, s, partial, gn_splits(HW), HW, C, gamma,
-                       beta, ss);
-    CHORE_LAUNCH_CHECK(h, s);
-    return CHORE_OK;
-}
-
-// finalize from the tile partials the conv epilogues wrote (fixed summation order -> deterministic)
-__global__ __launch_bounds__(256) void gn_finalize_tiles_kernel(TileStats ts, int HW, int C,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta,
-                                                                float* __restrict__ ss) {
-    __shared__ double sh[2][256];
-    const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int gs = C / GN_GROUPS;
-    int sl = 0;   // a group never straddles two slices (slice widths are multiples of the group size)
-    while (sl + 1 < ts.nslices && g * gs >= ts.c_end[sl]) ++sl;
-    const int nt = ts.ntiles[sl];
-    const float* base = ts.p + ((size_t)b * ts.max_tiles * C + g * gs) * 2;
-    double a = 0.0, q = 0.0;
-    for (int i = tid; i < nt * gs; i += 256) {   // element i = (tile, channel-in-group)
-        const int t = i / gs, j = i % gs;
-        const float* p = base + ((size_t)t * C + j) * 2;
-        a += (double)p[0];
-        q += (double)p[1];
-    }
-    block_reduce2(a, q, sh, tid);
-    write_scale_shift(a, q, HW, gs, C, b, g, gamma, beta, ss, tid);
-}
-
-int launch_gn_finalize_tiles(chore_handle* h, const TileStats& ts, int B, int HW, int C, const float* gamma,
-                             const float* beta, float* ss, hipStream_t s) {
-    if (C > 256 || C % GN_GROUPS) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", C);
-    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(GN_GROUPS, B), dim3(256), 0, s, ts, HW, C, gamma, beta, ss);
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, x.C, HW, S,
+                           st);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-// elementwise: y = relu(x*scale + shift)
+// elementwise: y = relu(groupnorm(x)); grid (blocks per image, B); the affine is derived per block
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict__ x, int xcs, int xco,
-                                                            const float* __restrict__ ss, T* __restrict__ y,
-                                                            int ycs, int yco, int C, int HW, size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
+                                                            const ChanStat* __restrict__ st,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
+                                                            int ycs, int yco, int C, int HW) {
+    __shared__ float ss[512];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < C) gn_scale_shift(st, b, C, tid, HW, gamma, beta, ss[2 * tid], ss[2 * tid + 1]);
+    __syncthreads();
     const int tpr = C / 4;
-    const int cv = (int)(i % tpr);
-    const size_t p = i / tpr;  // b*HW + pixel
-    const int b = (int)(p / HW);
-    const f32x4 v = Vec4<T>::ld(x + p * xcs + xco + cv * 4);
-    const float* s = ss + ((size_t)b * C + cv * 4) * 2;
-    f32x4 r;
+    const size_t total4 = (size_t)HW * tpr;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total4; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % tpr);
+        const size_t p = (size_t)b * HW + i / tpr;
+        const f32x4 v = Vec4<T>::ld(x + p * xcs + xco + cv * 4);
+        f32x4 r;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float t = fmaf(v[j], s[2 * j], s[2 * j + 1]);
-        r[j] = t > 0.f ? t : 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const float t = fmaf(v[j], ss[2 * (cv * 4 + j)], ss[2 * (cv * 4 + j) + 1]);
+            r[j] = t > 0.f ? t : 0.f;
+        }
+        Vec4<T>::st(y + p * ycs + yco + cv * 4, r);
     }
-    Vec4<T>::st(y + p * ycs + yco + cv * 4, r);
 }
 
-int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const float* ss, const View& y, int B, int HW,
-                         hipStream_t s) {
-    const size_t total4 = (size_t)B * HW * (x.C / 4);
-    const int blocks = (int)((total4 + 255) / 256);
+int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanStat* st, const float* gamma,
+                         const float* beta, const View& y, int B, int HW, hipStream_t s) {
+    if (x.C > 256 || x.C % GN_GROUPS) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
+    const size_t total4 = (size_t)HW * (x.C / 4);
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid(blocks, B);
     if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(gn_apply_relu_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x.p, x.cs, x.co,
-                           ss, (float*)y.p, y.cs, y.co, x.C, HW, total4);
+        hipLaunchKernelGGL(gn_apply_relu_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, st, gamma,
+                           beta, (float*)y.p, y.cs, y.co, x.C, HW);
     else
-        hipLaunchKernelGGL(gn_apply_relu_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x.p, x.cs,
-                           x.co, ss, (bf16_t*)y.p, y.cs, y.co, x.C, HW, total4);
+        hipLaunchKernelGGL(gn_apply_relu_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, st,
+                           gamma, beta, (bf16_t*)y.p, y.cs, y.co, x.C, HW);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -99,23 +99,21 @@ int check_cfg(chore_handle* h, const chore_encoder_cfg* cfg) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// program = list of closures; buffers are offsets into the workspace (or caller tensors)
+// program = list of steps (closures); buffers are offsets into per-stream pools of the workspace
+// (or caller tensors).  Independent branches of the hourglass run on auxiliary streams (fork/join
+// with events), each with its own pool so concurrent branches never alias.
 // ------------------------------------------------------------------------------------------------
-// GroupNorm tile partials attached to a buffer (written by the conv epilogues that produce it)
-struct StatInfo {
-    bool valid = false;    // storage attached
-    bool usable = true;    // false once the buffer has been modified after the producing convs
-    size_t off = 0, bytes = 0;
-    int max_tiles = 0, nslices = 0;
-    int c_end[3] = {0, 0, 0}, ntiles[3] = {0, 0, 0};
-};
+constexpr int MAX_STREAMS = 5;   // caller's stream + one per hourglass level
 
 struct Buf {
-    size_t off = 0;       // offset into workspace, or
+    size_t off = 0;       // offset inside pool `pool`, or
+    int pool = 0;
     int ext = -1;         // index of an external (caller) tensor: 0..n_out-1 feats, 100 tmpx, 101 normx
     int H = 0, W = 0, C = 0;
     size_t bytes = 0;
-    StatInfo st;
+    // GroupNorm statistics ([B][C] ChanStat accumulators in the stats arena) of the buffer's content
+    bool st_valid = false;
+    size_t st_off = 0;
 };
 
 struct Pool {
@@ -139,8 +137,9 @@ struct Pool {
 struct RunCtx {
     chore_handle* h;
     int dtype;
-    hipStream_t s;
-    char* ws;
+    hipStream_t s;                 // stream of the step being issued
+    char* pool_base[MAX_STREAMS];
+    char* stats;                   // stats arena
     const char* arena;
     const float* images;
     void* const* feats;
@@ -153,12 +152,17 @@ enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_CONV3_128, K_CONV3_64, K_CON
 const char* const kclass_names[K_NUM] = {"stem_conv7x7", "gn_stats", "gn_apply_relu", "conv3x3_n128", "conv3x3_n64",
                                          "conv3x3_n32", "conv1x1", "avgpool2", "bicubic_upadd"};
 
+enum StepKind { S_KERNEL = 0, S_RECORD, S_WAIT, S_MEMSET };
+
 struct Step {
+    int kind = S_KERNEL;
+    int stream = 0;        // stream index the step is issued on
+    int event = -1;        // S_RECORD / S_WAIT
     std::string label;
     std::function<void(RunCtx&)> fn;
     int klass = 0;
-    double flops = 0.0;  // algorithmic FLOPs of the launch (convolutions: 2*taps*Cin*Cout*B*H*W)
-    double bytes = 0.0;  // algorithmic HBM bytes of the launch (compulsory reads + writes)
+    double flops = 0.0;    // algorithmic FLOPs of the launch (convolutions: 2*taps*Cin*Cout*B*H*W)
+    double bytes = 0.0;    // algorithmic HBM bytes of the launch (compulsory reads + writes)
 };
 
 struct Profile {
@@ -174,28 +178,33 @@ struct Program {
     bool want_normx;
     WLayout L;
     std::vector<Step> steps;
+    size_t pool_off[MAX_STREAMS] = {0};   // base offset of each stream's pool inside the workspace
+    size_t stats_off = 0, stats_bytes = 0;
+    int n_events = 0, n_streams = 1;
     size_t ws_bytes = 0;
+    std::vector<hipEvent_t> events;       // created on first run
 };
 
 struct Builder {
     Program& P;
-    Pool pool;
+    Pool pools[MAX_STREAMS];
+    size_t stat_top = 0;
     int B, dtype;
-    size_t partial_off;
+    int cur = 0;           // stream the next steps are issued on
+    bool concurrent;
     std::string cur_label = "?";
     int cur_class = 0;
     double cur_flops = 0.0, cur_bytes = 0.0;
     double es() const { return (double)esize(dtype); }
 
-    explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) {
-        partial_off = pool.alloc((size_t)B * GN_SPLITS_MAX * GN_GROUPS * 2 * 4);
-    }
+    explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) { concurrent = getenv("CHORE_ENC_SERIAL") == nullptr; }
 
     Buf alloc(int H, int W, int C) {
         Buf b;
         b.H = H; b.W = W; b.C = C;
+        b.pool = cur;
         b.bytes = (size_t)B * H * W * C * esize(dtype);
-        b.off = pool.alloc(b.bytes);
+        b.off = pools[cur].alloc(b.bytes);
         return b;
     }
     Buf external(int id, int H, int W, int C) {
@@ -204,29 +213,17 @@ struct Builder {
         return b;
     }
     void release(const Buf& b) {
-        if (b.ext < 0) pool.release(b.off, b.bytes);
-        if (b.st.valid) pool.release(b.st.off, b.st.bytes);
+        if (b.ext < 0) pools[b.pool].release(b.off, b.bytes);
     }
-    // attach tile-partial storage for the slices [0,c_end0), [c_end0,c_end1) ... each produced by a conv
-    // with `cout_i` output channels (which fixes its tile configuration)
-    void attach_stats(Buf& b, int taps, int nslices, const int* c_end, const int* couts) {
-        StatInfo& st = b.st;
-        st.valid = true;
-        st.nslices = nslices;
-        st.max_tiles = 0;
-        for (int i = 0; i < nslices; ++i) {
-            st.c_end[i] = c_end[i];
-            st.ntiles[i] = conv_plan(taps, B, b.H, b.W, couts[i]).ntiles;
-            if (st.ntiles[i] > st.max_tiles) st.max_tiles = st.ntiles[i];
-        }
-        st.bytes = (size_t)B * st.max_tiles * b.C * 2 * 4;
-        st.off = pool.alloc(st.bytes);
+    // fresh, never-reused statistics accumulators for the tensor in `b` (zeroed once per encode)
+    void new_stats(Buf& b) {
+        b.st_valid = true;
+        b.st_off = stat_top;
+        stat_top += align_up((size_t)B * b.C * sizeof(ChanStat), 256);
     }
-    size_t alloc_ss(int C) { return pool.alloc((size_t)B * C * 2 * 4); }
-    void release_ss(size_t off, int C) { pool.release(off, (size_t)B * C * 2 * 4); }
 
     static void* ptr(RunCtx& r, const Buf& b) {
-        if (b.ext < 0) return r.ws + b.off;
+        if (b.ext < 0) return r.pool_base[b.pool] + b.off;
         if (b.ext == 100) return r.tmpx;
         if (b.ext == 101) return r.normx;
         return r.feats[b.ext];
@@ -244,83 +241,85 @@ struct Builder {
         if (it == P.L.e.end()) abort();
         return it->second;
     }
+    void push(std::function<void(RunCtx&)> fn) {
+        Step st;
+        st.kind = S_KERNEL; st.stream = cur; st.label = cur_label; st.fn = std::move(fn);
+        st.klass = cur_class; st.flops = cur_flops; st.bytes = cur_bytes;
+        P.steps.push_back(std::move(st));
+    }
+    // child stream starts after everything issued so far on the current stream
+    void fork(int child) {
+        if (!concurrent) return;
+        const int ev = P.n_events++;
+        Step a; a.kind = S_RECORD; a.stream = cur; a.event = ev; a.label = "fork";
+        Step b; b.kind = S_WAIT; b.stream = child; b.event = ev; b.label = "fork";
+        P.steps.push_back(a);
+        P.steps.push_back(b);
+        if (child + 1 > P.n_streams) P.n_streams = child + 1;
+    }
+    // current stream waits for everything issued so far on the child stream
+    void join(int child) {
+        if (!concurrent) return;
+        const int ev = P.n_events++;
+        Step a; a.kind = S_RECORD; a.stream = child; a.event = ev; a.label = "join";
+        Step b; b.kind = S_WAIT; b.stream = cur; b.event = ev; b.label = "join";
+        P.steps.push_back(a);
+        P.steps.push_back(b);
+    }
 
     // ---- op emitters ----
-    // GroupNorm statistics of view (x, co, C) -> scale/shift for `gn` (and optionally a second set
-    // `gn2` sharing the same statistics: bn1 / bn4 of a ConvBlock normalise the same tensor)
-    void gn_stats(const Buf& x, int co, int C, const std::string& gn, size_t ss, const std::string* gn2 = nullptr,
-                  size_t ss2 = 0) {
-        const WEntry g = w(gn + ".weight"), bt = w(gn + ".bias");
-        WEntry g2{}, bt2{};
-        const bool two = gn2 != nullptr;
-        if (two) { g2 = w(*gn2 + ".weight"); bt2 = w(*gn2 + ".bias"); }
-        const size_t poff = partial_off;
-        const int HW = x.H * x.W;
-        if (x.st.valid && x.st.usable && co == 0 && C == x.C) {   // statistics already produced by the conv epilogues
-            const StatInfo st = x.st;
-            cur_label = "gn_finalize_tiles " + gn;
-            cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * st.max_tiles * C * 8;
-            const int Bn = B;
-            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
-                if (r.rc) return;
-                TileStats ts;
-                ts.p = (const float*)(r.ws + st.off);
-                ts.max_tiles = st.max_tiles; ts.nslices = st.nslices;
-                for (int i = 0; i < 3; ++i) { ts.c_end[i] = st.c_end[i]; ts.ntiles[i] = st.ntiles[i]; }
-                r.rc = launch_gn_finalize_tiles(r.h, ts, Bn, HW, C, (const float*)(r.arena + g.off),
-                                                (const float*)(r.arena + bt.off), (float*)(r.ws + ss), r.s);
-                if (r.rc || !two) return;
-                r.rc = launch_gn_finalize_tiles(r.h, ts, Bn, HW, C, (const float*)(r.arena + g2.off),
-                                                (const float*)(r.arena + bt2.off), (float*)(r.ws + ss2), r.s);
-            }, cur_class, cur_flops, cur_bytes});
-            return;
-        }
-        cur_label = "gn_stats " + gn;
-        cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * HW * C * es();
-        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+    // make sure `x` carries statistics (tensors written by pool / upadd / stem get a stats pass)
+    void ensure_stats(Buf& x) {
+        if (x.st_valid) return;
+        new_stats(x);
+        const Buf xb = x;
+        const int HW = x.H * x.W, Bn = B;
+        cur_label = "gn_stats";
+        cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * HW * x.C * es();
+        push([=](RunCtx& r) {
             if (r.rc) return;
-            float* partial = (float*)(r.ws + poff);
-            r.rc = launch_gn_partial(r.h, r.dtype, view(r, x, co, C), Bn, HW, partial, r.s);
-            if (r.rc) return;
-            r.rc = launch_gn_finalize(r.h, partial, Bn, HW, C, (const float*)(r.arena + g.off),
-                                      (const float*)(r.arena + bt.off), (float*)(r.ws + ss), r.s);
-            if (r.rc || !two) return;
-            r.rc = launch_gn_finalize(r.h, partial, Bn, HW, C, (const float*)(r.arena + g2.off),
-                                      (const float*)(r.arena + bt2.off), (float*)(r.ws + ss2), r.s);
-        }, cur_class, cur_flops, cur_bytes});
+            r.rc = launch_gn_stats(r.h, r.dtype, view(r, xb), Bn, HW, (ChanStat*)(r.stats + xb.st_off), r.s);
+        });
     }
 
     struct ConvSpec {
-        Buf in; int in_co = 0, in_C = 0;
-        bool use_ss = false; size_t ss = 0;
+        Buf in; int in_C = 0;
+        std::string gn;                        // GroupNorm (+ReLU) fused into the operand load ("" = none)
         std::string wname; bool bias = false;
         Buf out; int out_co = 0;
         bool has_raw = false; Buf raw; int raw_co = 0;
         bool has_res = false; Buf res; int res_co = 0;
         bool has_res2 = false; Buf res2; int res2_co = 0;
         int taps = 9, cout = 0;
-        bool stat_raw = false, stat_out = false;   // emit GroupNorm tile partials into raw.st / out.st
+        bool stat_raw = false, stat_out = false;   // accumulate GroupNorm statistics of raw / out
     };
     void conv(const ConvSpec& c) {
         const WEntry we = w(c.wname + ".weight");
-        WEntry be{};
+        WEntry be{}, ge{}, bte{};
         if (c.bias) be = w(c.wname + ".bias");
+        const bool use_gn = !c.gn.empty();
+        if (use_gn) { ge = w(c.gn + ".weight"); bte = w(c.gn + ".bias"); }
+        if (use_gn && (!c.in.st_valid || c.in_C != c.in.C)) abort();
         const ConvSpec cs = c;
         cur_label = "conv " + c.wname + " taps=" + std::to_string(c.taps) + " cin=" + std::to_string(c.in_C) +
                     " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
         {
             const double px = (double)B * c.in.H * c.in.W;
-            cur_class = c.taps == 1 ? K_CONV1 : (c.cout % 128 == 0 ? K_CONV3_128 : (c.cout == 64 ? K_CONV3_64 : K_CONV3_32));
+            const int nt = conv_plan(c.taps, B, c.in.H, c.in.W, c.cout).nt;
+            cur_class = c.taps == 1 ? K_CONV1 : (nt == 128 ? K_CONV3_128 : (nt == 64 ? K_CONV3_64 : K_CONV3_32));
             cur_flops = 2.0 * c.taps * c.in_C * c.cout * px;
             cur_bytes = px * es() * (c.in_C + c.cout * (1 + (c.has_raw ? 1 : 0) + (c.has_res ? 1 : 0) + (c.has_res2 ? 1 : 0)));
         }
-        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+        const int Bn = B;
+        push([=](RunCtx& r) {
             if (r.rc) return;
             ConvArgs a{};
-            a.in = view(r, cs.in, cs.in_co, cs.in_C);
-            a.ss = cs.use_ss ? (const float*)(r.ws + cs.ss) : nullptr;
+            a.in = view(r, cs.in, 0, cs.in_C);
+            if (use_gn) {
+                a.in_st = (const ChanStat*)(r.stats + cs.in.st_off);
+                a.gamma = (const float*)(r.arena + ge.off);
+                a.beta = (const float*)(r.arena + bte.off);
+            }
             a.wpk = r.arena + we.off;
             a.bias = cs.bias ? (const float*)(r.arena + be.off) : nullptr;
             a.out = view(r, cs.out, cs.out_co, cs.cout);
@@ -329,66 +328,47 @@ struct Builder {
             if (cs.has_res2) a.res2 = view(r, cs.res2, cs.res2_co, cs.cout);
             a.B = Bn; a.H = cs.in.H; a.W = cs.in.W; a.Cout = cs.cout;
             if (cs.stat_raw) {
-                a.st_raw = (float*)(r.ws + cs.raw.st.off); a.st_raw_C = cs.raw.C; a.st_raw_co = cs.raw_co;
-                a.st_raw_tiles = cs.raw.st.max_tiles;
+                a.st_raw = (ChanStat*)(r.stats + cs.raw.st_off); a.st_raw_C = cs.raw.C; a.st_raw_co = cs.raw_co;
             }
             if (cs.stat_out) {
-                a.st_out = (float*)(r.ws + cs.out.st.off); a.st_out_C = cs.out.C; a.st_out_co = cs.out_co;
-                a.st_out_tiles = cs.out.st.max_tiles;
+                a.st_out = (ChanStat*)(r.stats + cs.out.st_off); a.st_out_C = cs.out.C; a.st_out_co = cs.out_co;
             }
             r.rc = launch_conv(r.h, r.dtype, cs.taps, a, r.s);
-        }, cur_class, cur_flops, cur_bytes});
+        });
     }
 
-    // ConvBlock (net_util.py:374-396): y = cat(o1,o2,o3) + residual.  `out` may be an external tensor.
-    Buf conv_block(const Buf& x, const std::string& n, int cin, int cout, const Buf* out_opt = nullptr) {
+    // ConvBlock (net_util.py:374-396): y = cat(o1,o2,o3) + residual; x must carry statistics
+    Buf conv_block(Buf& x, const std::string& n, int cin, int cout) {
         const int H = x.H, W = x.W;
-        Buf out = out_opt ? *out_opt : alloc(H, W, cout);
+        ensure_stats(x);
+        Buf out = alloc(H, W, cout);
         Buf o1 = alloc(H, W, cout / 2), o2 = alloc(H, W, cout / 4);
-        {
-            const int ce_out[3] = {cout / 2, 3 * cout / 4, cout}, co_out[3] = {cout / 2, cout / 4, cout / 4};
-            attach_stats(out, 9, 3, ce_out, co_out);
-            const int ce1[1] = {cout / 2}, co1[1] = {cout / 2}, ce2[1] = {cout / 4}, co2[1] = {cout / 4};
-            attach_stats(o1, 9, 1, ce1, co1);
-            attach_stats(o2, 9, 1, ce2, co2);
-        }
-        const size_t ss1 = alloc_ss(cin);
+        new_stats(out);
+        new_stats(o1);
+        new_stats(o2);
         Buf res = x;
         if (cin != cout) {
-            const size_t ss4 = alloc_ss(cin);
-            const std::string bn4 = n + ".bn4";
-            gn_stats(x, 0, cin, n + ".bn1", ss1, &bn4, ss4);
             ConvSpec d;  // residual = conv1x1(relu(gn4(x)))
-            d.in = x; d.in_C = cin; d.use_ss = true; d.ss = ss4; d.wname = n + ".downsample.2";
+            d.in = x; d.in_C = cin; d.gn = n + ".bn4"; d.wname = n + ".downsample.2";
             d.out = out; d.taps = 1; d.cout = cout;
             conv(d);
-            release_ss(ss4, cin);
             res = out;
-        } else {
-            gn_stats(x, 0, cin, n + ".bn1", ss1);
         }
         ConvSpec c1;
-        c1.in = x; c1.in_C = cin; c1.use_ss = true; c1.ss = ss1; c1.wname = n + ".conv1";
+        c1.in = x; c1.in_C = cin; c1.gn = n + ".bn1"; c1.wname = n + ".conv1";
         c1.out = out; c1.out_co = 0; c1.has_raw = true; c1.raw = o1; c1.has_res = true; c1.res = res; c1.res_co = 0;
         c1.cout = cout / 2; c1.stat_raw = true; c1.stat_out = true;
         conv(c1);
-        release_ss(ss1, cin);
-        const size_t ss2 = alloc_ss(cout / 2);
-        gn_stats(o1, 0, cout / 2, n + ".bn2", ss2);
         ConvSpec c2;
-        c2.in = o1; c2.in_C = cout / 2; c2.use_ss = true; c2.ss = ss2; c2.wname = n + ".conv2";
+        c2.in = o1; c2.in_C = cout / 2; c2.gn = n + ".bn2"; c2.wname = n + ".conv2";
         c2.out = out; c2.out_co = cout / 2; c2.has_raw = true; c2.raw = o2; c2.has_res = true; c2.res = res;
         c2.res_co = cout / 2; c2.cout = cout / 4; c2.stat_raw = true; c2.stat_out = true;
         conv(c2);
-        release_ss(ss2, cout / 2);
-        const size_t ss3 = alloc_ss(cout / 4);
-        gn_stats(o2, 0, cout / 4, n + ".bn3", ss3);
         ConvSpec c3;
-        c3.in = o2; c3.in_C = cout / 4; c3.use_ss = true; c3.ss = ss3; c3.wname = n + ".conv3";
+        c3.in = o2; c3.in_C = cout / 4; c3.gn = n + ".bn3"; c3.wname = n + ".conv3";
         c3.out = out; c3.out_co = 3 * cout / 4; c3.has_res = true; c3.res = res; c3.res_co = 3 * cout / 4;
         c3.cout = cout / 4; c3.stat_out = true;
         conv(c3);
-        release_ss(ss3, cout / 4);
         release(o1);
         release(o2);
         return out;
@@ -398,27 +378,36 @@ struct Builder {
         Buf y = out_opt ? *out_opt : alloc(x.H / 2, x.W / 2, x.C);
         cur_label = "avgpool2";
         cur_class = K_POOL; cur_flops = 0.0; cur_bytes = (double)B * x.H * x.W * x.C * es() * 1.25;
-        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+        const int Bn = B;
+        push([=](RunCtx& r) {
             if (r.rc) return;
             r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W, r.s);
-        }, cur_class, cur_flops, cur_bytes});
+        });
         return y;
     }
-    void upadd(const Buf& a, const Buf& low) {  // a += bicubic_up2(low)
+    void upadd(Buf& a, const Buf& low) {  // a += bicubic_up2(low)
         cur_label = "upadd";
         cur_class = K_UPADD; cur_flops = 0.0; cur_bytes = (double)B * low.H * low.W * low.C * es() * 9.0;
-        const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-        P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+        const Buf ab = a;
+        const int Bn = B;
+        push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_upadd(r.h, r.dtype, view(r, a), view(r, low), view(r, a), Bn, low.H, low.W, r.s);
-        }, cur_class, cur_flops, cur_bytes});
+            r.rc = launch_upadd(r.h, r.dtype, view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W, r.s);
+        });
+        a.st_valid = false;   // modified in place: the producers' statistics no longer describe it
     }
 
-    // HourGlass._forward (HGFilters.py:26-50)
-    Buf hourglass(const Buf& x, const std::string& n, int level) {
+    // HourGlass._forward (HGFilters.py:26-50).  The upper branch (b1 at full resolution) is independent
+    // of the whole lower branch: it runs on its own stream.
+    Buf hourglass(Buf& x, const std::string& n, int level) {
         const std::string l = std::to_string(level);
+        const int child = P.cfg.num_hourglass - level + 1;   // 1 for the outermost level
+        ensure_stats(x);   // on the current stream, before the fork: both branches read them
+        const int parent = cur;
+        fork(child);
+        if (concurrent) cur = child;
         Buf up1 = conv_block(x, n + ".b1_" + l, 256, 256);
+        cur = parent;
         Buf pooled = pool2(x);
         Buf low1 = conv_block(pooled, n + ".b2_" + l, 256, 256);
         release(pooled);
@@ -426,8 +415,8 @@ struct Builder {
         release(low1);
         Buf low3 = conv_block(low2, n + ".b3_" + l, 256, 256);
         release(low2);
+        join(child);
         upadd(up1, low3);
-        up1.st.usable = false;   // modified in place: the conv-epilogue statistics no longer describe it
         release(low3);
         return up1;
     }
@@ -436,6 +425,13 @@ struct Builder {
         const chore_encoder_cfg& cfg = P.cfg;
         const std::string p = "image_filter.";
         const int H2 = P.H / 2, W2 = P.W / 2, H4 = P.H / 4, W4 = P.W / 4;
+        const int Bn = B;
+        // zero the statistics accumulators of this pass (one memset; the arena is never reused inside a pass)
+        {
+            Step st;
+            st.kind = S_MEMSET; st.stream = 0; st.label = "zero stats";
+            P.steps.push_back(st);
+        }
         // stem: conv7x7/2 + GN + ReLU -> tmpx (HGFilters.py:149-150)
         Buf c1 = alloc(H2, W2, 64);
         {
@@ -444,26 +440,25 @@ struct Builder {
             cur_label = "stem";
             cur_class = K_STEM; cur_flops = 2.0 * 49 * Cin * 64 * (double)B * (H / 2) * (W / 2);
             cur_bytes = (double)B * H * W * Cin * 4 + (double)B * (H / 2) * (W / 2) * 64 * es();
-            const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+            push([=](RunCtx& r) {
                 if (r.rc) return;
                 r.rc = launch_stem(r.h, r.dtype, r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
                                    (const float*)(r.arena + be.off), ptr(r, c1), r.s);
-            }, cur_class, cur_flops, cur_bytes});
+            });
         }
         Buf tmpx = external(100, H2, W2, 64);
         {
-            const size_t ss = alloc_ss(64);
-            gn_stats(c1, 0, 64, p + "bn1", ss);
+            ensure_stats(c1);
+            const WEntry ge = w(p + "bn1.weight"), bte = w(p + "bn1.bias");
+            const Buf c1b = c1;
             cur_label = "gn_apply_relu bn1";
             cur_class = K_GN_APPLY; cur_flops = 0.0; cur_bytes = 2.0 * B * H2 * W2 * 64 * es();
-            const int Bn = B;  // lambdas must not capture `this` (the Builder dies after build())
-            P.steps.push_back(Step{cur_label, [=](RunCtx& r) {
+            push([=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1), (const float*)(r.ws + ss), view(r, tmpx), Bn,
-                                            H2 * W2, r.s);
-            }, cur_class, cur_flops, cur_bytes});
-            release_ss(ss, 64);
+                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1b), (const ChanStat*)(r.stats + c1b.st_off),
+                                            (const float*)(r.arena + ge.off), (const float*)(r.arena + bte.off),
+                                            view(r, tmpx), Bn, H2 * W2, r.s);
+            });
         }
         release(c1);
         Buf b2 = conv_block(tmpx, p + "conv2", 64, 128);
@@ -480,31 +475,23 @@ struct Builder {
             Buf t1 = conv_block(hg, p + "top_m_" + s, 256, 256);
             release(hg);
             Buf t2 = alloc(H4, W4, 256);
-            {
-                const int ce[1] = {256}, co[1] = {256};
-                attach_stats(t2, 1, 1, ce, co);
-            }
+            new_stats(t2);
             ConvSpec cl;
             cl.in = t1; cl.in_C = 256; cl.wname = p + "conv_last" + s; cl.bias = true; cl.out = t2; cl.taps = 1;
             cl.cout = 256; cl.stat_out = true;
             conv(cl);
             release(t1);
-            const size_t ss = alloc_ss(256);
-            gn_stats(t2, 0, 256, p + "bn_end" + s, ss);
             const int oi = i - (cfg.num_stack - P.n_out);
             Buf out_i = (oi >= 0) ? external(oi, H4, W4, 256) : alloc(H4, W4, 256);
             ConvSpec l;
-            l.in = t2; l.in_C = 256; l.use_ss = true; l.ss = ss; l.wname = p + "l" + s; l.bias = true; l.out = out_i;
+            l.in = t2; l.in_C = 256; l.gn = p + "bn_end" + s; l.wname = p + "l" + s; l.bias = true; l.out = out_i;
             l.taps = 1; l.cout = cfg.hourglass_dim;
             conv(l);
             if (i < cfg.num_stack - 1) {
                 Buf nprev = alloc(H4, W4, 256);
-                {
-                    const int ce[1] = {256}, co[1] = {256};
-                    attach_stats(nprev, 1, 1, ce, co);
-                }
+                new_stats(nprev);
                 ConvSpec bl;
-                bl.in = t2; bl.in_C = 256; bl.use_ss = true; bl.ss = ss; bl.wname = p + "bl" + s; bl.bias = true;
+                bl.in = t2; bl.in_C = 256; bl.gn = p + "bn_end" + s; bl.wname = p + "bl" + s; bl.bias = true;
                 bl.out = nprev; bl.has_res = true; bl.res = previous; bl.taps = 1; bl.cout = 256;
                 conv(bl);
                 ConvSpec al;
@@ -514,18 +501,26 @@ struct Builder {
                 release(previous);
                 previous = nprev;
             }
-            release_ss(ss, 256);
             release(t2);
             release(out_i);
         }
         release(previous);
-        P.ws_bytes = align_up(pool.top, 256);
+        // workspace layout: [pool 0][pool 1]...[stats arena]
+        size_t off = 0;
+        for (int i = 0; i < MAX_STREAMS; ++i) {
+            P.pool_off[i] = off;
+            off += align_up(pools[i].top, 256);
+        }
+        P.stats_off = off;
+        P.stats_bytes = align_up(stat_top, 256);
+        P.ws_bytes = off + P.stats_bytes;
     }
 };
 
 struct EncCache {
     std::vector<std::unique_ptr<Program>> progs;
     Profile prof;
+    hipStream_t aux[MAX_STREAMS] = {nullptr};   // [0] unused (caller's stream)
 };
 
 Program* get_program(chore_handle* h, const chore_encoder_cfg& cfg, int B, int H, int W, int dtype, int n_out,
@@ -569,7 +564,13 @@ extern "C" {
 
 void chore_encoder_cache_free(chore_handle* h) {
     if (h && h->enc_cache) {
-        delete (EncCache*)h->enc_cache;
+        EncCache* c = (EncCache*)h->enc_cache;
+        for (int i = 1; i < MAX_STREAMS; ++i)
+            if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+        for (auto& p : c->progs)
+            for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
+        for (hipEvent_t e : c->prof.ev) (void)hipEventDestroy(e);
+        delete c;
         h->enc_cache = nullptr;
     }
 }
@@ -638,43 +639,71 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     Program* P = get_program(h, *cfg, B, H, W, dtype, n_stack_out, normx != nullptr);
     if (workspace_bytes < P->ws_bytes)
         CHORE_FAIL(h, CHORE_ENOMEM, "chore_encode_fwd: workspace %zu < %zu bytes", workspace_bytes, P->ws_bytes);
+    EncCache* cache = (EncCache*)h->enc_cache;
+    hipStream_t streams[MAX_STREAMS];
+    streams[0] = (hipStream_t)stream;
+    for (int i = 1; i < P->n_streams; ++i) {   // auxiliary streams / events are created once, not per call
+        if (!cache->aux[i]) CHORE_HIP_CHECK(h, hipStreamCreateWithFlags(&cache->aux[i], hipStreamNonBlocking));
+        streams[i] = cache->aux[i];
+    }
+    while ((int)P->events.size() < P->n_events) {
+        hipEvent_t e;
+        CHORE_HIP_CHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        P->events.push_back(e);
+    }
     RunCtx r;
-    r.h = h; r.dtype = dtype; r.s = (hipStream_t)stream; r.ws = (char*)workspace; r.arena = (const char*)arena;
+    r.h = h; r.dtype = dtype; r.s = streams[0]; r.arena = (const char*)arena;
+    for (int i = 0; i < MAX_STREAMS; ++i) r.pool_base[i] = (char*)workspace + P->pool_off[i];
+    r.stats = (char*)workspace + P->stats_off;
     r.images = images; r.feats = feat_out; r.tmpx = tmpx; r.normx = normx;
     static const bool debug_sync = getenv("CHORE_DEBUG_SYNC") != nullptr;
-    Profile& prof = ((EncCache*)h->enc_cache)->prof;
-    if (prof.on) {  // bench/roofline aid: bracket every step with events on the caller's stream
+    Profile& prof = cache->prof;
+    const bool serial = prof.on || debug_sync;   // attribution / debugging: everything on the caller's stream
+    if (prof.on) {
         const size_t need = 2 * P->steps.size();
         while (prof.ev.size() < need) {
             hipEvent_t e;
             CHORE_HIP_CHECK(h, hipEventCreate(&e));
             prof.ev.push_back(e);
         }
-        for (size_t i = 0; i < P->steps.size(); ++i) {
-            CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i], r.s));
-            P->steps[i].fn(r);
-            if (r.rc) return r.rc;
-            CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i + 1], r.s));
+    }
+    for (size_t i = 0; i < P->steps.size(); ++i) {
+        Step& st = P->steps[i];
+        hipStream_t ss = serial ? streams[0] : streams[st.stream];
+        if (st.kind == S_RECORD) {
+            if (!serial) CHORE_HIP_CHECK(h, hipEventRecord(P->events[st.event], ss));
+            continue;
         }
-        CHORE_HIP_CHECK(h, hipStreamSynchronize(r.s));
+        if (st.kind == S_WAIT) {
+            if (!serial) CHORE_HIP_CHECK(h, hipStreamWaitEvent(ss, P->events[st.event], 0));
+            continue;
+        }
+        if (st.kind == S_MEMSET) {
+            CHORE_HIP_CHECK(h, hipMemsetAsync(r.stats, 0, P->stats_bytes, ss));
+            continue;
+        }
+        r.s = ss;
+        if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i], ss));
+        st.fn(r);
+        if (r.rc) return r.rc;
+        if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i + 1], ss));
+        if (debug_sync) {
+            fprintf(stderr, "[chore] step %s\n", st.label.c_str());
+            hipError_t e = hipStreamSynchronize(ss);
+            if (e != hipSuccess) CHORE_FAIL(h, CHORE_EHIP, "step '%s' failed: %s", st.label.c_str(), hipGetErrorString(e));
+        }
+    }
+    if (prof.on) {
+        CHORE_HIP_CHECK(h, hipStreamSynchronize(streams[0]));
         for (size_t i = 0; i < P->steps.size(); ++i) {
+            const Step& st = P->steps[i];
+            if (st.kind != S_KERNEL) continue;
             float ms = 0.f;
             CHORE_HIP_CHECK(h, hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]));
-            const Step& st = P->steps[i];
             prof.ms[st.klass] += ms;
             prof.flops[st.klass] += st.flops;
             prof.bytes[st.klass] += st.bytes;
             prof.launches[st.klass] += 1;
-        }
-        return CHORE_OK;
-    }
-    for (auto& st : P->steps) {
-        st.fn(r);
-        if (r.rc) return r.rc;
-        if (debug_sync) {
-            fprintf(stderr, "[chore] step %s\n", st.label.c_str());
-            hipError_t e = hipStreamSynchronize(r.s);
-            if (e != hipSuccess) CHORE_FAIL(h, CHORE_EHIP, "step '%s' failed: %s", st.label.c_str(), hipGetErrorString(e));
         }
     }
     return CHORE_OK;
