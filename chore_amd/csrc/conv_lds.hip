@@ -324,8 +324,44 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
 
+    // residual vectors of pixel row m are fetched one row ahead of their use (raw 16/32-byte loads)
+    constexpr int RV = sizeof(T) == 2 ? 1 : 2;               // u32x4 per 8 channels
+    u32x4 rq[2][NVE][RV], rq2[2][NVE][RV];
+    auto fetch_res = [&](int m, int slot) {
+        const int y = ty0 + wm * MB + m;
+#pragma unroll
+        for (int j = 0; j < NVE; ++j) {
+            const int x = tx0 + (lane + 64 * j) / G8;
+            const bool ok = (y < a.H) && (x < a.W);
+            const size_t pix = (size_t)y * a.W + x;
+#pragma unroll
+            for (int k = 0; k < RV; ++k) {
+                u32x4 z = {0u, 0u, 0u, 0u};
+                rq[slot][j][k] = (res_p && ok) ? *((const u32x4*)(res_p + pix * a.res.cs) + k) : z;
+                rq2[slot][j][k] = (res2_p && ok) ? *((const u32x4*)(res2_p + pix * a.res2.cs) + k) : z;
+            }
+        }
+    };
+    auto add_res = [&](float (&f)[8], const u32x4 (&v)[RV]) {
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f[2 * k] += __uint_as_float(v[0][k] << 16);
+                f[2 * k + 1] += __uint_as_float(v[0][k] & 0xffff0000u);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f[k] += __uint_as_float(v[0][k]);
+                f[4 + k] += __uint_as_float(v[RV - 1][k]);
+            }
+        }
+    };
+    fetch_res(0, 0);
+
 #pragma clang loop unroll(full)
     for (int m = 0; m < MB; ++m) {
+        if (m + 1 < MB) fetch_res(m + 1, (m + 1) & 1);
 #pragma clang loop unroll(full)
         for (int q = 0; q < NBW; ++q)
 #pragma clang loop unroll(full)
@@ -355,18 +391,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                         for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
                     }
                 }
-                if (res_p) {
-                    float g[8];
-                    load8<T>(res_p + pix * a.res.cs, g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += g[e];
-                }
-                if (res2_p) {
-                    float g[8];
-                    load8<T>(res2_p + pix * a.res2.cs, g);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[e] += g[e];
-                }
+                if (res_p) add_res(f, rq[m & 1][j]);
+                if (res2_p) add_res(f, rq2[m & 1][j]);
                 store8<T>(out_p + pix * a.out.cs, f);
                 if (want_stats) {
 #pragma unroll
@@ -407,6 +433,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
                 for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
             const int cg = n_tile * NT + tid;
+            if (a.dbg & 16) return;
             if (a.st_raw) {
                 ChanStat* o = a.st_raw + (size_t)b * a.st_raw_C + a.st_raw_co + cg;
                 stat_add(&o->sum, t[0]);
@@ -448,13 +475,14 @@ int launch_nt(chore_handle* h, int nt, const ConvArgs& a, hipStream_t s) {
 int tiles_of(int H, int W) { return ((W + TW - 1) / TW) * ((H + TH - 1) / TH); }
 
 // N-tile choice: the largest channel tile that still gives every CU about two workgroups
-int choose_nt(int B, int H, int W, int Cout) {
+int choose_nt(int dtype, int B, int H, int W, int Cout) {
     static const int nts[3] = {128, 64, 32};
     int best = 32;
     long best_wgs = -1;
     for (int i = 0; i < 3; ++i) {
         const int nt = nts[i];
         if (Cout % nt) continue;
+        if (nt == 128 && dtype == CHORE_F32) continue;   // the 4x2 fp32 register tile does not fit 256 VGPRs
         const long wgs = (long)B * tiles_of(H, W) * (Cout / nt);
         if (wgs >= 448) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
@@ -464,9 +492,9 @@ int choose_nt(int B, int H, int W, int Cout) {
 
 }  // namespace
 
-ConvPlan conv_plan(int taps, int B, int H, int W, int Cout) {
+ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cout) {
     (void)taps;
-    return ConvPlan{choose_nt(B, H, W, Cout), TH, tiles_of(H, W)};
+    return ConvPlan{choose_nt(dtype, B, H, W, Cout), TH, tiles_of(H, W)};
 }
 
 int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipStream_t s) {
@@ -478,7 +506,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
     ConvArgs a = a_in;
     a.dbg = dbg;
-    const int nt = choose_nt(a.B, a.H, a.W, a.Cout);
+    const int nt = choose_nt(dtype, a.B, a.H, a.W, a.Cout);
     if (dtype == CHORE_F32)
         return taps == 9 ? launch_nt<float, 9>(h, nt, a, s) : launch_nt<float, 1>(h, nt, a, s);
     return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, a, s) : launch_nt<bf16_t, 1>(h, nt, a, s);

@@ -86,7 +86,7 @@ struct ConvArgs {
 };
 
 struct ConvPlan { int nt, th, ntiles; };
-ConvPlan conv_plan(int taps, int B, int H, int W, int Cout);   // tile configuration launch_conv will use
+ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cout);   // tile configuration launch_conv will use
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);

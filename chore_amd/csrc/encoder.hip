@@ -305,7 +305,7 @@ struct Builder {
                     " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
         {
             const double px = (double)B * c.in.H * c.in.W;
-            const int nt = conv_plan(c.taps, B, c.in.H, c.in.W, c.cout).nt;
+            const int nt = conv_plan(dtype, c.taps, B, c.in.H, c.in.W, c.cout).nt;
             cur_class = c.taps == 1 ? K_CONV1 : (nt == 128 ? K_CONV3_128 : (nt == 64 ? K_CONV3_64 : K_CONV3_32));
             cur_flops = 2.0 * c.taps * c.in_C * c.cout * px;
             cur_bytes = px * es() * (c.in_C + c.cout * (1 + (c.has_raw ? 1 : 0) + (c.has_res ? 1 : 0) + (c.has_res2 ? 1 : 0)));
