@@ -49,6 +49,14 @@ SIGNATURES = {
     "chore_encode_fwd": (c_int, [c_void_p, POINTER(EncoderCfg), c_void_p, c_int, c_int, c_int, c_int,
                                  c_void_p, c_void_p, c_size_t, POINTER(c_void_p), c_int, c_void_p,
                                  c_void_p, c_void_p]),
+    "chore_smpl_arena_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "chore_smpl_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "chore_smpl_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                POINTER(c_int), c_void_p, c_void_p]),
+    "chore_smpl_lbs_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_smpl_lbs_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_profile_enable": (c_int, [c_void_p, c_int]),
     "chore_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),

@@ -67,3 +67,43 @@ def synth_points(B, N, seed=1):
 
 
 CROP_CENTER = (1008.0, 995.0)
+
+
+# ---- synthetic SMPL-H body model (the licensed SMPLH_{male,female}.pkl files are not redistributable) ----
+SMPLH_PARENTS = [-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19,
+                 20, 22, 23, 20, 25, 26, 20, 28, 29, 20, 31, 32, 20, 34, 35,
+                 21, 37, 38, 21, 40, 41, 21, 43, 44, 21, 46, 47, 21, 49, 50]
+
+
+def synth_smplh_model(seed: int = 0, V: int = 6890, num_betas: int = 10):
+    """A random model with SMPL-H's shapes and kinematic tree (52 joints, 459 pose blend directions):
+    v_template (V,3), shapedirs (V,3,num_betas), posedirs (V,3,459), J_regressor (52,V) dense with rows
+    summing to 1, weights (V,52) with 4 non-zeros per vertex summing to 1, parents (52,)."""
+    rs = np.random.RandomState(4000 + seed)
+    J = len(SMPLH_PARENTS)
+    vt = (rs.standard_normal((V, 3)) * np.array([0.25, 0.5, 0.12])).astype(np.float32)
+    shapedirs = (rs.standard_normal((V, 3, num_betas)) * 0.02).astype(np.float32)
+    posedirs = (rs.standard_normal((V, 3, (J - 1) * 9)) * 0.005).astype(np.float32)
+    jr = np.zeros((J, V), np.float32)
+    for j in range(J):
+        idx = rs.choice(V, 24, replace=False)
+        w = rs.random_sample(24).astype(np.float32)
+        jr[j, idx] = w / w.sum()
+    weights = np.zeros((V, J), np.float32)
+    for v0 in range(0, V, 1024):
+        n = min(1024, V - v0)
+        idx = np.stack([rs.choice(J, 4, replace=False) for _ in range(n)])
+        w = rs.random_sample((n, 4)).astype(np.float32) + 0.05
+        w /= w.sum(1, keepdims=True)
+        weights[np.arange(v0, v0 + n)[:, None], idx] = w
+    return dict(v_template=vt, shapedirs=shapedirs, posedirs=posedirs, J_regressor=jr, weights=weights,
+                parents=np.array(SMPLH_PARENTS, np.int32))
+
+
+def synth_smpl_params(B, seed=0):
+    """pose (B,156), betas (B,10), trans (B,3): moderate random articulation around the 2.2 m depth"""
+    rs = np.random.RandomState(5000 + seed)
+    pose = (rs.standard_normal((B, 156)) * 0.25).astype(np.float32)
+    betas = (rs.standard_normal((B, 10)) * 0.8).astype(np.float32)
+    trans = (rs.standard_normal((B, 3)) * 0.1 + np.array([0.0, 0.3, 2.2])).astype(np.float32)
+    return pose, betas, trans

@@ -139,6 +139,33 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
                      void* normx, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * SMPL / SMPL-H linear blend skinning  (replaces SMPL_Layer.forward,
+ * lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:72-175 -- batch_rodrigues
+ * rodrigues_layer.py:41-52, th_posemap_axisang / subtract_flat_id tensutils.py:6-53 -- and its
+ * autograd w.r.t. pose, betas and trans, which is what recon/recon_fit_behave.py:224-291 optimises)
+ *   model buffers (fp32, reference layouts): v_template (V,3), shapedirs (V,3,num_betas),
+ *   posedirs (V,3,9(J-1)), J_regressor (J,V) dense, weights (V,J); parents: HOST array of J ints
+ *   (kintree_table[0]; parents[0] ignored, parents[i] < i).
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_smpl_arena_bytes(int V, int J, int num_betas);
+size_t chore_smpl_workspace_bytes(int V, int J, int num_betas, int B);
+int chore_smpl_pack(chore_handle* h, int V, int J, int num_betas, const float* v_template,
+                    const float* shapedirs, const float* posedirs, const float* J_regressor,
+                    const float* weights, const int* parents_host, void* arena, chore_stream_t stream);
+/* pose (B,3J) axis-angle, betas (B,num_betas), trans (B,3), offsets (B,V,3) or NULL ->
+ * verts (B,V,3), joints (B,J,3), v_posed (B,V,3), naked (B,V,3).  `workspace` must be kept untouched
+ * until the matching chore_smpl_lbs_bwd call (it holds the rotations / transforms of this call). */
+int chore_smpl_lbs_fwd(chore_handle* h, const void* arena, int V, int J, int num_betas, const float* pose,
+                       const float* betas, const float* trans, const float* offsets, float scale, int B,
+                       float* verts, float* joints, float* v_posed, float* naked, void* workspace,
+                       chore_stream_t stream);
+/* g_verts (B,V,3) / g_joints (B,J,3) upstream gradients (either may be NULL) ->
+ * dpose (B,3J), dbetas (B,num_betas), dtrans (B,3) */
+int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num_betas, const float* pose,
+                       float scale, int B, const float* v_posed, const float* g_verts, const float* g_joints,
+                       float* dpose, float* dbetas, float* dtrans, void* workspace, chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch
  * with hipEvents on the caller's stream, synchronises at the end of the call and accumulates, per
  * kernel class, the elapsed milliseconds, the algorithmic FLOPs and bytes and the launch count.

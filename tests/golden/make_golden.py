@@ -147,6 +147,73 @@ def gen_encoder(net_eval):
                         tmpx_crop=tmpx[:, :, 128:132, 200:204])
 
 
+def gen_surface(net):
+    """reference Generator.approx_surface (recon/generator.py:50-79) for 3 projection steps on the
+    query_full inputs; the constructor (checkpoint folders) is bypassed"""
+    from recon.generator import Generator
+    g = np.load(os.path.join(HERE, "query_full.npz"))
+    gen = Generator.__new__(Generator)
+    gen.threshold, gen.filter_val = 2.0, 0.004
+    net.im_feat_list = [torch.from_numpy(g["feat"])]
+    net.tmpx = torch.from_numpy(g["tmpx"])
+    q = {"crop_center": torch.from_numpy(g["crop_center"])}
+    out = {}
+    for name in ("human", "object"):
+        samples = torch.from_numpy(g["points"]).clone().requires_grad_(True)
+        traj = []
+        for _ in range(3):
+            samples, preds = gen.approx_surface(net, samples, 1, q, df_type=name)
+            traj.append(samples.detach().numpy().copy())
+        out["traj_" + name] = np.stack(traj)
+        out["df_" + name] = preds[0].detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "surface_steps.npz"), **out)
+
+
+def gen_smpl():
+    """reference SMPL_Layer.forward on the synthetic SMPL-H model (constructor bypassed: it needs the
+    licensed pkl + chumpy) and autograd gradients of a random linear functional of (verts, joints)"""
+    for m in ("chumpy", "chumpy.ch"):   # only imported by the (unused here) pkl loader of the layer
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["chumpy.ch"].MatVecMult = None
+    sys.modules["chumpy"].ch = sys.modules["chumpy.ch"]
+    sys.modules["chumpy"].Ch = object   # base class of the chumpy Rodrigues node defined at import time
+    sys.path.insert(0, os.path.join(REF, "lib_smpl", "smplpytorch"))
+    from smplpytorch.pytorch.smpl_layer import SMPL_Layer
+    model = synth.synth_smplh_model(seed=0)
+    layer = SMPL_Layer.__new__(SMPL_Layer)
+    torch.nn.Module.__init__(layer)
+    layer.hands = True
+    layer.center_idx = None
+    layer.register_buffer("th_betas", torch.zeros(1, 10))
+    layer.register_buffer("th_shapedirs", torch.from_numpy(model["shapedirs"]))
+    layer.register_buffer("th_posedirs", torch.from_numpy(model["posedirs"]))
+    layer.register_buffer("th_v_template", torch.from_numpy(model["v_template"]).unsqueeze(0))
+    layer.register_buffer("th_J_regressor", torch.from_numpy(model["J_regressor"]))
+    layer.register_buffer("th_weights", torch.from_numpy(model["weights"]))
+    layer.kintree_parents = [int(p) for p in model["parents"]]
+    layer.num_joints = 52
+    B = 2
+    pose, betas, trans = synth.synth_smpl_params(B, seed=0)
+    pose[1, 6:9] = 0.0          # a zero rotation exercises the +1e-8 branch of batch_rodrigues
+    tp = torch.from_numpy(pose).requires_grad_(True)
+    tb = torch.from_numpy(betas).requires_grad_(True)
+    tt = torch.from_numpy(trans).requires_grad_(True)
+    rs = np.random.RandomState(15)
+    offs = (rs.standard_normal((B, 6890, 3)) * 0.003).astype(np.float32)
+    verts, jtr, v_posed, naked = layer(tp, th_betas=tb, th_trans=tt, th_offsets=torch.from_numpy(offs))
+    wv = rs.standard_normal(verts.shape).astype(np.float32)
+    wj = rs.standard_normal(jtr.shape).astype(np.float32)
+    loss = (verts * torch.from_numpy(wv)).sum() + (jtr * torch.from_numpy(wj)).sum()
+    loss.backward()
+    sel = rs.choice(6890, 600, replace=False)
+    np.savez_compressed(os.path.join(HERE, "smpl_lbs.npz"), pose=pose, betas=betas, trans=trans, offsets_seed=15,
+                        sel=sel, verts_sel=verts.detach().numpy()[:, sel], joints=jtr.detach().numpy(),
+                        v_posed_sel=v_posed.detach().numpy()[:, sel], naked_sel=naked.detach().numpy()[:, sel],
+                        verts_sum=verts.detach().numpy().sum(1), verts_abs=np.abs(verts.detach().numpy()).sum(1),
+                        w_joints=wj, w_verts_seed=15, dpose=tp.grad.numpy(), dbetas=tb.grad.numpy(),
+                        dtrans=tt.grad.numpy())
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -159,6 +226,8 @@ def main():
     gen_heads(net)
     gen_query(net)
     gen_encoder(net)
+    gen_surface(net)
+    gen_smpl()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
