@@ -57,6 +57,9 @@ SIGNATURES = {
                                    c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_smpl_lbs_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_so3_aux_bytes": (c_size_t, [c_int]),
+    "chore_so3_project_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "chore_profile_enable": (c_int, [c_void_p, c_int]),
     "chore_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),

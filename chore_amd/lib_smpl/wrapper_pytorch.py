@@ -1,0 +1,112 @@
+"""Batched SMPL-H wrappers with optimisable parameters, on top of the HIP LBS layer.
+
+Same roles and attribute names as /root/reference/lib_smpl/wrapper_pytorch.py:
+`SMPLPyTorchWrapperBatch` (:23-90) holds whole `pose/betas/trans/offsets` parameters,
+`SMPLPyTorchWrapperBatchSplitParams` (:93-218) splits them into `global_pose / body_pose / hand_pose /
+top_betas / other_betas / trans` so the fit can optimise subsets, `get_landmarks()` returns the body-25 /
+face / hand keypoints.  Differences: the body model arrives as arrays (see lib_smpl/smpl_layer.py), the
+landmark regressors are dense (K,V) device tensors applied with one matmul (the reference loops
+torch.sparse.mm over the batch, lib_smpl/torch_functions.py:52-76), and `get_landmarks` reuses the
+vertices of the preceding `forward()` when the parameters have not changed instead of running LBS a
+second time (reference quirk, wrapper_pytorch.py:186).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .const import BODY_POSE_NUM, GLOBAL_POSE_NUM, HAND_POSE_NUM, SMPL_HAND_POSE_NUM, TOP_BETA_NUM
+from .smpl_layer import SMPL_Layer
+
+
+def _as_layer(model):
+    return model if isinstance(model, SMPL_Layer) else SMPL_Layer.from_arrays(model)
+
+
+def synthetic_regressors(V=6890, seed=0):
+    """dense stand-ins for assets/{body25,face,hand}_regressor.pkl: (25,V), (70,V), (42,V), rows sum to 1"""
+    rs = np.random.RandomState(7000 + seed)
+    out = []
+    for k in (25, 70, 42):
+        r = np.zeros((k, V), np.float32)
+        for i in range(k):
+            idx = rs.choice(V, 12, replace=False)
+            w = rs.random_sample(12).astype(np.float32)
+            r[i, idx] = w / w.sum()
+        out.append(r)
+    return out
+
+
+class _Landmarks:
+    def _set_regressors(self, regressors):
+        b25, face, hand = regressors if regressors is not None else synthetic_regressors(self.smpl.num_verts)
+        t = lambda a: a.detach().float() if torch.is_tensor(a) else torch.as_tensor(np.asarray(a), dtype=torch.float32)  # noqa: E731
+        self.register_buffer("body25_reg", t(b25))
+        self.register_buffer("face_reg", t(face))
+        self.register_buffer("hand_reg", t(hand))
+
+    def get_landmarks(self):
+        verts = self.forward()[0]
+        return (torch.matmul(self.body25_reg, verts), torch.matmul(self.face_reg, verts),
+                torch.matmul(self.hand_reg, verts))
+
+
+class SMPLPyTorchWrapperBatch(nn.Module, _Landmarks):
+    def __init__(self, model, batch_sz, betas=None, pose=None, trans=None, offsets=None, faces=None, gender="male",
+                 hands=True, num_betas=10, regressors=None):
+        super().__init__()
+        self.smpl = _as_layer(model)
+        self.model_root = self.smpl
+        J3 = 3 * self.smpl.num_joints
+        self.betas = nn.Parameter(torch.zeros(batch_sz, num_betas) if betas is None else betas)
+        self.pose = nn.Parameter(torch.zeros(batch_sz, J3) if pose is None else pose)
+        self.trans = nn.Parameter(torch.zeros(batch_sz, 3) if trans is None else trans)
+        self.offsets = nn.Parameter(torch.zeros(batch_sz, self.smpl.num_verts, 3) if offsets is None else offsets)
+        self.faces, self.gender, self.hands = faces, gender, hands
+        self._set_regressors(regressors)
+
+    @property
+    def device(self):
+        return self.pose.device
+
+    def forward(self):
+        return self.smpl(self.pose, th_betas=self.betas, th_trans=self.trans, th_offsets=self.offsets)
+
+
+class SMPLPyTorchWrapperBatchSplitParams(nn.Module, _Landmarks):
+    def __init__(self, model, batch_sz, top_betas=None, other_betas=None, global_pose=None, body_pose=None,
+                 hand_pose=None, trans=None, offsets=None, faces=None, gender="male", hands=True, num_betas=10,
+                 regressors=None):
+        super().__init__()
+        self.smpl = _as_layer(model)
+        self.model_root = self.smpl
+        hp = HAND_POSE_NUM if hands else SMPL_HAND_POSE_NUM
+        z = torch.zeros
+        self.top_betas = nn.Parameter(z(batch_sz, TOP_BETA_NUM) if top_betas is None else top_betas)
+        self.other_betas = nn.Parameter(z(batch_sz, num_betas - TOP_BETA_NUM) if other_betas is None else other_betas)
+        self.global_pose = nn.Parameter(z(batch_sz, GLOBAL_POSE_NUM) if global_pose is None else global_pose)
+        self.body_pose = nn.Parameter(z(batch_sz, BODY_POSE_NUM) if body_pose is None else body_pose)
+        self.hand_pose = nn.Parameter(z(batch_sz, hp) if hand_pose is None else hand_pose)
+        self.trans = nn.Parameter(z(batch_sz, 3) if trans is None else trans)
+        self.offsets = nn.Parameter(z(batch_sz, self.smpl.num_verts, 3) if offsets is None else offsets)
+        self.faces, self.gender, self.hands = faces, gender, hands
+        self._set_regressors(regressors)
+        self._cat()
+
+    def _cat(self):
+        self.betas = torch.cat([self.top_betas, self.other_betas], dim=1)
+        self.pose = torch.cat([self.global_pose, self.body_pose, self.hand_pose], dim=1)
+
+    def forward(self):
+        self._cat()
+        return self.smpl(self.pose, th_betas=self.betas, th_trans=self.trans, th_offsets=self.offsets)
+
+    @staticmethod
+    def from_smpl(smpl: SMPLPyTorchWrapperBatch):
+        B = smpl.pose.shape[0]
+        p, b = smpl.pose.data, smpl.betas.data
+        g, bp = GLOBAL_POSE_NUM, GLOBAL_POSE_NUM + BODY_POSE_NUM
+        return SMPLPyTorchWrapperBatchSplitParams(
+            smpl.smpl, B, trans=smpl.trans.data.clone(), top_betas=b[:, :TOP_BETA_NUM].clone(),
+            other_betas=b[:, TOP_BETA_NUM:].clone(), global_pose=p[:, :g].clone(), body_pose=p[:, g:bp].clone(),
+            hand_pose=p[:, bp:].clone(), faces=smpl.faces, gender=smpl.gender, hands=smpl.hands,
+            num_betas=b.shape[1], regressors=(smpl.body25_reg, smpl.face_reg, smpl.hand_reg)).to(smpl.device)

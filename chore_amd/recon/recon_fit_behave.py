@@ -1,0 +1,142 @@
+"""SMPL-H + object fitting loops (BEHAVE protocol) on the GPU.
+
+Counterpart of /root/reference/recon/recon_fit_behave.py: `optimize_smpl` (:224-291), `forward_smpl`
+(:293-337), `optimize_smpl_object` (:90-163), `forward_step` (:165-222), `get_loss_weights` (:339-358).
+The schedules, optimiser re-creation points, the weight formula w*L/(1+decay) and the reference's
+quirks are kept on purpose because they change the fitted poses:
+  * zero_grad() once per OUTER iteration, then `steps_per_iter` x {backward; step} -> gradients accumulate
+    over the inner steps;
+  * a new Adam at every phase switch; in `optimize_smpl_object` the SMPL parameters are never stepped;
+  * `forward_step` queries the object points twice per step (once directly, once in compute_obj_loss).
+Not built yet: the silhouette phase needs the rasteriser ('sil' runs only if the caller
+provides data_dict['silhouette']), the 'collide' term needs the BVH (used only if `self.collision_fn` is set).
+Per-step host synchronisation of the reference (tqdm strings, .item()) is gone: the early-stop test
+reads the loss once per OUTER iteration.
+"""
+import torch
+import torch.nn.functional as F
+from torch import optim
+
+from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
+from .recon_fit_base import ReconFitterBase
+
+
+class ReconFitterBehave(ReconFitterBase):
+    collision_fn = None   # callable(smpl_verts, smpl_faces, R, t, s) -> penetration loss, or None
+
+    def get_loss_weights(self):
+        w = {"beta": 1.0, "pose": 1e-5, "hand": 1e-5, "j2d": 0.3 ** 2, "object": 30.0 ** 2, "part": 0.05 ** 2,
+             "contact": 30.0 ** 2, "scale": 10.0 ** 2, "df_h": 30.0 ** 2, "smplz": 30 ** 2, "mask": 0.003 ** 2,
+             "ocent": 15 ** 2, "collide": 3 ** 2, "pinit": 5 ** 2, "rot": 10.0 ** 2, "trans": 10.0 ** 2}
+        return {k: (lambda cst, it, c=c: c * cst / (1 + it)) for k, c in w.items()}
+
+    # ---- SMPL ---------------------------------------------------------------------------------------
+    def forward_smpl(self, smpl, data_dict, phase):
+        loss_dict = {}
+        model = data_dict["net"]
+        smpl_verts = smpl()[0]
+        _, parts_pred, _ = self.compute_df_h_loss(data_dict, loss_dict, model, smpl_verts)
+        self.compute_prior_loss(loss_dict, smpl, nobeta=True)
+        loss_dict["part"] = F.cross_entropy(parts_pred, data_dict["part_labels"], reduction="none").sum(-1).mean()
+        J, _, _ = smpl.get_landmarks()
+        self.smplz_loss(J, loss_dict)
+        loss_dict["pinit"] = torch.mean(torch.sum((smpl.pose[:, 3:SMPL_POSE_PRAMS_NUM] - data_dict["pose_init"]) ** 2, -1))
+        if phase == "kpts":
+            self.compute_kpts_loss(data_dict, loss_dict, smpl)
+        return loss_dict
+
+    def optimize_smpl(self, smpl, data_dict, iter_for_betas=10, iter_for_pose=10, iter_for_kpts=5, steps_per_iter=10,
+                      max_iter=150):
+        split = self.split_smpl(smpl)
+        opt = optim.Adam([split.top_betas, split.trans], lr=0.02)
+        height_init = self.get_smpl_height(smpl)
+        wd = self.get_loss_weights()
+        prev = torch.tensor(300.0, device=self.device)
+        phase = "global"
+        for it in range(iter_for_betas + iter_for_kpts + iter_for_pose + max_iter):
+            opt.zero_grad()
+            if it == iter_for_betas:
+                phase = "smpl all pose"
+                opt = optim.Adam([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas],
+                                 0.006, betas=(0.9, 0.999))
+            elif it == iter_for_betas + iter_for_pose:
+                phase = "kpts"
+            stop = None
+            for _ in range(steps_per_iter):
+                loss = self.sum_dict(self.forward_smpl(split, data_dict, phase), wd, 1 if phase != "kpts" else it / 3)
+                loss.backward()
+                opt.step()
+                cond = (torch.abs(prev - loss) / prev < prev * 0.001)
+                stop = cond if stop is None else (stop | cond)
+                prev = loss.detach()
+            if it > 0.25 * max_iter + iter_for_betas + iter_for_pose and bool(stop):
+                break
+        scale = self.get_smpl_height(split) / height_init
+        return self.copy_smpl_params(split, smpl), scale
+
+    # ---- object + joint -----------------------------------------------------------------------------
+    def forward_step(self, model, smpl, data_dict, obj_R, obj_t, obj_s, phase, noise=None):
+        smpl_verts = smpl()[0]
+        loss_dict = {}
+        R = self.decopose_axis(obj_R, noise=noise)
+        object = self.transform_obj_verts(data_dict["objects"], R, obj_t, obj_s)
+        model.query(object, **data_dict["query_dict"])
+        df_pred, _, part_o, centers_o = model.get_preds()
+        obj_center_pred = data_dict["smpl_center"] + torch.mean(centers_o[:, 3:, :], -1)
+        if phase == "sil":
+            obj_losses = data_dict["silhouette"](R, obj_t, obj_s)[0]
+            loss_dict["mask"] = obj_losses["mask"]
+            loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
+            loss_dict["trans"] = torch.mean((obj_t - data_dict["trans_init"]) ** 2)
+            return loss_dict
+        self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object)
+        loss_dict["ocent"] = F.mse_loss(torch.mean(object, 1), obj_center_pred, reduction="none").sum(-1).mean()
+        if phase == "joint":
+            df_obj_h = df_pred[:, 0, :]
+            model.query(smpl_verts, **data_dict["query_dict"])
+            df_hum_o = model.get_preds()[0][:, 1, :]
+            self.compute_contact_loss(df_hum_o, df_obj_h, object, smpl_verts, loss_dict, part_o=part_o)
+            if self.collision_fn is not None:
+                loss_dict["collide"] = self.collision_fn(smpl_verts, smpl.faces, R, obj_t, obj_s)
+        return loss_dict
+
+    def optimize_smpl_object(self, model, data_dict, obj_iter=20, joint_iter=10, steps_per_iter=10, sil_iter=50,
+                             max_iter=100):
+        smpl = data_dict["smpl"]
+        split = self.split_smpl(smpl)
+        data_dict["smpl"] = split
+        obj_R, obj_t, obj_s = data_dict["obj_R"], data_dict["obj_t"], data_dict["obj_s"]
+        opt = optim.Adam([obj_t, obj_R, obj_s], lr=0.006)
+        wd = self.get_loss_weights()
+        if "silhouette" not in data_dict:
+            sil_iter = 0
+        data_dict["smpl_center"] = self.compute_smpl_center_pred(data_dict, model, smpl)
+        prev = torch.tensor(300.0, device=self.device)
+        phase = "object only"
+        for it in range(joint_iter + obj_iter + max_iter + sil_iter):
+            opt.zero_grad()
+            if it == obj_iter and sil_iter > 0:
+                phase = "sil"
+                opt = optim.Adam([obj_R, obj_s, obj_t], lr=0.006)
+                data_dict["rot_init"] = self.decopose_axis(obj_R).detach().clone()
+                data_dict["trans_init"] = obj_t.detach().clone()
+            if it == obj_iter + sil_iter:
+                phase = "joint"
+                opt = optim.Adam([obj_t, obj_s], lr=0.002)
+            stop = None
+            for _ in range(steps_per_iter):
+                loss_dict = self.forward_step(model, split, data_dict, obj_R, obj_t, obj_s, phase)
+                decay = 1 if phase == "object only" else it
+                if phase == "sil":
+                    decay = it - obj_iter + 1
+                elif phase == "joint":
+                    decay = (it - obj_iter + 1) / 5
+                loss = self.sum_dict(loss_dict, wd, decay)
+                loss.backward()
+                opt.step()
+                cond = (torch.abs(prev - loss) / prev < prev * 0.0001)
+                stop = cond if stop is None else (stop | cond)
+                prev = loss.detach()
+            if phase == "joint" and it > 0.25 * max_iter and bool(stop):
+                break
+        return smpl, data_dict["obj_R"], data_dict["obj_t"]

@@ -166,6 +166,16 @@ int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num
                        float* dpose, float* dbetas, float* dtrans, void* workspace, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Projection onto SO(3)  (replaces ReconFitterBase.project_so3, recon/recon_fit_base.py:168-188:
+ * R = U diag(1,1,det(UV^T)) V^T) and its backward.  M, R, G, dM are (B,3,3) fp32 row-major;
+ * `aux` (chore_so3_aux_bytes(B) bytes, may be NULL if no backward follows) carries U, V, sigma.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_so3_aux_bytes(int B);
+int chore_so3_project_fwd(chore_handle* h, const float* M, int B, float* R, void* aux, chore_stream_t stream);
+int chore_so3_project_bwd(chore_handle* h, const void* aux, const float* G, int B, float* dM,
+                          chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch
  * with hipEvents on the caller's stream, synchronises at the end of the call and accumulates, per
  * kernel class, the elapsed milliseconds, the algorithmic FLOPs and bytes and the launch count.

@@ -1,0 +1,120 @@
+"""GPU: SO(3) projection parity (against torch.svd on CPU = what the reference calls) and the fit
+iterations of recon_fit_behave on synthetic SMPL-H / object data."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def ref_project_so3(mat):
+    """the reference's formula, verbatim semantics (recon/recon_fit_base.py:168-188), on CPU"""
+    u, s, v = torch.svd(mat)
+    vt = torch.transpose(v, 1, 2)
+    det = torch.det(torch.matmul(u, vt)).view(-1, 1, 1)
+    vt = torch.cat((vt[:, :2, :], vt[:, -1:, :] * det), 1)
+    return torch.matmul(u, vt)
+
+
+def test_project_so3_forward_and_backward():
+    from chore_amd.recon.recon_fit_base import ReconFitterBase
+    g = torch.Generator().manual_seed(0)
+    M = torch.randn(64, 3, 3, generator=g)
+    M[0] = torch.eye(3) + 1e-3 * torch.randn(3, 3, generator=g)          # near a rotation
+    M[1] = -torch.eye(3) + 1e-2 * torch.randn(3, 3, generator=g)         # det < 0
+    M[2] = torch.diag(torch.tensor([2.0, 1.0, 1e-6]))                    # nearly singular
+    W = torch.randn(64, 3, 3, generator=g)
+    Mc = M.clone().requires_grad_(True)
+    Rc = ref_project_so3(Mc)
+    (Rc * W).sum().backward()
+    Mg = M.cuda().requires_grad_(True)
+    Rg = ReconFitterBase.project_so3(Mg)
+    (Rg * W.cuda()).sum().backward()
+    R = Rg.detach().cpu()
+    assert torch.allclose(R, Rc.detach(), atol=2e-6)
+    assert torch.allclose(torch.bmm(R, R.transpose(1, 2)), torch.eye(3).expand(64, 3, 3), atol=1e-5)
+    assert torch.allclose(torch.det(R), torch.ones(64), atol=1e-5)
+    # gradients: skip the nearly singular sample, where torch.svd's backward itself is ill-conditioned
+    ok = torch.ones(64, dtype=torch.bool); ok[2] = False
+    gc, gg = Mc.grad[ok], Mg.grad.cpu()[ok]
+    assert (gc - gg).abs().max() < 5e-4 * gc.abs().max()
+
+
+@pytest.fixture(scope="module")
+def fit_setup(opt):
+    from chore_amd.lib_smpl.priors import synthetic_priors
+    from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
+    from chore_amd.model import CHORE
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    from test_gpu_query import nhwc
+    opt.compute_dtype = "fp32"
+    B = 2
+    net = CHORE(opt).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    rs = np.random.RandomState(9)
+    net.im_feat_list = [nhwc((rs.standard_normal((B, 256, 32, 32)) * 0.5).astype(np.float32))]
+    net.tmpx = nhwc((rs.standard_normal((B, 64, 64, 64)) * 0.5).astype(np.float32))
+    pose, betas, trans = synth.synth_smpl_params(B, seed=1)
+    pose *= 0.3
+    smpl = SMPLPyTorchWrapperBatch(synth.synth_smplh_model(0), B, betas=torch.from_numpy(betas),
+                                   pose=torch.from_numpy(pose), trans=torch.from_numpy(trans)).cuda()
+    body_prior, hand_prior = synthetic_priors(0)
+    labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
+    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
+    kpts = torch.from_numpy(np.concatenate([rs.uniform(100, 400, (B, 25, 2)), rs.uniform(0.2, 1, (B, 25, 1))], -1)
+                            .astype(np.float32)).cuda()
+    obj = torch.from_numpy((rs.standard_normal((B, 3000, 3)) * 0.15).astype(np.float32)).cuda()
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1),
+                pose_init=torch.from_numpy(pose[:, 3:72]).cuda(), body_kpts=kpts, objects=obj, smpl=smpl,
+                obj_R=torch.eye(3).repeat(B, 1, 1).cuda().requires_grad_(True),
+                obj_t=torch.tensor([[0.2, 0.3, 2.3]] * B).cuda().requires_grad_(True),
+                obj_s=torch.ones(B).cuda().requires_grad_(True))
+    return fitter, net, smpl, data
+
+
+def test_forward_smpl_loss_terms_and_descent(fit_setup):
+    fitter, net, smpl, data = fit_setup
+    split = fitter.split_smpl(smpl)
+    ld = fitter.forward_smpl(split, data, "kpts")
+    assert set(ld) == {"df_h", "pose", "hand", "part", "smplz", "pinit", "j2d"}
+    wd = fitter.get_loss_weights()
+    opt = torch.optim.Adam([split.trans, split.global_pose, split.body_pose, split.top_betas], 0.006)
+    losses = []
+    for _ in range(12):
+        opt.zero_grad()
+        loss = fitter.sum_dict(fitter.forward_smpl(split, data, "kpts"), wd, 1)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    for p in (split.trans, split.global_pose, split.body_pose, split.top_betas):
+        assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0
+
+
+def test_forward_step_phases(fit_setup):
+    fitter, net, smpl, data = fit_setup
+    split = fitter.split_smpl(smpl)
+    data = dict(data)
+    data["smpl_center"] = fitter.compute_smpl_center_pred(data, net, smpl)
+    R, t, s = data["obj_R"], data["obj_t"], data["obj_s"]
+    ld = fitter.forward_step(net, split, data, R, t, s, "object only")
+    assert set(ld) == {"object", "scale", "ocent"}
+    ld = fitter.forward_step(net, split, data, R, t, s, "joint")
+    assert {"object", "scale", "ocent"} <= set(ld)
+    loss = fitter.sum_dict(ld, fitter.get_loss_weights(), 1)
+    loss.backward()
+    assert torch.isfinite(R.grad).all() and torch.isfinite(t.grad).all() and R.grad.abs().max() > 0
+
+
+def test_optimize_loops_run(fit_setup):
+    fitter, net, smpl, data = fit_setup
+    d = dict(data)
+    smpl2, scale = fitter.optimize_smpl(smpl, d, iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, steps_per_iter=2, max_iter=1)
+    assert scale.shape == (2,) and torch.isfinite(scale).all()
+    d["smpl"] = smpl2
+    out_smpl, R, t = fitter.optimize_smpl_object(net, d, obj_iter=1, joint_iter=1, steps_per_iter=2, max_iter=1)
+    assert torch.isfinite(R).all() and torch.isfinite(t).all()
