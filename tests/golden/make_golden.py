@@ -214,6 +214,157 @@ def gen_smpl():
                         dtrans=tt.grad.numpy())
 
 
+def _install_stub_finder():
+    """stub every third-party module the reference's fit drivers import but never use on the maths path
+    (viewers, mesh IO, renderers, un-vendored CUDA extensions); see SURVEY 8(c)"""
+    import importlib.abc
+    import importlib.machinery
+    missing = ("cv2", "skimage", "trimesh", "psbody", "pytorch3d", "mesh_intersection", "neural_renderer",
+               "detectron2", "torchvision", "chumpy", "igl", "open3d", "tensorboard")
+
+    class Dummy:
+        def __init__(self, *a, **k): pass
+        def __call__(self, *a, **k): return Dummy()
+        def __getattr__(self, n): return Dummy()
+
+    class StubMod(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return Dummy
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in missing and name not in sys.modules:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            m = StubMod(spec.name)
+            m.__path__ = []
+            return m
+
+        def exec_module(self, module): pass
+
+    for k in [k for k in sys.modules if k.split(".")[0] in ("chumpy", "cv2", "skimage")]:
+        del sys.modules[k]
+    sys.meta_path.insert(0, Finder())
+
+
+def gen_fit(net):
+    """10 Adam steps of the reference's forward_smpl ('kpts') and forward_step ('object only') on synthetic
+    SMPL-H / object data, with the reference's gradient accumulation (zero_grad once, then backward+step
+    per inner step, recon_fit_behave.py:118,136-152).  Reference classes are instantiated with __new__
+    (their constructors need BEHAVE folders, the licensed SMPL-H pkl and .cuda())."""
+    cwd = os.getcwd()
+    os.chdir(REF)   # the reference reads PATHS.yml relative to the working directory at import time
+    try:
+        _install_stub_finder()
+        import recon.recon_fit_base as rfb
+        from recon.recon_fit_behave import ReconFitterBehave
+        from lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatchSplitParams
+        from lib_smpl.smplpytorch.smplpytorch.pytorch.smpl_layer import SMPL_Layer
+        from lib_smpl.th_smpl_prior import th_Mahalanobis
+        from lib_smpl.th_hand_prior import HandPrior
+        from model.camera import KinectColorCamera
+    finally:
+        os.chdir(cwd)
+    from chore_amd.lib_smpl.wrapper_pytorch import synthetic_regressors
+    B = 2
+    rs = np.random.RandomState(9)
+    feat = (rs.standard_normal((B, 256, 32, 32)) * 0.5).astype(np.float32)
+    tmpx = (rs.standard_normal((B, 64, 64, 64)) * 0.5).astype(np.float32)
+    net.im_feat_list = [torch.from_numpy(feat)]
+    net.tmpx = torch.from_numpy(tmpx)
+    pose, betas, trans = synth.synth_smpl_params(B, seed=1)
+    pose *= 0.3
+    model = synth.synth_smplh_model(0)
+    layer = SMPL_Layer.__new__(SMPL_Layer)
+    torch.nn.Module.__init__(layer)
+    layer.hands, layer.center_idx = True, None
+    layer.register_buffer("th_betas", torch.zeros(1, 10))
+    for k, n in (("th_shapedirs", "shapedirs"), ("th_posedirs", "posedirs"), ("th_J_regressor", "J_regressor"),
+                 ("th_weights", "weights")):
+        layer.register_buffer(k, torch.from_numpy(model[n]))
+    layer.register_buffer("th_v_template", torch.from_numpy(model["v_template"]).unsqueeze(0))
+    layer.kintree_parents, layer.num_joints = [int(p) for p in model["parents"]], 52
+    sp = SMPLPyTorchWrapperBatchSplitParams.__new__(SMPLPyTorchWrapperBatchSplitParams)
+    torch.nn.Module.__init__(sp)
+    P = torch.nn.Parameter
+    sp.top_betas, sp.other_betas = P(torch.from_numpy(betas[:, :2].copy())), P(torch.from_numpy(betas[:, 2:].copy()))
+    sp.global_pose, sp.body_pose = P(torch.from_numpy(pose[:, :3].copy())), P(torch.from_numpy(pose[:, 3:66].copy()))
+    sp.hand_pose, sp.trans = P(torch.from_numpy(pose[:, 66:].copy())), P(torch.from_numpy(trans.copy()))
+    sp.offsets = P(torch.zeros(B, 6890, 3))
+    sp.smpl, sp.faces, sp.gender = layer, None, "male"
+    regs = synthetic_regressors(6890)
+    def sparse_stack(r):
+        t = torch.from_numpy(r).to_sparse()
+        return torch.stack([t] * B)
+    sp.body25_reg_torch, sp.face_reg_torch, sp.hand_reg_torch = [sparse_stack(r) for r in regs]
+    sp.betas = torch.cat([sp.top_betas, sp.other_betas], 1)
+    sp.pose = torch.cat([sp.global_pose, sp.body_pose, sp.hand_pose], 1)
+    # priors with the synthetic arrays of chore_amd.lib_smpl.priors.synthetic_priors(0)
+    prs = np.random.RandomState(6000)
+    bmean, bprec = prs.standard_normal(63) * 0.1, np.tril(prs.standard_normal((63, 63)) * 0.3) + np.eye(63)
+    hmean = prs.standard_normal(90) * 0.1
+    lprec, rprec = np.eye(45) + prs.standard_normal((45, 45)) * 0.05, np.eye(45) + prs.standard_normal((45, 45)) * 0.05
+    body_prior = th_Mahalanobis.__new__(th_Mahalanobis)
+    body_prior.mean = torch.tensor(bmean.astype("float32")).unsqueeze(0)
+    body_prior.prec = torch.tensor(bprec.astype("float32"))
+    body_prior.prefix, body_prior.end = 3, 66
+    hand_prior = HandPrior.__new__(HandPrior)
+    hand_prior.prefix = 66
+    hand_prior.mean = torch.tensor(hmean, dtype=torch.float).unsqueeze(0)
+    hand_prior.lhand_prec = torch.tensor(lprec, dtype=torch.float).unsqueeze(0)
+    hand_prior.rhand_prec = torch.tensor(rprec, dtype=torch.float).unsqueeze(0)
+    rfb.get_prior = lambda: body_prior
+    rfb.HandPrior = lambda type="grab": hand_prior
+    labels = torch.from_numpy(rs.randint(0, 14, 6890))
+    fitter = ReconFitterBehave.__new__(ReconFitterBehave)
+    fitter.device, fitter.camera, fitter.net_in_size = "cpu", KinectColorCamera(1200), 512
+    fitter.z_0, fitter.obj_scale, fitter.debug, fitter.part_labels = 2.2, 1.0, False, labels
+    cc = torch.tensor([list(synth.CROP_CENTER)] * B)
+    kpts = torch.from_numpy(np.concatenate([rs.uniform(100, 400, (B, 25, 2)), rs.uniform(0.2, 1, (B, 25, 1))], -1)
+                            .astype(np.float32))
+    obj = torch.from_numpy((rs.standard_normal((B, 3000, 3)) * 0.15).astype(np.float32))
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1),
+                pose_init=torch.from_numpy(pose[:, 3:72].copy()), body_kpts=kpts, objects=obj)
+    wd = fitter.get_loss_weights()
+    out = {}
+    # ---- (a) SMPL phase 'kpts' ----
+    opt = torch.optim.Adam([sp.trans, sp.global_pose, sp.body_pose, sp.top_betas, sp.other_betas], 0.006)
+    opt.zero_grad()
+    rows = []
+    keys_a = ["df_h", "pose", "hand", "part", "smplz", "pinit", "j2d"]
+    for i in range(10):
+        ld = fitter.forward_smpl(sp, data, "kpts")
+        rows.append([float(ld[k]) for k in keys_a])
+        loss = ReconFitterBehave.sum_dict(ld, wd, 1)
+        loss.backward()
+        opt.step()
+    out["smpl_losses"] = np.array(rows, np.float64)
+    for k in ("trans", "global_pose", "body_pose", "top_betas", "other_betas"):
+        out["smpl_" + k] = getattr(sp, k).detach().numpy().copy()
+    # ---- (b) object phase 'object only' ----
+    data["smpl_center"] = torch.tensor([[0.0, 0.3, 2.2]] * B)
+    obj_R = torch.eye(3).repeat(B, 1, 1).requires_grad_(True)
+    obj_t = torch.tensor([[0.2, 0.3, 2.3]] * B).requires_grad_(True)
+    obj_s = torch.ones(B).requires_grad_(True)
+    opt = torch.optim.Adam([obj_t, obj_R, obj_s], lr=0.006)
+    opt.zero_grad()
+    torch.manual_seed(123)   # decopose_axis draws its 1e-4 noise from the CPU generator
+    rows = []
+    keys_b = ["object", "scale", "ocent"]
+    for i in range(10):
+        ld = fitter.forward_step(net, sp, data, obj_R, obj_t, obj_s, "object only")
+        rows.append([float(ld[k]) for k in keys_b])
+        loss = ReconFitterBehave.sum_dict(ld, wd, 1)
+        loss.backward()
+        opt.step()
+    out["obj_losses"] = np.array(rows, np.float64)
+    out["obj_R"], out["obj_t"], out["obj_s"] = obj_R.detach().numpy(), obj_t.detach().numpy(), obj_s.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "fit_trajectories.npz"), keys_a=np.array(keys_a), keys_b=np.array(keys_b), **out)
+
+
 def main():
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -228,6 +379,7 @@ def main():
     gen_encoder(net)
     gen_surface(net)
     gen_smpl()
+    gen_fit(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
