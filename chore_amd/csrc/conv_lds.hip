@@ -108,10 +108,12 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)
     *(u32x4*)p = o;
 }
 
-template <int TAPS, int NT> struct Geo {
+// TPS = taps per K-step: 3 (one kernel row) for large grids; 9 (the whole chunk) for the small maps, where a
+// workgroup's time is a chain of dependent weight fetches and fewer, longer steps mean fewer round trips
+template <int TAPS, int NT, int TPS_> struct Geo {
     static constexpr int PAD = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = TW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
-    static constexpr int TPS = (TAPS == 9) ? 3 : 1;                 // taps per K-step
+    static constexpr int TPS = TPS_;                                // taps per K-step
     static constexpr int SBYTES = TPS * KGC * (NT / 32) * 1024;     // weight bytes per K-step
     static constexpr int NBW = NT >= 64 ? 2 : 1;
     static constexpr int WAVES_N = (NT / 32) / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
@@ -120,9 +122,9 @@ template <int TAPS, int NT> struct Geo {
     static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
 };
 
-template <typename T, int TAPS, int NT>
+template <typename T, int TAPS, int NT, int TPS_>
 __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
-    using G = Geo<TAPS, NT>;
+    using G = Geo<TAPS, NT, TPS_>;
     constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
     constexpr int CC = KGC * KGE;                       // channels per chunk (32 bf16 / 16 fp32)
     constexpr int PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, TPS = G::TPS, SBYTES = G::SBYTES;
@@ -271,9 +273,10 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         // (b) the MFMAs of this K-step
         if (!(a.dbg & 4)) {
             const char* bs = b_ptr + (s & 1) * SBYTES;
-            const char* ar = a_ptr + (krow * PW) * ROWB;
+            const char* ar = a_ptr + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
 #pragma unroll
             for (int t = 0; t < TPS; ++t) {
+                const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
 #pragma unroll
                 for (int kg = 0; kg < KGC; ++kg) {
                     u32x4 af[MB], bf[NBW];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                         bf[q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
-                        af[m] = *(const u32x4*)(ar + (m * PW + t) * ROWB + kg * 32);
+                        af[m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -448,28 +451,40 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int TAPS, int NT>
+template <typename T, int TAPS, int NT, int TPS_>
 int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = Geo<TAPS, NT>;
+    using G = Geo<TAPS, NT, TPS_>;
     const size_t smem = G::smem_bytes(a.in.C);
     static bool attr = false;
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_lds_kernel<T, TAPS, NT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_lds_kernel<T, TAPS, NT, TPS_>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
         attr = true;
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
     dim3 grid(tiles, a.Cout / NT, a.B);
-    hipLaunchKernelGGL((conv_lds_kernel<T, TAPS, NT>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((conv_lds_kernel<T, TAPS, NT, TPS_>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
 template <typename T, int TAPS>
-int launch_nt(chore_handle* h, int nt, const ConvArgs& a, hipStream_t s) {
-    if (nt == 128) return launch_t<T, TAPS, 128>(h, a, s);
-    if (nt == 64) return launch_t<T, TAPS, 64>(h, a, s);
-    return launch_t<T, TAPS, 32>(h, a, s);
+int launch_nt(chore_handle* h, int nt, bool small_grid, const ConvArgs& a, hipStream_t s) {
+    if constexpr (TAPS == 9) {
+        if (small_grid && nt == 64) return launch_t<T, 9, 64, 9>(h, a, s);
+        if (small_grid && nt == 32) return launch_t<T, 9, 32, 9>(h, a, s);
+        if constexpr (sizeof(T) == 2) {   // the 4x2 register tile is bf16-only (choose_nt never picks it for fp32)
+            if (nt == 128) return launch_t<T, 9, 128, 3>(h, a, s);
+        }
+        if (nt == 64) return launch_t<T, 9, 64, 3>(h, a, s);
+        return launch_t<T, 9, 32, 3>(h, a, s);
+    } else {
+        if constexpr (sizeof(T) == 2) {
+            if (nt == 128) return launch_t<T, 1, 128, 1>(h, a, s);
+        }
+        if (nt == 64) return launch_t<T, 1, 64, 1>(h, a, s);
+        return launch_t<T, 1, 32, 1>(h, a, s);
+    }
 }
 
 int tiles_of(int H, int W) { return ((W + TW - 1) / TW) * ((H + TH - 1) / TH); }
@@ -507,9 +522,10 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     ConvArgs a = a_in;
     a.dbg = dbg;
     const int nt = choose_nt(dtype, a.B, a.H, a.W, a.Cout);
+    const bool small_grid = (long)a.B * tiles_of(a.H, a.W) * (a.Cout / nt) < 384;
     if (dtype == CHORE_F32)
-        return taps == 9 ? launch_nt<float, 9>(h, nt, a, s) : launch_nt<float, 1>(h, nt, a, s);
-    return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, a, s) : launch_nt<bf16_t, 1>(h, nt, a, s);
+        return taps == 9 ? launch_nt<float, 9>(h, nt, small_grid, a, s) : launch_nt<float, 1>(h, nt, small_grid, a, s);
+    return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, small_grid, a, s) : launch_nt<bf16_t, 1>(h, nt, small_grid, a, s);
 }
 
 // ------------------------------------------------------------------------------------------------
