@@ -159,11 +159,14 @@ def main():
                 kernels[k] = {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] // 3,
                               "tflops": v["flops"] / v["ms"] / 1e9 if v["flops"] else None,
                               "gbps": v["bytes"] / v["ms"] / 1e6}
-        kernels["query_fused_heads_f32"] = {"ms_per_step": qry_ms, "launches_per_step": 1,
-                                            "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
+        tname = "unsigned short" if args.dtype == "bf16" else "float"
+        kernels = {k.replace("<T,", "<%s, " % tname).replace(",", ", ").replace(",  ", ", "): v for k, v in kernels.items()}
+        qname = "query_fwd_f32_kernel<%s>" % tname
+        kernels[qname] = {"ms_per_step": qry_ms, "launches_per_step": 1,
+                          "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
         dom = max((k for k in kernels if kernels[k]["tflops"]), key=lambda k: kernels[k]["ms_per_step"])
         dv = kernels[dom]
-        dom_dtype = "fp32" if dom == "query_fused_heads_f32" else args.dtype
+        dom_dtype = "fp32" if dom == qname else args.dtype
         roof = {"kernel": dom, "bound": "mfma", "achieved": dv["tflops"], "peak": PEAK_TFLOPS[dom_dtype],
                 "unit": "TFLOP/s", "frac": dv["tflops"] / PEAK_TFLOPS[dom_dtype], "traffic": None,
                 "avg_launch_ms": dv["ms_per_step"] / dv["launches_per_step"],

@@ -62,6 +62,13 @@ __host__ __device__ inline unsigned short f2bf(float f) {
     unsigned int r = 0x7fffu + ((v.u >> 16) & 1u);
     return (unsigned short)((v.u + r) >> 16);
 }
+// two floats -> packed bf16 pair (x in the low half) with the hardware converter v_cvt_pk_bf16_f32 (same RNE rounding)
+typedef __bf16 chore_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float chore_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned int pack2bf(float x, float y) {
+    const chore_f32x2 f = {x, y};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(f, chore_bf16x2));
+}
 __host__ __device__ inline float bf2f(unsigned short b) {
     union { float f; unsigned int u; } v;
     v.u = ((unsigned int)b) << 16;

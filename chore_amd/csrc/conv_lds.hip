@@ -57,7 +57,7 @@ __device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* 
             float x = fmaf(lo, sc[2 * j], sh[2 * j]), y = fmaf(hi, sc[2 * j + 1], sh[2 * j + 1]);
             x = x > 0.f ? x : 0.f;
             y = y > 0.f ? y : 0.f;
-            o[j] = (unsigned)f2bf(x) | ((unsigned)f2bf(y) << 16);
+            o[j] = pack2bf(x, y);
         }
     }
     return o;
@@ -100,10 +100,9 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)
     u32x4 o;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const unsigned lo = f2bf(v[2 * j]), hi = f2bf(v[2 * j + 1]);
-        o[j] = lo | (hi << 16);
-        v[2 * j] = __uint_as_float(lo << 16);
-        v[2 * j + 1] = __uint_as_float(hi << 16);
+        o[j] = pack2bf(v[2 * j], v[2 * j + 1]);
+        v[2 * j] = __uint_as_float(o[j] << 16);
+        v[2 * j + 1] = __uint_as_float(o[j] & 0xffff0000u);
     }
     *(u32x4*)p = o;
 }
@@ -121,6 +120,8 @@ template <int TAPS, int NT, int TPS_> struct Geo {
     static constexpr size_t epi_bytes() { return (size_t)4 * 32 * SCR_LD * 4 + (size_t)4 * WAVES_M * NT * 4; }
     static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
 };
+
+constexpr int PD_SMALL = 2;
 
 template <typename T, int TAPS, int NT, int TPS_>
 __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
@@ -163,15 +164,21 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         const bool ok = (row < ROWS) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
         row_off[j] = ok ? (y * a.W + x) * a.in.cs : -1;
     }
-    u32x4 pre[NVP];
-    auto load_patch = [&](int c0) {
+    // PD = register-prefetch distance in chunks.  With a small grid every CU holds one workgroup and nothing hides a
+    // global round trip (~2 us) but the workgroup's own MFMA block (~0.5 us per chunk), so the loads of PD chunks are
+    // kept in flight; large grids rely on the co-resident workgroups instead and keep the registers for the tile.
+    constexpr int PD = (TPS == 9) ? PD_SMALL : 1;
+    u32x4 preq[PD][NVP];
+    // loads are unconditional (invalid rows re-read the tile's first pixel and are zeroed at publish time): a
+    // branch around a load makes the compiler's vmcnt bookkeeping give up and wait for everything in flight
+    auto load_patch = [&](u32x4 (&pre)[NVP], int c0) {
 #pragma unroll
         for (int j = 0; j < NVP; ++j) {
-            u32x4 z = {0u, 0u, 0u, 0u};
-            pre[j] = (row_off[j] >= 0) ? *(const u32x4*)(in_b + row_off[j] + c0 + v * VE) : z;
+            const int off = row_off[j] >= 0 ? row_off[j] : 0;
+            pre[j] = *(const u32x4*)(in_b + off + c0 + v * VE);
         }
     };
-    auto write_patch = [&](int c0) {
+    auto write_patch = [&](const u32x4 (&pre)[NVP], int c0) {
         float sc[VE], sh[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
@@ -191,19 +198,21 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // weight slice of K-step (chunk c, kernel row krow): [t][kg][nb][lane] vectors
     const u32x4* wbase = (const u32x4*)a.wpk + (size_t)(n_tile * (NT / 32)) * 64;
     const size_t wkg = (size_t)NB * 64;   // vectors between consecutive k-groups
-    u32x4 rb[SBV];
-    auto load_w = [&](int c, int krow) {
+    u32x4 rbq[PD][SBV];
+    int woff[SBV];   // per-thread vector offsets inside a K-step slice (step-independent)
 #pragma unroll
-        for (int j = 0; j < SBV; ++j) {
-            const int i = tid + j * 256;
-            if (i < SVEC) {
-                constexpr int PER_KG = (NT / 32) * 64;
-                const int t = i / (KGC * PER_KG), kg = (i / PER_KG) % KGC, r = i % PER_KG;
-                rb[j] = wbase[((size_t)(krow * TPS + t) * NKG + c * KGC + kg) * wkg + r];
-            }
-        }
+    for (int j = 0; j < SBV; ++j) {
+        const int i = (tid + j * 256 < SVEC) ? tid + j * 256 : SVEC - 1;
+        constexpr int PER_KG = (NT / 32) * 64;
+        const int t = i / (KGC * PER_KG), kg = (i / PER_KG) % KGC, r = i % PER_KG;
+        woff[j] = (t * NKG + kg) * (int)wkg + r;
+    }
+    auto load_w = [&](u32x4 (&rb)[SBV], int c, int krow) {
+        const u32x4* wb = wbase + (size_t)(krow * TPS * NKG + c * KGC) * wkg;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < SBV; ++j) rb[j] = wb[woff[j]];
     };
-    auto write_w = [&](int slot) {
+    auto write_w = [&](const u32x4 (&rb)[SBV], int slot) {
 #pragma unroll
         for (int j = 0; j < SBV; ++j) {
             const int i = tid + j * 256;
@@ -226,10 +235,14 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const int crot = (blockIdx.x * 5 + blockIdx.y * 3) % NCH;
     auto chunk_of = [&](int ci) -> int { int x = ci + crot; return x >= NCH ? x - NCH : x; };
 
-    // ---- prologue: first chunk's patch and K-step 0 weights ----
-    load_patch(chunk_of(0) * CC);
-    load_w(chunk_of(0), 0);
-    if (use_gn) {
+    // ---- prologue: first chunk's patch and K-step 0 weights (and the next PD-1 chunks) ----
+#pragma unroll
+    for (int q = 0; q < PD; ++q) {
+        const int cq = q < NCH ? q : NCH - 1;
+        load_patch(preq[q], chunk_of(cq) * CC);
+        load_w(rbq[q], chunk_of(cq), 0);
+    }
+    if (use_gn && !(a.dbg & 64)) {
         // GroupNorm affine of this image's input channels from the producers' exact totals: one
         // 32-byte load per channel (patch area as scratch: nothing has been staged yet), then a
         // fixed-order sum over the channels of the group
@@ -256,52 +269,77 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         }
     }
     __syncthreads();   // ss_lds visible, scratch free
-    write_patch(chunk_of(0) * CC);
-    write_w(0);
+    write_patch(preq[0], chunk_of(0) * CC);
+    write_w(rbq[0], 0);
     __syncthreads();
 
-    int c = 0, krow = 0;   // c counts chunks in visiting order
-#pragma unroll 1
-    for (int s = 0; s < S; ++s) {
-        const bool last_row = (krow == KROWS - 1);
-        const bool more_chunks = (c + 1 < NCH);
-        // (a) prefetch the next K-step's weights (and the next chunk's patch) into registers; they have
-        //     the whole MFMA block below to land
-        if (s + 1 < S && !(a.dbg & 1)) load_w(chunk_of(last_row ? c + 1 : c), last_row ? 0 : krow + 1);
-        if (krow == 0 && more_chunks && !(a.dbg & 2)) load_patch(chunk_of(c + 1) * CC);
-
-        // (b) the MFMAs of this K-step
-        if (!(a.dbg & 4)) {
-            const char* bs = b_ptr + (s & 1) * SBYTES;
-            const char* ar = a_ptr + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
+    // the MFMAs of one K-step: weights from ring slot `slot`, patch rows shifted by kernel row `krow`
+    auto mfma_step = [&](int slot, int krow) {
+        const char* bs = b_ptr + slot * SBYTES;
+        const char* ar = a_ptr + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
 #pragma unroll
-            for (int t = 0; t < TPS; ++t) {
-                const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
+        for (int t = 0; t < TPS; ++t) {
+            const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
 #pragma unroll
-                for (int kg = 0; kg < KGC; ++kg) {
-                    u32x4 af[MB], bf[NBW];
+            for (int kg = 0; kg < KGC; ++kg) {
+                u32x4 af[MB], bf[NBW];
 #pragma unroll
-                    for (int q = 0; q < NBW; ++q)
-                        bf[q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+                for (int q = 0; q < NBW; ++q)
+                    bf[q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
-                        af[m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
+                for (int m = 0; m < MB; ++m)
+                    af[m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
 #pragma unroll
-                    for (int m = 0; m < MB; ++m)
+                for (int m = 0; m < MB; ++m)
 #pragma unroll
-                        for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[m], bf[q]);
-                }
+                    for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[m], bf[q]);
             }
         }
+    };
 
-        // (c) publish the next step's operands
-        if (s + 1 < S) write_w((s + 1) & 1);
-        if (last_row && more_chunks) {
-            __syncthreads();   // every wave has finished reading this chunk's patch
-            write_patch(chunk_of(c + 1) * CC);
+    if constexpr (PD > 1) {
+        // one K-step per chunk; chunk c+1+j sits in register set (c+1+j) % PD.  The loop is unrolled by PD so the
+        // sets are named statically; the loads are unconditional (the tail re-fetches the last chunk) so that the
+        // wait before a publish counts only the loads issued after the ones it needs.  NCH % PD == 0 (launcher).
+#pragma unroll 1
+        for (int c0 = 0; c0 < NCH; c0 += PD) {
+#pragma unroll
+            for (int u = 0; u < PD; ++u) {
+                const int c = c0 + u;
+                const int cn = c + PD < NCH ? c + PD : NCH - 1;
+                if (!(a.dbg & 2)) load_patch(preq[u], chunk_of(cn) * CC);
+                if (!(a.dbg & 1)) load_w(rbq[u], chunk_of(cn), 0);
+                __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA block
+                if (!(a.dbg & 4)) mfma_step(c & 1, 0);
+                if (c + 1 < NCH) {
+                    write_w(rbq[(u + 1) % PD], (c + 1) & 1);
+                    __syncthreads();   // every wave has finished reading this chunk's patch
+                    if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC);
+                }
+                __syncthreads();
+            }
         }
-        __syncthreads();
-        if (last_row) { krow = 0; ++c; } else ++krow;
+    } else {
+        int c = 0, krow = 0;   // c counts chunks in visiting order
+#pragma unroll 1
+        for (int s = 0; s < S; ++s) {
+            const bool last_row = (krow == KROWS - 1);
+            const bool more_chunks = (c + 1 < NCH);
+            // (a) prefetch the next K-step's weights (and the next chunk's patch) into registers; they have
+            //     the whole MFMA block below to land
+            if (s + 1 < S && !(a.dbg & 1)) load_w(rbq[0], chunk_of(last_row ? c + 1 : c), last_row ? 0 : krow + 1);
+            if (krow == 0 && more_chunks && !(a.dbg & 2)) load_patch(preq[0], chunk_of(c + 1) * CC);
+            // (b) the MFMAs of this K-step
+            if (!(a.dbg & 4)) mfma_step(s & 1, krow);
+            // (c) publish the next step's operands
+            if (s + 1 < S) write_w(rbq[0], (s + 1) & 1);
+            if (last_row && more_chunks) {
+                __syncthreads();   // every wave has finished reading this chunk's patch
+                write_patch(preq[0], chunk_of(c + 1) * CC);
+            }
+            __syncthreads();
+            if (last_row) { krow = 0; ++c; } else ++krow;
+        }
     }
     if (a.dbg & 8) return;
 
@@ -507,9 +545,17 @@ int choose_nt(int dtype, int B, int H, int W, int Cout) {
 
 }  // namespace
 
-ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cout) {
-    (void)taps;
-    return ConvPlan{choose_nt(dtype, B, H, W, Cout), TH, tiles_of(H, W)};
+// small grid: fewer workgroups than 1.5 per CU -> whole-chunk K-steps with deep register prefetch (needs the chunk
+// count to be a multiple of the prefetch distance)
+static bool is_small_grid(int dtype, int B, int H, int W, int Cin, int Cout, int nt) {
+    const int nch = Cin / (dtype == CHORE_F32 ? 16 : 32);
+    return nt <= 64 && nch % PD_SMALL == 0 && (long)B * tiles_of(H, W) * (Cout / nt) < 384;
+}
+
+ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+    const int nt = choose_nt(dtype, B, H, W, Cout);
+    const int tps = taps == 1 ? 1 : (is_small_grid(dtype, B, H, W, Cin, Cout, nt) ? 9 : 3);
+    return ConvPlan{nt, TH, tiles_of(H, W), tps};
 }
 
 int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipStream_t s) {
@@ -522,7 +568,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     ConvArgs a = a_in;
     a.dbg = dbg;
     const int nt = choose_nt(dtype, a.B, a.H, a.W, a.Cout);
-    const bool small_grid = (long)a.B * tiles_of(a.H, a.W) * (a.Cout / nt) < 384;
+    const bool small_grid = is_small_grid(dtype, a.B, a.H, a.W, a.in.C, a.Cout, nt);
     if (dtype == CHORE_F32)
         return taps == 9 ? launch_nt<float, 9>(h, nt, small_grid, a, s) : launch_nt<float, 1>(h, nt, small_grid, a, s);
     return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, small_grid, a, s) : launch_nt<bf16_t, 1>(h, nt, small_grid, a, s);

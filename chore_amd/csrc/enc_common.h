@@ -85,8 +85,8 @@ struct ConvArgs {
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
 
-struct ConvPlan { int nt, th, ntiles; };
-ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cout);   // tile configuration launch_conv will use
+struct ConvPlan { int nt, th, ntiles, tps; };   // N tile, tile height, tiles per image, taps per K-step
+ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // tile configuration launch_conv will use
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
@@ -102,8 +102,8 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Ch
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanStat* st, const float* gamma,
                          const float* beta, const View& y, int B, int HW, hipStream_t s);
-int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, hipStream_t s);
+int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, ChanStat* st, hipStream_t s);
 // y = a + bicubic_up2(low)   (low is (B,H,W,C), a and y are (B,2H,2W,C); y may alias a)
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
-                 hipStream_t s);
+                 ChanStat* st, hipStream_t s);
 int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s);

@@ -12,6 +12,7 @@ template <typename T> struct Vec4;
 template <> struct Vec4<float> {
     static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
     static __device__ __forceinline__ void st(float* p, f32x4 v) { *(f32x4*)p = v; }
+    static __device__ __forceinline__ f32x4 st_round(float* p, f32x4 v) { *(f32x4*)p = v; return v; }
 };
 template <> struct Vec4<bf16_t> {
     static __device__ __forceinline__ f32x4 ld(const bf16_t* p) {
@@ -20,8 +21,16 @@ template <> struct Vec4<bf16_t> {
         return r;
     }
     static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) {
-        u16x4 r = {f2bf(v[0]), f2bf(v[1]), f2bf(v[2]), f2bf(v[3])};
-        *(u16x4*)p = r;
+        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
+        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    // store and return the values as stored (rounded to bf16)
+    static __device__ __forceinline__ f32x4 st_round(bf16_t* p, f32x4 v) {
+        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
+        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        f32x4 r = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                   __uint_as_float(hi & 0xffff0000u)};
+        return r;
     }
 };
 
@@ -229,42 +238,26 @@ int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanSt
 }
 
 // ------------------------------------------------------------------------------------------------
+// Pixel-wise producers with fused GroupNorm statistics.  A block owns a slice of MAP_PIX output pixels
+// of one image and all C channels: thread = (channel quad, pixel lane); it stores its values and sums
+// the values AS STORED; the block then reduces in a fixed order and adds its partials to the exact
+// accumulators (enc_common.h), so no separate statistics pass over the output is needed.
+// ------------------------------------------------------------------------------------------------
+constexpr int MAP_PIX = 64;
+
 // 2x2 average pooling   (F.avg_pool2d(x, 2, stride=2), HGFilters.py:32,152)
-// ------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(256) void avgpool2_kernel(const T* __restrict__ x, int xcs, int xco, T* __restrict__ y,
-                                                       int ycs, int yco, int C, int H, int W, size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int tpr = C / 4, OH = H / 2, OW = W / 2;
-    const int cv = (int)(i % tpr);
-    size_t p = i / tpr;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int b = (int)(p / OH);
-    const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + cv * 4;
-    const f32x4 a = Vec4<T>::ld(src), bb = Vec4<T>::ld(src + xcs);
-    const f32x4 c = Vec4<T>::ld(src + (size_t)W * xcs), d = Vec4<T>::ld(src + (size_t)W * xcs + xcs);
-    const f32x4 r = (((a + bb) + c) + d) * 0.25f;
-    Vec4<T>::st(y + (((size_t)b * OH + oy) * OW + ox) * ycs + yco + cv * 4, r);
-}
+template <typename T> struct PoolOp {
+    const T* x; int xcs, xco, H, W;   // input view and size
+    __device__ __forceinline__ f32x4 operator()(int b, int p, int cv) const {
+        const int OW = W / 2, oy = p / OW, ox = p % OW;
+        const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + cv * 4;
+        const f32x4 a = Vec4<T>::ld(src), bb = Vec4<T>::ld(src + xcs);
+        const f32x4 c = Vec4<T>::ld(src + (size_t)W * xcs), d = Vec4<T>::ld(src + (size_t)W * xcs + xcs);
+        return (((a + bb) + c) + d) * 0.25f;
+    }
+};
 
-int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, hipStream_t s) {
-    const size_t total4 = (size_t)B * (H / 2) * (W / 2) * (x.C / 4);
-    const int blocks = (int)((total4 + 255) / 256);
-    if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(avgpool2_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)x.p, x.cs, x.co,
-                           (float*)y.p, y.cs, y.co, x.C, H, W, total4);
-    else
-        hipLaunchKernelGGL(avgpool2_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co,
-                           (bf16_t*)y.p, y.cs, y.co, x.C, H, W, total4);
-    CHORE_LAUNCH_CHECK(h, s);
-    return CHORE_OK;
-}
-
-// ------------------------------------------------------------------------------------------------
-// y = a + bicubic_up2(low), align_corners=True      (HGFilters.py:47,50)
-// ------------------------------------------------------------------------------------------------
+// a + bicubic_up2(low), align_corners=True      (HGFilters.py:47,50)
 __device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
     const float A = -0.75f;
     const float x0 = t + 1.0f, x1 = t, x2 = 1.0f - t, x3 = 2.0f - t;
@@ -273,59 +266,99 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
     c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
     c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
 }
-
-template <typename T>
-__global__ __launch_bounds__(256) void upadd_kernel(const T* a, int acs, int aco,
-                                                    const T* __restrict__ low, int lcs, int lco, T* y,
-                                                    int ycs, int yco, int C, int H, int W, size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int tpr = C / 4, OH = 2 * H, OW = 2 * W;
-    const int cv = (int)(i % tpr);
-    size_t p = i / tpr;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int b = (int)(p / OH);
-    const float sy = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
-    const float sx = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-    const float ry = sy * (float)oy, rx = sx * (float)ox;
-    const float fy = floorf(ry), fx = floorf(rx);
-    const int iy = (int)fy, ix = (int)fx;
-    float cy[4], cx[4];
-    cubic_coeffs(ry - fy, cy);
-    cubic_coeffs(rx - fx, cx);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+template <typename T> struct UpAddOp {
+    const T* a; int acs, aco;
+    const T* low; int lcs, lco, H, W;   // low-resolution view and size (output is 2H x 2W)
+    __device__ __forceinline__ f32x4 operator()(int b, int p, int cv) const {
+        const int OH = 2 * H, OW = 2 * W, oy = p / OW, ox = p % OW;
+        const float sy = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
+        const float sx = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+        const float ry = sy * (float)oy, rx = sx * (float)ox;
+        const float fy = floorf(ry), fx = floorf(rx);
+        const int iy = (int)fy, ix = (int)fx;
+        float cy[4], cx[4];
+        cubic_coeffs(ry - fy, cy);
+        cubic_coeffs(rx - fx, cx);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        int yy = iy - 1 + r;
-        yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < 4; ++r) {
+            int yy = iy - 1 + r;
+            yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
+            f32x4 row = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            int xx = ix - 1 + q;
-            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-            const f32x4 v = Vec4<T>::ld(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + cv * 4);
-            row += v * cx[q];
+            for (int q = 0; q < 4; ++q) {
+                int xx = ix - 1 + q;
+                xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+                const f32x4 v = Vec4<T>::ld(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + cv * 4);
+                row += v * cx[q];
+            }
+            acc += row * cy[r];
         }
-        acc += row * cy[r];
+        const f32x4 av = Vec4<T>::ld(a + ((size_t)b * OH * OW + p) * acs + aco + cv * 4);
+        return av + acc;
     }
-    const size_t o = ((size_t)b * OH + oy) * OW + ox;
-    const f32x4 av = Vec4<T>::ld(a + o * acs + aco + cv * 4);
-    Vec4<T>::st(y + o * ycs + yco + cv * 4, av + acc);
+};
+
+template <typename T, typename Op>
+__global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, int yco, int C, int HWo,
+                                                        ChanStat* __restrict__ st) {
+    __shared__ float red[2][1024];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int tpr = C / 4, P = 256 / tpr;
+    const int cv = tid % tpr, pl = tid / tpr;
+    const int p0 = blockIdx.x * MAP_PIX, p1 = min(p0 + MAP_PIX, HWo);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
+    for (int p = p0 + pl; p < p1; p += P) {
+        const f32x4 v = Vec4<T>::st_round(y + ((size_t)b * HWo + p) * ycs + yco + cv * 4, op(b, p, cv));
+        sum += v;
+        sq += v * v;
+    }
+    if (!st) return;   // uniform
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][pl * C + cv * 4 + j] = sum[j];
+        red[1][pl * C + cv * 4 + j] = sq[j];
+    }
+    __syncthreads();
+    if (tid < C) {
+        float a = 0.f, q = 0.f;
+        for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
+        ChanStat* o = st + (size_t)b * C + tid;
+        stat_add(&o->sum, a);
+        stat_add(&o->sq, q);
+    }
 }
 
-int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
-                 hipStream_t s) {
-    const size_t total4 = (size_t)B * (2 * H) * (2 * W) * (a.C / 4);
-    const int blocks = (int)((total4 + 255) / 256);
-    if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(upadd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)a.p, a.cs, a.co,
-                           (const float*)low.p, low.cs, low.co, (float*)y.p, y.cs, y.co, a.C, H, W, total4);
-    else
-        hipLaunchKernelGGL(upadd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)a.p, a.cs, a.co,
-                           (const bf16_t*)low.p, low.cs, low.co, (bf16_t*)y.p, y.cs, y.co, a.C, H, W, total4);
+template <typename T, typename Op>
+static int launch_map(chore_handle* h, const Op& op, const View& y, int B, int HWo, ChanStat* st, hipStream_t s) {
+    if (y.C % 4 || y.C > 256 || 256 % (y.C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "map: unsupported C=%d", y.C);
+    dim3 grid((HWo + MAP_PIX - 1) / MAP_PIX, B);
+    hipLaunchKernelGGL((map_stats_kernel<T, Op>), grid, dim3(256), 0, s, op, (T*)y.p, y.cs, y.co, y.C, HWo, st);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
+}
+
+int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, ChanStat* st,
+                    hipStream_t s) {
+    const int HWo = (H / 2) * (W / 2);
+    if (dtype == CHORE_F32) {
+        PoolOp<float> op{(const float*)x.p, x.cs, x.co, H, W};
+        return launch_map<float>(h, op, y, B, HWo, st, s);
+    }
+    PoolOp<bf16_t> op{(const bf16_t*)x.p, x.cs, x.co, H, W};
+    return launch_map<bf16_t>(h, op, y, B, HWo, st, s);
+}
+
+// y may alias a (in-place add): every element is read and written by the same thread
+int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
+                 ChanStat* st, hipStream_t s) {
+    const int HWo = 4 * H * W;
+    if (dtype == CHORE_F32) {
+        UpAddOp<float> op{(const float*)a.p, a.cs, a.co, (const float*)low.p, low.cs, low.co, H, W};
+        return launch_map<float>(h, op, y, B, HWo, st, s);
+    }
+    UpAddOp<bf16_t> op{(const bf16_t*)a.p, a.cs, a.co, (const bf16_t*)low.p, low.cs, low.co, H, W};
+    return launch_map<bf16_t>(h, op, y, B, HWo, st, s);
 }
 
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {

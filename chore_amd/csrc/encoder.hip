@@ -148,9 +148,20 @@ struct RunCtx {
     int rc = CHORE_OK;
 };
 
-enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_CONV3_128, K_CONV3_64, K_CONV3_32, K_CONV1, K_POOL, K_UPADD, K_NUM };
-const char* const kclass_names[K_NUM] = {"stem_conv7x7", "gn_stats", "gn_apply_relu", "conv3x3_n128", "conv3x3_n64",
-                                         "conv3x3_n32", "conv1x1", "avgpool2", "bicubic_upadd"};
+// one class per kernel instantiation, named like the kernel in a rocprofv3 trace so that bench.py's live
+// hipEvent numbers can be checked against profiles/*_kernel_stats.csv line by line
+enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_NUM = K_CONV_FIRST + 8 };
+const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "avgpool2_kernel",
+                                         "upadd_kernel", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
+                                         "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
+                                         "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
+                                         "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>"};
+inline int conv_class(const ConvPlan& p, int taps) {
+    const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
+    if (taps == 1) return K_CONV_FIRST + 5 + ni;
+    if (p.tps == 9) return K_CONV_FIRST + 3 + (ni - 1);
+    return K_CONV_FIRST + ni;
+}
 
 enum StepKind { S_KERNEL = 0, S_RECORD, S_WAIT, S_MEMSET };
 
@@ -305,8 +316,7 @@ struct Builder {
                     " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
         {
             const double px = (double)B * c.in.H * c.in.W;
-            const int nt = conv_plan(dtype, c.taps, B, c.in.H, c.in.W, c.cout).nt;
-            cur_class = c.taps == 1 ? K_CONV1 : (nt == 128 ? K_CONV3_128 : (nt == 64 ? K_CONV3_64 : K_CONV3_32));
+            cur_class = conv_class(conv_plan(dtype, c.taps, B, c.in.H, c.in.W, c.in_C, c.cout), c.taps);
             cur_flops = 2.0 * c.taps * c.in_C * c.cout * px;
             cur_bytes = px * es() * (c.in_C + c.cout * (1 + (c.has_raw ? 1 : 0) + (c.has_res ? 1 : 0) + (c.has_res2 ? 1 : 0)));
         }
@@ -376,25 +386,28 @@ struct Builder {
 
     Buf pool2(const Buf& x, const Buf* out_opt = nullptr) {
         Buf y = out_opt ? *out_opt : alloc(x.H / 2, x.W / 2, x.C);
+        new_stats(y);   // the pooling kernel also accumulates the statistics of its output
         cur_label = "avgpool2";
         cur_class = K_POOL; cur_flops = 0.0; cur_bytes = (double)B * x.H * x.W * x.C * es() * 1.25;
         const int Bn = B;
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W, r.s);
+            r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W,
+                                   (ChanStat*)(r.stats + y.st_off), r.s);
         });
         return y;
     }
     void upadd(Buf& a, const Buf& low) {  // a += bicubic_up2(low)
         cur_label = "upadd";
         cur_class = K_UPADD; cur_flops = 0.0; cur_bytes = (double)B * low.H * low.W * low.C * es() * 9.0;
+        new_stats(a);   // modified in place: fresh accumulators, filled by the same kernel
         const Buf ab = a;
         const int Bn = B;
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_upadd(r.h, r.dtype, view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W, r.s);
+            r.rc = launch_upadd(r.h, r.dtype, view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W,
+                                (ChanStat*)(r.stats + ab.st_off), r.s);
         });
-        a.st_valid = false;   // modified in place: the producers' statistics no longer describe it
     }
 
     // HourGlass._forward (HGFilters.py:26-50).  The upper branch (b1 at full resolution) is independent
@@ -463,7 +476,7 @@ struct Builder {
         release(c1);
         Buf b2 = conv_block(tmpx, p + "conv2", 64, 128);
         Buf normx = P.want_normx ? external(101, H4, W4, 128) : alloc(H4, W4, 128);
-        pool2(b2, &normx);
+        normx = pool2(b2, &normx);
         release(b2);
         Buf x3 = conv_block(normx, p + "conv3", 128, 128);
         release(normx);
