@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         // sets are named statically; the loads are unconditional (the tail re-fetches the last chunk) so that the
         // wait before a publish counts only the loads issued after the ones it needs.  NCH % PD == 0 (launcher).
 #pragma unroll 1
-        for (int c0 = 0; c0 < NCH; c0 += PD) {
+        for (int c0 = 0; c0 < ((a.dbg & 128) ? 0 : NCH); c0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const int c = c0 + u;
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     } else {
         int c = 0, krow = 0;   // c counts chunks in visiting order
 #pragma unroll 1
-        for (int s = 0; s < S; ++s) {
+        for (int s = 0; s < ((a.dbg & 128) ? 0 : S); ++s) {
             const bool last_row = (krow == KROWS - 1);
             const bool more_chunks = (c + 1 < NCH);
             // (a) prefetch the next K-step's weights (and the next chunk's patch) into registers; they have
