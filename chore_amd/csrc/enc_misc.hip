@@ -7,6 +7,7 @@
 // border-clamped taps and source coordinate dst*(in-1)/(out-1).
 // All tensors NHWC; every thread moves 4 channels (16 B fp32 / 8 B bf16) so accesses coalesce.
 #include "enc_common.h"
+#include <type_traits>
 
 template <typename T> struct Vec4;
 template <> struct Vec4<float> {
@@ -238,22 +239,31 @@ int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanSt
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pixel-wise producers with fused GroupNorm statistics.  A block owns a slice of MAP_PIX output pixels
-// of one image and all C channels: thread = (channel quad, pixel lane); it stores its values and sums
-// the values AS STORED; the block then reduces in a fixed order and adds its partials to the exact
-// accumulators (enc_common.h), so no separate statistics pass over the output is needed.
+// Pixel-wise producers with fused GroupNorm statistics.  A block owns an 8x8 tile of output pixels of one
+// image and all C channels: thread = (channel quad, pixel lane); it stores its values and sums the values
+// AS STORED; the block then reduces in a fixed order and adds its partials to the exact accumulators
+// (enc_common.h), so no separate statistics pass over the output is needed.  C is a template parameter so
+// that every per-thread loop has a compile-time trip count: the loads of a loop are then issued together
+// instead of one global round trip per iteration.
 // ------------------------------------------------------------------------------------------------
-constexpr int MAP_PIX = 64;
+constexpr int MAP_T = 8;   // tile edge
 
 // 2x2 average pooling   (F.avg_pool2d(x, 2, stride=2), HGFilters.py:32,152)
-template <typename T> struct PoolOp {
+template <typename T, int C> struct PoolOp {
     const T* x; int xcs, xco, H, W;   // input view and size
-    __device__ __forceinline__ f32x4 operator()(int b, int p, int cv) const {
-        const int OW = W / 2, oy = p / OW, ox = p % OW;
-        const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + cv * 4;
-        const f32x4 a = Vec4<T>::ld(src), bb = Vec4<T>::ld(src + xcs);
-        const f32x4 c = Vec4<T>::ld(src + (size_t)W * xcs), d = Vec4<T>::ld(src + (size_t)W * xcs + xcs);
-        return (((a + bb) + c) + d) * 0.25f;
+    static constexpr size_t SMEM = 0;
+    __device__ __forceinline__ void stage(char*, int, int, int, int, int) const {}
+    // the MAP_T outputs of tile column ox, rows oy0.. (rows beyond OH repeat the last row; the caller skips them)
+    __device__ __forceinline__ void column(const char*, int b, int oy0, int ox, int cv, int OH,
+                                           f32x4 (&out)[MAP_T]) const {
+#pragma unroll
+        for (int r = 0; r < MAP_T; ++r) {
+            const int oy = oy0 + r < OH ? oy0 + r : OH - 1;
+            const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + cv * 4;
+            const f32x4 a = Vec4<T>::ld(src), bb = Vec4<T>::ld(src + xcs);
+            const f32x4 c = Vec4<T>::ld(src + (size_t)W * xcs), d = Vec4<T>::ld(src + (size_t)W * xcs + xcs);
+            out[r] = (((a + bb) + c) + d) * 0.25f;
+        }
     }
 };
 
@@ -266,52 +276,118 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
     c[2] = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
     c[3] = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
 }
-template <typename T> struct UpAddOp {
+// The 16 taps of an output pixel come from an 8x8 low-resolution neighbourhood shared by the whole tile
+// (scale < 1/2: 8 output rows span at most 5 source rows, +3 for the kernel support).  It is staged in LDS
+// once -- border clamping applied while staging -- instead of being fetched 64x through the 32 KB L1, which
+// the tile's working set does not fit.  One thread then produces a whole tile column: the horizontal
+// interpolation of the 8 patch rows is done once (8 x 4 taps) and every output row combines 4 of those
+// (same two-pass order as ATen's upsample_bicubic2d: x first, then y).
+template <typename T, int C> struct UpAddOp {
+    static constexpr int PS = 8;   // patch edge
+    static constexpr int TPR = C / 4, P = 256 / TPR;
+    static constexpr size_t SMEM = (size_t)PS * PS * C * sizeof(T);
     const T* a; int acs, aco;
     const T* low; int lcs, lco, H, W;   // low-resolution view and size (output is 2H x 2W)
-    __device__ __forceinline__ f32x4 operator()(int b, int p, int cv) const {
-        const int OH = 2 * H, OW = 2 * W, oy = p / OW, ox = p % OW;
-        const float sy = (OH > 1) ? (float)(H - 1) / (float)(OH - 1) : 0.f;
-        const float sx = (OW > 1) ? (float)(W - 1) / (float)(OW - 1) : 0.f;
-        const float ry = sy * (float)oy, rx = sx * (float)ox;
-        const float fy = floorf(ry), fx = floorf(rx);
-        const int iy = (int)fy, ix = (int)fx;
-        float cy[4], cx[4];
-        cubic_coeffs(ry - fy, cy);
-        cubic_coeffs(rx - fx, cx);
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    __device__ __forceinline__ float scale_y() const { return (float)(H - 1) / (float)(2 * H - 1); }
+    __device__ __forceinline__ float scale_x() const { return (float)(W - 1) / (float)(2 * W - 1); }
+    __device__ __forceinline__ void stage(char* sm, int b, int oy0, int ox0, int cv, int pl) const {
+        const int iy0 = (int)floorf(scale_y() * (float)oy0) - 1, ix0 = (int)floorf(scale_x() * (float)ox0) - 1;
+        constexpr int N = PS * PS / P;
+        typedef typename std::conditional<sizeof(T) == 2, unsigned long long, f32x4>::type Raw;
+        Raw v[N];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int yy = iy - 1 + r;
+        for (int i = 0; i < N; ++i) {
+            const int q = pl + i * P;
+            int yy = iy0 + q / PS, xx = ix0 + q % PS;
             yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
-            f32x4 row = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                int xx = ix - 1 + q;
-                xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-                const f32x4 v = Vec4<T>::ld(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + cv * 4);
-                row += v * cx[q];
-            }
-            acc += row * cy[r];
+            xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
+            v[i] = *(const Raw*)(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + cv * 4);
         }
-        const f32x4 av = Vec4<T>::ld(a + ((size_t)b * OH * OW + p) * acs + aco + cv * 4);
-        return av + acc;
+#pragma unroll
+        for (int i = 0; i < N; ++i) *(Raw*)((T*)sm + (size_t)(pl + i * P) * C + cv * 4) = v[i];
+    }
+    __device__ __forceinline__ void column(const char* sm, int b, int oy0, int ox, int cv, int OH,
+                                           f32x4 (&out)[MAP_T]) const {
+        const int OW = 2 * W;
+        const int ox0 = ox & ~(MAP_T - 1);
+        const int iy0 = (int)floorf(scale_y() * (float)oy0) - 1, ix0 = (int)floorf(scale_x() * (float)ox0) - 1;
+        f32x4 av[MAP_T];
+#pragma unroll
+        for (int r = 0; r < MAP_T; ++r) {   // issued first: they land while the interpolation runs
+            const int oy = oy0 + r < OH ? oy0 + r : OH - 1;
+            av[r] = Vec4<T>::ld(a + (((size_t)b * 2 * H + oy) * OW + ox) * acs + aco + cv * 4);
+        }
+        const float rx = scale_x() * (float)ox, fx = floorf(rx);
+        const int kx = (int)fx - 1 - ix0;
+        float cx[4];
+        cubic_coeffs(rx - fx, cx);
+        f32x4 rows[PS];
+#pragma unroll
+        for (int k = 0; k < PS; ++k) {
+            const T* pr = (const T*)sm + (size_t)(k * PS + kx) * C + cv * 4;
+            f32x4 acc = Vec4<T>::ld(pr) * cx[0];
+#pragma unroll
+            for (int q = 1; q < 4; ++q) {
+                const f32x4 v = Vec4<T>::ld(pr + (size_t)q * C);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], cx[q], acc[e]);
+            }
+            rows[k] = acc;
+        }
+#pragma unroll
+        for (int r = 0; r < MAP_T; ++r) {
+            const int oy = oy0 + r < OH ? oy0 + r : OH - 1;
+            const float ry = scale_y() * (float)oy, fy = floorf(ry);
+            const int ky = (int)fy - 1 - iy0;   // 0..4
+            float cy[4];
+            cubic_coeffs(ry - fy, cy);
+            // weights of the 8 patch rows for this output row (zero outside ky..ky+3): static register indexing
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            bool first = true;
+#pragma unroll
+            for (int k = 0; k < PS; ++k) {
+                const int j = k - ky;
+                if (j >= 0 && j < 4) {   // wave-uniform (oy is the same for the whole wave)
+                    const float w = cy[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = first ? rows[k][e] * w : fmaf(rows[k][e], w, acc[e]);
+                    first = false;
+                }
+            }
+            out[r] = av[r] + acc;
+        }
     }
 };
 
-template <typename T, typename Op>
-__global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, int yco, int C, int HWo,
+template <typename T, int C, typename Op>
+__global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, int yco, int OH, int OW,
                                                         ChanStat* __restrict__ st) {
+    extern __shared__ __attribute__((aligned(16))) char map_sm[];
     __shared__ float red[2][1024];
+    constexpr int TPR = C / 4, P = 256 / TPR;
     const int b = blockIdx.y, tid = threadIdx.x;
-    const int tpr = C / 4, P = 256 / tpr;
-    const int cv = tid % tpr, pl = tid / tpr;
-    const int p0 = blockIdx.x * MAP_PIX, p1 = min(p0 + MAP_PIX, HWo);
+    const int cv = tid % TPR, pl = tid / TPR;
+    const int tiles_x = (OW + MAP_T - 1) / MAP_T;
+    const int oy0 = (blockIdx.x / tiles_x) * MAP_T, ox0 = (blockIdx.x % tiles_x) * MAP_T;
+    op.stage(map_sm, b, oy0, ox0, cv, pl);
+    __syncthreads();
     f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + pl; p < p1; p += P) {
-        const f32x4 v = Vec4<T>::st_round(y + ((size_t)b * HWo + p) * ycs + yco + cv * 4, op(b, p, cv));
-        sum += v;
-        sq += v * v;
+#pragma unroll
+    for (int col = pl; col < MAP_T; col += P) {
+        const int ox = ox0 + col;
+        if (ox < OW) {
+            f32x4 out[MAP_T];
+            op.column(map_sm, b, oy0, ox, cv, OH, out);
+#pragma unroll
+            for (int r = 0; r < MAP_T; ++r) {
+                const int oy = oy0 + r;
+                if (oy < OH) {
+                    const f32x4 v = Vec4<T>::st_round(y + (((size_t)b * OH + oy) * OW + ox) * ycs + yco + cv * 4, out[r]);
+                    sum += v;
+                    sq += v * v;
+                }
+            }
+        }
     }
     if (!st) return;   // uniform
 #pragma unroll
@@ -322,6 +398,7 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
     __syncthreads();
     if (tid < C) {
         float a = 0.f, q = 0.f;
+#pragma unroll
         for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
         ChanStat* o = st + (size_t)b * C + tid;
         stat_add(&o->sum, a);
@@ -329,36 +406,54 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
     }
 }
 
-template <typename T, typename Op>
-static int launch_map(chore_handle* h, const Op& op, const View& y, int B, int HWo, ChanStat* st, hipStream_t s) {
-    if (y.C % 4 || y.C > 256 || 256 % (y.C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "map: unsupported C=%d", y.C);
-    dim3 grid((HWo + MAP_PIX - 1) / MAP_PIX, B);
-    hipLaunchKernelGGL((map_stats_kernel<T, Op>), grid, dim3(256), 0, s, op, (T*)y.p, y.cs, y.co, y.C, HWo, st);
+template <typename T, int C, typename Op>
+static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int OH, int OW, ChanStat* st,
+                        hipStream_t s) {
+    dim3 grid(((OH + MAP_T - 1) / MAP_T) * ((OW + MAP_T - 1) / MAP_T), B);
+    static bool attr = false;   // per instantiation
+    if (!attr && Op::SMEM > 32 * 1024) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)map_stats_kernel<T, C, Op>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)Op::SMEM));
+        attr = true;
+    }
+    hipLaunchKernelGGL((map_stats_kernel<T, C, Op>), grid, dim3(256), Op::SMEM, s, op, (T*)y.p, y.cs, y.co, OH, OW, st);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
+template <typename T>
+static int launch_pool_t(chore_handle* h, const View& x, const View& y, int B, int H, int W, ChanStat* st,
+                         hipStream_t s) {
+    switch (y.C) {
+        case 64: return launch_map_c<T, 64>(h, PoolOp<T, 64>{(const T*)x.p, x.cs, x.co, H, W}, y, B, H / 2, W / 2, st, s);
+        case 128: return launch_map_c<T, 128>(h, PoolOp<T, 128>{(const T*)x.p, x.cs, x.co, H, W}, y, B, H / 2, W / 2, st, s);
+        case 256: return launch_map_c<T, 256>(h, PoolOp<T, 256>{(const T*)x.p, x.cs, x.co, H, W}, y, B, H / 2, W / 2, st, s);
+    }
+    CHORE_FAIL(h, CHORE_EINVAL, "avgpool2: unsupported C=%d (64, 128, 256)", y.C);
+}
+
 int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, ChanStat* st,
                     hipStream_t s) {
-    const int HWo = (H / 2) * (W / 2);
-    if (dtype == CHORE_F32) {
-        PoolOp<float> op{(const float*)x.p, x.cs, x.co, H, W};
-        return launch_map<float>(h, op, y, B, HWo, st, s);
+    return dtype == CHORE_F32 ? launch_pool_t<float>(h, x, y, B, H, W, st, s)
+                              : launch_pool_t<bf16_t>(h, x, y, B, H, W, st, s);
+}
+
+template <typename T>
+static int launch_upadd_t(chore_handle* h, const View& a, const View& low, const View& y, int B, int H, int W,
+                          ChanStat* st, hipStream_t s) {
+    switch (y.C) {
+        case 64: return launch_map_c<T, 64>(h, UpAddOp<T, 64>{(const T*)a.p, a.cs, a.co, (const T*)low.p, low.cs, low.co, H, W}, y, B, 2 * H, 2 * W, st, s);
+        case 128: return launch_map_c<T, 128>(h, UpAddOp<T, 128>{(const T*)a.p, a.cs, a.co, (const T*)low.p, low.cs, low.co, H, W}, y, B, 2 * H, 2 * W, st, s);
+        case 256: return launch_map_c<T, 256>(h, UpAddOp<T, 256>{(const T*)a.p, a.cs, a.co, (const T*)low.p, low.cs, low.co, H, W}, y, B, 2 * H, 2 * W, st, s);
     }
-    PoolOp<bf16_t> op{(const bf16_t*)x.p, x.cs, x.co, H, W};
-    return launch_map<bf16_t>(h, op, y, B, HWo, st, s);
+    CHORE_FAIL(h, CHORE_EINVAL, "upadd: unsupported C=%d (64, 128, 256)", y.C);
 }
 
 // y may alias a (in-place add): every element is read and written by the same thread
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
                  ChanStat* st, hipStream_t s) {
-    const int HWo = 4 * H * W;
-    if (dtype == CHORE_F32) {
-        UpAddOp<float> op{(const float*)a.p, a.cs, a.co, (const float*)low.p, low.cs, low.co, H, W};
-        return launch_map<float>(h, op, y, B, HWo, st, s);
-    }
-    UpAddOp<bf16_t> op{(const bf16_t*)a.p, a.cs, a.co, (const bf16_t*)low.p, low.cs, low.co, H, W};
-    return launch_map<bf16_t>(h, op, y, B, HWo, st, s);
+    return dtype == CHORE_F32 ? launch_upadd_t<float>(h, a, low, y, B, H, W, st, s)
+                              : launch_upadd_t<bf16_t>(h, a, low, y, B, H, W, st, s);
 }
 
 __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
