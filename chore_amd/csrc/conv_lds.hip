@@ -243,57 +243,47 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         load_w(rbq[q], chunk_of(cq), 0);
     }
     if (use_gn && !(a.dbg & 64)) {
-        // GroupNorm affine of this image's input channels from the producers' exact totals: one
-        // 32-byte load per channel (patch area as scratch: nothing has been staged yet), then a
-        // fixed-order sum over the channels of the group
-        double* dsum = (double*)smem;          // [Cin] sum, [Cin] sum of squares
-        for (int ci = tid; ci < Cin; ci += 256) {
-            const ChanStat st = a.in_st[(size_t)b * Cin + ci];
-            dsum[ci] = stat_read(st.sum);
-            dsum[Cin + ci] = stat_read(st.sq);
-        }
-        __syncthreads();
-        const int gs = Cin / GN_GROUPS;
-        const double n = (double)a.H * a.W * gs;
-        for (int ci = tid; ci < Cin; ci += 256) {
-            const int g0 = (ci / gs) * gs;
-            double sa = 0.0, sq = 0.0;
-            for (int j = 0; j < gs; ++j) { sa += dsum[g0 + j]; sq += dsum[Cin + g0 + j]; }
-            const double mean = sa / n;
-            double var = sq / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
-            const float scale = rstd * a.gamma[ci];
-            ss_lds[2 * ci] = scale;
-            ss_lds[2 * ci + 1] = a.beta[ci] - (float)mean * scale;
-        }
+        // GroupNorm affine of this image's input channels from the producers' exact group totals
+        for (int ci = tid; ci < Cin; ci += 256)
+            gn_scale_shift(a.in_st, b, Cin, ci, a.H * a.W, a.gamma, a.beta, ss_lds[2 * ci], ss_lds[2 * ci + 1]);
     }
     __syncthreads();   // ss_lds visible, scratch free
     write_patch(preq[0], chunk_of(0) * CC);
     write_w(rbq[0], 0);
     __syncthreads();
 
-    // the MFMAs of one K-step: weights from ring slot `slot`, patch rows shifted by kernel row `krow`
+    // the MFMAs of one K-step: weights from ring slot `slot`, patch rows shifted by kernel row `krow`.  The
+    // fragments of k-step ks+FD are requested before the MFMAs of k-step ks are issued and the scheduler is fenced
+    // so that it keeps that order: left alone it sinks the ds_reads to just before their use and every other MFMA
+    // pair then waits a full LDS round trip (one wave per SIMD: nothing else hides it).
+    constexpr int NKS = TPS * KGC;                     // k-steps (one MFMA K each) per K-step
+    constexpr int FD = (NT >= 128 || NKS < 3) ? 1 : 2; // fragment prefetch distance
     auto mfma_step = [&](int slot, int krow) {
         const char* bs = b_ptr + slot * SBYTES;
         const char* ar = a_ptr + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
-#pragma unroll
-        for (int t = 0; t < TPS; ++t) {
+        u32x4 af[FD + 1][MB], bf[FD + 1][NBW];
+        auto load_frag = [&](int fs, int ks) {
+            const int t = ks / KGC, kg = ks % KGC;
             const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
 #pragma unroll
-            for (int kg = 0; kg < KGC; ++kg) {
-                u32x4 af[MB], bf[NBW];
+            for (int q = 0; q < NBW; ++q)
+                bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
 #pragma unroll
-                for (int q = 0; q < NBW; ++q)
-                    bf[q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+            for (int m = 0; m < MB; ++m)
+                af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
+        };
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
-                    af[m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
+        for (int d = 0; d < FD; ++d)
+            if (d < NKS) load_frag(d, d);
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+        for (int ks = 0; ks < NKS; ++ks) {
+            if (ks + FD < NKS) load_frag((ks + FD) % (FD + 1), ks + FD);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[m], bf[q]);
-            }
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[ks % (FD + 1)][m], bf[ks % (FD + 1)][q]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -358,9 +348,9 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const size_t img = (size_t)b * a.H * a.W;
     T* out_p = (T*)a.out.p + img * a.out.cs + a.out.co + nv;
     T* raw_p = a.raw.p ? (T*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
-    const T* res_p = a.res.p ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
-    const T* res2_p = a.res2.p ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
-    const bool want_stats = a.st_raw || a.st_out;
+    const T* res_p = (a.res.p && !(a.dbg & 1024)) ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    const T* res2_p = (a.res2.p && !(a.dbg & 1024)) ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
+    const bool want_stats = (a.st_raw || a.st_out) && !(a.dbg & 256);
     float sr[8], qr[8], so[8], qo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
@@ -420,7 +410,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 const f32x4 lo = *(const f32x4*)(scr + p * SCR_LD + g8 * 8), hi = *(const f32x4*)(scr + p * SCR_LD + g8 * 8 + 4);
                 f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
             }
-            if (y < a.H && x < a.W) {
+            if (y < a.H && x < a.W && !(a.dbg & 512)) {
                 const size_t pix = (size_t)y * a.W + x;
                 if (raw_p) {
                     float g[8];
@@ -475,15 +465,24 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
             const int cg = n_tile * NT + tid;
             if (a.dbg & 16) return;
+            // channels -> GroupNorm groups of the tensor the slice belongs to (gs consecutive lanes), one lane adds
             if (a.st_raw) {
-                ChanStat* o = a.st_raw + (size_t)b * a.st_raw_C + a.st_raw_co + cg;
-                stat_add(&o->sum, t[0]);
-                stat_add(&o->sq, t[1]);
+                const int gs = a.st_raw_C / GN_GROUPS;
+                const float s1 = group_lane_sum(t[0], gs), s2 = group_lane_sum(t[1], gs);
+                if (tid % gs == 0) {
+                    GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
+                    stat_add(&o->sum, s1);
+                    stat_add(&o->sq, s2);
+                }
             }
             if (a.st_out) {
-                ChanStat* o = a.st_out + (size_t)b * a.st_out_C + a.st_out_co + cg;
-                stat_add(&o->sum, t[2]);
-                stat_add(&o->sq, t[3]);
+                const int gs = a.st_out_C / GN_GROUPS;
+                const float s1 = group_lane_sum(t[2], gs), s2 = group_lane_sum(t[3], gs);
+                if (tid % gs == 0) {
+                    GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
+                    stat_add(&o->sum, s1);
+                    stat_add(&o->sq, s2);
+                }
             }
         }
     }
@@ -564,6 +563,11 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     if (a_in.Cout % 32) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cout=%d", a_in.Cout);
     if (a_in.B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "conv: B too large");
     if (taps != 1 && taps != 9) CHORE_FAIL(h, CHORE_EINVAL, "conv: taps must be 1 or 9");
+    for (int c : {a_in.st_raw ? a_in.st_raw_C : 32, a_in.st_out ? a_in.st_out_C : 32, a_in.in_st ? a_in.in.C : 32}) {
+        const int gs = c / GN_GROUPS;
+        if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
+            CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
+    }
     static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
     ConvArgs a = a_in;
     a.dbg = dbg;

@@ -19,13 +19,15 @@ constexpr int GN_GROUPS = 32;
 constexpr int GN_SPLITS_MAX = 64;
 
 // ---- exact, order-independent GroupNorm statistics -------------------------------------------------
-// Every producer adds its per-channel partial sums into a 128-bit fixed-point accumulator (unit 2^-40)
-// with 64-bit integer atomics.  Integer addition is associative, so the totals -- and everything
+// Every producer adds its partial sums per (image, GroupNorm group) into a 128-bit fixed-point accumulator
+// (unit 2^-40) with 64-bit integer atomics.  (Per group, not per channel: device-scope atomics execute at the
+// memory side and their COUNT is what a producer kernel pays for -- a per-channel version spent 10-30 % of
+// every producer on them.)  Integer addition is associative, so the totals -- and everything
 // derived from them -- are bit-identical whatever order the workgroups run in, across runs and batch
 // compositions; no finalize kernel and no per-tile partial buffers are needed.  A consumer turns the
 // totals into the per-(image,channel) affine  relu(x*scale+shift)  in its own prologue.
 struct StatCell { unsigned long long lo; long long hi; };
-struct ChanStat { StatCell sum, sq; };   // per (image, channel): sum and sum of squares of the stored values
+struct GroupStat { StatCell sum, sq; };   // per (image, group): sum and sum of squares of the stored values
 
 __device__ __forceinline__ void stat_add(StatCell* c, float x) {
     const double d = (double)x * 0x1p40;             // exact (power-of-two scaling)
@@ -47,19 +49,19 @@ __device__ __forceinline__ double stat_read(const StatCell& c) {
     const double v = ((double)hi * 0x1p64 + (double)lo) * 0x1p-40;
     return neg ? -v : v;
 }
+// sum over the gs (power of two <= 8) consecutive channels of a group held by gs consecutive lanes: fixed tree
+__device__ __forceinline__ float group_lane_sum(float v, int gs) {
+    for (int o = 1; o < gs; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
 // scale/shift of channel c of image b: GroupNorm(32 groups, eps 1e-5, biased variance) folded to an affine
-__device__ __forceinline__ void gn_scale_shift(const ChanStat* st, int b, int C, int c, int HW,
+__device__ __forceinline__ void gn_scale_shift(const GroupStat* st, int b, int C, int c, int HW,
                                                const float* gamma, const float* beta, float& scale, float& shift) {
-    const int gs = C / GN_GROUPS, g = c / gs;
-    double a = 0.0, q = 0.0;
-    for (int j = 0; j < gs; ++j) {
-        const ChanStat s = st[(size_t)b * C + g * gs + j];
-        a += stat_read(s.sum);
-        q += stat_read(s.sq);
-    }
+    const int gs = C / GN_GROUPS;
+    const GroupStat s = st[(size_t)b * GN_GROUPS + c / gs];
     const double n = (double)HW * gs;
-    const double mean = a / n;
-    double var = q / n - mean * mean;
+    const double mean = stat_read(s.sum) / n;
+    double var = stat_read(s.sq) / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
     scale = rstd * gamma[c];
@@ -68,7 +70,7 @@ __device__ __forceinline__ void gn_scale_shift(const ChanStat* st, int b, int C,
 
 struct ConvArgs {
     View in;                 // input activations (a whole tensor when GroupNorm is fused: co = 0, C = cs)
-    const ChanStat* in_st;   // [B][Cin] statistics of the input, or null: no GroupNorm+ReLU prologue
+    const GroupStat* in_st;  // [B][32] statistics of the input, or null: no GroupNorm+ReLU prologue
     const float* gamma;      // [Cin] GroupNorm affine of the fused prologue
     const float* beta;
     const void* wpk;         // fragment-ordered weights (launch_pack_conv)
@@ -77,10 +79,10 @@ struct ConvArgs {
     View raw;                // optional: acc + bias
     View res, res2;          // optional residuals (may alias out)
     int B, H, W, Cout;
-    // optional statistics of what this launch stores (for the next GroupNorm): [B][C] accumulators of
-    // the tensor `raw` / `out` belong to; *_C = channels of that tensor, *_co = offset of this slice
-    ChanStat* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0;
-    ChanStat* st_out = nullptr; int st_out_C = 0, st_out_co = 0;
+    // optional statistics of what this launch stores (for the next GroupNorm): [B][32] accumulators of
+    // the tensor `raw` / `out` belong to; *_C = channels of that tensor (group size = C/32), *_co = offset of this slice
+    GroupStat* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0;
+    GroupStat* st_out = nullptr; int st_out_C = 0, st_out_co = 0;
     int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
@@ -98,12 +100,12 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
                 const float* wk /*[Cin*49][64]*/, const float* bias, void* out /*(B,H/2,W/2,64)*/, hipStream_t s);
 int launch_pack_stem(chore_handle* h, int Cin, const float* w /*(64,Cin,7,7)*/, float* dst, hipStream_t s);
 // statistics of a tensor no convolution produced (pooling / upsampling / stem outputs): one pass, atomics
-int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, ChanStat* st, hipStream_t s);
+int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, GroupStat* st, hipStream_t s);
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
-int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanStat* st, const float* gamma,
+int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
                          const float* beta, const View& y, int B, int HW, hipStream_t s);
-int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, ChanStat* st, hipStream_t s);
+int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, GroupStat* st, hipStream_t s);
 // y = a + bicubic_up2(low)   (low is (B,H,W,C), a and y are (B,2H,2W,C); y may alias a)
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
-                 ChanStat* st, hipStream_t s);
+                 GroupStat* st, hipStream_t s);
 int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s);

@@ -151,7 +151,7 @@ int gn_splits(int HW) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, int cs, int co, int C, int HW,
-                                                       int S, ChanStat* __restrict__ st) {
+                                                       int S, GroupStat* __restrict__ st) {
     __shared__ float red[2][1024];
     const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int tpr = C / 4, P = 256 / tpr;
@@ -173,13 +173,18 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     if (tid < C) {
         float a = 0.f, q = 0.f;
         for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
-        ChanStat* o = st + (size_t)b * C + tid;
-        stat_add(&o->sum, a);
-        stat_add(&o->sq, q);
+        const int gs = C / GN_GROUPS;
+        a = group_lane_sum(a, gs);
+        q = group_lane_sum(q, gs);
+        if (tid % gs == 0) {
+            GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;
+            stat_add(&o->sum, a);
+            stat_add(&o->sq, q);
+        }
     }
 }
 
-int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, ChanStat* st, hipStream_t s) {
+int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, GroupStat* st, hipStream_t s) {
     if (x.C % GN_GROUPS || x.C > 256 || x.C < 32) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
     const int S = gn_splits(HW);
     dim3 grid(S, B);
@@ -197,7 +202,7 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Ch
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict__ x, int xcs, int xco,
-                                                            const ChanStat* __restrict__ st,
+                                                            const GroupStat* __restrict__ st,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
                                                             int ycs, int yco, int C, int HW) {
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict_
     }
 }
 
-int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const ChanStat* st, const float* gamma,
+int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
                          const float* beta, const View& y, int B, int HW, hipStream_t s) {
     if (x.C > 256 || x.C % GN_GROUPS) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
     const size_t total4 = (size_t)HW * (x.C / 4);
@@ -361,7 +366,7 @@ template <typename T, int C> struct UpAddOp {
 
 template <typename T, int C, typename Op>
 __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, int yco, int OH, int OW,
-                                                        ChanStat* __restrict__ st) {
+                                                        GroupStat* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) char map_sm[];
     __shared__ float red[2][1024];
     constexpr int TPR = C / 4, P = 256 / TPR;
@@ -400,14 +405,19 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
         float a = 0.f, q = 0.f;
 #pragma unroll
         for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
-        ChanStat* o = st + (size_t)b * C + tid;
-        stat_add(&o->sum, a);
-        stat_add(&o->sq, q);
+        const int gs = C / GN_GROUPS;
+        a = group_lane_sum(a, gs);
+        q = group_lane_sum(q, gs);
+        if (tid % gs == 0) {
+            GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;
+            stat_add(&o->sum, a);
+            stat_add(&o->sq, q);
+        }
     }
 }
 
 template <typename T, int C, typename Op>
-static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int OH, int OW, ChanStat* st,
+static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int OH, int OW, GroupStat* st,
                         hipStream_t s) {
     dim3 grid(((OH + MAP_T - 1) / MAP_T) * ((OW + MAP_T - 1) / MAP_T), B);
     static bool attr = false;   // per instantiation
@@ -422,7 +432,7 @@ static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int
 }
 
 template <typename T>
-static int launch_pool_t(chore_handle* h, const View& x, const View& y, int B, int H, int W, ChanStat* st,
+static int launch_pool_t(chore_handle* h, const View& x, const View& y, int B, int H, int W, GroupStat* st,
                          hipStream_t s) {
     switch (y.C) {
         case 64: return launch_map_c<T, 64>(h, PoolOp<T, 64>{(const T*)x.p, x.cs, x.co, H, W}, y, B, H / 2, W / 2, st, s);
@@ -432,7 +442,7 @@ static int launch_pool_t(chore_handle* h, const View& x, const View& y, int B, i
     CHORE_FAIL(h, CHORE_EINVAL, "avgpool2: unsupported C=%d (64, 128, 256)", y.C);
 }
 
-int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, ChanStat* st,
+int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, GroupStat* st,
                     hipStream_t s) {
     return dtype == CHORE_F32 ? launch_pool_t<float>(h, x, y, B, H, W, st, s)
                               : launch_pool_t<bf16_t>(h, x, y, B, H, W, st, s);
@@ -440,7 +450,7 @@ int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, in
 
 template <typename T>
 static int launch_upadd_t(chore_handle* h, const View& a, const View& low, const View& y, int B, int H, int W,
-                          ChanStat* st, hipStream_t s) {
+                          GroupStat* st, hipStream_t s) {
     switch (y.C) {
         case 64: return launch_map_c<T, 64>(h, UpAddOp<T, 64>{(const T*)a.p, a.cs, a.co, (const T*)low.p, low.cs, low.co, H, W}, y, B, 2 * H, 2 * W, st, s);
         case 128: return launch_map_c<T, 128>(h, UpAddOp<T, 128>{(const T*)a.p, a.cs, a.co, (const T*)low.p, low.cs, low.co, H, W}, y, B, 2 * H, 2 * W, st, s);
@@ -451,7 +461,7 @@ static int launch_upadd_t(chore_handle* h, const View& a, const View& low, const
 
 // y may alias a (in-place add): every element is read and written by the same thread
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
-                 ChanStat* st, hipStream_t s) {
+                 GroupStat* st, hipStream_t s) {
     return dtype == CHORE_F32 ? launch_upadd_t<float>(h, a, low, y, B, H, W, st, s)
                               : launch_upadd_t<bf16_t>(h, a, low, y, B, H, W, st, s);
 }

@@ -111,7 +111,7 @@ struct Buf {
     int ext = -1;         // index of an external (caller) tensor: 0..n_out-1 feats, 100 tmpx, 101 normx
     int H = 0, W = 0, C = 0;
     size_t bytes = 0;
-    // GroupNorm statistics ([B][C] ChanStat accumulators in the stats arena) of the buffer's content
+    // GroupNorm statistics ([B][32] GroupStat accumulators in the stats arena) of the buffer's content
     bool st_valid = false;
     size_t st_off = 0;
 };
@@ -230,7 +230,7 @@ struct Builder {
     void new_stats(Buf& b) {
         b.st_valid = true;
         b.st_off = stat_top;
-        stat_top += align_up((size_t)B * b.C * sizeof(ChanStat), 256);
+        stat_top += align_up((size_t)B * GN_GROUPS * sizeof(GroupStat), 256);
     }
 
     static void* ptr(RunCtx& r, const Buf& b) {
@@ -289,7 +289,7 @@ struct Builder {
         cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * HW * x.C * es();
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_gn_stats(r.h, r.dtype, view(r, xb), Bn, HW, (ChanStat*)(r.stats + xb.st_off), r.s);
+            r.rc = launch_gn_stats(r.h, r.dtype, view(r, xb), Bn, HW, (GroupStat*)(r.stats + xb.st_off), r.s);
         });
     }
 
@@ -326,7 +326,7 @@ struct Builder {
             ConvArgs a{};
             a.in = view(r, cs.in, 0, cs.in_C);
             if (use_gn) {
-                a.in_st = (const ChanStat*)(r.stats + cs.in.st_off);
+                a.in_st = (const GroupStat*)(r.stats + cs.in.st_off);
                 a.gamma = (const float*)(r.arena + ge.off);
                 a.beta = (const float*)(r.arena + bte.off);
             }
@@ -338,10 +338,10 @@ struct Builder {
             if (cs.has_res2) a.res2 = view(r, cs.res2, cs.res2_co, cs.cout);
             a.B = Bn; a.H = cs.in.H; a.W = cs.in.W; a.Cout = cs.cout;
             if (cs.stat_raw) {
-                a.st_raw = (ChanStat*)(r.stats + cs.raw.st_off); a.st_raw_C = cs.raw.C; a.st_raw_co = cs.raw_co;
+                a.st_raw = (GroupStat*)(r.stats + cs.raw.st_off); a.st_raw_C = cs.raw.C; a.st_raw_co = cs.raw_co;
             }
             if (cs.stat_out) {
-                a.st_out = (ChanStat*)(r.stats + cs.out.st_off); a.st_out_C = cs.out.C; a.st_out_co = cs.out_co;
+                a.st_out = (GroupStat*)(r.stats + cs.out.st_off); a.st_out_C = cs.out.C; a.st_out_co = cs.out_co;
             }
             r.rc = launch_conv(r.h, r.dtype, cs.taps, a, r.s);
         });
@@ -393,7 +393,7 @@ struct Builder {
         push([=](RunCtx& r) {
             if (r.rc) return;
             r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W,
-                                   (ChanStat*)(r.stats + y.st_off), r.s);
+                                   (GroupStat*)(r.stats + y.st_off), r.s);
         });
         return y;
     }
@@ -406,7 +406,7 @@ struct Builder {
         push([=](RunCtx& r) {
             if (r.rc) return;
             r.rc = launch_upadd(r.h, r.dtype, view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W,
-                                (ChanStat*)(r.stats + ab.st_off), r.s);
+                                (GroupStat*)(r.stats + ab.st_off), r.s);
         });
     }
 
@@ -468,7 +468,7 @@ struct Builder {
             cur_class = K_GN_APPLY; cur_flops = 0.0; cur_bytes = 2.0 * B * H2 * W2 * 64 * es();
             push([=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1b), (const ChanStat*)(r.stats + c1b.st_off),
+                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1b), (const GroupStat*)(r.stats + c1b.st_off),
                                             (const float*)(r.arena + ge.off), (const float*)(r.arena + bte.off),
                                             view(r, tmpx), Bn, H2 * W2, r.s);
             });
