@@ -15,9 +15,10 @@ per-GPU workload on its own seeded inputs, no data-path collective ("scaling": "
 bracketed by barrier + synchronize on both sides and the MAX over ranks is reported.
 
 Extra objects in the JSON line:
-  roofline      -- the dominant kernel class of the step (by measured time), its ALGORITHMIC FLOPs
+  roofline      -- the dominant kernel of the step (by measured time), its ALGORITHMIC FLOPs
                    per launch / average launch duration measured live with hipEvents on the launch
-                   stream (chore_profile_enable), against the dense MFMA peak of the dtype.
+                   stream (chore_profile_enable; that pass runs the encoder on ONE stream so kernels do not
+                   overlap), against the dense MFMA peak of the dtype.  Kernel names are the rocprofv3 names.
   cpu_baseline  -- the numpy oracle ("port") timed on this host on a bounded sample of the same
                    workload (1 image encode + 20 000-point query = 1/4 step), rank 0, N=1 only.
 """
@@ -161,6 +162,12 @@ def main():
                               "gbps": v["bytes"] / v["ms"] / 1e6}
         tname = "unsigned short" if args.dtype == "bf16" else "float"
         kernels = {k.replace("<T,", "<%s, " % tname).replace(",", ", ").replace(",  ", ", "): v for k, v in kernels.items()}
+        # HBM-side bytes per launch of each kernel from the committed rocprofv3 counter passes (FETCH_SIZE x2 +
+        # WRITE_SIZE, scripts/pmc_traffic.py) -- counters cannot be read live, so this is the last profiled build
+        traffic = {}
+        tpath = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % args.dtype)
+        if os.path.exists(tpath):
+            traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
         qname = "query_fwd_f32_kernel<%s>" % tname
         kernels[qname] = {"ms_per_step": qry_ms, "launches_per_step": 1,
                           "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
@@ -168,7 +175,9 @@ def main():
         dv = kernels[dom]
         dom_dtype = "fp32" if dom == qname else args.dtype
         roof = {"kernel": dom, "bound": "mfma", "achieved": dv["tflops"], "peak": PEAK_TFLOPS[dom_dtype],
-                "unit": "TFLOP/s", "frac": dv["tflops"] / PEAK_TFLOPS[dom_dtype], "traffic": None,
+                "unit": "TFLOP/s", "frac": dv["tflops"] / PEAK_TFLOPS[dom_dtype], "traffic": traffic.get(dom),
+                "traffic_source": "profiles/pmc_traffic_%s.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
+                                  % args.dtype if dom in traffic else None,
                 "avg_launch_ms": dv["ms_per_step"] / dv["launches_per_step"],
                 "flops_per_launch": dv["tflops"] * 1e9 * dv["ms_per_step"] / dv["launches_per_step"]}
         out = {

@@ -151,8 +151,8 @@ struct RunCtx {
 // one class per kernel instantiation, named like the kernel in a rocprofv3 trace so that bench.py's live
 // hipEvent numbers can be checked against profiles/*_kernel_stats.csv line by line
 enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_NUM = K_CONV_FIRST + 8 };
-const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "avgpool2_kernel",
-                                         "upadd_kernel", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
+const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "map_stats_kernel<T,C,PoolOp>",
+                                         "map_stats_kernel<T,C,UpAddOp>", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
                                          "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
                                          "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
                                          "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>"};
