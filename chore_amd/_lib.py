@@ -60,6 +60,9 @@ SIGNATURES = {
     "chore_so3_aux_bytes": (c_size_t, [c_int]),
     "chore_so3_project_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "chore_contact_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "chore_contact_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_void_p]),
+    "chore_contact_bwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5),
     "chore_profile_enable": (c_int, [c_void_p, c_int]),
     "chore_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double),
                                    POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(c_int64)]),

@@ -1,0 +1,328 @@
+// contact.hip -- the human-object contact term of the joint fitting phase, forward and backward.
+//
+// Replaces ReconFitterBase.compute_contact_loss (recon/recon_fit_base.py:553-608) together with the
+// pytorch3d.loss.chamfer_distance call it ends in (:605-607; pytorch3d is not vendored: defaults restated --
+// squared-L2 nearest neighbour, mean over the points of a cloud, mean over the clouds, both directions added).
+// The reference builds ragged per-(frame, part) point clouds with data-dependent Python loops and host
+// synchronisations (mask.sum(), torch.where per part).  Here everything is a fixed-shape device computation,
+// so a fitting step has no host round trip and can be captured in a hipGraph:
+//   1. prep: contact masks df < thres, argmax part label of every object point, per-frame contact counts
+//   2. select: which points take part (a frame with no contact at all is skipped; a side with no contact point
+//      uses ALL its points -- reference :573-584) and how many per (frame, part)
+//   3. nn: for every participating point the nearest participating point OF THE SAME PART in the other cloud
+//      (brute force through LDS tiles; 6890 x 3000 candidates per frame)
+//   4. reduce: per (frame, part, direction) sums in a fixed order, then
+//        loss = 1/P sum_pairs mean_a min_b |a-b|^2 + 1/P sum_pairs mean_b min_a |a-b|^2,  P = #(frame, part)
+//      pairs where both clouds are non-empty (0 if there is none: the reference then omits the term)
+//   backward: gather form (every point sums the contributions of the points it is the nearest neighbour of,
+//      in index order) -- deterministic, no float atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int CP_MAX = 32;      // max part count (14 in CHORE)
+constexpr int TILE = 256;
+
+struct CWs {                    // workspace layout (element offsets, see contact_ws)
+    int* label_o;               // [B][No] argmax part of the object points
+    int* sel_h;                 // [B][Nh] 1 if the vertex takes part
+    int* sel_o;                 // [B][No]
+    int* cnt;                   // [B][2] contact counts (human, object)
+    int* n_part;                // [B][P][2] participating points per part (human, object)
+    int* npairs;                // [1]
+    int* nn_h;                  // [B][Nh] nearest object point of the same part, or -1
+    int* nn_o;                  // [B][No] nearest human vertex of the same part, or -1
+    float* m_h;                 // [B][Nh] squared distance to it
+    float* m_o;                 // [B][No]
+    float* pair_sum;            // [B][P][2]
+    size_t bytes;
+};
+
+CWs contact_ws(void* base, int B, int Nh, int No, int P) {
+    CWs w;
+    char* p = (char*)base;
+    size_t off = 0;
+    auto take = [&](size_t n) { char* r = p + off; off += (n + 255) / 256 * 256; return r; };
+    w.label_o = (int*)take(sizeof(int) * B * No);
+    w.sel_h = (int*)take(sizeof(int) * B * Nh);
+    w.sel_o = (int*)take(sizeof(int) * B * No);
+    w.cnt = (int*)take(sizeof(int) * B * 2);
+    w.n_part = (int*)take(sizeof(int) * B * P * 2);
+    w.npairs = (int*)take(sizeof(int));
+    w.nn_h = (int*)take(sizeof(int) * B * Nh);
+    w.nn_o = (int*)take(sizeof(int) * B * No);
+    w.m_h = (float*)take(sizeof(float) * B * Nh);
+    w.m_o = (float*)take(sizeof(float) * B * No);
+    w.pair_sum = (float*)take(sizeof(float) * B * P * 2);
+    w.bytes = off;
+    return w;
+}
+
+// ---- 1. masks, labels, contact counts ---------------------------------------------------------------
+__global__ void contact_prep_kernel(const float* __restrict__ df_hum_o, const float* __restrict__ df_obj_h,
+                                    const float* __restrict__ logits /*(B,P,No)*/, int B, int Nh, int No, int P,
+                                    float thres, CWs w) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int ch = 0, co = 0;
+    if (i < Nh) {
+        const int m = df_hum_o[(size_t)b * Nh + i] < thres;
+        w.sel_h[(size_t)b * Nh + i] = m;   // contact mask for now; turned into the selection by the next kernel
+        ch = m;
+    }
+    if (i < No) {
+        const int m = df_obj_h[(size_t)b * No + i] < thres;
+        w.sel_o[(size_t)b * No + i] = m;
+        co = m;
+        const float* l = logits + (size_t)b * P * No + i;
+        int best = 0;
+        float bv = l[0];
+        for (int p = 1; p < P; ++p) {      // first maximum, like torch.argmax
+            const float v = l[(size_t)p * No];
+            if (v > bv) { bv = v; best = p; }
+        }
+        w.label_o[(size_t)b * No + i] = best;
+    }
+    // integer atomics: exact and order-independent
+    __shared__ int s[2];
+    if (threadIdx.x < 2) s[threadIdx.x] = 0;
+    __syncthreads();
+    if (ch) atomicAdd(&s[0], 1);
+    if (co) atomicAdd(&s[1], 1);
+    __syncthreads();
+    if (threadIdx.x < 2 && s[threadIdx.x]) atomicAdd(&w.cnt[b * 2 + threadIdx.x], s[threadIdx.x]);
+}
+
+// ---- 2. selection and per-part counts ---------------------------------------------------------------
+__global__ void contact_select_kernel(const int* __restrict__ label_h, int B, int Nh, int No, int P, CWs w) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = w.cnt[b * 2], co = w.cnt[b * 2 + 1];
+    const bool frame = ch + co > 0;
+    __shared__ int s[CP_MAX * 2];
+    for (int k = threadIdx.x; k < P * 2; k += blockDim.x) s[k] = 0;
+    __syncthreads();
+    if (i < Nh) {
+        const int sel = frame && (ch > 0 ? w.sel_h[(size_t)b * Nh + i] : 1);
+        w.sel_h[(size_t)b * Nh + i] = sel;
+        if (sel) atomicAdd(&s[label_h[i] * 2], 1);
+    }
+    if (i < No) {
+        const int sel = frame && (co > 0 ? w.sel_o[(size_t)b * No + i] : 1);
+        w.sel_o[(size_t)b * No + i] = sel;
+        if (sel) atomicAdd(&s[w.label_o[(size_t)b * No + i] * 2 + 1], 1);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < P * 2; k += blockDim.x)
+        if (s[k]) atomicAdd(&w.n_part[(size_t)b * P * 2 + k], s[k]);
+}
+
+__global__ void contact_pairs_kernel(int B, int P, CWs w) {
+    __shared__ int s;
+    if (threadIdx.x == 0) s = 0;
+    __syncthreads();
+    int c = 0;
+    for (int k = threadIdx.x; k < B * P; k += blockDim.x)
+        c += (w.n_part[(size_t)k * 2] > 0 && w.n_part[(size_t)k * 2 + 1] > 0);
+    if (c) atomicAdd(&s, c);
+    __syncthreads();
+    if (threadIdx.x == 0) *w.npairs = s;
+}
+
+// ---- 3. same-part nearest neighbour ------------------------------------------------------------------
+// queries Q (Nq points of frame b), candidates C (Nc points); a query takes part if sel_q and its (frame, part)
+// pair is valid; candidates must be selected and carry the same label.  First minimum in index order.
+__global__ __launch_bounds__(TILE) void contact_nn_kernel(const float* __restrict__ Q, const int* __restrict__ sel_q,
+                                                          const int* __restrict__ lab_q, int lab_q_stride, int Nq,
+                                                          const float* __restrict__ C, const int* __restrict__ sel_c,
+                                                          const int* __restrict__ lab_c, int lab_c_stride, int Nc,
+                                                          int P, const int* __restrict__ n_part,
+                                                          int* __restrict__ nn, float* __restrict__ mind) {
+    __shared__ float cx[TILE], cy[TILE], cz[TILE];
+    __shared__ int cl[TILE];                  // label, or -1 if the candidate does not take part
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * TILE + threadIdx.x;
+    const bool inq = q < Nq;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int lq = -1;
+    if (inq) {
+        const float* p = Q + ((size_t)b * Nq + q) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+        const int l = lab_q[(size_t)b * lab_q_stride + q];
+        const int* np = n_part + ((size_t)b * P + l) * 2;
+        if (sel_q[(size_t)b * Nq + q] && np[0] > 0 && np[1] > 0) lq = l;
+    }
+    float best = 3.0e38f;
+    int bi = -1;
+    for (int c0 = 0; c0 < Nc; c0 += TILE) {
+        const int c = c0 + threadIdx.x;
+        if (c < Nc) {
+            const float* p = C + ((size_t)b * Nc + c) * 3;
+            cx[threadIdx.x] = p[0]; cy[threadIdx.x] = p[1]; cz[threadIdx.x] = p[2];
+            cl[threadIdx.x] = sel_c[(size_t)b * Nc + c] ? lab_c[(size_t)b * lab_c_stride + c] : -1;
+        } else {
+            cl[threadIdx.x] = -1;
+        }
+        __syncthreads();
+        if (lq >= 0) {
+            const int n = min(TILE, Nc - c0);
+            for (int j = 0; j < n; ++j) {
+                if (cl[j] == lq) {
+                    const float dx = x - cx[j], dy = y - cy[j], dz = z - cz[j];
+                    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+                    if (d < best) { best = d; bi = c0 + j; }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inq) {
+        nn[(size_t)b * Nq + q] = bi;
+        mind[(size_t)b * Nq + q] = bi >= 0 ? best : 0.f;
+    }
+}
+
+// ---- 4. per-(frame, part, direction) sums, fixed order -------------------------------------------------
+__global__ __launch_bounds__(256) void contact_pair_sum_kernel(const int* __restrict__ label_h, int B, int Nh, int No,
+                                                               int P, CWs w) {
+    const int dir = blockIdx.x & 1, part = (blockIdx.x >> 1) % P, b = (blockIdx.x >> 1) / P;
+    const int N = dir ? No : Nh;
+    const int* nn = dir ? w.nn_o + (size_t)b * No : w.nn_h + (size_t)b * Nh;
+    const float* m = dir ? w.m_o + (size_t)b * No : w.m_h + (size_t)b * Nh;
+    const int* lab = dir ? w.label_o + (size_t)b * No : label_h;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < N; i += 256)
+        if (nn[i] >= 0 && lab[i] == part) acc += m[i];
+    __shared__ float s[256];
+    s[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) w.pair_sum[((size_t)b * P + part) * 2 + dir] = s[0];
+}
+
+__global__ void contact_finish_kernel(int B, int P, CWs w, float* __restrict__ loss) {
+    if (threadIdx.x || blockIdx.x) return;
+    const int np = *w.npairs;
+    float a = 0.f, c = 0.f;
+    for (int k = 0; k < B * P; ++k) {
+        const int nh = w.n_part[(size_t)k * 2], no = w.n_part[(size_t)k * 2 + 1];
+        if (nh > 0 && no > 0) {
+            a += w.pair_sum[(size_t)k * 2] / (float)nh;
+            c += w.pair_sum[(size_t)k * 2 + 1] / (float)no;
+        }
+    }
+    *loss = np > 0 ? a / (float)np + c / (float)np : 0.f;
+}
+
+// ---- backward: d loss / d point, gather form ------------------------------------------------------------
+// own term: w_q * 2 (q - nn(q));  received: for every point r of the other cloud with nn(r) == q: -w_r * 2 (r - q)
+__global__ __launch_bounds__(TILE) void contact_bwd_kernel(const float* __restrict__ Q, const int* __restrict__ nn_q,
+                                                           const int* __restrict__ lab_q, int lab_q_stride, int Nq,
+                                                           int side_q /*0 human, 1 object*/,
+                                                           const float* __restrict__ C, const int* __restrict__ nn_c,
+                                                           const int* __restrict__ lab_c, int lab_c_stride, int Nc,
+                                                           int P, const int* __restrict__ n_part,
+                                                           const int* __restrict__ npairs, const float* __restrict__ g,
+                                                           float* __restrict__ dQ) {
+    __shared__ float cx[TILE], cy[TILE], cz[TILE], cw[TILE];
+    __shared__ int cn[TILE];
+    const int b = blockIdx.y;
+    const int q = blockIdx.x * TILE + threadIdx.x;
+    const bool inq = q < Nq;
+    const int np = *npairs;
+    const float gs = np > 0 ? g[0] / (float)np : 0.f;
+    float x = 0.f, y = 0.f, z = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
+    if (inq) {
+        const float* p = Q + ((size_t)b * Nq + q) * 3;
+        x = p[0]; y = p[1]; z = p[2];
+        const int j = nn_q[(size_t)b * Nq + q];
+        if (j >= 0) {
+            const int l = lab_q[(size_t)b * lab_q_stride + q];
+            const float wq = 2.f * gs / (float)n_part[((size_t)b * P + l) * 2 + side_q];
+            const float* o = C + ((size_t)b * Nc + j) * 3;
+            gx = wq * (x - o[0]); gy = wq * (y - o[1]); gz = wq * (z - o[2]);
+        }
+    }
+    for (int c0 = 0; c0 < Nc; c0 += TILE) {
+        const int c = c0 + threadIdx.x;
+        int j = -1;
+        if (c < Nc) {
+            j = nn_c[(size_t)b * Nc + c];
+            if (j >= 0) {
+                const float* p = C + ((size_t)b * Nc + c) * 3;
+                cx[threadIdx.x] = p[0]; cy[threadIdx.x] = p[1]; cz[threadIdx.x] = p[2];
+                const int l = lab_c[(size_t)b * lab_c_stride + c];
+                cw[threadIdx.x] = 2.f * gs / (float)n_part[((size_t)b * P + l) * 2 + (1 - side_q)];
+            }
+        }
+        cn[threadIdx.x] = j;
+        __syncthreads();
+        if (inq) {
+            const int n = min(TILE, Nc - c0);
+            for (int k = 0; k < n; ++k) {
+                if (cn[k] == q) {   // r = candidate k has q as its nearest neighbour: d m_r / d q = -2 (r - q)
+                    gx -= cw[k] * (cx[k] - x); gy -= cw[k] * (cy[k] - y); gz -= cw[k] * (cz[k] - z);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (inq) {
+        float* o = dQ + ((size_t)b * Nq + q) * 3;
+        o[0] = gx; o[1] = gy; o[2] = gz;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t chore_contact_workspace_bytes(int B, int Nh, int No, int P) {
+    return contact_ws(nullptr, B, Nh, No, P).bytes;
+}
+
+extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float* obj, const float* df_hum_o,
+                                 const float* df_obj_h, const int* label_h, const float* part_logits, int B, int Nh,
+                                 int No, int P, float thres, float* loss, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!hum || !obj || !df_hum_o || !df_obj_h || !label_h || !part_logits || !loss || !workspace)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_fwd: null argument");
+    if (B <= 0 || Nh <= 0 || No <= 0 || P <= 0 || P > CP_MAX)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_fwd: bad sizes B=%d Nh=%d No=%d P=%d", B, Nh, No, P);
+    hipStream_t s = (hipStream_t)stream;
+    CWs w = contact_ws(workspace, B, Nh, No, P);
+    // counters: cnt, n_part (contiguous up to npairs)
+    CHORE_HIP_CHECK(h, hipMemsetAsync(w.cnt, 0, (char*)w.npairs - (char*)w.cnt + sizeof(int), s));
+    const int Nm = Nh > No ? Nh : No;
+    dim3 gm((Nm + 255) / 256, B);
+    hipLaunchKernelGGL(contact_prep_kernel, gm, dim3(256), 0, s, df_hum_o, df_obj_h, part_logits, B, Nh, No, P, thres, w);
+    hipLaunchKernelGGL(contact_select_kernel, gm, dim3(256), 0, s, label_h, B, Nh, No, P, w);
+    hipLaunchKernelGGL(contact_pairs_kernel, dim3(1), dim3(256), 0, s, B, P, w);
+    hipLaunchKernelGGL(contact_nn_kernel, dim3((Nh + TILE - 1) / TILE, B), dim3(TILE), 0, s, hum, w.sel_h, label_h, 0, Nh,
+                       obj, w.sel_o, w.label_o, No, No, P, w.n_part, w.nn_h, w.m_h);
+    hipLaunchKernelGGL(contact_nn_kernel, dim3((No + TILE - 1) / TILE, B), dim3(TILE), 0, s, obj, w.sel_o, w.label_o, No, No,
+                       hum, w.sel_h, label_h, 0, Nh, P, w.n_part, w.nn_o, w.m_o);
+    hipLaunchKernelGGL(contact_pair_sum_kernel, dim3(B * P * 2), dim3(256), 0, s, label_h, B, Nh, No, P, w);
+    hipLaunchKernelGGL(contact_finish_kernel, dim3(1), dim3(64), 0, s, B, P, w, loss);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+extern "C" int chore_contact_bwd(chore_handle* h, const float* hum, const float* obj, const int* label_h, int B, int Nh,
+                                 int No, int P, const float* g_loss, const void* workspace, float* d_hum, float* d_obj,
+                                 chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!hum || !obj || !label_h || !g_loss || !workspace || !d_hum || !d_obj)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: null argument");
+    if (B <= 0 || Nh <= 0 || No <= 0 || P <= 0 || P > CP_MAX)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    CWs w = contact_ws(const_cast<void*>(workspace), B, Nh, No, P);
+    hipLaunchKernelGGL(contact_bwd_kernel, dim3((Nh + TILE - 1) / TILE, B), dim3(TILE), 0, s, hum, w.nn_h, label_h, 0, Nh, 0,
+                       obj, w.nn_o, w.label_o, No, No, P, w.n_part, w.npairs, g_loss, d_hum);
+    hipLaunchKernelGGL(contact_bwd_kernel, dim3((No + TILE - 1) / TILE, B), dim3(TILE), 0, s, obj, w.nn_o, w.label_o, No, No, 1,
+                       hum, w.nn_h, label_h, 0, Nh, P, w.n_part, w.npairs, g_loss, d_obj);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}

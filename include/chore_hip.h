@@ -176,6 +176,26 @@ int chore_so3_project_bwd(chore_handle* h, const void* aux, const float* G, int 
                           chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Human-object contact term of the joint fitting phase  (replaces ReconFitterBase.compute_contact_loss,
+ * recon/recon_fit_base.py:553-608, and the pytorch3d.loss.chamfer_distance call at :605-607 with its
+ * defaults: squared-L2 nearest neighbour, mean over the points of a cloud, mean over clouds, both
+ * directions added).  hum (B,Nh,3), obj (B,No,3); df_hum_o (B,Nh) = object distance field at the human
+ * vertices, df_obj_h (B,No) = human distance field at the object points (contact = value < thres);
+ * label_h (Nh) int32 part label of every human vertex; part_logits (B,P,No) object part logits (argmax
+ * inside).  loss: 1 float on the device (0 when no (frame, part) pair has contact points on both sides).
+ * `workspace` (chore_contact_workspace_bytes) carries the nearest-neighbour indices to the backward.
+ * No host synchronisation: the step can be captured in a hipGraph.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_contact_workspace_bytes(int B, int Nh, int No, int P);
+int chore_contact_fwd(chore_handle* h, const float* hum, const float* obj, const float* df_hum_o,
+                      const float* df_obj_h, const int* label_h, const float* part_logits, int B, int Nh, int No,
+                      int P, float thres, float* loss, void* workspace, chore_stream_t stream);
+/* g_loss: 1 float on the device (upstream gradient) -> d_hum (B,Nh,3), d_obj (B,No,3) */
+int chore_contact_bwd(chore_handle* h, const float* hum, const float* obj, const int* label_h, int B, int Nh,
+                      int No, int P, const float* g_loss, const void* workspace, float* d_hum, float* d_obj,
+                      chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch
  * with hipEvents on the caller's stream, synchronises at the end of the call and accumulates, per
  * kernel class, the elapsed milliseconds, the algorithmic FLOPs and bytes and the launch count.

@@ -40,6 +40,65 @@ def test_project_so3_forward_and_backward():
     assert (gc - gg).abs().max() < 5e-4 * gc.abs().max()
 
 
+def ref_contact_loss(df_hum_o, df_obj_h, obj, hum, part_logits, part_labels, n_parts=14):
+    """restatement of compute_contact_loss (recon/recon_fit_base.py:553-608) with pytorch3d.loss.chamfer_distance's
+    documented defaults (squared L2 nearest neighbour, mean over the points of a cloud, mean over clouds, both
+    directions added) on ragged clouds, torch ops with autograd; returns None where the reference omits the term"""
+    mask_o, mask_h = df_obj_h < 0.08, df_hum_o < 0.08
+    part_o = torch.argmax(part_logits, 1)
+    da, db = [], []
+    for hv, ov, mh, mo, po in zip(hum, obj, mask_h, mask_o, part_o):
+        ch, co = int(mh.sum()), int(mo.sum())
+        if ch + co == 0:
+            continue
+        obj_v, label_o = (ov[mo], po[mo]) if co > 0 else (ov, po)
+        hum_v, label_h = (hv[mh], part_labels[mh]) if ch > 0 else (hv, part_labels)
+        for i in range(n_parts):
+            hi, oi = torch.where(label_h == i)[0], torch.where(label_o == i)[0]
+            if hi.numel() == 0 or oi.numel() == 0:
+                continue
+            a, b = hum_v[hi], obj_v[oi]
+            d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+            da.append(d.min(1)[0].mean())
+            db.append(d.min(0)[0].mean())
+    if not da:
+        return None
+    return torch.stack(da).mean() + torch.stack(db).mean()
+
+
+def test_contact_term_matches_restatement():
+    """chore_contact_fwd/bwd against the ragged torch restatement: value and gradients, including a frame without
+    any contact (skipped), a frame whose human side has no contact vertex (all vertices are used) and a part that
+    occurs on one side only"""
+    from chore_amd.recon.recon_fit_base import _ContactFn
+    g = torch.Generator().manual_seed(3)
+    B, Nh, No, P = 4, 700, 300, 14
+    hum = (torch.randn(B, Nh, 3, generator=g) * 0.3).cuda()
+    obj = (torch.randn(B, No, 3, generator=g) * 0.3 + 0.1).cuda()
+    df_h = torch.rand(B, Nh, generator=g) * 0.3          # ~27 % below 0.08
+    df_o = torch.rand(B, No, generator=g) * 0.3
+    df_h[1] = 1.0; df_o[1] = 1.0                         # frame 1: no contact at all
+    df_h[2] = 1.0                                        # frame 2: no human contact -> all vertices take part
+    logits = torch.randn(B, P, No, generator=g)
+    logits[:, 13] = -50.0                                # part 13 never predicted on the object
+    labels = torch.randint(0, P, (Nh,), generator=g).cuda()
+    df_h, df_o, logits = df_h.cuda(), df_o.cuda(), logits.cuda()
+    h1, o1 = hum.clone().requires_grad_(True), obj.clone().requires_grad_(True)
+    ref = ref_contact_loss(df_h, df_o, o1, h1, logits, labels)
+    (ref * 3.0).backward()
+    h2, o2 = hum.clone().requires_grad_(True), obj.clone().requires_grad_(True)
+    got = _ContactFn.apply(h2, o2, df_h, df_o, logits, labels, 0.08)
+    (got * 3.0).backward()
+    assert abs(float(got) - float(ref)) < 1e-6 * max(1.0, abs(float(ref)))
+    for a, b in ((h1.grad, h2.grad), (o1.grad, o2.grad)):
+        assert (a - b).abs().max() < 1e-6 * max(1e-3, float(a.abs().max()))
+    assert h2.grad[1].abs().max() == 0 and o2.grad[1].abs().max() == 0
+    # nothing in contact anywhere: the reference omits the term, here it is exactly zero with zero gradients
+    none = ref_contact_loss(df_h * 0 + 1, df_o * 0 + 1, obj, hum, logits, labels)
+    z = _ContactFn.apply(h2, o2, df_h * 0 + 1, df_o * 0 + 1, logits, labels, 0.08)
+    assert none is None and float(z) == 0.0
+
+
 @pytest.fixture()
 def fit_setup(opt):   # function scope: the tests optimise the parameters in place
     from chore_amd.lib_smpl.priors import synthetic_priors
