@@ -82,29 +82,42 @@ def main():
     obj_s = torch.ones(B, device=dev).requires_grad_(True)
     data["smpl_center"] = fitter.compute_smpl_center_pred(data, net, smpl)
 
-    def run(phase, n):
+    from chore_amd.recon.graph_step import EagerStep, GraphedStep
+    noise = torch.rand(8 * args.steps + 64, B, 3, 3).to(dev)
+    kidx = torch.zeros(1, dtype=torch.long, device=dev)
+
+    def run(phase, n, graphed):
+        """n inner steps of one phase (gradients zeroed every 10 steps like the reference's outer loop)"""
         if phase == "kpts":
-            opt_ = torch.optim.Adam([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas], 0.006)
-            step = lambda: fitter.forward_smpl(split, data, "kpts")  # noqa: E731
+            params = [split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas]
+            lr = 0.006
+            loss_fn = lambda d: fitter.sum_dict(fitter.forward_smpl(split, data, "kpts"), wd, d)  # noqa: E731
         else:
-            opt_ = torch.optim.Adam([obj_t, obj_R, obj_s] if phase == "object only" else [obj_t, obj_s],
-                                    lr=0.006 if phase == "object only" else 0.002)
-            step = lambda: fitter.forward_step(net, split, data, obj_R, obj_t, obj_s, phase)  # noqa: E731
-        for w in range(3):   # warm-up
-            opt_.zero_grad()
-            fitter.sum_dict(step(), wd, 1).backward()
-            opt_.step()
+            params = [obj_t, obj_R, obj_s] if phase == "object only" else [obj_t, obj_s]
+            lr = 0.006 if phase == "object only" else 0.002
+
+            def loss_fn(d):
+                nz = noise.index_select(0, kidx).squeeze(0)
+                kidx.add_(1)
+                return fitter.sum_dict(fitter.forward_step(net, split, data, obj_R, obj_t, obj_s, phase, noise=nz), wd, d)
+        prev = torch.tensor(300.0, device=dev)
+        print("phase", phase, "graphed", graphed, file=sys.stderr, flush=True)
+        st = (GraphedStep if graphed else EagerStep)(params, lr, loss_fn, 1e-4, prev, state=[kidx],
+                                                     release=fitter.release_graphs(split, net))
+        st.begin_outer(1)
+        for _ in range(3):   # warm-up
+            st.step()
         torch.cuda.synchronize()
         t = time.perf_counter()
         for i in range(n):
             if i % 10 == 0:
-                opt_.zero_grad()   # the reference zeroes once per outer iteration of 10 inner steps
-            fitter.sum_dict(step(), wd, 1).backward()
-            opt_.step()
+                st.begin_outer(1)
+            st.step()
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
-    ms = {ph: run(ph, args.steps) for ph in ("kpts", "object only", "joint")}
+    ms_eager = {ph: run(ph, args.steps, False) for ph in ("kpts", "object only", "joint")}
+    ms = {ph: run(ph, args.steps, True) for ph in ("kpts", "object only", "joint")}
     fitted = gather_fitted({"trans": split.trans.detach(), "obj_t": obj_t.detach()}, args.frames, rank, world, device=dev)
     if world > 1:
         import torch.distributed as dist
@@ -117,7 +130,7 @@ def main():
             "metric": "ms per fit iteration (SMPL-H LBS + field queries + Adam), mean over the three phases",
             "value": mean_ms, "unit": "ms", "higher_is_better": False, "n_gpus": world, "frames": args.frames,
             "frames_per_gpu": B, "steps_per_phase": args.steps, "dtype": args.dtype, "data": "synthetic",
-            "ms_per_iter": ms, "frames_per_s_300_iters": args.frames / (3 * args.steps * mean_ms / 1e3) * (args.steps / 100),
+            "ms_per_iter": ms, "ms_per_iter_eager": ms_eager, "inner_step": "hipGraph replay (chore_amd/recon/graph_step.py)", "frames_per_s_300_iters": args.frames / (3 * args.steps * mean_ms / 1e3) * (args.steps / 100),
             "encode_ms_first_call": enc_ms,
             "config": {"workload": "BASELINE configs[2]/[4]: 100 x forward_smpl(kpts) + 100 x forward_step(object only) + "
                                    "100 x forward_step(joint, no collide); 6890 SMPL-H vertices + 3000 object points per frame",

@@ -15,14 +15,31 @@ reads the loss once per OUTER iteration.
 """
 import torch
 import torch.nn.functional as F
-from torch import optim
 
 from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
+from .graph_step import EagerStep, GraphedStep
 from .recon_fit_base import ReconFitterBase
 
 
 class ReconFitterBehave(ReconFitterBase):
     collision_fn = None   # callable(smpl_verts, smpl_faces, R, t, s) -> penetration loss, or None
+    use_graphs = False    # True: every inner step is a hipGraph replay (graph_step.py); same update rule
+    adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
+
+    def _stepper(self, *a, **k):
+        if self.use_graphs:
+            return GraphedStep(*a, **k)
+        return EagerStep(*a, capturable=self.adam_capturable, **k)
+
+    @staticmethod
+    def release_graphs(split, model):
+        """forget what holds autograd graphs of earlier steps (see GraphedStep)"""
+        def f():
+            split.betas = split.pose = None
+            model.preds = None
+            model.points = None            # CHORE.query keeps its last inputs (reference attribute): a graph too
+            model.intermediate_preds_list = []
+        return f
 
     def get_loss_weights(self):
         w = {"beta": 1.0, "pose": 1e-5, "hand": 1e-5, "j2d": 0.3 ** 2, "object": 30.0 ** 2, "part": 0.05 ** 2,
@@ -48,28 +65,28 @@ class ReconFitterBehave(ReconFitterBase):
     def optimize_smpl(self, smpl, data_dict, iter_for_betas=10, iter_for_pose=10, iter_for_kpts=5, steps_per_iter=10,
                       max_iter=150):
         split = self.split_smpl(smpl)
-        opt = optim.Adam([split.top_betas, split.trans], lr=0.02)
         height_init = self.get_smpl_height(smpl)
         wd = self.get_loss_weights()
         prev = torch.tensor(300.0, device=self.device)
+
+        def loss_of(phase):
+            return lambda decay: self.sum_dict(self.forward_smpl(split, data_dict, phase), wd, decay)
+
         phase = "global"
+        rel = self.release_graphs(split, data_dict["net"])
+        st = self._stepper([split.top_betas, split.trans], 0.02, loss_of(phase), 0.001, prev, release=rel)
         for it in range(iter_for_betas + iter_for_kpts + iter_for_pose + max_iter):
-            opt.zero_grad()
             if it == iter_for_betas:
-                phase = "smpl all pose"
-                opt = optim.Adam([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas],
-                                 0.006, betas=(0.9, 0.999))
+                phase = "smpl all pose"   # new Adam
+                st = self._stepper([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas],
+                                   0.006, loss_of(phase), 0.001, prev, release=rel)
             elif it == iter_for_betas + iter_for_pose:
-                phase = "kpts"
-            stop = None
+                phase = "kpts"            # same Adam, the loss gains the keypoint term
+                st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel)
+            st.begin_outer(1 if phase != "kpts" else it / 3)
             for _ in range(steps_per_iter):
-                loss = self.sum_dict(self.forward_smpl(split, data_dict, phase), wd, 1 if phase != "kpts" else it / 3)
-                loss.backward()
-                opt.step()
-                cond = (torch.abs(prev - loss) / prev < prev * 0.001)
-                stop = cond if stop is None else (stop | cond)
-                prev = loss.detach()
-            if it > 0.25 * max_iter + iter_for_betas + iter_for_pose and bool(stop):
+                st.step()
+            if it > 0.25 * max_iter + iter_for_betas + iter_for_pose and st.stopped():
                 break
         scale = self.get_smpl_height(split) / height_init
         return self.copy_smpl_params(split, smpl), scale
@@ -106,37 +123,46 @@ class ReconFitterBehave(ReconFitterBase):
         split = self.split_smpl(smpl)
         data_dict["smpl"] = split
         obj_R, obj_t, obj_s = data_dict["obj_R"], data_dict["obj_t"], data_dict["obj_s"]
-        opt = optim.Adam([obj_t, obj_R, obj_s], lr=0.006)
         wd = self.get_loss_weights()
         if "silhouette" not in data_dict:
             sil_iter = 0
         data_dict["smpl_center"] = self.compute_smpl_center_pred(data_dict, model, smpl)
         prev = torch.tensor(300.0, device=self.device)
+        n_outer = joint_iter + obj_iter + max_iter + sil_iter
+        # the SO(3) perturbation of every step (recon_fit_base.py:384) is drawn from the CPU generator like the
+        # reference does, but for all steps at once (one call yields the same stream as one call per step) so that
+        # a step only reads noise[k] on the device
+        B = obj_R.shape[0]
+        noise = torch.rand(n_outer * steps_per_iter, B, 3, 3).to(self.device)
+        k = torch.zeros(1, dtype=torch.long, device=self.device)
+
+        def loss_of(phase):
+            def f(decay):
+                nz = noise.index_select(0, k).squeeze(0)
+                k.add_(1)
+                return self.sum_dict(self.forward_step(model, split, data_dict, obj_R, obj_t, obj_s, phase, noise=nz), wd, decay)
+            return f
+
         phase = "object only"
-        for it in range(joint_iter + obj_iter + max_iter + sil_iter):
-            opt.zero_grad()
+        rel = self.release_graphs(split, model)
+        st = self._stepper([obj_t, obj_R, obj_s], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
+        for it in range(n_outer):
             if it == obj_iter and sil_iter > 0:
                 phase = "sil"
-                opt = optim.Adam([obj_R, obj_s, obj_t], lr=0.006)
+                st = self._stepper([obj_R, obj_s, obj_t], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
                 data_dict["rot_init"] = self.decopose_axis(obj_R).detach().clone()
                 data_dict["trans_init"] = obj_t.detach().clone()
             if it == obj_iter + sil_iter:
                 phase = "joint"
-                opt = optim.Adam([obj_t, obj_s], lr=0.002)
-            stop = None
+                st = self._stepper([obj_t, obj_s], 0.002, loss_of(phase), 0.0001, prev, state=[k], release=rel)
+            decay = 1 if phase == "object only" else it
+            if phase == "sil":
+                decay = it - obj_iter + 1
+            elif phase == "joint":
+                decay = (it - obj_iter + 1) / 5
+            st.begin_outer(decay)
             for _ in range(steps_per_iter):
-                loss_dict = self.forward_step(model, split, data_dict, obj_R, obj_t, obj_s, phase)
-                decay = 1 if phase == "object only" else it
-                if phase == "sil":
-                    decay = it - obj_iter + 1
-                elif phase == "joint":
-                    decay = (it - obj_iter + 1) / 5
-                loss = self.sum_dict(loss_dict, wd, decay)
-                loss.backward()
-                opt.step()
-                cond = (torch.abs(prev - loss) / prev < prev * 0.0001)
-                stop = cond if stop is None else (stop | cond)
-                prev = loss.detach()
-            if phase == "joint" and it > 0.25 * max_iter and bool(stop):
+                st.step()
+            if phase == "joint" and it > 0.25 * max_iter and st.stopped():
                 break
         return smpl, data_dict["obj_R"], data_dict["obj_t"]

@@ -179,6 +179,65 @@ def test_optimize_loops_run(fit_setup):
     assert torch.isfinite(R).all() and torch.isfinite(t).all()
 
 
+def _run_fit(opt, use_graphs):
+    """both optimisation loops, short schedules, from identical initial state"""
+    import copy
+    from chore_amd.lib_smpl.priors import synthetic_priors
+    from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
+    from chore_amd.model import CHORE
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    from test_gpu_query import nhwc
+    opt = copy.copy(opt)
+    opt.compute_dtype = "fp32"
+    B = 2
+    net = CHORE(opt).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    rs = np.random.RandomState(9)
+    net.im_feat_list = [nhwc((rs.standard_normal((B, 256, 32, 32)) * 0.5).astype(np.float32))]
+    net.tmpx = nhwc((rs.standard_normal((B, 64, 64, 64)) * 0.5).astype(np.float32))
+    pose, betas, trans = synth.synth_smpl_params(B, seed=1)
+    pose *= 0.3
+    smpl = SMPLPyTorchWrapperBatch(synth.synth_smplh_model(0), B, betas=torch.from_numpy(betas),
+                                   pose=torch.from_numpy(pose), trans=torch.from_numpy(trans)).cuda()
+    body_prior, hand_prior = synthetic_priors(0)
+    labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
+    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    fitter.use_graphs = use_graphs
+    fitter.adam_capturable = True   # the same Adam arithmetic in both runs
+    cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
+    kpts = torch.from_numpy(np.concatenate([rs.uniform(100, 400, (B, 25, 2)), rs.uniform(0.2, 1, (B, 25, 1))], -1)
+                            .astype(np.float32)).cuda()
+    obj = torch.from_numpy((rs.standard_normal((B, 3000, 3)) * 0.15).astype(np.float32)).cuda()
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1),
+                pose_init=torch.from_numpy(pose[:, 3:72]).cuda(), body_kpts=kpts, objects=obj, smpl=smpl,
+                obj_R=torch.eye(3).repeat(B, 1, 1).cuda().requires_grad_(True),
+                obj_t=torch.tensor([[0.2, 0.3, 2.3]] * B).cuda().requires_grad_(True),
+                obj_s=torch.ones(B).cuda().requires_grad_(True))
+    torch.manual_seed(11)   # CPU stream of the SO(3) perturbation
+    smpl2, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5,
+                                        max_iter=1)
+    data["smpl"] = smpl2
+    _, R, t = fitter.optimize_smpl_object(net, data, obj_iter=2, joint_iter=2, steps_per_iter=5, max_iter=1)
+    return [x.detach().cpu().numpy().copy() for x in (smpl2.pose, smpl2.betas, smpl2.trans, scale, R, t, data["obj_s"])]
+
+
+def test_graph_replay_equals_eager(opt):
+    """every inner step as a hipGraph replay (config 5) must fit the same parameters as issuing the ops one by one:
+    same kernels in the same order with the same Adam arithmetic (capturable=True in both runs) -> equal to a few
+    ulps"""
+    eager = _run_fit(opt, False)
+    graph = _run_fit(opt, True)
+    for name, a, b in zip(("pose", "betas", "trans", "scale", "R", "t", "s"), eager, graph):
+        assert np.isfinite(b).all(), name
+        d = np.abs(a - b)
+        assert d.max() < 1e-5, (name, d.max(), np.median(d))
+    # and the run must have moved the parameters (the graph really executed)
+    assert np.abs(graph[5] - np.array([[0.2, 0.3, 2.3]] * 2, np.float32)).max() > 1e-3
+
+
 def test_fit_trajectories_match_reference(fit_setup):
     """10 Adam steps of forward_smpl('kpts') and forward_step('object only') against the trajectories the
     reference's own ReconFitterBehave produced on CPU (tests/golden/fit_trajectories.npz): per-step loss
