@@ -101,7 +101,6 @@ def main():
                 kidx.add_(1)
                 return fitter.sum_dict(fitter.forward_step(net, split, data, obj_R, obj_t, obj_s, phase, noise=nz), wd, d)
         prev = torch.tensor(300.0, device=dev)
-        print("phase", phase, "graphed", graphed, file=sys.stderr, flush=True)
         st = (GraphedStep if graphed else EagerStep)(params, lr, loss_fn, 1e-4, prev, state=[kidx],
                                                      release=fitter.release_graphs(split, net))
         st.begin_outer(1)
@@ -116,16 +115,17 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t) / n * 1e3
 
-    ms_eager = {ph: run(ph, args.steps, False) for ph in ("kpts", "object only", "joint")}
-    ms = {ph: run(ph, args.steps, True) for ph in ("kpts", "object only", "joint")}
+    phases = tuple(os.environ.get("CHORE_FIT_PHASES", "kpts,object only,joint").split(","))   # debugging aid
+    ms_eager = {ph: run(ph, args.steps, False) for ph in phases} if not os.environ.get("CHORE_FIT_NO_EAGER") else {}
+    ms = {ph: run(ph, args.steps, True) for ph in phases}
     fitted = gather_fitted({"trans": split.trans.detach(), "obj_t": obj_t.detach()}, args.frames, rank, world, device=dev)
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([ms["kpts"], ms["object only"], ms["joint"]], dtype=torch.float64, device=dev)
+        t = torch.tensor([ms[ph] for ph in phases], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = dict(zip(("kpts", "object only", "joint"), t.tolist()))
+        ms = dict(zip(phases, t.tolist()))
     if rank == 0:
-        mean_ms = sum(ms.values()) / 3
+        mean_ms = sum(ms.values()) / len(ms)
         print(json.dumps({
             "metric": "ms per fit iteration (SMPL-H LBS + field queries + Adam), mean over the three phases",
             "value": mean_ms, "unit": "ms", "higher_is_better": False, "n_gpus": world, "frames": args.frames,

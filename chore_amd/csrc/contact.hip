@@ -35,6 +35,10 @@ struct CWs {                    // workspace layout (element offsets, see contac
     float* m_h;                 // [B][Nh] squared distance to it
     float* m_o;                 // [B][No]
     float* pair_sum;            // [B][P][2]
+    unsigned long long* key_h;  // [B][Nh] packed (distance bits << 32 | index) minima, ~0 = none
+    unsigned long long* key_o;  // [B][No]
+    float* part_h;              // [chunks_o][B][Nh][3] backward partials of the human side (one per candidate chunk)
+    float* part_o;              // [chunks_h][B][No][3]
     size_t bytes;
 };
 
@@ -54,8 +58,19 @@ CWs contact_ws(void* base, int B, int Nh, int No, int P) {
     w.m_h = (float*)take(sizeof(float) * B * Nh);
     w.m_o = (float*)take(sizeof(float) * B * No);
     w.pair_sum = (float*)take(sizeof(float) * B * P * 2);
+    w.key_h = (unsigned long long*)take(sizeof(unsigned long long) * B * Nh);
+    w.key_o = (unsigned long long*)take(sizeof(unsigned long long) * B * No);   // contiguous with key_h: one memset
+    w.part_h = (float*)take(sizeof(float) * (size_t)((No + TILE - 1) / TILE) * B * Nh * 3);
+    w.part_o = (float*)take(sizeof(float) * (size_t)((Nh + TILE - 1) / TILE) * B * No * 3);
     w.bytes = off;
     return w;
+}
+
+// plain fill instead of hipMemsetAsync: the step is recorded into hipGraphs, and byte-memset nodes of odd sizes
+// replayed unreliably there (sporadic GPU memory faults), kernel nodes do not
+__global__ void contact_fill_kernel(unsigned* __restrict__ p, unsigned v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 
 // ---- 1. masks, labels, contact counts ---------------------------------------------------------------
@@ -131,30 +146,23 @@ __global__ void contact_pairs_kernel(int B, int P, CWs w) {
 
 // ---- 3. same-part nearest neighbour ------------------------------------------------------------------
 // queries Q (Nq points of frame b), candidates C (Nc points); a query takes part if sel_q and its (frame, part)
-// pair is valid; candidates must be selected and carry the same label.  First minimum in index order.
+// pair is valid; candidates must be selected and carry the same label.  A block compares TILE queries with ONE
+// chunk of TILE candidates (grid = query tiles x candidate chunks x frames, so the 6890 x 3000 comparisons of a
+// frame spread over ~320 blocks) and merges its minimum with a 64-bit atomicMin on (distance bits << 32 | index):
+// distances are non-negative, so the bit pattern orders like the value, and equal distances resolve to the
+// smaller index -- the same first-minimum a sequential scan finds, whatever order the blocks run in.
 __global__ __launch_bounds__(TILE) void contact_nn_kernel(const float* __restrict__ Q, const int* __restrict__ sel_q,
                                                           const int* __restrict__ lab_q, int lab_q_stride, int Nq,
                                                           const float* __restrict__ C, const int* __restrict__ sel_c,
                                                           const int* __restrict__ lab_c, int lab_c_stride, int Nc,
                                                           int P, const int* __restrict__ n_part,
-                                                          int* __restrict__ nn, float* __restrict__ mind) {
+                                                          unsigned long long* __restrict__ key) {
     __shared__ float cx[TILE], cy[TILE], cz[TILE];
     __shared__ int cl[TILE];                  // label, or -1 if the candidate does not take part
-    const int b = blockIdx.y;
+    const int b = blockIdx.z;
     const int q = blockIdx.x * TILE + threadIdx.x;
-    const bool inq = q < Nq;
-    float x = 0.f, y = 0.f, z = 0.f;
-    int lq = -1;
-    if (inq) {
-        const float* p = Q + ((size_t)b * Nq + q) * 3;
-        x = p[0]; y = p[1]; z = p[2];
-        const int l = lab_q[(size_t)b * lab_q_stride + q];
-        const int* np = n_part + ((size_t)b * P + l) * 2;
-        if (sel_q[(size_t)b * Nq + q] && np[0] > 0 && np[1] > 0) lq = l;
-    }
-    float best = 3.0e38f;
-    int bi = -1;
-    for (int c0 = 0; c0 < Nc; c0 += TILE) {
+    const int c0 = blockIdx.y * TILE;
+    {
         const int c = c0 + threadIdx.x;
         if (c < Nc) {
             const float* p = C + ((size_t)b * Nc + c) * 3;
@@ -163,23 +171,36 @@ __global__ __launch_bounds__(TILE) void contact_nn_kernel(const float* __restric
         } else {
             cl[threadIdx.x] = -1;
         }
-        __syncthreads();
-        if (lq >= 0) {
-            const int n = min(TILE, Nc - c0);
-            for (int j = 0; j < n; ++j) {
-                if (cl[j] == lq) {
-                    const float dx = x - cx[j], dy = y - cy[j], dz = z - cz[j];
-                    const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
-                    if (d < best) { best = d; bi = c0 + j; }
-                }
-            }
+    }
+    __syncthreads();
+    if (q >= Nq) return;
+    const int l = lab_q[(size_t)b * lab_q_stride + q];
+    const int* np = n_part + ((size_t)b * P + l) * 2;
+    if (!(sel_q[(size_t)b * Nq + q] && np[0] > 0 && np[1] > 0)) return;
+    const float* p = Q + ((size_t)b * Nq + q) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    float best = 3.0e38f;
+    int bi = -1;
+    const int n = min(TILE, Nc - c0);
+    for (int j = 0; j < n; ++j) {
+        if (cl[j] == l) {
+            const float dx = x - cx[j], dy = y - cy[j], dz = z - cz[j];
+            const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+            if (d < best) { best = d; bi = c0 + j; }
         }
-        __syncthreads();
     }
-    if (inq) {
-        nn[(size_t)b * Nq + q] = bi;
-        mind[(size_t)b * Nq + q] = bi >= 0 ? best : 0.f;
-    }
+    if (bi >= 0)
+        atomicMin(key + (size_t)b * Nq + q, ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
+}
+
+__global__ void contact_unpack_kernel(const unsigned long long* __restrict__ key, size_t n, int* __restrict__ nn,
+                                      float* __restrict__ mind) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long k = key[i];
+    const bool none = k == ~0ull;
+    nn[i] = none ? -1 : (int)(unsigned)(k & 0xffffffffu);
+    mind[i] = none ? 0.f : __uint_as_float((unsigned)(k >> 32));
 }
 
 // ---- 4. per-(frame, part, direction) sums, fixed order -------------------------------------------------
@@ -218,35 +239,24 @@ __global__ void contact_finish_kernel(int B, int P, CWs w, float* __restrict__ l
 }
 
 // ---- backward: d loss / d point, gather form ------------------------------------------------------------
-// own term: w_q * 2 (q - nn(q));  received: for every point r of the other cloud with nn(r) == q: -w_r * 2 (r - q)
-__global__ __launch_bounds__(TILE) void contact_bwd_kernel(const float* __restrict__ Q, const int* __restrict__ nn_q,
-                                                           const int* __restrict__ lab_q, int lab_q_stride, int Nq,
-                                                           int side_q /*0 human, 1 object*/,
+// own term: w_q * 2 (q - nn(q));  received: for every point r of the other cloud with nn(r) == q: -w_r * 2 (r - q).
+// As in the forward a block pairs TILE points with one chunk of the other cloud; the received terms of a chunk are
+// summed in index order into a per-chunk partial and contact_bwd_finish_kernel adds the chunks in order: no float
+// atomics, bit-reproducible.
+__global__ __launch_bounds__(TILE) void contact_bwd_kernel(const float* __restrict__ Q, int Nq, int side_q,
                                                            const float* __restrict__ C, const int* __restrict__ nn_c,
                                                            const int* __restrict__ lab_c, int lab_c_stride, int Nc,
                                                            int P, const int* __restrict__ n_part,
                                                            const int* __restrict__ npairs, const float* __restrict__ g,
-                                                           float* __restrict__ dQ) {
+                                                           float* __restrict__ part /*[chunks][B][Nq][3]*/) {
     __shared__ float cx[TILE], cy[TILE], cz[TILE], cw[TILE];
     __shared__ int cn[TILE];
-    const int b = blockIdx.y;
+    const int b = blockIdx.z, B = gridDim.z;
     const int q = blockIdx.x * TILE + threadIdx.x;
-    const bool inq = q < Nq;
+    const int c0 = blockIdx.y * TILE;
     const int np = *npairs;
     const float gs = np > 0 ? g[0] / (float)np : 0.f;
-    float x = 0.f, y = 0.f, z = 0.f, gx = 0.f, gy = 0.f, gz = 0.f;
-    if (inq) {
-        const float* p = Q + ((size_t)b * Nq + q) * 3;
-        x = p[0]; y = p[1]; z = p[2];
-        const int j = nn_q[(size_t)b * Nq + q];
-        if (j >= 0) {
-            const int l = lab_q[(size_t)b * lab_q_stride + q];
-            const float wq = 2.f * gs / (float)n_part[((size_t)b * P + l) * 2 + side_q];
-            const float* o = C + ((size_t)b * Nc + j) * 3;
-            gx = wq * (x - o[0]); gy = wq * (y - o[1]); gz = wq * (z - o[2]);
-        }
-    }
-    for (int c0 = 0; c0 < Nc; c0 += TILE) {
+    {
         const int c = c0 + threadIdx.x;
         int j = -1;
         if (c < Nc) {
@@ -259,21 +269,47 @@ __global__ __launch_bounds__(TILE) void contact_bwd_kernel(const float* __restri
             }
         }
         cn[threadIdx.x] = j;
-        __syncthreads();
-        if (inq) {
-            const int n = min(TILE, Nc - c0);
-            for (int k = 0; k < n; ++k) {
-                if (cn[k] == q) {   // r = candidate k has q as its nearest neighbour: d m_r / d q = -2 (r - q)
-                    gx -= cw[k] * (cx[k] - x); gy -= cw[k] * (cy[k] - y); gz -= cw[k] * (cz[k] - z);
-                }
-            }
+    }
+    __syncthreads();
+    if (q >= Nq) return;
+    const float* p = Q + ((size_t)b * Nq + q) * 3;
+    const float x = p[0], y = p[1], z = p[2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int n = min(TILE, Nc - c0);
+    for (int k = 0; k < n; ++k) {
+        if (cn[k] == q) {   // r = candidate k has q as its nearest neighbour: d m_r / d q = -2 (r - q)
+            gx -= cw[k] * (cx[k] - x); gy -= cw[k] * (cy[k] - y); gz -= cw[k] * (cz[k] - z);
         }
-        __syncthreads();
     }
-    if (inq) {
-        float* o = dQ + ((size_t)b * Nq + q) * 3;
-        o[0] = gx; o[1] = gy; o[2] = gz;
+    float* o = part + (((size_t)blockIdx.y * B + b) * Nq + q) * 3;
+    o[0] = gx; o[1] = gy; o[2] = gz;
+}
+
+__global__ void contact_bwd_finish_kernel(const float* __restrict__ Q, const int* __restrict__ nn_q,
+                                          const int* __restrict__ lab_q, int lab_q_stride, int Nq, int side_q,
+                                          const float* __restrict__ C, int Nc, int P, const int* __restrict__ n_part,
+                                          const int* __restrict__ npairs, const float* __restrict__ g,
+                                          const float* __restrict__ part, int chunks, float* __restrict__ dQ) {
+    const int b = blockIdx.y, B = gridDim.y;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Nq) return;
+    const int np = *npairs;
+    const float gs = np > 0 ? g[0] / (float)np : 0.f;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    const int j = nn_q[(size_t)b * Nq + q];
+    if (j >= 0) {
+        const float* p = Q + ((size_t)b * Nq + q) * 3;
+        const int l = lab_q[(size_t)b * lab_q_stride + q];
+        const float wq = 2.f * gs / (float)n_part[((size_t)b * P + l) * 2 + side_q];
+        const float* o = C + ((size_t)b * Nc + j) * 3;
+        gx = wq * (p[0] - o[0]); gy = wq * (p[1] - o[1]); gz = wq * (p[2] - o[2]);
     }
+    for (int c = 0; c < chunks; ++c) {
+        const float* o = part + (((size_t)c * B + b) * Nq + q) * 3;
+        gx += o[0]; gy += o[1]; gz += o[2];
+    }
+    float* o = dQ + ((size_t)b * Nq + q) * 3;
+    o[0] = gx; o[1] = gy; o[2] = gz;
 }
 
 }  // namespace
@@ -293,16 +329,29 @@ extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float*
     hipStream_t s = (hipStream_t)stream;
     CWs w = contact_ws(workspace, B, Nh, No, P);
     // counters: cnt, n_part (contiguous up to npairs)
-    CHORE_HIP_CHECK(h, hipMemsetAsync(w.cnt, 0, (char*)w.npairs - (char*)w.cnt + sizeof(int), s));
+    {
+        const size_t n = ((char*)w.npairs - (char*)w.cnt) / 4 + 1;   // cnt, n_part, npairs
+        hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)w.cnt, 0u, n);
+    }
     const int Nm = Nh > No ? Nh : No;
     dim3 gm((Nm + 255) / 256, B);
     hipLaunchKernelGGL(contact_prep_kernel, gm, dim3(256), 0, s, df_hum_o, df_obj_h, part_logits, B, Nh, No, P, thres, w);
     hipLaunchKernelGGL(contact_select_kernel, gm, dim3(256), 0, s, label_h, B, Nh, No, P, w);
     hipLaunchKernelGGL(contact_pairs_kernel, dim3(1), dim3(256), 0, s, B, P, w);
-    hipLaunchKernelGGL(contact_nn_kernel, dim3((Nh + TILE - 1) / TILE, B), dim3(TILE), 0, s, hum, w.sel_h, label_h, 0, Nh,
-                       obj, w.sel_o, w.label_o, No, No, P, w.n_part, w.nn_h, w.m_h);
-    hipLaunchKernelGGL(contact_nn_kernel, dim3((No + TILE - 1) / TILE, B), dim3(TILE), 0, s, obj, w.sel_o, w.label_o, No, No,
-                       hum, w.sel_h, label_h, 0, Nh, P, w.n_part, w.nn_o, w.m_o);
+    const int th = (Nh + TILE - 1) / TILE, to = (No + TILE - 1) / TILE;
+    {
+        const size_t n = ((char*)w.part_h - (char*)w.key_h) / 4;     // key_h and key_o
+        hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)w.key_h,
+                           0xffffffffu, n);
+    }
+    hipLaunchKernelGGL(contact_nn_kernel, dim3(th, to, B), dim3(TILE), 0, s, hum, w.sel_h, label_h, 0, Nh,
+                       obj, w.sel_o, w.label_o, No, No, P, w.n_part, w.key_h);
+    hipLaunchKernelGGL(contact_nn_kernel, dim3(to, th, B), dim3(TILE), 0, s, obj, w.sel_o, w.label_o, No, No,
+                       hum, w.sel_h, label_h, 0, Nh, P, w.n_part, w.key_o);
+    hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * Nh + 255) / 256)), dim3(256), 0, s, w.key_h,
+                       (size_t)B * Nh, w.nn_h, w.m_h);
+    hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * No + 255) / 256)), dim3(256), 0, s, w.key_o,
+                       (size_t)B * No, w.nn_o, w.m_o);
     hipLaunchKernelGGL(contact_pair_sum_kernel, dim3(B * P * 2), dim3(256), 0, s, label_h, B, Nh, No, P, w);
     hipLaunchKernelGGL(contact_finish_kernel, dim3(1), dim3(64), 0, s, B, P, w, loss);
     CHORE_LAUNCH_CHECK(h, s);
@@ -319,10 +368,15 @@ extern "C" int chore_contact_bwd(chore_handle* h, const float* hum, const float*
         CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     CWs w = contact_ws(const_cast<void*>(workspace), B, Nh, No, P);
-    hipLaunchKernelGGL(contact_bwd_kernel, dim3((Nh + TILE - 1) / TILE, B), dim3(TILE), 0, s, hum, w.nn_h, label_h, 0, Nh, 0,
-                       obj, w.nn_o, w.label_o, No, No, P, w.n_part, w.npairs, g_loss, d_hum);
-    hipLaunchKernelGGL(contact_bwd_kernel, dim3((No + TILE - 1) / TILE, B), dim3(TILE), 0, s, obj, w.nn_o, w.label_o, No, No, 1,
-                       hum, w.nn_h, label_h, 0, Nh, P, w.n_part, w.npairs, g_loss, d_obj);
+    const int th = (Nh + TILE - 1) / TILE, to = (No + TILE - 1) / TILE;
+    hipLaunchKernelGGL(contact_bwd_kernel, dim3(th, to, B), dim3(TILE), 0, s, hum, Nh, 0, obj, w.nn_o, w.label_o, No, No, P,
+                       w.n_part, w.npairs, g_loss, w.part_h);
+    hipLaunchKernelGGL(contact_bwd_kernel, dim3(to, th, B), dim3(TILE), 0, s, obj, No, 1, hum, w.nn_h, label_h, 0, Nh, P,
+                       w.n_part, w.npairs, g_loss, w.part_o);
+    hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(th, B), dim3(TILE), 0, s, hum, w.nn_h, label_h, 0, Nh, 0, obj, No, P,
+                       w.n_part, w.npairs, g_loss, w.part_h, to, d_hum);
+    hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(to, B), dim3(TILE), 0, s, obj, w.nn_o, w.label_o, No, No, 1, hum, Nh, P,
+                       w.n_part, w.npairs, g_loss, w.part_o, th, d_obj);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

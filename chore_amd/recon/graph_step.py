@@ -88,6 +88,7 @@ class GraphedStep(EagerStep):
         mutable += [v for st in self.opt.state.values() for v in st.values() if torch.is_tensor(v)]   # continued Adam
         snap = [t.clone() for t in mutable]
         known = {id(t) for t in mutable}
+        self.release = release
         if release is not None:
             release()
         cur = torch.cuda.current_stream(dev)
@@ -111,6 +112,8 @@ class GraphedStep(EagerStep):
                 for v in st.values():
                     if torch.is_tensor(v) and id(v) not in known:
                         v.zero_()
+        if self.release is not None:
+            self.release()   # results memoised during the warm-up are stale now (.data writes bump no version)
 
     def begin_outer(self, decay):
         for p in self.params:

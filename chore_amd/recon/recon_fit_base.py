@@ -59,10 +59,12 @@ class _ContactFn(torch.autograd.Function):
         ws = torch.empty(_lib.lib.chore_contact_workspace_bytes(B, Nh, No, P), dtype=torch.uint8, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.lib.chore_contact_fwd(h, hum_c.data_ptr(), obj_c.data_ptr(),
-                                              df_hum_o.float().contiguous().data_ptr(),
-                                              df_obj_h.float().contiguous().data_ptr(), lab.data_ptr(),
-                                              part_logits.float().contiguous().data_ptr(), B, Nh, No, P, float(thres),
+        # keep the converted inputs in locals until the launch is enqueued: a temporary freed inside the argument
+        # list hands its block to the next temporary and the two pointers alias
+        dfh, dfo = df_hum_o.float().contiguous(), df_obj_h.float().contiguous()
+        logits = part_logits.float().contiguous()
+        _lib.check(_lib.lib.chore_contact_fwd(h, hum_c.data_ptr(), obj_c.data_ptr(), dfh.data_ptr(), dfo.data_ptr(),
+                                              lab.data_ptr(), logits.data_ptr(), B, Nh, No, P, float(thres),
                                               loss.data_ptr(), ws.data_ptr(), stream), h, "chore_contact_fwd")
         ctx.save_for_backward(hum_c, obj_c, lab, ws)
         ctx.P = P
@@ -210,6 +212,7 @@ class ReconFitterBase:
         smpl.pose.data[:, 66:] = split_smpl.hand_pose.data
         smpl.betas.data[:, :2] = split_smpl.top_betas.data   # (other_betas are not copied back: reference quirk, :682-690)
         smpl.trans.data = split_smpl.trans.data
+        smpl.forget()   # writes through .data are invisible to the version counters the LBS memo is keyed on
         return smpl
 
     @staticmethod

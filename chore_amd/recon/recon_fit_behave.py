@@ -36,6 +36,7 @@ class ReconFitterBehave(ReconFitterBase):
         """forget what holds autograd graphs of earlier steps (see GraphedStep)"""
         def f():
             split.betas = split.pose = None
+            split.forget()
             model.preds = None
             model.points = None            # CHORE.query keeps its last inputs (reference attribute): a graph too
             model.intermediate_preds_list = []
@@ -51,6 +52,7 @@ class ReconFitterBehave(ReconFitterBase):
     def forward_smpl(self, smpl, data_dict, phase):
         loss_dict = {}
         model = data_dict["net"]
+        smpl.forget()   # the LBS memo lives for one step (its autograd graph is consumed by this step's backward)
         smpl_verts = smpl()[0]
         _, parts_pred, _ = self.compute_df_h_loss(data_dict, loss_dict, model, smpl_verts)
         self.compute_prior_loss(loss_dict, smpl, nobeta=True)
@@ -88,11 +90,13 @@ class ReconFitterBehave(ReconFitterBase):
                 st.step()
             if it > 0.25 * max_iter + iter_for_betas + iter_for_pose and st.stopped():
                 break
+        rel()   # graph replays change the parameters without touching their version counters: drop memoised results
         scale = self.get_smpl_height(split) / height_init
         return self.copy_smpl_params(split, smpl), scale
 
     # ---- object + joint -----------------------------------------------------------------------------
     def forward_step(self, model, smpl, data_dict, obj_R, obj_t, obj_s, phase, noise=None):
+        smpl.forget()
         smpl_verts = smpl()[0]
         loss_dict = {}
         R = self.decopose_axis(obj_R, noise=noise)
@@ -165,4 +169,5 @@ class ReconFitterBehave(ReconFitterBase):
                 st.step()
             if phase == "joint" and it > 0.25 * max_iter and st.stopped():
                 break
+        rel()
         return smpl, data_dict["obj_R"], data_dict["obj_t"]
