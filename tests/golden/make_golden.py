@@ -147,6 +147,32 @@ def gen_encoder(net_eval):
                         tmpx_crop=tmpx[:, :, 128:132, 200:204])
 
 
+def train_batch(seed=21, B=2, N=512):
+    """synthetic training batch with the tensor contract of data/ (SURVEY 3.5); shared with the tests"""
+    rs = np.random.RandomState(seed)
+    return dict(images=synth.synth_images(B, 64, 96, seed=5), points=synth.synth_points(B, N, seed=6),
+                df_h=rs.uniform(0, 0.3, (B, N)).astype(np.float32), df_o=rs.uniform(0, 0.3, (B, N)).astype(np.float32),
+                parts_gt=rs.randint(0, 14, (B, N)).astype(np.int64),
+                pca_gt=rs.standard_normal((B, 3, 3, N)).astype(np.float32),
+                body_center=rs.standard_normal((B, 3)).astype(np.float32) * 0.3,
+                obj_center=rs.standard_normal((B, 3, N)).astype(np.float32) * 0.3,
+                crop_center=np.array([[1008.0, 995.0], [960.5, 1010.25]], np.float32)[:B])
+
+
+def gen_train_loss(net):
+    """CHORE.forward in training mode (all 5 stacks): total error and the six averaged loss terms
+    (model/chore.py:176-237).  print_errors only formats/prints, it is silenced."""
+    b = train_batch()
+    net.train(True)
+    net.print_errors = lambda *a, **k: None
+    with torch.no_grad():
+        error, losses_all = net.forward(**{k: torch.from_numpy(v) for k, v in b.items()})
+        preds0 = [p.numpy() for p in net.intermediate_preds_list[0]]
+    net.train(False)
+    np.savez_compressed(os.path.join(HERE, "train_loss.npz"), error=np.float32(error), losses_all=losses_all.numpy(),
+                        df_stack0=preds0[0][:, :, :64], **b)
+
+
 def gen_surface(net):
     """reference Generator.approx_surface (recon/generator.py:50-79) for 3 projection steps on the
     query_full inputs; the constructor (checkpoint folders) is bypassed"""
@@ -380,6 +406,7 @@ def main():
     gen_surface(net)
     gen_smpl()
     gen_fit(net)
+    gen_train_loss(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

@@ -129,3 +129,22 @@ def test_end_to_end_filter_query_matches_oracle(net32, synth_sd):
     o = oq.query(pts, cc, outs[-1], tmpx, synth_sd)
     for k, v in dict(df=df, pca=pca, parts=parts, centers=centers).items():
         assert np.abs(v - o[k]).max() < 1e-4 * max(1.0, np.abs(o[k]).max()), k
+
+
+def test_training_forward_loss_matches_reference(opt):
+    """CHORE.forward in training mode = encoder with all 5 stack outputs + 5 field queries + get_errors
+    (model/chore.py:176-237): total error and the six averaged loss terms against the reference's
+    values (tests/golden/train_loss.npz).  fp32 mode, 1e-4 relative; forward only (the backward to the network
+    parameters is not built: the parameters are frozen and the loss is evaluated under no_grad)."""
+    import copy
+    g = golden("train_loss.npz")
+    net = make_net(copy.copy(opt), "fp32")
+    net.train(True)
+    keys = ("images", "points", "df_h", "df_o", "parts_gt", "pca_gt", "body_center", "obj_center", "crop_center")
+    with torch.no_grad():
+        error, losses_all = net.forward(**{k: torch.from_numpy(g[k]).cuda() for k in keys})
+    assert len(net.intermediate_preds_list) == 5
+    np.testing.assert_allclose(net.intermediate_preds_list[0][0][:, :, :64].cpu().numpy(), g["df_stack0"], atol=2e-5)
+    np.testing.assert_allclose(losses_all.numpy(), g["losses_all"], rtol=1e-4)
+    assert abs(float(error) - float(g["error"])) < 1e-4 * abs(float(g["error"]))
+    assert set(net.format_sep_losses(losses_all)) == {"df_h", "df_o", "parts", "pca", "smpl", "obj"}
