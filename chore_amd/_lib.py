@@ -60,6 +60,10 @@ SIGNATURES = {
     "chore_so3_aux_bytes": (c_size_t, [c_int]),
     "chore_so3_project_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "chore_silhouette_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "chore_silhouette_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
+                                     c_void_p, c_void_p]),
+    "chore_silhouette_bwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "chore_contact_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "chore_contact_fwd": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_float, c_void_p, c_void_p, c_void_p]),
     "chore_contact_bwd": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p] * 5),

@@ -1,0 +1,269 @@
+// silhouette.hip -- differentiable silhouette rasterisation for the occlusion-aware mask loss of the object fit.
+//
+// Replaces what SilLossROI.forward (recon/obj_pose_roi.py:159-172) gets from the vendored neural_renderer:
+// RasterizeFunction with return_alpha only (external/neural_renderer/neural_renderer/rasterize.py:14-170) and its
+// CUDA kernels forward_face_index_map (cuda/rasterize_cuda_kernel.cu:24-215) and backward_pixel_map (:290-549).
+// Same mathematics -- back-face culling, inside test in normalised coordinates, clamped barycentric weights from the
+// pixel-space inverse, perspective-correct depth, z-buffer with near/far; the backward walks every edge of every
+// front-facing triangle along both axes and distributes diff_grad / distance to the two edge vertices -- organised
+// for this part instead of translated:
+//   * the reference bins triangles into 4x4-pixel blocks through an atomically appended list with room for 512
+//     entries (faces beyond that are silently dropped, and the z-buffer winner among equal depths depends on the
+//     append order).  Here a setup kernel computes, per triangle, the inverse matrix and an integer pixel bounding
+//     box; a workgroup owns a 16x16 pixel tile, streams all triangles of the image through LDS in chunks of 256
+//     and every lane tests only those whose box meets the tile.  No list, no dropped faces, the winner is the
+//     smallest depth and, among equal depths, the smallest triangle index: deterministic.
+//     (5 000 triangles x 65 536 pixels is 0.3 G box tests per image: ~20 us.)
+//   * the backward keeps the reference's one-thread-per-triangle walk (its sum order is part of the result) and
+//     reads the alpha / gradient images through a per-image row pointer.
+// Degenerate edges (a zero denominator makes the crossing coordinate non-finite) are skipped, like the
+// restatement in oracle/silhouette.py does; with real-valued vertices they have measure zero.
+#include "common.h"
+
+namespace {
+
+struct TriSetup {            // per (image, triangle)
+    float f[9];              // projected vertices: x0 y0 z0 x1 y1 z1 x2 y2 z2 (normalised [-1,1] + depth)
+    float inv[9];            // pixel-space inverse (barycentric weights = inv * (xi, yi, 1))
+    int x0, x1, y0, y1;      // inclusive pixel bounding box, x0 > x1 if the triangle is culled
+};
+
+__device__ __forceinline__ bool tri_backside(const float* f) {
+    return __fmul_rn(f[7] - f[1], f[3] - f[0]) < __fmul_rn(f[4] - f[1], f[6] - f[0]);
+}
+
+__global__ void sil_setup_kernel(const float* __restrict__ faces, int n /*B*F*/, int size, TriSetup* __restrict__ ts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    TriSetup t;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t.f[k] = faces[(size_t)i * 9 + k];
+    t.x0 = 1; t.x1 = 0; t.y0 = 1; t.y1 = 0;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t.inv[k] = 0.f;
+    if (!tri_backside(t.f)) {
+        const float S = (float)size;
+        float p[3][2];
+#pragma unroll
+        for (int v = 0; v < 3; ++v)
+#pragma unroll
+            for (int d = 0; d < 2; ++d) p[v][d] = 0.5f * ((t.f[3 * v + d] * S + S) - 1.0f);
+        const float den = (p[2][0] * (p[0][1] - p[1][1]) + p[0][0] * (p[1][1] - p[2][1])) + p[1][0] * (p[2][1] - p[0][1]);
+        const float m[9] = {p[1][1] - p[2][1], p[2][0] - p[1][0], p[1][0] * p[2][1] - p[2][0] * p[1][1],
+                            p[2][1] - p[0][1], p[0][0] - p[2][0], p[2][0] * p[0][1] - p[0][0] * p[2][1],
+                            p[0][1] - p[1][1], p[1][0] - p[0][0], p[0][0] * p[1][1] - p[1][0] * p[0][1]};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) t.inv[k] = m[k] / den;
+        // conservative box: pixel centres inside the triangle lie within [min, max] of the vertex pixel coordinates;
+        // one pixel of slack covers the rounding of the normalised-coordinate inside test
+        const float xmin = fminf(fminf(p[0][0], p[1][0]), p[2][0]), xmax = fmaxf(fmaxf(p[0][0], p[1][0]), p[2][0]);
+        const float ymin = fminf(fminf(p[0][1], p[1][1]), p[2][1]), ymax = fmaxf(fmaxf(p[0][1], p[1][1]), p[2][1]);
+        if (xmin == xmin && ymin == ymin && xmax == xmax && ymax == ymax) {   // not NaN
+            t.x0 = (int)fmaxf(floorf(xmin) - 1.f, 0.f);
+            t.y0 = (int)fmaxf(floorf(ymin) - 1.f, 0.f);
+            t.x1 = (int)fminf(ceilf(xmax) + 1.f, S - 1.f);
+            t.y1 = (int)fminf(ceilf(ymax) + 1.f, S - 1.f);
+        }
+    }
+    ts[i] = t;
+}
+
+constexpr int TILE_PX = 16, CHUNK = 256;
+
+__global__ __launch_bounds__(256) void sil_fwd_kernel(const TriSetup* __restrict__ ts, int F, int size, float near,
+                                                      float far, int* __restrict__ face_index,
+                                                      float* __restrict__ alpha) {
+    __shared__ TriSetup tri[CHUNK];      // 256 x 88 B = 22 KB
+    __shared__ int hits[CHUNK];          // indices (within the chunk) of the triangles whose box meets this tile
+    __shared__ int nhit;
+    const int b = blockIdx.z;
+    const int tx0 = blockIdx.x * TILE_PX, ty0 = blockIdx.y * TILE_PX;
+    const int lx = threadIdx.x % TILE_PX, ly = threadIdx.x / TILE_PX;
+    const int xi = tx0 + lx, yi = ty0 + ly;
+    const bool inside = xi < size && yi < size;
+    const float xp = (float)((2.0 * xi + 1 - size) / size), yp = (float)((2.0 * yi + 1 - size) / size);
+    const float xf = (float)xi, yf = (float)yi;
+    float depth = far;
+    int best = -1;
+    for (int c0 = 0; c0 < F; c0 += CHUNK) {
+        const int n = min(CHUNK, F - c0);
+        if (threadIdx.x == 0) nhit = 0;
+        __syncthreads();
+        if ((int)threadIdx.x < n) {
+            const TriSetup t = ts[(size_t)b * F + c0 + threadIdx.x];
+            const bool meets = t.x0 <= t.x1 && t.x0 <= tx0 + TILE_PX - 1 && t.x1 >= tx0 && t.y0 <= ty0 + TILE_PX - 1 &&
+                               t.y1 >= ty0;
+            tri[threadIdx.x] = t;
+            hits[threadIdx.x] = meets ? 1 : 0;
+        }
+        __syncthreads();
+        // compact in index order (serial over at most 256 flags by one wave: keeps the z-buffer order deterministic)
+        if (threadIdx.x == 0) {
+            int k = 0;
+            for (int j = 0; j < n; ++j)
+                if (hits[j]) hits[k++] = j;
+            nhit = k;
+        }
+        __syncthreads();
+        const int nh = nhit;
+        if (inside) {
+            for (int h = 0; h < nh; ++h) {
+                const int j = hits[h];
+                const float* f = tri[j].f;
+                if (__fmul_rn(yp - f[1], f[3] - f[0]) < __fmul_rn(xp - f[0], f[4] - f[1]) ||
+                    __fmul_rn(yp - f[4], f[6] - f[3]) < __fmul_rn(xp - f[3], f[7] - f[4]) ||
+                    __fmul_rn(yp - f[7], f[0] - f[6]) < __fmul_rn(xp - f[6], f[1] - f[7]))
+                    continue;
+                const float* m = tri[j].inv;
+                float w[3], ws = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float v = (m[3 * k] * xf + m[3 * k + 1] * yf) + m[3 * k + 2];
+                    v = fminf(fmaxf(v, 0.f), 1.f);     // NaN -> 0 like CUDA's fmax/fmin
+                    w[k] = v;
+                }
+                ws = (w[0] + w[1]) + w[2];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) w[k] = w[k] / ws;
+                const float zp = 1.0f / ((w[0] / f[2] + w[1] / f[5]) + w[2] / f[8]);
+                if (zp <= near || far <= zp) continue;
+                if (zp < depth) { depth = zp; best = c0 + j; }
+            }
+        }
+        __syncthreads();
+    }
+    if (inside) {
+        const size_t o = ((size_t)b * size + yi) * size + xi;
+        face_index[o] = best;
+        alpha[o] = best >= 0 ? 1.f : 0.f;
+    }
+}
+
+// one walk along edge (P0 -> P1) of triangle fn on one axis; P2 is the opposite vertex.  u = coordinate along the
+// walk axis, v = across it.  Adds to g0 / g1 (the gradient of P0 / P1 along v).
+struct Img {
+    const int* fim; const float* alpha; const float* grad; int size;
+    __device__ __forceinline__ size_t at(int axis, int d0, int d1) const {
+        return axis == 0 ? (size_t)d1 * size + d0 : (size_t)d0 * size + d1;
+    }
+};
+
+__device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v0, float u1, float v1, float u2, float v2,
+                              float eps, float& g0, float& g1) {
+    const int size = im.size;
+    const float S = (float)size;
+    int direction;
+    if (axis == 0) direction = (u0 < u1) ? -1 : 1;
+    else direction = (u0 < u1) ? 1 : -1;
+    const int d0_from = (int)fmaxf(ceilf(fminf(u0, u1)), 0.f);
+    const int d0_to = (int)fminf(fmaxf(u0, u1), S - 1.f);
+    for (int d0 = d0_from; d0 <= d0_to; ++d0) {
+        const float fd0 = (float)d0;
+        const float cross = (v1 - v0) / (u1 - u0) * (fd0 - u0) + v0;
+        if (!(fabsf(cross) <= 3.0e38f)) continue;          // non-finite: degenerate edge
+        const int d1_in = direction > 0 ? (int)floorf(cross) : (int)ceilf(cross);
+        const int d1_out = d1_in + direction;
+        if (d1_in < 0 || d1_in >= size || d1_out < 0 || d1_out >= size) continue;
+        const float a_in = im.alpha[im.at(axis, d0, d1_in)], a_out = im.alpha[im.at(axis, d0, d1_out)];
+        auto push = [&](int d1, float diff) {
+            if (!(diff > 0.f)) return;
+            const float t = ((float)d1 - cross);
+            if (u1 != fd0) {
+                float dist = (u1 - u0) / (u1 - fd0) * t * 2.0f / S;
+                dist = dist > 0.f ? dist + eps : dist - eps;
+                g0 -= diff / dist;
+            }
+            if (u0 != fd0) {
+                float dist = (u1 - u0) / (fd0 - u0) * t * 2.0f / S;
+                dist = dist > 0.f ? dist + eps : dist - eps;
+                g1 -= diff / dist;
+            }
+        };
+        if (im.fim[im.at(axis, d0, d1_in)] == fn) {          // 'out': beyond the edge up to the image border
+            const int lim = direction > 0 ? size - 1 : 0;
+            const int lo = max(min(d1_out, lim), 0), hi = min(max(d1_out, lim), size - 1);
+            for (int d1 = lo; d1 <= hi; ++d1) {
+                const size_t q = im.at(axis, d0, d1);
+                push(d1, (im.alpha[q] - a_in) * im.grad[q]);
+            }
+        }
+        float c2;                                            // 'in': this face's pixels up to the opposite edge
+        if ((fd0 - u0) * (fd0 - u2) < 0.f) c2 = (v2 - v0) / (u2 - u0) * (fd0 - u0) + v0;
+        else c2 = (v1 - v2) / (u1 - u2) * (fd0 - u2) + v2;
+        if (!(fabsf(c2) <= 3.0e38f)) continue;
+        const int lim = direction > 0 ? (int)ceilf(c2) : (int)floorf(c2);
+        const int lo = max(min(d1_in, lim), 0), hi = min(max(d1_in, lim), size - 1);
+        for (int d1 = lo; d1 <= hi; ++d1) {
+            const size_t q = im.at(axis, d0, d1);
+            if (im.fim[q] != fn) continue;
+            push(d1, (im.alpha[q] - a_out) * im.grad[q]);
+        }
+    }
+}
+
+__global__ void sil_bwd_kernel(const float* __restrict__ faces, const int* __restrict__ face_index,
+                               const float* __restrict__ alpha, const float* __restrict__ grad_alpha, int B, int F,
+                               int size, float eps, float* __restrict__ grad_faces) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * F) return;
+    const int b = i / F, fn = i % F;
+    float f[9], g[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { f[k] = faces[(size_t)i * 9 + k]; g[k] = 0.f; }
+    if (!tri_backside(f)) {
+        const size_t img = (size_t)b * size * size;
+        const Img im{face_index + img, alpha + img, grad_alpha + img, size};
+        const float S = (float)size;
+        float px[3], py[3];
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            px[v] = 0.5f * ((f[3 * v] * S + S) - 1.0f);
+            py[v] = 0.5f * ((f[3 * v + 1] * S + S) - 1.0f);
+        }
+        for (int e = 0; e < 3; ++e) {
+            const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+            // axis 0: walk x, the gradient goes to y; axis 1: walk y, the gradient goes to x
+            sil_edge_walk(im, fn, 0, px[i0], py[i0], px[i1], py[i1], px[i2], py[i2], eps, g[3 * i0 + 1], g[3 * i1 + 1]);
+            sil_edge_walk(im, fn, 1, py[i0], px[i0], py[i1], px[i1], py[i2], px[i2], eps, g[3 * i0 + 0], g[3 * i1 + 0]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) grad_faces[(size_t)i * 9 + k] = g[k];
+}
+
+}  // namespace
+
+extern "C" size_t chore_silhouette_workspace_bytes(int B, int F) { return (size_t)B * F * sizeof(TriSetup); }
+
+extern "C" int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, int F, int size, float near_z,
+                                    float far_z, int* face_index, float* alpha, void* workspace,
+                                    chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!faces || !face_index || !alpha || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_fwd: null argument");
+    if (B <= 0 || F <= 0 || size <= 0 || size > 4096 || B > 65535)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_fwd: bad sizes B=%d F=%d size=%d", B, F, size);
+    hipStream_t s = (hipStream_t)stream;
+    TriSetup* ts = (TriSetup*)workspace;
+    const int n = B * F;
+    hipLaunchKernelGGL(sil_setup_kernel, dim3((n + 255) / 256), dim3(256), 0, s, faces, n, size, ts);
+    const int tiles = (size + TILE_PX - 1) / TILE_PX;
+    hipLaunchKernelGGL(sil_fwd_kernel, dim3(tiles, tiles, B), dim3(256), 0, s, ts, F, size, near_z, far_z, face_index,
+                       alpha);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+extern "C" int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_index, const float* alpha,
+                                    const float* grad_alpha, int B, int F, int size, float eps, float* grad_faces,
+                                    chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!faces || !face_index || !alpha || !grad_alpha || !grad_faces)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_bwd: null argument");
+    if (B <= 0 || F <= 0 || size <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_bwd: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    const int n = B * F;
+    hipLaunchKernelGGL(sil_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, faces, face_index, alpha, grad_alpha, B, F,
+                       size, eps, grad_faces);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}

@@ -196,6 +196,25 @@ int chore_contact_bwd(chore_handle* h, const float* hum, const float* obj, const
                       chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Differentiable silhouette rasterisation for the mask loss of the object fit  (replaces neural_renderer's
+ * RasterizeFunction with return_alpha only, external/neural_renderer/neural_renderer/rasterize.py:14-170, i.e.
+ * the CUDA kernels forward_face_index_map cuda/rasterize_cuda_kernel.cu:24-215 and backward_pixel_map
+ * :290-549, as used by SilLossROI.forward recon/obj_pose_roi.py:159-172).
+ * faces (B,F,3,3) fp32: projected triangle vertices [u, v in [-1,1], depth] (after fill_back, i.e. both windings);
+ * face_index (B,size,size) int32 (-1 = background), alpha (B,size,size) fp32 in {0,1}; rows are NOT flipped
+ * (the caller flips like rasterize_rgbad does, rasterize.py:345).  near/far/eps defaults of the reference:
+ * 0.1, 100, 1e-4.  No face is dropped (the reference keeps at most 512 per 4x4-pixel block) and equal depths
+ * resolve to the smaller face index.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_silhouette_workspace_bytes(int B, int F);
+int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, int F, int size, float near_z, float far_z,
+                         int* face_index, float* alpha, void* workspace, chore_stream_t stream);
+/* grad_alpha (B,size,size) -> grad_faces (B,F,3,3) (depth components are zero) */
+int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_index, const float* alpha,
+                         const float* grad_alpha, int B, int F, int size, float eps, float* grad_faces,
+                         chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch
  * with hipEvents on the caller's stream, synchronises at the end of the call and accumulates, per
  * kernel class, the elapsed milliseconds, the algorithmic FLOPs and bytes and the launch count.

@@ -180,6 +180,10 @@ def test_optimize_loops_run(fit_setup):
 
 
 def _run_fit(opt, use_graphs):
+    return run_fit_with(opt, use_graphs)
+
+
+def run_fit_with(opt, use_graphs, silhouette=None, obj_iter=2, sil_iter=0, joint_iter=2):
     """both optimisation loops, short schedules, from identical initial state"""
     import copy
     from chore_amd.lib_smpl.priors import synthetic_priors
@@ -220,7 +224,10 @@ def _run_fit(opt, use_graphs):
     smpl2, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5,
                                         max_iter=1)
     data["smpl"] = smpl2
-    _, R, t = fitter.optimize_smpl_object(net, data, obj_iter=2, joint_iter=2, steps_per_iter=5, max_iter=1)
+    if silhouette is not None:
+        data["silhouette"] = silhouette
+    _, R, t = fitter.optimize_smpl_object(net, data, obj_iter=obj_iter, joint_iter=joint_iter, steps_per_iter=5, max_iter=1,
+                                          sil_iter=sil_iter)
     return [x.detach().cpu().numpy().copy() for x in (smpl2.pose, smpl2.betas, smpl2.trans, scale, R, t, data["obj_s"])]
 
 
