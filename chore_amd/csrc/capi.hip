@@ -141,4 +141,48 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
                               : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);
 }
 
+size_t chore_query_train_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * N * (2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float);
+}
+
+static void train_staging(QueryArgs& a, void* staging) {
+    const size_t P = (size_t)a.B * a.N;
+    float* f = (float*)staging;
+    a.tX = f;
+    a.tH = a.tX + P * QF_KPAD;
+    a.tdZ = a.tH + P * 3 * HEAD_NUM * HEAD_HID;
+    a.tdX = a.tdZ + P * 3 * HEAD_NUM * HEAD_HID;
+}
+
+int chore_query_bwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                          const void* heads_arena, const float* cam6_host, const float* g_df, const float* g_pca,
+                          const float* g_parts, const float* g_centers, void* staging, float* dpoints,
+                          chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
+                             cam6_host);
+    if (rc) return rc;
+    a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
+    a.dpoints = dpoints;
+    train_staging(a, staging);
+    return launch_query_bwd_train(h, dtype, a, (hipStream_t)stream);
+}
+
+int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,
+                           int TH, int TW, const float* cam6_host, const void* staging, float* dfeat, float* dtmpx,
+                           int accumulate, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!staging || (!dfeat && !dtmpx)) CHORE_FAIL(h, CHORE_EINVAL, "chore_scatter_features: null argument");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, staging /*unused*/, FH, FW, staging /*unused*/, TH, TW,
+                             CHORE_F32, staging /*unused*/, cam6_host);
+    if (rc) return rc;
+    train_staging(a, const_cast<void*>(staging));
+    return launch_scatter_features(h, a, a.tdX, dfeat, dtmpx, accumulate, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -129,9 +129,17 @@ struct QueryArgs {
     // backward only
     const float* g[HEAD_NUM];
     float* dpoints;
+    // training backward only (chore_query_bwd_train): staging for the parameter gradients, see query_bwd.hip
+    float* tX = nullptr;    // [B*N][QF_KPAD]           the 323-vector of every point (zero padded)
+    float* tH = nullptr;    // [3][HEAD_NUM][B*N][128]  relu outputs of hidden layers 1..3
+    float* tdZ = nullptr;   // [3][HEAD_NUM][B*N][128]  gradients w.r.t. the pre-activations of layers 1..3
+    float* tdX = nullptr;   // [B*N][QF_KPAD]           gradient w.r.t. the 323-vector (summed over the heads)
 };
 
 // launchers implemented in the .hip files
 int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s);
 int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s);
+int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX, float* dfeat, float* dtmpx,
+                            int accumulate, hipStream_t s);

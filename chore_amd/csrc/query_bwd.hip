@@ -65,7 +65,31 @@ __device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][2], const f32x16 (&in)[
     }
 }
 
-template <typename T>
+// training staging: one wave stores its head's 128 x 64 activation (or gradient) tile as [point][channel] rows.
+// A D fragment holds, per lane, 4 runs of 4 consecutive channels of one point: four 16-byte stores per fragment.
+__device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/, const f32x16 (&f)[4][2], bool relu_it,
+                                           size_t row0, int n0, int N, int lane) {
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int pt = cb * 32 + col;
+        if (n0 + pt >= N) continue;
+        float* row = base + (row0 + pt) * HEAD_HID;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = {f[rb][cb][4 * j], f[rb][cb][4 * j + 1], f[rb][cb][4 * j + 2], f[rb][cb][4 * j + 3]};
+                if (relu_it) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *(f32x4*)(row + rb * 32 + 8 * j + 4 * half) = v;
+            }
+    }
+}
+
+template <typename T, bool TRAIN>
 __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryBwdSmem& sm = *reinterpret_cast<QueryBwdSmem*>(smem_raw);
@@ -87,6 +111,14 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     const float* arena = (const float*)a.arena;
     const int head = wid;
     const int odim = head_out_dim(head);
+    const size_t row0 = (size_t)b * a.N + n0;                    // first point of the tile in the [B*N] staging rows
+    const size_t plane = (size_t)a.B * a.N * HEAD_HID;           // one (layer, head) plane of tH / tdZ
+    if constexpr (TRAIN) {
+        for (int i = tid; i < QT_PTS * (QF_KPAD / 4); i += 256) {
+            const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
+            if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
+        }
+    }
 
     // ---- forward recompute, keep ReLU sign bits only ----
     unsigned m1[4], m2[4], m3[4];
@@ -94,12 +126,15 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     heads_layer1(u, sm.X, arena, head, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask(u[rb][0], u[rb][1]);
+    if constexpr (TRAIN) store_tile(a.tH + (0 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
     heads_layer_hid(v, u, arena, head, 1, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask(v[rb][0], v[rb][1]);
+    if constexpr (TRAIN) store_tile(a.tH + (1 * HEAD_NUM + head) * plane, v, true, row0, n0, a.N, lane);
     heads_layer_hid(u, v, arena, head, 2, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask(u[rb][0], u[rb][1]);
+    if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
 
     // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
     {
@@ -137,10 +172,13 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
         }
     }
     apply_mask(v, m3);
+    if constexpr (TRAIN) store_tile(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
     bwd_hid(u, v, arena, head, 0, lane);  // d2 = W3^T d3
     apply_mask(u, m2);
+    if constexpr (TRAIN) store_tile(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane);
     bwd_hid(v, u, arena, head, 1, lane);  // d1 = W2^T d2
     apply_mask(v, m1);
+    if constexpr (TRAIN) store_tile(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
 
     // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
     __syncthreads();  // every wave is done reading X as the forward tile
@@ -181,6 +219,13 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
         __syncthreads();
     }
 
+    if constexpr (TRAIN) {   // the d(323-vector) tile, consumed by the feature-map scatter
+        for (int i = tid; i < QT_PTS * (QF_KPAD / 4); i += 256) {
+            const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
+            if (n0 + pt < a.N) *(f32x4*)(a.tdX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
+        }
+        if (!a.dpoints) return;   // uniform
+    }
     // ---- taps again: d(value)/d(ix,iy), then the projection Jacobian ----
     using L = MapLoad<T>;
 #pragma unroll 1
@@ -239,24 +284,28 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     }
 }
 
-template <typename T>
+template <typename T, bool TRAIN>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     static bool attr_set = false;
     const size_t smem = sizeof(QueryBwdSmem);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
-    hipLaunchKernelGGL(query_bwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return launch_query_bwd_t<float>(h, a, s);
+    return launch_query_bwd_t<float, false>(h, a, s);
 }
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return launch_query_bwd_t<unsigned short>(h, a, s);
+    return launch_query_bwd_t<unsigned short, false>(h, a, s);
+}
+
+int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {
+    return dtype == CHORE_F32 ? launch_query_bwd_t<float, true>(h, a, s) : launch_query_bwd_t<unsigned short, true>(h, a, s);
 }

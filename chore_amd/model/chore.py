@@ -83,6 +83,97 @@ class _QueryFn(torch.autograd.Function):
         return dpoints, None, None, None, None, None, None
 
 
+class _QueryTrainFn(torch.autograd.Function):
+    """the query as a TRAINABLE node: gradients w.r.t. the head parameters and the two feature maps (and the points).
+
+    forward = chore_query_fwd; backward = chore_query_bwd_train (recompute + staging of activations / pre-activation
+    gradients), library GEMMs over the point dimension for the weight gradients, chore_scatter_features for the
+    maps.  `params` = 32 tensors: for df, part_predictor, pca_predictor, center_predictor the (weight, bias) of
+    Sequential indices 0, 2, 4, 6 (the reference's make_decoder, model/chore.py:74-85)."""
+
+    KORDER = (0, 1, 2, 3)          # module order above -> kernel head order df, parts, pca, centers
+    ODIM = (2, 14, 9, 6)
+
+    @staticmethod
+    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype, *params):
+        B, N, _ = points.shape
+        dev = points.device
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(feat, 256)
+        tp, TH, TW = _nhwc_ptr(tmpx, 64)
+        df = torch.empty(B, 2, N, device=dev, dtype=torch.float32)
+        pca = torch.empty(B, 9, N, device=dev, dtype=torch.float32)
+        parts = torch.empty(B, 14, N, device=dev, dtype=torch.float32)
+        centers = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
+        in_img = torch.empty(B, N, device=dev, dtype=torch.uint8)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_query_fwd(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
+                                            tp, TH, TW, dtype, arena.data_ptr(), cam6, df.data_ptr(),
+                                            pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), in_img.data_ptr(),
+                                            stream), h, "chore_query_fwd")
+        ctx.save_for_backward(points, crop_center, feat, tmpx, arena, in_img)
+        ctx.cam6, ctx.dtype = cam6, dtype
+        return df, pca, parts, centers
+
+    @staticmethod
+    def backward(ctx, g_df, g_pca, g_parts, g_centers):
+        points, crop_center, feat, tmpx, arena, in_img = ctx.saved_tensors
+        B, N, _ = points.shape
+        P = B * N
+        dev = points.device
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(feat, 256)
+        tp, TH, TW = _nhwc_ptr(tmpx, 64)
+        zero = lambda c: torch.zeros(B, c, N, device=dev)  # noqa: E731
+        g_df = zero(2) if g_df is None else g_df.contiguous().float()
+        g_pca = zero(9) if g_pca is None else g_pca.contiguous().float()
+        g_parts = zero(14) if g_parts is None else g_parts.contiguous().float()
+        g_centers = zero(6) if g_centers is None else g_centers.contiguous().float()
+        staging = torch.empty(_lib.lib.chore_query_train_bytes(B, N), dtype=torch.uint8, device=dev)
+        need_pts = ctx.needs_input_grad[0]
+        dpoints = torch.empty_like(points) if need_pts else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_query_bwd_train(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW, tp, TH,
+                                                  TW, ctx.dtype, arena.data_ptr(), ctx.cam6, g_df.data_ptr(),
+                                                  g_pca.data_ptr(), g_parts.data_ptr(), g_centers.data_ptr(),
+                                                  staging.data_ptr(), None if dpoints is None else dpoints.data_ptr(),
+                                                  stream), h, "chore_query_bwd_train")
+        fl = staging.view(torch.float32)
+        KP, HD = 328, 128
+        X = fl[:P * KP].view(P, KP)
+        o = P * KP
+        H = fl[o:o + 12 * P * HD].view(3, 4, P, HD)
+        o += 12 * P * HD
+        dZ = fl[o:o + 12 * P * HD].view(3, 4, P, HD)
+        # the df head sees no gradient where the point is outside the image (df is overwritten there, chore.py:147-150)
+        g_df = g_df * in_img.unsqueeze(1).float()
+        g_out = (g_df, g_parts, g_pca, g_centers)                     # kernel head order
+        grads = [None] * 32
+        for mi, hk in enumerate((0, 1, 2, 3)):                        # module order df, part, pca, center
+            k = (0, 1, 2, 3)[hk]                                      # = kernel order df, parts, pca, centers
+            base = mi * 8
+            gw1 = dZ[0, k].t() @ X[:, :323]
+            gw2 = dZ[1, k].t() @ H[0, k]
+            gw3 = dZ[2, k].t() @ H[1, k]
+            gw4 = torch.einsum("bon,bnk->ok", g_out[k], H[2, k].view(B, N, HD))
+            grads[base + 0], grads[base + 1] = gw1.unsqueeze(-1), dZ[0, k].sum(0)
+            grads[base + 2], grads[base + 3] = gw2.unsqueeze(-1), dZ[1, k].sum(0)
+            grads[base + 4], grads[base + 5] = gw3.unsqueeze(-1), dZ[2, k].sum(0)
+            grads[base + 6], grads[base + 7] = gw4.unsqueeze(-1), g_out[k].sum((0, 2))
+        dfeat = dtmpx = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dfe = torch.empty(B, FH, FW, 256, device=dev) if ctx.needs_input_grad[2] else None
+            dtm = torch.empty(B, TH, TW, 64, device=dev) if ctx.needs_input_grad[3] else None
+            _lib.check(_lib.lib.chore_scatter_features(h, points.data_ptr(), crop_center.data_ptr(), B, N, FH, FW, TH, TW,
+                                                       ctx.cam6, staging.data_ptr(),
+                                                       None if dfe is None else dfe.data_ptr(),
+                                                       None if dtm is None else dtm.data_ptr(), 0, stream), h,
+                       "chore_scatter_features")
+            dfeat = None if dfe is None else dfe.permute(0, 3, 1, 2).to(feat.dtype)
+            dtmpx = None if dtm is None else dtm.permute(0, 3, 1, 2).to(tmpx.dtype)
+        return (dpoints, None, dfeat, dtmpx, None, None, None) + tuple(grads)
+
+
 def _mlp(input_sz, output_sz, hidden_sz):
     # parameter container with the reference's Sequential indices 0,2,4,6 (model/chore.py:74-85)
     return nn.Sequential(nn.Conv1d(input_sz, hidden_sz, 1), nn.ReLU(),
@@ -204,15 +295,22 @@ class CHORE(nn.Module):
         cc = crop_center.to(device=points.device, dtype=torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
             raise ValueError("points must be (B,N,3) and crop_center (B,2)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
             raise NotImplementedError(
-                "gradients w.r.t. network parameters are not implemented yet (training backward); "
-                "freeze the parameters (as recon/generator.py:41-42 does) or use torch.no_grad()")
+                "gradients w.r.t. the encoder parameters are not implemented yet (encoder backward); freeze "
+                "image_filter (the heads and the feature maps are differentiable) or use torch.no_grad()")
         arena = self._heads_arena(points.device)
         dtype = _DT[self.compute_dtype]
+        head_params = [p for _, m in self._head_modules() for p in m.parameters()]
+        train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
+                                             any(f.requires_grad for f in self.im_feat_list))
         self.intermediate_preds_list = []
         for feat in self.im_feat_list:
-            df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype)
+            if train:
+                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
+                                                              *head_params)
+            else:
+                df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype)
             B, _, N = df.shape
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]

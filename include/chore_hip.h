@@ -115,6 +115,30 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
                            const float* g_centers, float* dpoints, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Training backward of the query (first half of the backward of CHORE.forward, model/chore.py:176-190: what the
+ * reference's autograd computes for Trainer.train_step, trainer/trainer.py:76-131, through decode :156-167 and
+ * index / grid_sample model/geometry.py:4-14).  chore_query_bwd_train recomputes the forward like
+ * chore_query_bwd_points and, besides dpoints (optional), stages in `staging` (chore_query_train_bytes):
+ *   X   [B*N][328]          the 323-vector of every point, zero padded
+ *   H   [3][4][B*N][128]    relu outputs of hidden layers 1..3, heads in the order df, parts, pca, centers
+ *   dZ  [3][4][B*N][128]    gradients w.r.t. the pre-activations of layers 1..3
+ *   dX  [B*N][328]          gradient w.r.t. the 323-vector, summed over the heads
+ * The weight gradients are then plain GEMMs over the point dimension (dW_l = dZ_l^T H_{l-1}, db_l = column sums of
+ * dZ_l; the output layer uses the upstream gradients directly) -- the host runs them as library GEMMs.
+ * chore_scatter_features turns dX into the gradients of the two feature maps: dfeat (B,FH,FW,256) and dtmpx
+ * (B,TH,TW,64), fp32 NHWC, written (accumulate = 0) or added to (accumulate = 1); tile-gather, no atomics.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_query_train_bytes(int B, int N);
+int chore_query_bwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int map_dtype,
+                          const void* heads_arena, const float* camera, const float* g_df, const float* g_pca,
+                          const float* g_parts, const float* g_centers, void* staging, float* dpoints,
+                          chore_stream_t stream);
+int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,
+                           int TH, int TW, const float* camera, const void* staging, float* dfeat, float* dtmpx,
+                           int accumulate, chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Stacked-hourglass encoder  (replaces HGFilter.forward model/HGFilters.py:144-185,
  * HourGlass._forward :26-50, ConvBlock.forward model/net_util.py:374-396)
  * ------------------------------------------------------------------------------------------- */

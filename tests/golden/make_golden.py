@@ -123,6 +123,47 @@ def gen_query(net):
                         **{"w_" + k: v for k, v in wts.items()})
 
 
+def gen_query_train(net):
+    """gradients of the same functional w.r.t. the head parameters and the two feature maps (the reference's
+    autograd through CHORE.query, model/chore.py:107-167): the first half of the training backward"""
+    g = np.load(os.path.join(HERE, "query_full.npz"))
+    heads = {"df": net.df, "part_predictor": net.part_predictor, "pca_predictor": net.pca_predictor,
+             "center_predictor": net.center_predictor}
+    params = {f"{hn}.{k}": p for hn, m in heads.items() for k, p in m.named_parameters()}
+    for p in params.values():
+        p.requires_grad_(True)
+        p.grad = None
+    feat = torch.from_numpy(g["feat"]).requires_grad_(True)
+    tmpx = torch.from_numpy(g["tmpx"]).requires_grad_(True)
+    net.im_feat_list, net.tmpx = [feat], tmpx
+    net.query(torch.from_numpy(g["points"]), crop_center=torch.from_numpy(g["crop_center"]))
+    preds = net.get_preds()
+    # points on a ReLU kink (|pre-activation| < 5e-6 in some hidden unit) have an order-dependent gradient in any fp32
+    # implementation (DESIGN.md, gradient parity note); they are taken out of the functional so that every
+    # gradient below can be compared tightly
+    from oracle import query as oq
+    spec = [(k, tuple(v.shape)) for k, v in net.state_dict().items()]
+    sd = synth.synth_state_dict(spec, seed=0)
+    o = oq.query(g["points"], g["crop_center"], g["feat"], g["tmpx"], sd)
+    stable = (oq.relu_margin(o["features"], sd) > 5e-6).astype(np.float32)          # (B,N)
+    st = torch.from_numpy(stable)
+    loss = sum((o_ * torch.from_numpy(g["w_" + k]) * st.view(st.shape[0], *([1] * (o_.dim() - 2)), -1)).sum()
+               for k, o_ in zip(("df", "pca", "parts", "centers"), preds))
+    loss.backward()
+    out = dict(dfeat=feat.grad.numpy(), dtmpx=tmpx.grad.numpy(), stable=stable)
+    for name, p in params.items():
+        gr = p.grad.numpy()
+        if name.startswith("df.") or gr.size <= 4096:
+            out["g_" + name] = gr                                  # full gradient
+        else:                                                      # large matrices of the other heads: checksums + crop
+            out["s_" + name] = np.array([gr.sum(), np.abs(gr).sum(), np.sqrt((gr.astype(np.float64) ** 2).sum())], np.float64)
+            out["c_" + name] = gr.reshape(gr.shape[0], -1)[:16, :24].copy()
+    for p in params.values():
+        p.requires_grad_(False)
+        p.grad = None
+    np.savez_compressed(os.path.join(HERE, "query_train_grads.npz"), **out)
+
+
 def gen_encoder(net_eval):
     img = synth.synth_images(1, 64, 96, seed=3)
     with torch.no_grad():
@@ -407,6 +448,7 @@ def main():
     gen_smpl()
     gen_fit(net)
     gen_train_loss(net)
+    gen_query_train(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

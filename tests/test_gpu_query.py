@@ -159,3 +159,62 @@ def test_rejects_bad_inputs(net):
     net.tmpx = nhwc(g["tmpx"])
     with pytest.raises(ValueError):
         net.query(torch.from_numpy(g["points"]).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
+
+
+def test_training_backward_heads_and_feature_maps(opt):
+    """first half of the training backward: gradients of a random linear functional of the four outputs
+    w.r.t. the 32 head parameters, the hourglass feature map and tmpx, against the reference's autograd
+    (tests/golden/query_train_grads.npz: full tensors for the df head, the small tensors and the two maps; sums,
+    abs-sums, L2 norms and a 16x24 crop for the large matrices of the other heads).  fp32 mode, 2e-5 relative."""
+    import copy
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    g, gg = golden("query_full.npz"), golden("query_train_grads.npz")
+    o = copy.copy(opt)
+    o.compute_dtype = "fp32"
+    net = CHORE(o).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    for p in net.image_filter.parameters():
+        p.requires_grad_(False)
+    feat = nhwc(g["feat"]).requires_grad_(True)
+    tmpx = nhwc(g["tmpx"]).requires_grad_(True)
+    net.im_feat_list, net.tmpx = [feat], tmpx
+    pts = torch.from_numpy(g["points"]).cuda().requires_grad_(True)
+    net.query(pts, crop_center=torch.from_numpy(g["crop_center"]).cuda())
+    preds = net.get_preds()
+    for k, v in zip(("df", "pca", "parts", "centers"), preds):
+        assert np.abs(v.detach().cpu().numpy() - g[k]).max() < 2e-5
+    # the functional leaves out the ReLU-kink points (mask stored with the fixture, see make_golden.gen_query_train)
+    st = torch.from_numpy(gg["stable"]).cuda()
+    loss = sum((o_ * torch.from_numpy(g["w_" + k]).cuda() * st.view(st.shape[0], *([1] * (o_.dim() - 2)), -1)).sum()
+               for k, o_ in zip(("df", "pca", "parts", "centers"), preds))
+    loss.backward()
+
+    def close(a, b, what, tol=2e-5):
+        a = a.detach().float().cpu().numpy().reshape(b.shape)
+        assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(b).max()), (what, np.abs(a - b).max(), np.abs(b).max())
+
+    stable = gg["stable"] > 0
+    assert stable.mean() > 0.95
+    close(feat.grad, gg["dfeat"], "dfeat")
+    close(tmpx.grad, gg["dtmpx"], "dtmpx")
+    dp = pts.grad.cpu().numpy()
+    assert np.abs(dp[~stable]).max() == 0          # no functional, no gradient
+    heads = {"df": net.df, "part_predictor": net.part_predictor, "pca_predictor": net.pca_predictor,
+             "center_predictor": net.center_predictor}
+    n_checked = 0
+    for hn, m in heads.items():
+        for k, p in m.named_parameters():
+            name = f"{hn}.{k}"
+            gr = p.grad
+            assert gr is not None and torch.isfinite(gr).all(), name
+            if "g_" + name in gg.files:
+                close(gr, gg["g_" + name], name, tol=5e-5)
+            else:
+                a = gr.detach().cpu().numpy().astype(np.float64)
+                ref = gg["s_" + name]
+                got = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a ** 2).sum())])
+                assert np.abs(got - ref).max() < 5e-5 * ref[1], (name, got, ref)
+                close(gr.reshape(gr.shape[0], -1)[:16, :24], gg["c_" + name], name + " crop", tol=5e-5)
+            n_checked += 1
+    assert n_checked == 32
