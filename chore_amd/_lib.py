@@ -67,6 +67,21 @@ SIGNATURES = {
     "chore_so3_aux_bytes": (c_size_t, [c_int]),
     "chore_so3_project_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "chore_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "chore_gn_stats_bytes": (c_size_t, [c_int]),
+    "chore_gn_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chore_gn_relu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_void_p]),
+    "chore_conv2d_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_conv2d_bwd_data": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                      c_void_p, c_void_p, c_void_p]),
+    "chore_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "chore_conv2d_bwd_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_gn_relu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "chore_gn_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_silhouette_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_silhouette_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),

@@ -588,9 +588,11 @@ size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout) {
     return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024;
 }
 
+// transposed = 1 packs the weights of the DATA-GRADIENT convolution of a layer whose forward weights are
+// w (O = Cin here, C = Cout here, taps): dX = conv(dY, w^T flipped), i.e. this conv's w'[n][c][tap] = w[c][n][taps-1-tap]
 template <typename T>
 __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __restrict__ w, u32x4* __restrict__ dst,
-                                 size_t nvec) {
+                                 size_t nvec, int transposed) {
     constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvec) return;
@@ -604,7 +606,9 @@ __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __res
     const int c0 = kg * KGE + VE * (lane >> 5);
     float vals[VE];
 #pragma unroll
-    for (int j = 0; j < VE; ++j) vals[j] = w[((size_t)n * Cin + c0 + j) * taps + tap];
+    for (int j = 0; j < VE; ++j)
+        vals[j] = transposed ? w[((size_t)(c0 + j) * Cout + n) * taps + (taps - 1 - tap)]
+                             : w[((size_t)n * Cin + c0 + j) * taps + tap];
     u32x4 o;
     if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -617,14 +621,15 @@ __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __res
 }
 
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w, void* dst,
-                     hipStream_t s) {
+                     hipStream_t s, int transposed) {
     const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16;
     const unsigned blocks = (unsigned)((nvec + 255) / 256);
     if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec);
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec,
+                           transposed);
     else
         hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst,
-                           nvec);
+                           nvec, transposed);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -93,7 +93,7 @@ ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w /*(O,C,k,k)*/,
-                     void* dst, hipStream_t s);
+                     void* dst, hipStream_t s, int transposed = 0);
 
 // --- misc kernels (enc_misc.hip) ---
 int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W,

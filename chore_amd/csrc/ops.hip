@@ -1,0 +1,76 @@
+// ops.hip -- layer-level entry points of the encoder kernels (C ABI), used by the TRAINING path.
+//
+// Inference runs the whole encoder as one launch program (encoder.hip).  Training needs every intermediate tensor
+// and a backward per layer, so the host composes the network from these operators instead (chore_amd/model/
+// hgfilter_train.py): the same kernels -- conv_lds (forward, and the data gradient on transposed + flipped weights),
+// the exact GroupNorm statistics, GroupNorm+ReLU apply -- plus the backward kernels of train_bwd.hip.
+// Activations are NHWC (T = fp32 or bf16), weights arrive in the reference layout (O,C,kh,kw) fp32 and are packed
+// into the caller's workspace on every call (they change every optimiser step).
+#include "enc_common.h"
+
+extern "C" {
+
+size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout) {
+    if ((dtype != CHORE_F32 && dtype != CHORE_BF16) || (taps != 1 && taps != 9)) return 0;
+    return packed_conv_bytes(dtype, taps, Cin, Cout);
+}
+
+size_t chore_gn_stats_bytes(int B) { return (size_t)B * GN_GROUPS * sizeof(GroupStat); }
+
+// statistics of x (B,HW,C) for GroupNorm(32, C): stats is zeroed and filled
+int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !stats || B <= 0 || HW <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_stats: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    CHORE_HIP_CHECK(h, hipMemsetAsync(stats, 0, chore_gn_stats_bytes(B), s));
+    View v; v.p = const_cast<void*>(x); v.cs = C; v.co = 0; v.C = C;
+    return launch_gn_stats(h, dtype, v, B, HW, (GroupStat*)stats, s);
+}
+
+// y = relu(groupnorm(x))
+int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
+                      void* y, int B, int HW, int C, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !stats || !gamma || !beta || !y) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_fwd: null argument");
+    View vx; vx.p = const_cast<void*>(x); vx.cs = C; vx.co = 0; vx.C = C;
+    View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
+    return launch_gn_apply_relu(h, dtype, vx, (const GroupStat*)stats, gamma, beta, vy, B, HW, (hipStream_t)stream);
+}
+
+// y (B,H,W,Cout) = conv_{taps}(a) + bias, a = relu(groupnorm(x)) if stats != NULL else x; stride 1, zero padding
+int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                     const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
+                     int Cout, void* y, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !w || !y || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: null argument");
+    if (stats && (!gamma || !beta)) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: GroupNorm needs gamma and beta");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_pack_conv(h, dtype, taps, Cin, Cout, w, workspace, s, 0);
+    if (rc) return rc;
+    ConvArgs a{};
+    a.in.p = const_cast<void*>(x); a.in.cs = Cin; a.in.co = 0; a.in.C = Cin;
+    a.in_st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta;
+    a.wpk = workspace; a.bias = bias;
+    a.out.p = y; a.out.cs = Cout; a.out.co = 0; a.out.C = Cout;
+    a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+    return launch_conv(h, dtype, taps, a, s);
+}
+
+// dx (B,H,W,Cin) = gradient of the convolution's INPUT (the tensor the conv saw, after any GroupNorm+ReLU):
+// the same kernel on the transposed, spatially flipped weights
+int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, int B, int H, int W, int Cout,
+                          const float* w, int Cin, void* dx, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!dy || !w || !dx || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_data: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_pack_conv(h, dtype, taps, /*Cin of this conv*/ Cout, /*Cout of this conv*/ Cin, w, workspace, s, 1);
+    if (rc) return rc;
+    ConvArgs a{};
+    a.in.p = const_cast<void*>(dy); a.in.cs = Cout; a.in.co = 0; a.in.C = Cout;
+    a.wpk = workspace;
+    a.out.p = dx; a.out.cs = Cin; a.out.co = 0; a.out.C = Cin;
+    a.B = B; a.H = H; a.W = W; a.Cout = Cin;
+    return launch_conv(h, dtype, taps, a, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,420 @@
+// train_bwd.hip -- backward kernels of the encoder layers (training path).
+//
+//   * weight gradient of a 3x3 / 1x1 convolution whose input is relu(groupnorm(x)) (or x itself):
+//       dW[o][c][t] = sum_{b,y,x} dY[b,y,x,o] * A[b,y+dy(t),x+dx(t),c]          (model/net_util.py:346-396 layers)
+//     an MFMA GEMM whose contraction index is the PIXEL, while both tensors are stored channel-contiguous.
+//       fp32: v_mfma_f32_32x32x2_f32 takes one scalar per lane and k = lane>>5 -- the [pixel][channel] images feed it
+//             directly (exact fp32, the parity mode);
+//       bf16: v_mfma_f32_32x32x16_bf16 wants 8 consecutive k per lane = 8 consecutive pixels of one channel; the
+//             fragments come from the same row-major images through ds_read_b64_tr_b16 (in a 16-lane group lane i
+//             addresses 4 contiguous elements of row i>>2, column chunk i&3 of a 4x16 block and receives column i;
+//             measured with scripts/probes/tr_probe.hip), two reads per fragment, no software transpose.
+//     A workgroup owns 32 output x 32 input channels (all taps) and walks a share of the 8x32-pixel tiles; its four
+//     waves split the tile rows and reduce through LDS in a fixed order at the end; the per-share partials are
+//     summed in order by a second kernel: no float atomics, bit-reproducible.
+//   * GroupNorm+ReLU backward: one streaming pass accumulates, exactly (the integer accumulators of
+//     enc_common.h), dgamma/dbeta per channel and the two per-(image, group) sums the input gradient needs; a
+//     second pass writes dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)), g = dA * [y > 0].
+#include "enc_common.h"
+
+typedef __bf16 tb_bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TH = 8, TW = 32;                 // pixel tile
+constexpr int PW = TW + 2, PH = TH + 2;        // halo tile of the 3x3 case
+constexpr int CT32 = 32;                       // channels per operand tile
+
+template <typename T> __device__ __forceinline__ float ld1(const T* p);
+template <> __device__ __forceinline__ float ld1<float>(const float* p) { return *p; }
+template <> __device__ __forceinline__ float ld1<bf16_t>(const bf16_t* p) { return bf2f(*p); }
+template <typename T> __device__ __forceinline__ void st1(T* p, float v);
+template <> __device__ __forceinline__ void st1<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void st1<bf16_t>(bf16_t* p, float v) { *p = f2bf(v); }
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const void* x;            // (B,H,W,Cin) input of the layer (before GroupNorm)
+    const GroupStat* st;      // statistics of x, or null: the conv saw x itself
+    const float* gamma; const float* beta;
+    const void* dy;           // (B,H,W,Cout)
+    int B, H, W, Cin, Cout;
+    float* part;              // [S][Cout/32][Cin/32][TAPS][32][32] partial sums
+    float* part_bias;         // [S][Cout] or null
+    int S;                    // shares of the pixel tiles
+};
+
+template <typename T, int TAPS>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int AW = TW + 2 * PAD, AH = TH + 2 * PAD, AROWS = AH * AW;
+    constexpr int ES = sizeof(T);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    T* imgA = (T*)smem;                                   // [AROWS][32]  relu(gn(x)) halo tile, zero outside the image
+    T* imgY = (T*)(smem + AROWS * CT32 * ES);             // [256][32]    dY tile
+    float* ss = (float*)(smem + (AROWS + TH * TW) * CT32 * ES);   // [32][2] scale/shift of this image's channels
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int co0 = blockIdx.x * CT32, ci0 = blockIdx.y * CT32, share = blockIdx.z;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tiles = a.B * tiles_x * tiles_y;
+    const bool use_gn = a.st != nullptr;
+    const T* X = (const T*)a.x;
+    const T* DY = (const T*)a.dy;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bias_acc = 0.f;                                 // thread tid < 32: column sum of dY for channel co0 + tid
+    int cur_b = -1;
+
+    for (int tile = share; tile < tiles; tile += a.S) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
+        __syncthreads();                                  // previous tile fully consumed
+        if (use_gn && b != cur_b) {
+            if (tid < CT32) gn_scale_shift(a.st, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            __syncthreads();
+        }
+        cur_b = b;
+        // ---- stage: 8 channels (fp32: 4) per thread-vector ----
+        constexpr int VE = 16 / ES, VPR = CT32 / VE;      // elements per 16-byte vector, vectors per row
+        for (int i = tid; i < AROWS * VPR; i += 256) {
+            const int row = i / VPR, v = i % VPR;
+            const int y = ty0 + row / AW - PAD, x = tx0 + row % AW - PAD;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
+                val = *(const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.Cin + ci0 + v * VE);
+                if (use_gn) {
+                    float f[8];
+                    if constexpr (ES == 2) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(val[j] << 16); f[2 * j + 1] = __uint_as_float(val[j] & 0xffff0000u); }
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], ss[2 * (v * 8 + j)], ss[2 * (v * 8 + j) + 1]); f[j] = t > 0.f ? t : 0.f; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) val[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float t = fmaf(__uint_as_float(val[j]), ss[2 * (v * 4 + j)], ss[2 * (v * 4 + j) + 1]);
+                            val[j] = __float_as_uint(t > 0.f ? t : 0.f);
+                        }
+                    }
+                }
+            }
+            *(u32x4*)(imgA + row * CT32 + v * VE) = val;
+        }
+        for (int i = tid; i < TH * TW * VPR; i += 256) {
+            const int row = i / VPR, v = i % VPR;
+            const int y = ty0 + row / TW, x = tx0 + row % TW;
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (y < a.H && x < a.W) val = *(const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.Cout + co0 + v * VE);
+            *(u32x4*)(imgY + row * CT32 + v * VE) = val;
+        }
+        __syncthreads();
+        if (a.part_bias && blockIdx.y == 0 && tid < CT32) {
+            for (int p = 0; p < TH * TW; ++p) bias_acc += ld1<T>(imgY + p * CT32 + tid);
+        }
+        // ---- MFMAs: wave `wid` owns tile rows 2*wid, 2*wid+1 ----
+        if constexpr (ES == 4) {
+            const int half = lane >> 5, col = lane & 31;
+#pragma unroll 1
+            for (int yy = 0; yy < 2; ++yy) {
+                const int y = 2 * wid + yy;
+#pragma unroll 4
+                for (int x = 0; x < TW; x += 2) {
+                    const float av = ((const float*)imgY)[(y * TW + x + half) * CT32 + col];     // A[m = co][k = pixel]
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                        const float bv = ((const float*)imgA)[((y + ky) * AW + x + kx + half) * CT32 + col];   // B[k][n = ci]
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // transposing reads: lane -> (row within the 4-row block, 4-column chunk) of its 16-lane group
+            const int i16 = lane & 15, g = (lane >> 4) & 1, h = lane >> 5;
+            const int rsel = i16 >> 2, csel = (i16 & 3) * 4 + g * 16;
+            auto frag = [&](const T* img, int row0) -> tb_bf16x8 {      // rows row0 + 8h + {0..3} and {4..7}
+                unsigned long long lo, hi;
+                const unsigned a0 = (unsigned)(size_t)(img + (row0 + 8 * h + rsel) * CT32 + csel);
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi) : "v"(a0));   // +4 rows x 64 B
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+                const u64x2 v = {lo, hi};
+                return __builtin_bit_cast(tb_bf16x8, v);
+            };
+#pragma unroll 1
+            for (int yy = 0; yy < 2; ++yy) {
+                const int y = 2 * wid + yy;
+#pragma unroll 1
+                for (int x = 0; x < TW; x += 16) {
+                    const tb_bf16x8 av = frag(imgY, y * TW + x);
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                        const tb_bf16x8 bv = frag(imgA, (y + ky) * AW + x + kx);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+    // ---- reduce the four waves (fixed order) and write this share's partial ----
+    __syncthreads();
+    float* red = (float*)smem;                            // [4][32][32] one tap at a time
+    const int half = lane >> 5, col = lane & 31;
+    float* out = a.part + ((((size_t)share * gridDim.x + blockIdx.x) * gridDim.y + blockIdx.y) * TAPS) * 1024;
+#pragma unroll 1
+    for (int t = 0; t < TAPS; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wid * 32 + mfma32_row(r, half)) * 32 + col] = acc[t][r];
+        __syncthreads();
+        for (int i = tid; i < 1024; i += 256)
+            out[(size_t)t * 1024 + i] = ((red[i] + red[1024 + i]) + red[2048 + i]) + red[3072 + i];
+        __syncthreads();
+    }
+    if (a.part_bias && blockIdx.y == 0 && tid < CT32) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc;
+}
+
+// dW (O,C,kh,kw) = sum over the shares, in order
+__global__ void wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int S, int Cout,
+                                    int Cin, int taps, float* __restrict__ dw, float* __restrict__ dbias) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)Cout * Cin * taps;
+    if (i < n) {
+        const int t = (int)(i % taps), c = (int)((i / taps) % Cin), o = (int)(i / ((size_t)taps * Cin));
+        const int nbo = Cout / 32, nbc = Cin / 32;
+        float s = 0.f;
+        for (int k = 0; k < S; ++k)
+            s += part[(((((size_t)k * nbo + o / 32) * nbc + c / 32) * taps + t) * 32 + o % 32) * 32 + c % 32];
+        dw[i] = s;
+    }
+    if (dbias && i < (size_t)Cout) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part_bias[(size_t)k * Cout + i];
+        dbias[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm + ReLU backward
+// ------------------------------------------------------------------------------------------------
+struct GnBwdAcc {                 // exact accumulators, zeroed by the caller
+    GroupStat* grp;               // [B][32]: sum = S1 = sum(g*gamma), sq = S2 = sum(g*gamma*xhat)
+    GroupStat* chan;              // [C]:     sum = dbeta, sq = dgamma
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ da,
+                                                            const GroupStat* __restrict__ st, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int C, int HW, int S, GnBwdAcc acc) {
+    __shared__ float red[4][1024];
+    __shared__ float mr[1024];         // [C][4] mean, rstd, scale, shift per channel of this image (scale/shift exactly
+                                       // as the forward folds them, so that the ReLU mask is the forward's)
+    const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
+    const int gs = C / GN_GROUPS;
+    if (tid < C) {
+        const GroupStat g = st[(size_t)b * GN_GROUPS + tid / gs];
+        const double n = (double)HW * gs;
+        const double mean = stat_read(g.sum) / n;
+        double var = stat_read(g.sq) / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+        const float scale = rstd * gamma[tid];
+        mr[4 * tid] = (float)mean;
+        mr[4 * tid + 1] = rstd;
+        mr[4 * tid + 2] = scale;
+        mr[4 * tid + 3] = beta[tid] - (float)mean * scale;
+    }
+    __syncthreads();
+    const int tpr = C / 4, P = 256 / tpr, cv = tid % tpr, pl = tid / tpr;
+    const int p0 = (int)((long long)HW * s / S), p1 = (int)((long long)HW * (s + 1) / S);
+    float dgam[4] = {0, 0, 0, 0}, dbet[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    for (int p = p0 + pl; p < p1; p += P) {
+        const size_t o = ((size_t)b * HW + p) * C + cv * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = cv * 4 + j;
+            const float xv = ld1<T>(x + o + j);
+            const float xh = (xv - mr[4 * c]) * mr[4 * c + 1];
+            const float g = fmaf(xv, mr[4 * c + 2], mr[4 * c + 3]) > 0.f ? ld1<T>(da + o + j) : 0.f;
+            dbet[j] += g;
+            dgam[j] += g * xh;
+            const float gy = g * gamma[c];
+            s1[j] += gy;
+            s2[j] += gy * xh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[0][pl * C + cv * 4 + j] = dbet[j];
+        red[1][pl * C + cv * 4 + j] = dgam[j];
+        red[2][pl * C + cv * 4 + j] = s1[j];
+        red[3][pl * C + cv * 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (tid < C) {
+        float t[4] = {0, 0, 0, 0};
+        for (int i = 0; i < P; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t[k] += red[k][i * C + tid];
+        stat_add(&acc.chan[tid].sum, t[0]);
+        stat_add(&acc.chan[tid].sq, t[1]);
+        const float g1 = group_lane_sum(t[2], gs), g2 = group_lane_sum(t[3], gs);
+        if (tid % gs == 0) {
+            GroupStat* o = acc.grp + (size_t)b * GN_GROUPS + tid / gs;
+            stat_add(&o->sum, g1);
+            stat_add(&o->sq, g2);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ da,
+                                                           const GroupStat* __restrict__ st, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int C, int HW, GnBwdAcc acc,
+                                                           T* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+    __shared__ float pc[1792];         // [C][7] mean, rstd, gamma, S1/n, S2/n, scale, shift
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int gs = C / GN_GROUPS;
+    if (tid < C) {
+        const int gi = tid / gs;
+        const GroupStat g = st[(size_t)b * GN_GROUPS + gi];
+        const double n = (double)HW * gs;
+        const double mean = stat_read(g.sum) / n;
+        double var = stat_read(g.sq) / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const GroupStat ga = acc.grp[(size_t)b * GN_GROUPS + gi];
+        const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+        const float scale = rstd * gamma[tid];
+        pc[7 * tid] = (float)mean;
+        pc[7 * tid + 1] = rstd;
+        pc[7 * tid + 2] = gamma[tid];
+        pc[7 * tid + 3] = (float)(stat_read(ga.sum) / n);
+        pc[7 * tid + 4] = (float)(stat_read(ga.sq) / n);
+        pc[7 * tid + 5] = scale;
+        pc[7 * tid + 6] = beta[tid] - (float)mean * scale;
+        if (blockIdx.x == 0 && b == 0) {     // the parameter gradients: totals over the whole batch
+            dbeta[tid] = (float)stat_read(acc.chan[tid].sum);
+            dgamma[tid] = (float)stat_read(acc.chan[tid].sq);
+        }
+    }
+    __syncthreads();
+    const size_t total = (size_t)HW * C;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const size_t o = (size_t)b * total + i;
+        const float* q = pc + 7 * c;
+        const float xv = ld1<T>(x + o);
+        const float xh = (xv - q[0]) * q[1];
+        const float gy = fmaf(xv, q[5], q[6]) > 0.f ? ld1<T>(da + o) * q[2] : 0.f;
+        st1<T>(dx + o, q[1] * ((gy - q[3]) - xh * q[4]));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// shares of the pixel tiles: enough workgroups to fill the chip, at least 4 tiles per share
+static int wgrad_shares(int B, int H, int W, int Cin, int Cout) {
+    const int tiles = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    const int pairs = (Cout / 32) * (Cin / 32);
+    int S = (1024 + pairs - 1) / pairs;
+    if (S > tiles / 2) S = tiles / 2;
+    if (S < 1) S = 1;
+    return S;
+}
+
+size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin, int Cout) {
+    if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || B <= 0) return 0;
+    const int S = wgrad_shares(B, H, W, Cin, Cout);
+    return ((size_t)S * (Cout / 32) * (Cin / 32) * taps * 1024 + (size_t)S * Cout) * sizeof(float);
+}
+
+// dw (Cout,Cin,k,k) fp32 and dbias (Cout, or NULL) of y = conv(a) + bias, a = relu(groupnorm(x)) if stats else x
+int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                            const void* stats, const float* gamma, const float* beta, const void* dy, int Cout, float* dw,
+                            float* dbias, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: null argument");
+    if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || Cin > 256)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: unsupported taps=%d Cin=%d Cout=%d", taps, Cin, Cout);
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs a;
+    a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.S = wgrad_shares(B, H, W, Cin, Cout);
+    a.part = (float*)workspace;
+    a.part_bias = dbias ? a.part + (size_t)a.S * (Cout / 32) * (Cin / 32) * taps * 1024 : nullptr;
+    const size_t es = dtype == CHORE_F32 ? 4 : 2;
+    const int arows = taps == 9 ? PH * PW : TH * TW;
+    size_t smem = (size_t)(arows + TH * TW) * CT32 * es + 256;
+    if (smem < 4 * 1024 * sizeof(float)) smem = 4 * 1024 * sizeof(float);
+    dim3 grid(Cout / 32, Cin / 32, a.S);
+#define LAUNCH_WG(T, TP)                                                                                              \
+    do {                                                                                                              \
+        static bool attr = false;                                                                                     \
+        if (!attr) {                                                                                                  \
+            CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad_kernel<T, TP>,                                 \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
+            attr = true;                                                                                              \
+        }                                                                                                             \
+        hipLaunchKernelGGL((wgrad_kernel<T, TP>), grid, dim3(256), smem, s, a);                                      \
+    } while (0)
+    if (dtype == CHORE_F32) { if (taps == 9) LAUNCH_WG(float, 9); else LAUNCH_WG(float, 1); }
+    else { if (taps == 9) LAUNCH_WG(bf16_t, 9); else LAUNCH_WG(bf16_t, 1); }
+#undef LAUNCH_WG
+    const size_t n = (size_t)Cout * Cin * taps;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
+                       Cin, taps, dw, dbias);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+size_t chore_gn_relu_bwd_workspace_bytes(int B, int C) { return ((size_t)B * GN_GROUPS + C) * sizeof(GroupStat); }
+
+// da = gradient w.r.t. relu(groupnorm(x)) -> dx, dgamma (C), dbeta (C)
+int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
+                      const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
+                      chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
+    if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);
+    hipStream_t s = (hipStream_t)stream;
+    CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, chore_gn_relu_bwd_workspace_bytes(B, C), s));
+    GnBwdAcc acc;
+    acc.grp = (GroupStat*)workspace;
+    acc.chan = acc.grp + (size_t)B * GN_GROUPS;
+    int S = HW / 64;
+    if (S < 1) S = 1;
+    if (S > GN_SPLITS_MAX) S = GN_SPLITS_MAX;
+    const size_t total = (size_t)HW * C;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    if (dtype == CHORE_F32) {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(S, B), dim3(256), 0, s, (const float*)x, (const float*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(blocks, B), dim3(256), 0, s, (const float*)x, (const float*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, acc, (float*)dx, dgamma, dbeta);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(S, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(blocks, B), dim3(256), 0, s, (const bf16_t*)x,
+                           (const bf16_t*)da, (const GroupStat*)stats, gamma, beta, C, HW, acc, (bf16_t*)dx, dgamma, dbeta);
+    }
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+"""Layer operators of the encoder as autograd nodes (training path).
+
+Every node runs HIP kernels of libchore_hip.so forward AND backward:
+  conv_gn(x, w, bias, gamma, beta)   y = conv_{3x3|1x1}(relu(groupnorm32(x))) + bias   (one fused op = one layer of
+                                     ConvBlock, /root/reference/model/net_util.py:374-396; gamma=None: plain conv)
+  gn_relu(x, gamma, beta)            y = relu(groupnorm32(x))                        (HGFilters.py:150,170)
+Tensors are NHWC (B,H,W,C) contiguous, float32 or bfloat16; parameters are float32 in the reference layouts.
+Backward of conv_gn: data gradient = the forward convolution kernel on transposed, flipped weights
+(chore_conv2d_bwd_data); weight gradient = pixel-contraction MFMA GEMM (chore_conv2d_bwd_weight, recomputes
+relu(gn(x)) while staging); GroupNorm+ReLU backward from the exact group statistics (chore_gn_relu_bwd).
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+
+
+def _u8(n, dev):
+    return torch.empty(max(int(n), 16), dtype=torch.uint8, device=dev)
+
+
+def _env(x):
+    if not x.is_cuda:
+        raise RuntimeError("chore_amd needs device tensors (no CPU path)")
+    if x.dtype not in _DT or not x.is_contiguous() or x.dim() != 4:
+        raise ValueError("expected a contiguous NHWC (B,H,W,C) float32 / bfloat16 tensor")
+    dev = x.device
+    return dev, _lib.handle(dev.index or 0), _DT[x.dtype], torch.cuda.current_stream(dev).cuda_stream
+
+
+def gn_stats(x):
+    dev, h, dt, stream = _env(x)
+    B, H, W, C = x.shape
+    st = _u8(_lib.lib.chore_gn_stats_bytes(B), dev)
+    _lib.check(_lib.lib.chore_gn_stats(h, dt, x.data_ptr(), B, H * W, C, st.data_ptr(), stream), h, "chore_gn_stats")
+    return st
+
+
+class _GNReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        dev, h, dt, stream = _env(x)
+        B, H, W, C = x.shape
+        st = gn_stats(x)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib.chore_gn_relu_fwd(h, dt, x.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), B,
+                                              H * W, C, stream), h, "chore_gn_relu_fwd")
+        ctx.save_for_backward(x, st, g, b)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st, g, b = ctx.saved_tensors
+        dx, dg, db = _gn_relu_bwd(x, st, g, b, dy.contiguous().to(x.dtype))
+        return dx, dg, db
+
+
+def _gn_relu_bwd(x, st, g, b, da):
+    dev, h, dt, stream = _env(x)
+    B, H, W, C = x.shape
+    dx = torch.empty_like(x)
+    dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ws = _u8(_lib.lib.chore_gn_relu_bwd_workspace_bytes(B, C), dev)
+    _lib.check(_lib.lib.chore_gn_relu_bwd(h, dt, x.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), da.data_ptr(), B,
+                                          H * W, C, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), stream), h,
+               "chore_gn_relu_bwd")
+    return dx, dg, db
+
+
+class _ConvGN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, gamma, beta):
+        dev, h, dt, stream = _env(x)
+        B, H, W, Cin = x.shape
+        Cout, taps = w.shape[0], w.shape[2] * w.shape[3]
+        wf = w.detach().float().contiguous()
+        bf = None if bias is None else bias.detach().float().contiguous()
+        st = g = b = None
+        if gamma is not None:
+            st = gn_stats(x)
+            g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=dev)
+        ws = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cin, Cout), dev)
+        _lib.check(_lib.lib.chore_conv2d_fwd(h, dt, taps, x.data_ptr(), B, H, W, Cin, None if st is None else st.data_ptr(),
+                                             None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
+                                             wf.data_ptr(), None if bf is None else bf.data_ptr(), Cout, y.data_ptr(),
+                                             ws.data_ptr(), stream), h, "chore_conv2d_fwd")
+        ctx.has_gn, ctx.has_bias = gamma is not None, bias is not None
+        ctx.save_for_backward(x, wf, *([st, g, b] if gamma is not None else []))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wf = ctx.saved_tensors[:2]
+        st, g, b = ctx.saved_tensors[2:] if ctx.has_gn else (None, None, None)
+        dev, h, dt, stream = _env(x)
+        B, H, W, Cin = x.shape
+        Cout, taps = wf.shape[0], wf.shape[2] * wf.shape[3]
+        dy = dy.contiguous().to(x.dtype)
+        dw = torch.empty_like(wf)
+        dbias = torch.empty(Cout, device=dev) if ctx.has_bias else None
+        ws = _u8(_lib.lib.chore_conv2d_wgrad_workspace_bytes(taps, B, H, W, Cin, Cout), dev)
+        _lib.check(_lib.lib.chore_conv2d_bwd_weight(h, dt, taps, x.data_ptr(), B, H, W, Cin,
+                                                    None if st is None else st.data_ptr(),
+                                                    None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
+                                                    dy.data_ptr(), Cout, dw.data_ptr(),
+                                                    None if dbias is None else dbias.data_ptr(), ws.data_ptr(), stream), h,
+                   "chore_conv2d_bwd_weight")
+        dx = dg = db = None
+        if ctx.needs_input_grad[0] or ctx.has_gn:
+            da = torch.empty_like(x)                      # gradient w.r.t. what the convolution saw
+            ws2 = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cout, Cin), dev)
+            _lib.check(_lib.lib.chore_conv2d_bwd_data(h, dt, taps, dy.data_ptr(), B, H, W, Cout, wf.data_ptr(), Cin,
+                                                      da.data_ptr(), ws2.data_ptr(), stream), h, "chore_conv2d_bwd_data")
+            if ctx.has_gn:
+                dx, dg, db = _gn_relu_bwd(x, st, g, b, da)
+            else:
+                dx = da
+        return dx, dw, dbias, dg, db
+
+
+def conv_gn(x, w, bias=None, gamma=None, beta=None):
+    return _ConvGN.apply(x, w, bias, gamma, beta)
+
+
+def gn_relu(x, gamma, beta):
+    return _GNReLU.apply(x, gamma, beta)
