@@ -266,7 +266,14 @@ class CHORE(nn.Module):
         """encode images (B,5,H,W); keeps all stacks in training, the last one in eval
         (/root/reference/model/chore.py:87-96)"""
         n_out = self.image_filter.num_modules if self.training else 1
-        feats, self.tmpx, self.normx = self.image_filter(images, _DT[self.compute_dtype], n_out)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
+            # training: the layer-by-layer differentiable forward (model/hgfilter_train.py)
+            from .hgfilter_train import forward_train
+            tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
+            feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt)
+            feats = feats[-n_out:]
+        else:
+            feats, self.tmpx, self.normx = self.image_filter(images, _DT[self.compute_dtype], n_out)
         self.im_feat_list = feats
 
     def project_points(self, points, offsets):
@@ -295,10 +302,6 @@ class CHORE(nn.Module):
         cc = crop_center.to(device=points.device, dtype=torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
             raise ValueError("points must be (B,N,3) and crop_center (B,2)")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
-            raise NotImplementedError(
-                "gradients w.r.t. the encoder parameters are not implemented yet (encoder backward); freeze "
-                "image_filter (the heads and the feature maps are differentiable) or use torch.no_grad()")
         arena = self._heads_arena(points.device)
         dtype = _DT[self.compute_dtype]
         head_params = [p for _, m in self._head_modules() for p in m.parameters()]

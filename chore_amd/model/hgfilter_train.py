@@ -1,0 +1,70 @@
+"""Differentiable forward of the stacked-hourglass encoder (training path).
+
+Inference runs the whole encoder as one launch program with aggressive fusion and buffer reuse
+(HGFilter.forward -> chore_encode_fwd).  Training needs every intermediate tensor and a backward per layer, so here
+the same network (/root/reference/model/HGFilters.py:144-185, HourGlass :26-50, ConvBlock net_util.py:374-396) is
+composed from autograd nodes whose forward AND backward are HIP kernels (chore_amd/ops.py):
+  every GroupNorm -> ReLU -> conv3x3 / conv1x1 layer   = ops.conv_gn   (150 of the 151 convolutions)
+  bn_end -> ReLU                                        = ops.gn_relu
+Glue that moves no FLOPs -- concat, residual adds, 2x2 average pooling, the bicubic x2 upsampling -- and the 7x7
+stem (0.8 % of the FLOPs, Cin = 5) are torch ops on channels-last views for now; tensors are NHWC throughout.
+"""
+import torch
+import torch.nn.functional as F
+
+from .. import ops
+
+
+def _nchw(x):          # NHWC tensor -> (B,C,H,W) channels-last view
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):          # (B,C,H,W) any layout -> contiguous NHWC
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def conv_block(m, x):
+    """ConvBlock.forward (net_util.py:374-396)"""
+    o1 = ops.conv_gn(x, m.conv1.weight, None, m.bn1.weight, m.bn1.bias)
+    o2 = ops.conv_gn(o1, m.conv2.weight, None, m.bn2.weight, m.bn2.bias)
+    o3 = ops.conv_gn(o2, m.conv3.weight, None, m.bn3.weight, m.bn3.bias)
+    out = torch.cat((o1, o2, o3), dim=3)
+    res = x if m.downsample is None else ops.conv_gn(x, m.downsample[2].weight, None, m.bn4.weight, m.bn4.bias)
+    return out + res
+
+
+def hourglass(m, level, x):
+    """HourGlass._forward (HGFilters.py:26-50)"""
+    up1 = conv_block(getattr(m, f"b1_{level}"), x)
+    low1 = _nhwc(F.avg_pool2d(_nchw(x), 2, stride=2))
+    low1 = conv_block(getattr(m, f"b2_{level}"), low1)
+    low2 = hourglass(m, level - 1, low1) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1)
+    low3 = conv_block(getattr(m, f"b3_{level}"), low2)
+    up2 = _nhwc(F.interpolate(_nchw(low3), scale_factor=2, mode="bicubic", align_corners=True))
+    return up1 + up2
+
+
+def forward_train(enc, images, tdt):
+    """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype.
+    Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad."""
+    x = F.conv2d(images.float(), enc.conv1.weight, enc.conv1.bias, stride=2, padding=3)
+    x = ops.gn_relu(_nhwc(x).to(tdt), enc.bn1.weight, enc.bn1.bias)
+    tmpx = x
+    x = _nhwc(F.avg_pool2d(_nchw(conv_block(enc.conv2, x)), 2, stride=2))
+    normx = x
+    x = conv_block(enc.conv3, x)
+    previous = conv_block(enc.conv4, x)
+    outputs = []
+    n = enc.num_modules
+    for i in range(n):
+        hg = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous)
+        ll = conv_block(getattr(enc, f"top_m_{i}"), hg)
+        cl, be = getattr(enc, f"conv_last{i}"), getattr(enc, f"bn_end{i}")
+        ll = ops.gn_relu(ops.conv_gn(ll, cl.weight, cl.bias), be.weight, be.bias)
+        li = getattr(enc, f"l{i}")
+        tmp_out = ops.conv_gn(ll, li.weight, li.bias)
+        outputs.append(tmp_out)
+        if i < n - 1:
+            bl, al = getattr(enc, f"bl{i}"), getattr(enc, f"al{i}")
+            previous = previous + ops.conv_gn(ll, bl.weight, bl.bias) + ops.conv_gn(tmp_out, al.weight, al.bias)
+    return [_nchw(o) for o in outputs], _nchw(tmpx.detach()), _nchw(normx)

@@ -214,6 +214,44 @@ def gen_train_loss(net):
                         df_stack0=preds0[0][:, :, :64], **b)
 
 
+def gen_train_grads(net):
+    """the full training backward of the reference (Trainer.compute_loss -> CHORE.forward -> backward,
+    trainer/trainer.py:76-131) on the batch of gen_train_loss: for every parameter [sum, abs-sum, L2] of its
+    gradient, the complete gradient for the small tensors (GroupNorm affines, biases) and a 16x24 crop for three
+    convolution kernels.  Parameters that receive no gradient (bn4 of the blocks without downsample: reference quirk,
+    net_util.py:357-362, the reason for find_unused_parameters=True) are recorded as absent."""
+    b = train_batch()
+    net.train(True)
+    net.print_errors = lambda *a, **k: None
+    for p in net.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    error, _ = net.forward(**{k: torch.from_numpy(v) for k, v in b.items()})
+    error.backward()
+    out, names = {}, []
+    seen = set()
+    for name, p in net.named_parameters():
+        if id(p) in seen:
+            continue
+        seen.add(id(p))
+        names.append(name)
+        if p.grad is None:
+            out["s_" + name] = np.full(3, np.nan)
+            continue
+        g = p.grad.numpy()
+        out["s_" + name] = np.array([g.sum(), np.abs(g).sum(), np.sqrt((g.astype(np.float64) ** 2).sum())], np.float64)
+        if g.size <= 512:
+            out["g_" + name] = g.copy()
+    for name in ("image_filter.conv2.conv1.weight", "image_filter.m2.b2_plus_1.conv2.weight", "image_filter.top_m_4.conv3.weight"):
+        g = dict(net.named_parameters())[name].grad.numpy()
+        out["c_" + name] = g.reshape(g.shape[0], -1)[:16, :24].copy()
+    net.train(False)
+    for p in net.parameters():
+        p.requires_grad_(False)
+        p.grad = None
+    np.savez_compressed(os.path.join(HERE, "train_grads.npz"), error=np.float32(error.detach()), names=np.array(names), **out)
+
+
 def gen_surface(net):
     """reference Generator.approx_surface (recon/generator.py:50-79) for 3 projection steps on the
     query_full inputs; the constructor (checkpoint folders) is bypassed"""
@@ -449,6 +487,7 @@ def main():
     gen_fit(net)
     gen_train_loss(net)
     gen_query_train(net)
+    gen_train_grads(net)
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
