@@ -41,6 +41,8 @@ struct WgradArgs {
     const float* gamma; const float* beta;
     const void* dy;           // (B,H,W,Cout)
     int B, H, W, Cin, Cout;
+    int xs, ys;               // row strides (elements) of x and dy: Cin / Cout for dense NHWC tensors
+    long long npix;           // pixels that exist (B*H*W, or fewer when a row list is walked as a ragged image)
     float* part;              // [S][Cout/32][Cin/32][TAPS][32][32] partial sums
     float* part_bias;         // [S][Cout] or null
     int S;                    // shares of the pixel tiles
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const int row = i / VPR, v = i % VPR;
             const int y = ty0 + row / AW - PAD, x = tx0 + row % AW - PAD;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (y >= 0 && y < a.H && x >= 0 && x < a.W) {
-                val = *(const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.Cin + ci0 + v * VE);
+            if (y >= 0 && y < a.H && x >= 0 && x < a.W && ((long long)b * a.H + y) * a.W + x < a.npix) {
+                val = *(const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.xs + ci0 + v * VE);
                 if (use_gn) {
                     float f[8];
                     if constexpr (ES == 2) {
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
             const int row = i / VPR, v = i % VPR;
             const int y = ty0 + row / TW, x = tx0 + row % TW;
             u32x4 val = {0u, 0u, 0u, 0u};
-            if (y < a.H && x < a.W) val = *(const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.Cout + co0 + v * VE);
+            if (y < a.H && x < a.W && ((long long)b * a.H + y) * a.W + x < a.npix)
+                val = *(const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.ys + co0 + v * VE);
             *(u32x4*)(imgY + row * CT32 + v * VE) = val;
         }
         __syncthreads();
@@ -353,6 +356,7 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
     WgradArgs a;
     a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+    a.xs = Cin; a.ys = Cout; a.npix = (long long)B * H * W;
     a.S = wgrad_shares(B, H, W, Cin, Cout);
     a.part = (float*)workspace;
     a.part_bias = dbias ? a.part + (size_t)a.S * (Cout / 32) * (Cin / 32) * taps * 1024 : nullptr;
@@ -377,6 +381,45 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
     const size_t n = (size_t)Cout * Cin * taps;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
                        Cin, taps, dw, dbias);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// C (M x N, fp32, row-major) = A^T B for row-major A (P x M, row stride lda) and B (P x N, row stride ldb), fp32, exact
+// matrix-core arithmetic: the contraction runs over the ROWS, like the weight gradient (it is the taps = 1 case with
+// the rows as "pixels").  M, N multiples of 32; the P rows are walked as a (ceil(P/32) x 32) image.
+// Used for the weight gradients of the MLP heads (dW_l = dZ_l^T H_{l-1}, 80 000 rows): the BLAS library's skinny
+// GEMM took 14 ms per product there.
+size_t chore_gemm_tn_workspace_bytes(int P, int M, int N) {
+    if (P <= 0 || M % 32 || N % 32) return 0;
+    const int S = wgrad_shares(1, (P + 31) / 32, 32, N, M);
+    return (size_t)S * (M / 32) * (N / 32) * 1024 * sizeof(float);
+}
+
+int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, int ldb, int P, int M, int N, float* C,
+                      void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!A || !B || !C || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_gemm_tn_f32: null argument");
+    if (P <= 0 || M % 32 || N % 32 || lda % 4 || ldb % 4)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_gemm_tn_f32: M, N must be multiples of 32 (P=%d M=%d N=%d)", P, M, N);
+    hipStream_t s = (hipStream_t)stream;
+    WgradArgs a;
+    a.x = B; a.st = nullptr; a.gamma = nullptr; a.beta = nullptr; a.dy = A;
+    a.B = 1; a.H = (P + 31) / 32; a.W = 32; a.Cin = N; a.Cout = M; a.xs = ldb; a.ys = lda; a.npix = P;
+    a.S = wgrad_shares(1, a.H, a.W, N, M);
+    a.part = (float*)workspace;
+    a.part_bias = nullptr;
+    size_t smem = (size_t)(2 * TH * TW) * CT32 * 4 + 256;
+    static bool attr = false;
+    if (!attr) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               96 * 1024));
+        attr = true;
+    }
+    hipLaunchKernelGGL((wgrad_kernel<float, 1>), dim3(M / 32, N / 32, a.S), dim3(256), smem, s, a);
+    const size_t n = (size_t)M * N;
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, nullptr, a.S, M, N, 1, C,
+                       nullptr);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -149,12 +149,22 @@ class _QueryTrainFn(torch.autograd.Function):
         g_df = g_df * in_img.unsqueeze(1).float()
         g_out = (g_df, g_parts, g_pca, g_centers)                     # kernel head order
         grads = [None] * 32
-        for mi, hk in enumerate((0, 1, 2, 3)):                        # module order df, part, pca, center
-            k = (0, 1, 2, 3)[hk]                                      # = kernel order df, parts, pca, centers
-            base = mi * 8
-            gw1 = dZ[0, k].t() @ X[:, :323]
-            gw2 = dZ[1, k].t() @ H[0, k]
-            gw3 = dZ[2, k].t() @ H[1, k]
+
+        def gemm_tn(a, lda, b, ldb, m, n):
+            """C (m,n) = A^T B over the P staged rows (chore_gemm_tn_f32: the pixel-contraction MFMA kernel)"""
+            c = torch.empty(m, n, device=dev)
+            ws = torch.empty(max(_lib.lib.chore_gemm_tn_workspace_bytes(P, m, n), 16), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib.chore_gemm_tn_f32(h, a.data_ptr(), lda, b.data_ptr(), ldb, P, m, n, c.data_ptr(),
+                                                  ws.data_ptr(), stream), h, "chore_gemm_tn_f32")
+            return c
+
+        for k in range(4):                                            # module order = kernel head order
+            base = k * 8
+            # layer 1: the 328-column X rows in two pieces (the second one runs past column 327 into the next row:
+            # those columns belong to the zero padding of the weight and are cut off)
+            gw1 = torch.cat((gemm_tn(dZ[0, k], HD, X, KP, HD, 256), gemm_tn(dZ[0, k], HD, X[:, 256:], KP, HD, 96)), 1)[:, :323]
+            gw2 = gemm_tn(dZ[1, k], HD, H[0, k], HD, HD, HD)
+            gw3 = gemm_tn(dZ[2, k], HD, H[1, k], HD, HD, HD)
             gw4 = torch.einsum("bon,bnk->ok", g_out[k], H[2, k].view(B, N, HD))
             grads[base + 0], grads[base + 1] = gw1.unsqueeze(-1), dZ[0, k].sum(0)
             grads[base + 2], grads[base + 3] = gw2.unsqueeze(-1), dZ[1, k].sum(0)
