@@ -109,3 +109,5 @@ int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, in
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
                  GroupStat* st, hipStream_t s);
 int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s);
+int launch_up2_bwd(chore_handle* h, int dtype, const void* dy /*(B,2H,2W,C)*/, void* dlow /*(B,H,W,C)*/, int B, int H, int W, int C,
+                   hipStream_t s);

@@ -475,3 +475,78 @@ int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hip
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// backward of the bicubic x2 upsampling (align_corners=True, A=-0.75; HGFilters.py:47): d_low = U^T dy.
+// Gather form -- every low-resolution pixel sums the high-resolution pixels whose 4x4 support contains it, with
+// the separable weights recomputed on the fly (border clamping folds several taps onto the edge pixels) -- so there
+// are no atomics (ATen's upsample_bicubic2d_backward scatters with atomics and took 125 ms per call here).
+// ------------------------------------------------------------------------------------------------
+// weight of high-resolution coordinate o (of 2n) on low-resolution coordinate l (of n)
+__device__ __forceinline__ float up2_weight(int o, int l, int n) {
+    const float s = (float)(n - 1) / (float)(2 * n - 1);
+    const float r = s * (float)o, f = floorf(r);
+    const int i = (int)f;
+    if (i < l - 2 || i > l + 2) return 0.f;
+    float c[4];
+    cubic_coeffs(r - f, c);
+    float w = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int t = i - 1 + k;
+        t = t < 0 ? 0 : (t > n - 1 ? n - 1 : t);
+        if (t == l) w += c[k];
+    }
+    return w;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dlow, int C, int H, int W,
+                                                      size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int tpr = C / 4;
+    const int cv = (int)(i % tpr);
+    size_t p = i / tpr;
+    const int lx = (int)(p % W); p /= W;
+    const int ly = (int)(p % H);
+    const int b = (int)(p / H);
+    constexpr int NC = 12;
+    const int oy0 = max(0, 2 * ly - 5), ox0 = max(0, 2 * lx - 5);
+    float wy[NC], wx[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) {
+        wy[k] = (oy0 + k < 2 * H) ? up2_weight(oy0 + k, ly, H) : 0.f;
+        wx[k] = (ox0 + k < 2 * W) ? up2_weight(ox0 + k, lx, W) : 0.f;
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < NC; ++ky) {
+        if (wy[ky] == 0.f) continue;
+        f32x4 row = {0.f, 0.f, 0.f, 0.f};
+        const T* src = dy + (((size_t)b * 2 * H + oy0 + ky) * 2 * W) * C + cv * 4;
+#pragma unroll
+        for (int kx = 0; kx < NC; ++kx) {
+            if (wx[kx] == 0.f) continue;
+            const f32x4 v = Vec4<T>::ld(src + (size_t)(ox0 + kx) * C);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) row[e] = fmaf(v[e], wx[kx], row[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = fmaf(row[e], wy[ky], acc[e]);
+    }
+    Vec4<T>::st(dlow + i * 4, acc);
+}
+
+int launch_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 4 || H < 2 || W < 2) CHORE_FAIL(h, CHORE_EINVAL, "up2_bwd: unsupported shape");
+    const size_t total4 = (size_t)B * H * W * (C / 4);
+    const unsigned blocks = (unsigned)((total4 + 255) / 256);
+    if (dtype == CHORE_F32)
+        hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dy, (float*)dlow, C, H, W, total4);
+    else
+        hipLaunchKernelGGL(up2_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dlow, C, H, W,
+                           total4);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}

@@ -73,4 +73,22 @@ int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, 
     return launch_conv(h, dtype, taps, a, s);
 }
 
+// y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C)), align_corners=True  (HourGlass._forward, HGFilters.py:47-50); y may be a
+int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
+                    chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!a || !low || !y) CHORE_FAIL(h, CHORE_EINVAL, "chore_upadd_fwd: null argument");
+    View va; va.p = const_cast<void*>(a); va.cs = C; va.co = 0; va.C = C;
+    View vl; vl.p = const_cast<void*>(low); vl.cs = C; vl.co = 0; vl.C = C;
+    View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
+    return launch_upadd(h, dtype, va, vl, vy, B, H, W, nullptr, (hipStream_t)stream);
+}
+
+// d_low (B,H,W,C) = transpose of the bicubic x2 upsampling applied to dy (B,2H,2W,C)
+int chore_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!dy || !dlow) CHORE_FAIL(h, CHORE_EINVAL, "chore_up2_bwd: null argument");
+    return launch_up2_bwd(h, dtype, dy, dlow, B, H, W, C, (hipStream_t)stream);
+}
+
 }  // extern "C"

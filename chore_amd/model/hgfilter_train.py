@@ -6,8 +6,9 @@ the same network (/root/reference/model/HGFilters.py:144-185, HourGlass :26-50, 
 composed from autograd nodes whose forward AND backward are HIP kernels (chore_amd/ops.py):
   every GroupNorm -> ReLU -> conv3x3 / conv1x1 layer   = ops.conv_gn   (150 of the 151 convolutions)
   bn_end -> ReLU                                        = ops.gn_relu
-Glue that moves no FLOPs -- concat, residual adds, 2x2 average pooling, the bicubic x2 upsampling -- and the 7x7
-stem (0.8 % of the FLOPs, Cin = 5) are torch ops on channels-last views for now; tensors are NHWC throughout.
+  up1 + bicubic_up2(low3)                               = ops.upadd     (gather-form transpose in the backward)
+Glue that moves no FLOPs -- concat, residual adds, 2x2 average pooling -- and the 7x7 stem (0.8 % of the FLOPs,
+Cin = 5) are torch ops on channels-last views for now; tensors are NHWC throughout.
 """
 import torch
 import torch.nn.functional as F
@@ -40,8 +41,7 @@ def hourglass(m, level, x):
     low1 = conv_block(getattr(m, f"b2_{level}"), low1)
     low2 = hourglass(m, level - 1, low1) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1)
     low3 = conv_block(getattr(m, f"b3_{level}"), low2)
-    up2 = _nhwc(F.interpolate(_nchw(low3), scale_factor=2, mode="bicubic", align_corners=True))
-    return up1 + up2
+    return ops.upadd(up1, low3)
 
 
 def forward_train(enc, images, tdt):

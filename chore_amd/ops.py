@@ -121,6 +121,35 @@ class _ConvGN(torch.autograd.Function):
         return dx, dw, dbias, dg, db
 
 
+class _UpAdd(torch.autograd.Function):
+    """y = a + bicubic_up2(low), align_corners=True (HourGlass._forward, HGFilters.py:47-50)"""
+
+    @staticmethod
+    def forward(ctx, a, low):
+        dev, h, dt, stream = _env(low)
+        B, H, W, C = low.shape
+        if a.shape != (B, 2 * H, 2 * W, C) or a.dtype != low.dtype or not a.is_contiguous():
+            raise ValueError("upadd: a must be (B,2H,2W,C), contiguous, same dtype as low")
+        y = torch.empty_like(a)
+        _lib.check(_lib.lib.chore_upadd_fwd(h, dt, a.data_ptr(), low.data_ptr(), y.data_ptr(), B, H, W, C, stream), h,
+                   "chore_upadd_fwd")
+        ctx.shape = (B, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C = ctx.shape
+        dy = dy.contiguous()
+        dev, h, dt, stream = _env(dy)
+        dlow = torch.empty(B, H, W, C, dtype=dy.dtype, device=dev)
+        _lib.check(_lib.lib.chore_up2_bwd(h, dt, dy.data_ptr(), dlow.data_ptr(), B, H, W, C, stream), h, "chore_up2_bwd")
+        return dy, dlow
+
+
+def upadd(a, low):
+    return _UpAdd.apply(a, low)
+
+
 def conv_gn(x, w, bias=None, gamma=None, beta=None):
     return _ConvGN.apply(x, w, bias, gamma, beta)
 

@@ -83,3 +83,26 @@ def test_gn_relu(dtype):
     check(xd.grad.permute(0, 3, 1, 2), xr.grad, dtype, "dx")
     check(gd.grad, gr.grad, dtype, "dgamma")
     check(bd.grad, br.grad, dtype, "dbeta")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 16, 16, 256), (2, 2, 3, 64)])
+def test_upadd(dtype, shape):
+    """a + bicubic x2 (align_corners) and its transpose, against F.interpolate + autograd on the CPU"""
+    from chore_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    B, H, W, C = shape
+    low = torch.randn(B, C, H, W, generator=g)
+    a = torch.randn(B, C, 2 * H, 2 * W, generator=g)
+    up = torch.randn(B, C, 2 * H, 2 * W, generator=g)
+    lr = low.to(dtype).float().clone().requires_grad_(True)
+    ar = a.to(dtype).float().clone().requires_grad_(True)
+    yr = ar + F.interpolate(lr, scale_factor=2, mode="bicubic", align_corners=True)
+    (yr * up).sum().backward()
+    ld = low.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
+    ad = a.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
+    yd = ops.upadd(ad, ld)
+    (yd.float() * up.permute(0, 2, 3, 1).cuda()).sum().backward()
+    check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
+    check(ld.grad.permute(0, 3, 1, 2), lr.grad, dtype, "dlow")
+    check(ad.grad.permute(0, 3, 1, 2), ar.grad, dtype, "da")
