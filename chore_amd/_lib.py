@@ -81,6 +81,14 @@ SIGNATURES = {
                                         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_upadd_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "chore_up2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "chore_avgpool2_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "chore_avgpool2_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "chore_stem_workspace_bytes": (c_size_t, [c_int]),
+    "chore_stem_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p]),
+    "chore_stem_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "chore_stem_bwd_weight": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p]),
     "chore_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_gemm_tn_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),

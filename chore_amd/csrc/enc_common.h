@@ -87,6 +87,35 @@ struct ConvArgs {
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
 
+// four consecutive channels of a T tensor <-> four floats (device code only)
+#ifdef __HIPCC__
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *(f32x4*)p = v; }
+    static __device__ __forceinline__ f32x4 st_round(float* p, f32x4 v) { *(f32x4*)p = v; return v; }
+};
+template <> struct Vec4<bf16_t> {
+    static __device__ __forceinline__ f32x4 ld(const bf16_t* p) {
+        const u16x4 v = *(const u16x4*)p;
+        f32x4 r = {bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
+        return r;
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) {
+        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
+        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    // store and return the values as stored (rounded to bf16)
+    static __device__ __forceinline__ f32x4 st_round(bf16_t* p, f32x4 v) {
+        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
+        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
+        f32x4 r = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                   __uint_as_float(hi & 0xffff0000u)};
+        return r;
+    }
+};
+#endif
+
 struct ConvPlan { int nt, th, ntiles, tps; };   // N tile, tile height, tiles per image, taps per K-step
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // tile configuration launch_conv will use
 
@@ -109,5 +138,7 @@ int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, in
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
                  GroupStat* st, hipStream_t s);
 int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hipStream_t s);
+int launch_pool2_bwd(chore_handle* h, int dtype, const void* dy /*(B,H/2,W/2,C)*/, void* dx /*(B,H,W,C)*/, int B, int H, int W, int C,
+                     hipStream_t s);
 int launch_up2_bwd(chore_handle* h, int dtype, const void* dy /*(B,2H,2W,C)*/, void* dlow /*(B,H,W,C)*/, int B, int H, int W, int C,
                    hipStream_t s);

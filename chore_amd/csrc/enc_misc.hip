@@ -9,32 +9,6 @@
 #include "enc_common.h"
 #include <type_traits>
 
-template <typename T> struct Vec4;
-template <> struct Vec4<float> {
-    static __device__ __forceinline__ f32x4 ld(const float* p) { return *(const f32x4*)p; }
-    static __device__ __forceinline__ void st(float* p, f32x4 v) { *(f32x4*)p = v; }
-    static __device__ __forceinline__ f32x4 st_round(float* p, f32x4 v) { *(f32x4*)p = v; return v; }
-};
-template <> struct Vec4<bf16_t> {
-    static __device__ __forceinline__ f32x4 ld(const bf16_t* p) {
-        const u16x4 v = *(const u16x4*)p;
-        f32x4 r = {bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])};
-        return r;
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, f32x4 v) {
-        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
-        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
-    }
-    // store and return the values as stored (rounded to bf16)
-    static __device__ __forceinline__ f32x4 st_round(bf16_t* p, f32x4 v) {
-        const unsigned lo = pack2bf(v[0], v[1]), hi = pack2bf(v[2], v[3]);
-        *(unsigned long long*)p = (unsigned long long)lo | ((unsigned long long)hi << 32);
-        f32x4 r = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
-                   __uint_as_float(hi & 0xffff0000u)};
-        return r;
-    }
-};
-
 // ------------------------------------------------------------------------------------------------
 // stem: conv 7x7 stride 2 pad 3, Cin(5) -> 64, + bias      (model/HGFilters.py:102,149)
 // block = 8x8 output pixels x 4 groups of 16 channels; input patch and weights staged in LDS.
@@ -546,6 +520,37 @@ int launch_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B
         hipLaunchKernelGGL(up2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dy, (float*)dlow, C, H, W, total4);
     else
         hipLaunchKernelGGL(up2_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dlow, C, H, W,
+                           total4);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// backward of the 2x2 average pooling (HourGlass._forward HGFilters.py:33, HGFilter.forward :153): dx = dy / 4 replicated
+template <typename T>
+__global__ __launch_bounds__(256) void pool2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int C, int H, int W,
+                                                        size_t total4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // over dx (B,H,W,C/4)
+    if (i >= total4) return;
+    const int tpr = C / 4;
+    const int cv = (int)(i % tpr);
+    size_t p = i / tpr;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const size_t b = p / H;
+    f32x4 v = Vec4<T>::ld(dy + ((b * (H / 2) + y / 2) * (W / 2) + x / 2) * C + cv * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= 0.25f;
+    Vec4<T>::st(dx + i * 4, v);
+}
+
+int launch_pool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C, hipStream_t s) {
+    if (C % 4 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "pool2_bwd: unsupported shape");
+    const size_t total4 = (size_t)B * H * W * (C / 4);
+    const unsigned blocks = (unsigned)((total4 + 255) / 256);
+    if (dtype == CHORE_F32)
+        hipLaunchKernelGGL(pool2_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)dy, (float*)dx, C, H, W, total4);
+    else
+        hipLaunchKernelGGL(pool2_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)dy, (bf16_t*)dx, C, H, W,
                            total4);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;

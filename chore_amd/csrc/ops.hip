@@ -73,6 +73,39 @@ int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, 
     return launch_conv(h, dtype, taps, a, s);
 }
 
+// stem: y (B,H/2,W/2,64) = conv7x7 stride 2 pad 3 (images (B,Cin,H,W) fp32 NCHW) + bias   (HGFilters.py:102,149);
+// workspace: chore_stem_workspace_bytes(Cin) for the repacked weights
+size_t chore_stem_workspace_bytes(int Cin) { return Cin > 0 ? (size_t)Cin * 49 * 64 * sizeof(float) : 0; }
+
+int chore_stem_fwd(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const float* w,
+                   const float* bias, void* y, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!images || !w || !bias || !y || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: null argument");
+    if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: bad shape");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: dtype");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_pack_stem(h, Cin, w, (float*)workspace, s);
+    if (rc) return rc;
+    return launch_stem(h, dtype, images, B, Cin, H, W, (const float*)workspace, bias, y, s);
+}
+
+// y (B,H/2,W/2,C) = 2x2 average pooling of x (B,H,W,C), C in {64,128,256}; dx = its transpose applied to dy
+int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: bad argument");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: dtype");
+    View vx; vx.p = const_cast<void*>(x); vx.cs = C; vx.co = 0; vx.C = C;
+    View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
+    return launch_avgpool2(h, dtype, vx, vy, B, H, W, nullptr, (hipStream_t)stream);
+}
+
+int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!dy || !dx || B <= 0 || H <= 0 || W <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_bwd: bad argument");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_bwd: dtype");
+    return launch_pool2_bwd(h, dtype, dy, dx, B, H, W, C, (hipStream_t)stream);
+}
+
 // y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C)), align_corners=True  (HourGlass._forward, HGFilters.py:47-50); y may be a
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
                     chore_stream_t stream) {

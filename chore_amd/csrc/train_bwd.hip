@@ -207,6 +207,93 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ part, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
+// stem weight gradient: dW[o][c][ky][kx] = sum_{b,oy,ox} dy[b,oy,ox,o] * img[b,c,2oy+ky-3,2ox+kx-3], dbias = sum dy
+// (conv 7x7 stride 2 pad 3, Cin <= 8 -> 64; the images need no gradient).  K = Cin*49 (245) rows x 64 columns contracted
+// over B*OH*OW pixels: 0.8 % of the step's FLOPs and no MFMA shape (a gathered operand), so plain FMAs from LDS.
+// A workgroup walks a fixed share of the 8x8-pixel tiles; thread = 4 output channels x 16 rows k = kg + 16 j
+// (64 accumulators); the row k = Cin*49 is a row of ones (its sum is dbias).  Partials are summed in order.
+// ------------------------------------------------------------------------------------------------
+constexpr int SW_T = 8, SW_P = 2 * SW_T + 5, SW_MAXC = 5, SW_ROWS = 256;
+constexpr int SW_FILL = (2 * (SW_T - 1)) * SW_P + 2 * (SW_T - 1) + 1;   // pixel offsets reach this far: constant regions of ones / zeros
+
+template <typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ img, const T* __restrict__ dy, int B, int Cin,
+                                                         int H, int W, float* __restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float patch[SW_MAXC * SW_P * SW_P + 2 * SW_FILL];
+    __shared__ __attribute__((aligned(16))) float dyl[64 * 64];
+    const int OH = H / 2, OW = W / 2;
+    const int tx_n = (OW + SW_T - 1) / SW_T, ty_n = (OH + SW_T - 1) / SW_T, ntile = B * ty_n * tx_n;
+    const int tid = threadIdx.x, oq = tid & 15, kg = tid >> 4;
+    const int K = Cin * 49, ONE = Cin * SW_P * SW_P, ZERO = ONE + SW_FILL;
+    int off[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int k = kg + 16 * j;
+        const int c = k / 49, r = k % 49;
+        off[j] = k < K ? (c * SW_P + r / 7) * SW_P + r % 7 : (k == K ? ONE : ZERO);
+    }
+    for (int i = tid; i < 2 * SW_FILL; i += 256) patch[ONE + i] = i < SW_FILL ? 1.f : 0.f;
+    float acc[16][4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j][0] = acc[j][1] = acc[j][2] = acc[j][3] = 0.f;
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const int b = t / (ty_n * tx_n), ty0 = (t / tx_n) % ty_n * SW_T, tx0 = t % tx_n * SW_T;
+        __syncthreads();
+        const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+        for (int i = tid; i < Cin * SW_P * SW_P; i += 256) {
+            const int c = i / (SW_P * SW_P), r = i % (SW_P * SW_P);
+            const int y = iy0 + r / SW_P, x = ix0 + r % SW_P;
+            float v = 0.f;
+            if (y >= 0 && y < H && x >= 0 && x < W) v = img[(((size_t)b * Cin + c) * H + y) * W + x];
+            patch[i] = v;
+        }
+        for (int i = tid; i < 64 * 16; i += 256) {
+            const int pix = i >> 4, q = i & 15;
+            const int oy = ty0 + (pix >> 3), ox = tx0 + (pix & 7);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (oy < OH && ox < OW) v = Vec4<T>::ld(dy + (((size_t)b * OH + oy) * OW + ox) * 64 + q * 4);
+            *(f32x4*)(dyl + pix * 64 + q * 4) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int pix = 0; pix < 64; ++pix) {
+            const f32x4 d = *(const f32x4*)(dyl + pix * 64 + oq * 4);
+            const int po = (2 * (pix >> 3)) * SW_P + 2 * (pix & 7);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const float v = patch[off[j] + po];
+                acc[j][0] = fmaf(v, d[0], acc[j][0]);
+                acc[j][1] = fmaf(v, d[1], acc[j][1]);
+                acc[j][2] = fmaf(v, d[2], acc[j][2]);
+                acc[j][3] = fmaf(v, d[3], acc[j][3]);
+            }
+        }
+    }
+    float* o = part + (size_t)blockIdx.x * SW_ROWS * 64;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        f32x4 v = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        *(f32x4*)(o + (kg + 16 * j) * 64 + oq * 4) = v;
+    }
+}
+
+// dw (64,Cin,7,7) and dbias (64) = ordered sums of the partials: 4 lanes per entry (shares r, r+4, ...), fixed tree
+__global__ void stem_wgrad_finish_kernel(const float* __restrict__ part, int S, int Cin, float* __restrict__ dw,
+                                         float* __restrict__ dbias) {
+    const int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, r = threadIdx.x & 3;
+    const int K = Cin * 49, n = (K + 1) * 64;
+    const int e = i < n ? i : n - 1;
+    float s = 0.f;
+    for (int k = r; k < S; k += 4) s += part[(size_t)k * SW_ROWS * 64 + e];
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    if (r || i >= n) return;
+    const int k = e >> 6, o = e & 63;
+    if (k < K) dw[(size_t)o * K + k] = s;
+    else if (dbias) dbias[o] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
 // GroupNorm + ReLU backward
 // ------------------------------------------------------------------------------------------------
 struct GnBwdAcc {                 // exact accumulators, zeroed by the caller
@@ -420,6 +507,39 @@ int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, 
     const size_t n = (size_t)M * N;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, nullptr, a.S, M, N, 1, C,
                        nullptr);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+static int stem_wgrad_shares(int B, int H, int W) {
+    const int nt = B * ((H / 2 + SW_T - 1) / SW_T) * ((W / 2 + SW_T - 1) / SW_T);
+    return nt < 512 ? nt : 512;
+}
+
+size_t chore_stem_wgrad_workspace_bytes(int B, int Cin, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cin > SW_MAXC || H <= 0 || W <= 0) return 0;
+    return (size_t)stem_wgrad_shares(B, H, W) * SW_ROWS * 64 * sizeof(float);
+}
+
+// dw (64,Cin,7,7), dbias (64, or NULL) of the stem convolution y = conv7x7/2(images) + bias; dy is (B,H/2,W/2,64)
+int chore_stem_bwd_weight(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const void* dy,
+                          float* dw, float* dbias, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!images || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: null argument");
+    if (B <= 0 || Cin <= 0 || Cin > SW_MAXC || H <= 0 || W <= 0 || (H & 1) || (W & 1))
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: Cin <= %d and even H, W (Cin=%d H=%d W=%d)", SW_MAXC, Cin, H, W);
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: dtype");
+    hipStream_t s = (hipStream_t)stream;
+    const int S = stem_wgrad_shares(B, H, W);
+    if (dtype == CHORE_F32)
+        hipLaunchKernelGGL(stem_wgrad_kernel<float>, dim3(S), dim3(256), 0, s, images, (const float*)dy, B, Cin, H, W,
+                           (float*)workspace);
+    else
+        hipLaunchKernelGGL(stem_wgrad_kernel<bf16_t>, dim3(S), dim3(256), 0, s, images, (const bf16_t*)dy, B, Cin, H, W,
+                           (float*)workspace);
+    CHORE_LAUNCH_CHECK(h, s);
+    const int n = (Cin * 49 + 1) * 64 * 4;
+    hipLaunchKernelGGL(stem_wgrad_finish_kernel, dim3((n + 255) / 256), dim3(256), 0, s, (const float*)workspace, S, Cin, dw, dbias);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

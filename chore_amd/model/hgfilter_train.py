@@ -7,21 +7,17 @@ composed from autograd nodes whose forward AND backward are HIP kernels (chore_a
   every GroupNorm -> ReLU -> conv3x3 / conv1x1 layer   = ops.conv_gn   (150 of the 151 convolutions)
   bn_end -> ReLU                                        = ops.gn_relu
   up1 + bicubic_up2(low3)                               = ops.upadd     (gather-form transpose in the backward)
-Glue that moves no FLOPs -- concat, residual adds, 2x2 average pooling -- and the 7x7 stem (0.8 % of the FLOPs,
-Cin = 5) are torch ops on channels-last views for now; tensors are NHWC throughout.
+  7x7 stem, 2x2 average pooling                         = ops.stem, ops.avgpool2
+Only the glue that moves no FLOPs -- concat and residual adds -- is torch; tensors are NHWC throughout and no library
+convolution / GEMM is on the path (results are bit-reproducible run to run).
 """
 import torch
-import torch.nn.functional as F
 
 from .. import ops
 
 
 def _nchw(x):          # NHWC tensor -> (B,C,H,W) channels-last view
     return x.permute(0, 3, 1, 2)
-
-
-def _nhwc(x):          # (B,C,H,W) any layout -> contiguous NHWC
-    return x.permute(0, 2, 3, 1).contiguous()
 
 
 def conv_block(m, x):
@@ -37,7 +33,7 @@ def conv_block(m, x):
 def hourglass(m, level, x):
     """HourGlass._forward (HGFilters.py:26-50)"""
     up1 = conv_block(getattr(m, f"b1_{level}"), x)
-    low1 = _nhwc(F.avg_pool2d(_nchw(x), 2, stride=2))
+    low1 = ops.avgpool2(x)
     low1 = conv_block(getattr(m, f"b2_{level}"), low1)
     low2 = hourglass(m, level - 1, low1) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1)
     low3 = conv_block(getattr(m, f"b3_{level}"), low2)
@@ -47,10 +43,10 @@ def hourglass(m, level, x):
 def forward_train(enc, images, tdt):
     """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype.
     Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad."""
-    x = F.conv2d(images.float(), enc.conv1.weight, enc.conv1.bias, stride=2, padding=3)
-    x = ops.gn_relu(_nhwc(x).to(tdt), enc.bn1.weight, enc.bn1.bias)
+    x = ops.stem(images, enc.conv1.weight, enc.conv1.bias, tdt)
+    x = ops.gn_relu(x, enc.bn1.weight, enc.bn1.bias)
     tmpx = x
-    x = _nhwc(F.avg_pool2d(_nchw(conv_block(enc.conv2, x)), 2, stride=2))
+    x = ops.avgpool2(conv_block(enc.conv2, x))
     normx = x
     x = conv_block(enc.conv3, x)
     previous = conv_block(enc.conv4, x)

@@ -4,6 +4,8 @@ Every node runs HIP kernels of libchore_hip.so forward AND backward:
   conv_gn(x, w, bias, gamma, beta)   y = conv_{3x3|1x1}(relu(groupnorm32(x))) + bias   (one fused op = one layer of
                                      ConvBlock, /root/reference/model/net_util.py:374-396; gamma=None: plain conv)
   gn_relu(x, gamma, beta)            y = relu(groupnorm32(x))                        (HGFilters.py:150,170)
+  stem(images, w, bias, dtype)       y = conv7x7/2(images) + bias, NCHW fp32 -> NHWC  (HGFilters.py:102,149)
+  avgpool2(x), upadd(a, low)         2x2 average pooling; a + bicubic_up2(low)        (HGFilters.py:33,47-50)
 Tensors are NHWC (B,H,W,C) contiguous, float32 or bfloat16; parameters are float32 in the reference layouts.
 Backward of conv_gn: data gradient = the forward convolution kernel on transposed, flipped weights
 (chore_conv2d_bwd_data); weight gradient = pixel-contraction MFMA GEMM (chore_conv2d_bwd_weight, recomputes
@@ -144,6 +146,68 @@ class _UpAdd(torch.autograd.Function):
         dlow = torch.empty(B, H, W, C, dtype=dy.dtype, device=dev)
         _lib.check(_lib.lib.chore_up2_bwd(h, dt, dy.data_ptr(), dlow.data_ptr(), B, H, W, C, stream), h, "chore_up2_bwd")
         return dy, dlow
+
+
+class _AvgPool2(torch.autograd.Function):
+    """2x2 average pooling (HGFilters.py:33,153)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        dev, h, dt, stream = _env(x)
+        B, H, W, C = x.shape
+        y = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=dev)
+        _lib.check(_lib.lib.chore_avgpool2_fwd(h, dt, x.data_ptr(), y.data_ptr(), B, H, W, C, stream), h, "chore_avgpool2_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dev, h, dt, stream = _env(dy)
+        B, H, W, C = ctx.shape
+        dx = torch.empty(B, H, W, C, dtype=dy.dtype, device=dev)
+        _lib.check(_lib.lib.chore_avgpool2_bwd(h, dt, dy.data_ptr(), dx.data_ptr(), B, H, W, C, stream), h, "chore_avgpool2_bwd")
+        return dx
+
+
+class _Stem(torch.autograd.Function):
+    """y (B,H/2,W/2,64) = conv7x7/2(images (B,Cin,H,W) fp32) + bias (HGFilters.py:102,149); the images take no gradient"""
+
+    @staticmethod
+    def forward(ctx, images, w, bias, tdt):
+        if not images.is_cuda:
+            raise RuntimeError("chore_amd needs device tensors (no CPU path)")
+        dev = images.device
+        h, stream = _lib.handle(dev.index or 0), torch.cuda.current_stream(dev).cuda_stream
+        img = images.detach().float().contiguous()
+        wf, bf = w.detach().float().contiguous(), bias.detach().float().contiguous()
+        B, Cin, H, W = img.shape
+        y = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
+        ws = _u8(_lib.lib.chore_stem_workspace_bytes(Cin), dev)
+        _lib.check(_lib.lib.chore_stem_fwd(h, _DT[tdt], img.data_ptr(), B, Cin, H, W, wf.data_ptr(), bf.data_ptr(), y.data_ptr(),
+                                           ws.data_ptr(), stream), h, "chore_stem_fwd")
+        ctx.save_for_backward(img)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (img,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dev, h, dt, stream = _env(dy)
+        B, Cin, H, W = img.shape
+        dw, db = torch.empty(64, Cin, 7, 7, device=dev), torch.empty(64, device=dev)
+        ws = _u8(_lib.lib.chore_stem_wgrad_workspace_bytes(B, Cin, H, W), dev)
+        _lib.check(_lib.lib.chore_stem_bwd_weight(h, dt, img.data_ptr(), B, Cin, H, W, dy.data_ptr(), dw.data_ptr(), db.data_ptr(),
+                                                  ws.data_ptr(), stream), h, "chore_stem_bwd_weight")
+        return None, dw, db, None
+
+
+def avgpool2(x):
+    return _AvgPool2.apply(x)
+
+
+def stem(images, w, bias, tdt):
+    return _Stem.apply(images, w, bias, tdt)
 
 
 def upadd(a, low):

@@ -124,7 +124,7 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
  *   dZ  [3][4][B*N][128]    gradients w.r.t. the pre-activations of layers 1..3
  *   dX  [B*N][328]          gradient w.r.t. the 323-vector, summed over the heads
  * The weight gradients are then plain GEMMs over the point dimension (dW_l = dZ_l^T H_{l-1}, db_l = column sums of
- * dZ_l; the output layer uses the upstream gradients directly) -- the host runs them as library GEMMs.
+ * dZ_l; the output layer uses the upstream gradients directly) -- the host runs them through chore_gemm_tn_f32.
  * chore_scatter_features turns dX into the gradients of the two feature maps: dfeat (B,FH,FW,256) and dtmpx
  * (B,TH,TW,64), fp32 NHWC, written (accumulate = 0) or added to (accumulate = 1); tile-gather, no atomics.
  * ------------------------------------------------------------------------------------------- */
@@ -237,6 +237,71 @@ int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, int F, int 
 int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_index, const float* alpha,
                          const float* grad_alpha, int B, int F, int size, float eps, float* grad_faces,
                          chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Encoder layers as differentiable operators (training path).  Replace what torch autograd runs for
+ * the reference's encoder modules: nn.Conv2d 3x3 / 1x1 (model/net_util.py:346-349, 356-372,
+ * model/HGFilters.py:88-116), nn.GroupNorm(32, C) + F.relu (model/net_util.py:374-396, HGFilters.py:153-176),
+ * F.interpolate(scale 2, bicubic, align_corners=True) + add (HGFilters.py:47-50), and their backward passes.
+ * The host (chore_amd/ops.py, model/hgfilter_train.py) wires them into torch.autograd.Function nodes.
+ *
+ * Activations: NHWC (B,H,W,C), `dtype` = CHORE_F32 or CHORE_BF16.  Parameters and parameter gradients: fp32
+ * in the reference layouts (weight (Cout,Cin,k,k), bias/gamma/beta (C)).  taps = 1 (1x1) or 9 (3x3, pad 1).
+ * C, Cin, Cout multiples of 32.  `stats`: chore_gn_stats_bytes(B) bytes, the exact per-(image, group)
+ * sum / sum of squares of x, filled by chore_gn_stats; wherever an operator takes (stats, gamma, beta) != NULL
+ * it sees relu(groupnorm(x)) instead of x, applied while the tile is staged (the normalised tensor is never
+ * written).  Workspaces are caller-owned, sized by the *_bytes functions, and may be reused between calls on
+ * one stream.  All reductions are order-fixed (integer accumulators or ordered partial sums): results are
+ * bit-reproducible run to run.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout);
+size_t chore_gn_stats_bytes(int B);
+int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, chore_stream_t stream);
+/* y = relu(groupnorm(x)) */
+int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
+                      const float* beta, void* y, int B, int HW, int C, chore_stream_t stream);
+/* y (B,H,W,Cout) = conv(a) + bias (bias may be NULL) */
+int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                     const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
+                     int Cout, void* y, void* workspace, chore_stream_t stream);
+/* dx (B,H,W,Cin) = gradient w.r.t. the tensor the convolution saw (a) */
+int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, int B, int H, int W, int Cout,
+                          const float* w, int Cin, void* dx, void* workspace, chore_stream_t stream);
+/* dw (Cout,Cin,k,k), dbias (Cout, or NULL) */
+size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin, int Cout);
+int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                            const void* stats, const float* gamma, const float* beta, const void* dy, int Cout,
+                            float* dw, float* dbias, void* workspace, chore_stream_t stream);
+/* da = gradient w.r.t. relu(groupnorm(x))  ->  dx, dgamma (C), dbeta (C) */
+size_t chore_gn_relu_bwd_workspace_bytes(int B, int C);
+int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
+                      const float* beta, const void* da, int B, int HW, int C, void* dx, float* dgamma,
+                      float* dbeta, void* workspace, chore_stream_t stream);
+/* y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C));  d_low = transpose of the upsampling applied to dy */
+int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
+                    chore_stream_t stream);
+int chore_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C,
+                  chore_stream_t stream);
+/* y (B,H/2,W/2,C) = 2x2 average pooling of x (B,H,W,C) (nn.AvgPool2d / F.avg_pool2d(2, stride 2), HGFilters.py:33,153),
+ * C in {64,128,256}; dx (B,H,W,C) = its transpose applied to dy */
+int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C,
+                       chore_stream_t stream);
+int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C,
+                       chore_stream_t stream);
+/* stem: y (B,H/2,W/2,64) = conv 7x7 stride 2 pad 3 of images (B,Cin,H,W) fp32 NCHW, + bias (model/HGFilters.py:102,149;
+ * Cin <= 8 forward, <= 5 for the weight gradient; the images take no gradient).  dy has y's layout and dtype. */
+size_t chore_stem_workspace_bytes(int Cin);
+int chore_stem_fwd(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const float* w,
+                   const float* bias, void* y, void* workspace, chore_stream_t stream);
+size_t chore_stem_wgrad_workspace_bytes(int B, int Cin, int H, int W);
+int chore_stem_bwd_weight(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const void* dy,
+                          float* dw, float* dbias, void* workspace, chore_stream_t stream);
+/* C (M,N) = A^T B, fp32 (exact fp32 matrix-core arithmetic), A (P,M) row stride lda, B (P,N) row stride ldb;
+ * M, N multiples of 32, any P.  The weight gradients of the MLP heads (what autograd computes for the
+ * nn.Conv1d layers of model/net_util.py:218-262). */
+size_t chore_gemm_tn_workspace_bytes(int P, int M, int N);
+int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, int ldb, int P, int M, int N,
+                      float* C, void* workspace, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Measurement aid (bench.py roofline): while enabled, chore_encode_fwd brackets every kernel launch

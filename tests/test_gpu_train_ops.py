@@ -106,3 +106,42 @@ def test_upadd(dtype, shape):
     check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
     check(ld.grad.permute(0, 3, 1, 2), lr.grad, dtype, "dlow")
     check(ad.grad.permute(0, 3, 1, 2), ar.grad, dtype, "da")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 5, 64, 96), (1, 5, 22, 18), (3, 3, 16, 16)])
+def test_stem(dtype, shape):
+    """7x7 stride-2 stem (HGFilters.py:102,149): forward, weight and bias gradient (ragged tiles, Cin 3 and 5)"""
+    from chore_amd import ops
+    torch.manual_seed(7)
+    B, Cin, H, W = shape
+    img = torch.randn(B, Cin, H, W)
+    w = (torch.randn(64, Cin, 7, 7) * 0.1).requires_grad_(True)
+    bias = torch.randn(64).requires_grad_(True)
+    up = torch.randn(B, 64, H // 2, W // 2)
+    yr = F.conv2d(img, w, bias, stride=2, padding=3)
+    (yr * up).sum().backward()
+    wd, bd = w.detach().clone().cuda().requires_grad_(True), bias.detach().clone().cuda().requires_grad_(True)
+    yd = ops.stem(img.cuda(), wd, bd, dtype)
+    assert yd.dtype == dtype and yd.shape == (B, H // 2, W // 2, 64)
+    (yd * up.permute(0, 2, 3, 1).cuda().to(dtype)).sum().backward()
+    check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
+    check(wd.grad, w.grad, dtype, "dw")
+    check(bd.grad, bias.grad, dtype, "dbias")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(2, 8, 12, 64), (1, 16, 16, 256), (2, 2, 6, 128)])
+def test_avgpool2(dtype, shape):
+    from chore_amd import ops
+    torch.manual_seed(8)
+    B, H, W, C = shape
+    x = torch.randn(B, C, H, W).to(dtype).float().requires_grad_(True)
+    up = torch.randn(B, C, H // 2, W // 2).to(dtype).float()
+    yr = F.avg_pool2d(x, 2, stride=2)
+    (yr * up).sum().backward()
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
+    yd = ops.avgpool2(xd)
+    (yd * up.permute(0, 2, 3, 1).cuda().to(dtype)).sum().backward()
+    check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
+    check(xd.grad.permute(0, 3, 1, 2), x.grad, dtype, "dx")
