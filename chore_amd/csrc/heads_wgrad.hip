@@ -1,0 +1,274 @@
+// heads_wgrad.hip -- parameter gradients of the four per-point MLP heads (gfx950), training path.
+//
+// What autograd computes for the nn.Conv1d(k=1) layers of CHORE.make_decoder (/root/reference/model/chore.py:74-85):
+//     dW_l = dZ_l^T H_{l-1}      db_l = column sums of dZ_l          (contraction over the P = B*N points)
+// from the rows chore_query_bwd_train staged (X = the 323-vectors, H_l = ReLU outputs, dZ_l = pre-activation gradients)
+// and, for the output layers, from the upstream gradients themselves.
+//
+// The products are tall-skinny (P = 80 000 rows, 128 x {323,128} results) and exact fp32: the bound is HBM -- every
+// staged row has to be read -- so the kernel reads each row once per 128x128 result tile:
+//   heads_wgrad_kernel   grid (S shares, 20 tiles = 4 heads x {3 column tiles of layer 1, layer 2, layer 3});
+//                        a workgroup streams its share of 32-row chunks of A = dZ and B = X / H through a
+//                        double-buffered LDS image [32][128 | 128] and accumulates a 128x128 tile with
+//                        v_mfma_f32_32x32x2_f32 (four waves, 64x64 each, 64 accumulator registers); the k = lane>>5
+//                        operand layout of that instruction reads both operands straight from the row-major image.
+//                        The column sums of A (the bias gradients) ride along in the waves that own column tile 0.
+//   heads_out_wgrad_kernel  output layers ({2,14,9,6} x 128): one thread per hidden channel, FMA chain over the
+//                        share's points with the upstream gradients of a 64-point chunk staged in LDS.
+//   heads_wgrad_finish_kernel  ordered sums of the per-share partials into the reference parameter layouts
+//                        (no float atomics anywhere: results are bit-reproducible).
+// Algorithmic traffic per call: P x (328 + 24 x 128) x 4 B read once (1.09 GB at P = 80 000); FLOPs 2 P (4 x (323 + 256 +
+// 31) x 128).
+#include "common.h"
+
+namespace {
+
+constexpr int HW_KT = 32;                 // rows per LDS stage
+constexpr int HW_TILES = HEAD_NUM * 5;
+constexpr int HW_S = 26;                  // shares: 20 x 26 = 520 workgroups (two per CU)
+constexpr int HW_S4 = 128;                // shares of the output-layer kernel
+constexpr int HW_OMAX = 14;
+
+struct HeadsWgradArgs {
+    const float* X;        // [P][328]
+    const float* H;        // [3][4][P][128]
+    const float* dZ;       // [3][4][P][128]
+    const float* g[HEAD_NUM];   // upstream gradients (B,out,N), kernel head order (df already masked)
+    int B, N;
+    float* part;           // [20][S][128*128]
+    float* part_b;         // [20][S][128]
+    float* part4;          // [4][S4][14*128]
+    float* part_b4;        // [4][S4][16]
+    float* out;            // parameter gradients, module order per head: W1 b1 W2 b2 W3 b3 W4 b4
+};
+
+__host__ __device__ inline size_t head_grad_floats(int k) {
+    return (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) +
+           (size_t)head_out_dim(k) * HEAD_HID + head_out_dim(k);
+}
+__host__ __device__ inline size_t head_grad_offset(int k) {
+    size_t o = 0;
+    for (int i = 0; i < k; ++i) o += head_grad_floats(i);
+    return o;
+}
+
+__global__ __launch_bounds__(256) void heads_wgrad_kernel(HeadsWgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][HW_KT][256]
+    const int s = blockIdx.x, t = blockIdx.y, head = t / 5, sub = t % 5;
+    const int P = a.B * a.N;
+    const int layer = sub < 3 ? 0 : sub - 2;
+    const float* A = a.dZ + ((size_t)layer * HEAD_NUM + head) * P * HEAD_HID;
+    const float* Bm;
+    int ldb, ncols;
+    if (sub < 3) { Bm = a.X + sub * 128; ldb = QF_KPAD; ncols = min(128, QF_KPAD - sub * 128); }
+    else { Bm = a.H + ((size_t)(layer - 1) * HEAD_NUM + head) * P * HEAD_HID; ldb = HEAD_HID; ncols = 128; }
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w & 1, wn = w >> 1;
+    const int nchunk = (P + HW_KT - 1) / HW_KT;
+    const int lr = tid >> 5, lc = (tid & 31) * 4;       // this thread's float4 of rows lr, lr+8, lr+16, lr+24
+
+    f32x4 ra[4], rb[4];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = chunk * HW_KT + lr + 8 * q;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[q] = z; rb[q] = z;
+            if (row < P) {
+                ra[q] = *(const f32x4*)(A + (size_t)row * HEAD_HID + lc);
+                if (lc < ncols) rb[q] = *(const f32x4*)(Bm + (size_t)row * ldb + lc);
+            }
+        }
+    };
+    auto stash = [&](int buf) {
+        float* d = sm + buf * HW_KT * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            *(f32x4*)(d + (lr + 8 * q) * 256 + lc) = ra[q];
+            *(f32x4*)(d + (lr + 8 * q) * 256 + 128 + lc) = rb[q];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float asum0 = 0.f, asum1 = 0.f;
+
+    int chunk = s, cur = 0;
+    if (chunk < nchunk) { fetch(chunk); stash(0); }
+    __syncthreads();
+    for (; chunk < nchunk; chunk += HW_S) {
+        const bool more = chunk + HW_S < nchunk;
+        if (more) fetch(chunk + HW_S);
+        const float* L = sm + cur * HW_KT * 256 + (lane >> 5) * 256 + (lane & 31);
+#pragma unroll
+        for (int kk = 0; kk < HW_KT / 2; ++kk) {
+            const float a0 = L[kk * 512 + wm * 64], a1 = L[kk * 512 + wm * 64 + 32];
+            const float b0 = L[kk * 512 + 128 + wn * 64], b1 = L[kk * 512 + 128 + wn * 64 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            asum0 += a0; asum1 += a1;
+        }
+        if (more) stash(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    float* o = a.part + ((size_t)t * HW_S + s) * (128 * 128);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                o[m * 128 + wn * 64 + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+    if (wn == 0) {
+        asum0 += __shfl_xor(asum0, 32);
+        asum1 += __shfl_xor(asum1, 32);
+        if (lane < 32) {
+            float* ob = a.part_b + ((size_t)t * HW_S + s) * 128 + wm * 64 + lane;
+            ob[0] = asum0; ob[32] = asum1;
+        }
+    }
+}
+
+// output layers: dW4[o][c] = sum_p g[o][p] * H3[p][c], db4[o] = sum_p g[o][p]
+__global__ __launch_bounds__(256) void heads_out_wgrad_kernel(HeadsWgradArgs a) {
+    __shared__ float gl[HW_OMAX][64];
+    __shared__ float red[HW_OMAX][128];
+    const int s = blockIdx.x, head = blockIdx.y, od = head_out_dim(head);
+    const int P = a.B * a.N, tid = threadIdx.x, c = tid & 127, half = tid >> 7;
+    const float* H3 = a.H + ((size_t)2 * HEAD_NUM + head) * P * HEAD_HID;
+    const float* g = a.g[head];
+    float acc[HW_OMAX];
+#pragma unroll
+    for (int o = 0; o < HW_OMAX; ++o) acc[o] = 0.f;
+    float bsum = 0.f;
+    const int nchunk = (P + 63) / 64;
+    for (int chunk = s; chunk < nchunk; chunk += HW_S4) {
+        __syncthreads();
+        for (int i = tid; i < od * 64; i += 256) {
+            const int o = i >> 6, p = chunk * 64 + (i & 63);
+            float v = 0.f;
+            if (p < P) { const int b = p / a.N, n = p - b * a.N; v = g[((size_t)b * od + o) * a.N + n]; }
+            gl[o][i & 63] = v;
+        }
+        __syncthreads();
+        const int p0 = chunk * 64 + half * 32;
+#pragma unroll 4
+        for (int q = 0; q < 32; ++q) {
+            const int p = p0 + q;
+            const float hv = p < P ? H3[(size_t)p * HEAD_HID + c] : 0.f;
+#pragma unroll
+            for (int o = 0; o < HW_OMAX; ++o)
+                if (o < od) acc[o] = fmaf(gl[o][half * 32 + q], hv, acc[o]);
+        }
+        if (tid < od)
+            for (int q = 0; q < 64; ++q) bsum += gl[tid][q];
+    }
+    __syncthreads();
+    if (half == 1)
+#pragma unroll
+        for (int o = 0; o < HW_OMAX; ++o) red[o][c] = acc[o];
+    __syncthreads();
+    if (half == 0) {
+        float* out = a.part4 + ((size_t)head * HW_S4 + s) * (HW_OMAX * 128);
+#pragma unroll
+        for (int o = 0; o < HW_OMAX; ++o)
+            if (o < od) out[o * 128 + c] = acc[o] + red[o][c];
+    }
+    if (tid < od) a.part_b4[((size_t)head * HW_S4 + s) * 16 + tid] = bsum;
+}
+
+// ordered sums of the partials -> the parameter gradients in the reference layouts
+__global__ void heads_wgrad_finish_kernel(HeadsWgradArgs a) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr size_t N1 = (size_t)HW_TILES * 128 * 128, N2 = N1 + (size_t)HW_TILES * 128,
+                     N3 = N2 + (size_t)HEAD_NUM * HW_OMAX * 128, N4 = N3 + (size_t)HEAD_NUM * 16;
+    if (i < N1) {
+        const int t = (int)(i >> 14), e = (int)(i & 16383), m = e >> 7, n = e & 127, head = t / 5, sub = t % 5;
+        if (sub < 3 && sub * 128 + n >= HEAD_IN) return;
+        float sum = 0.f;
+        for (int k = 0; k < HW_S; ++k) sum += a.part[((size_t)t * HW_S + k) * 16384 + e];
+        float* o = a.out + head_grad_offset(head);
+        if (sub < 3) o[(size_t)m * HEAD_IN + sub * 128 + n] = sum;
+        else o[(size_t)HEAD_HID * HEAD_IN + HEAD_HID + (size_t)(sub - 3) * (HEAD_HID * HEAD_HID + HEAD_HID) + m * HEAD_HID + n] = sum;
+    } else if (i < N2) {
+        const int j = (int)(i - N1), t = j >> 7, m = j & 127, head = t / 5, sub = t % 5;
+        if (sub == 1 || sub == 2) return;
+        float sum = 0.f;
+        for (int k = 0; k < HW_S; ++k) sum += a.part_b[((size_t)t * HW_S + k) * 128 + m];
+        float* o = a.out + head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN;
+        if (sub >= 3) o += HEAD_HID + (size_t)(sub - 3) * (HEAD_HID * HEAD_HID + HEAD_HID) + (size_t)HEAD_HID * HEAD_HID;
+        o[m] = sum;
+    } else if (i < N3) {
+        const int j = (int)(i - N2), head = j / (HW_OMAX * 128), e = j % (HW_OMAX * 128), od = head_out_dim(head);
+        if (e >= od * 128) return;
+        float sum = 0.f;
+        for (int k = 0; k < HW_S4; ++k) sum += a.part4[((size_t)head * HW_S4 + k) * (HW_OMAX * 128) + e];
+        a.out[head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) + e] = sum;
+    } else if (i < N4) {
+        const int j = (int)(i - N3), head = j >> 4, o = j & 15, od = head_out_dim(head);
+        if (o >= od) return;
+        float sum = 0.f;
+        for (int k = 0; k < HW_S4; ++k) sum += a.part_b4[((size_t)head * HW_S4 + k) * 16 + o];
+        a.out[head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) +
+              (size_t)od * HEAD_HID + o] = sum;
+    }
+}
+
+constexpr size_t HW_PART = (size_t)HW_TILES * HW_S * 128 * 128, HW_PART_B = (size_t)HW_TILES * HW_S * 128,
+                 HW_PART4 = (size_t)HEAD_NUM * HW_S4 * HW_OMAX * 128, HW_PART_B4 = (size_t)HEAD_NUM * HW_S4 * 16;
+
+}  // namespace
+
+extern "C" {
+
+// floats of the gradient arena: per head (df, parts, pca, centers) W1 (128,323) b1 W2 (128,128) b2 W3 b3 W4 (out,128) b4
+size_t chore_heads_wgrad_floats(void) { return head_grad_offset(HEAD_NUM); }
+
+size_t chore_heads_wgrad_workspace_bytes(void) { return (HW_PART + HW_PART_B + HW_PART4 + HW_PART_B4) * sizeof(float); }
+
+int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
+                      const float* g_parts, const float* g_centers, float* grads, void* workspace, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!staging || !g_df || !g_pca || !g_parts || !g_centers || !grads || !workspace)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_wgrad: null argument");
+    if (B <= 0 || N <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_wgrad: B, N must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t P = (size_t)B * N;
+    HeadsWgradArgs a;
+    a.X = (const float*)staging;
+    a.H = a.X + P * QF_KPAD;
+    a.dZ = a.H + P * 3 * HEAD_NUM * HEAD_HID;
+    a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
+    a.B = B; a.N = N;
+    a.part = (float*)workspace;
+    a.part_b = a.part + HW_PART;
+    a.part4 = a.part_b + HW_PART_B;
+    a.part_b4 = a.part4 + HW_PART4;
+    a.out = grads;
+    const size_t smem = (size_t)2 * HW_KT * 256 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)heads_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    hipLaunchKernelGGL(heads_wgrad_kernel, dim3(HW_S, HW_TILES), dim3(256), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    hipLaunchKernelGGL(heads_out_wgrad_kernel, dim3(HW_S4, HEAD_NUM), dim3(256), 0, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    const size_t n = (size_t)HW_TILES * 128 * 128 + (size_t)HW_TILES * 128 + (size_t)HEAD_NUM * HW_OMAX * 128 + HEAD_NUM * 16;
+    hipLaunchKernelGGL(heads_wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+}  // extern "C"

@@ -138,38 +138,28 @@ class _QueryTrainFn(torch.autograd.Function):
                                                   g_pca.data_ptr(), g_parts.data_ptr(), g_centers.data_ptr(),
                                                   staging.data_ptr(), None if dpoints is None else dpoints.data_ptr(),
                                                   stream), h, "chore_query_bwd_train")
-        fl = staging.view(torch.float32)
-        KP, HD = 328, 128
-        X = fl[:P * KP].view(P, KP)
-        o = P * KP
-        H = fl[o:o + 12 * P * HD].view(3, 4, P, HD)
-        o += 12 * P * HD
-        dZ = fl[o:o + 12 * P * HD].view(3, 4, P, HD)
+        HD = 128
         # the df head sees no gradient where the point is outside the image (df is overwritten there, chore.py:147-150)
         g_df = g_df * in_img.unsqueeze(1).float()
         g_out = (g_df, g_parts, g_pca, g_centers)                     # kernel head order
         grads = [None] * 32
 
-        def gemm_tn(a, lda, b, ldb, m, n):
-            """C (m,n) = A^T B over the P staged rows (chore_gemm_tn_f32: the pixel-contraction MFMA kernel)"""
-            c = torch.empty(m, n, device=dev)
-            ws = torch.empty(max(_lib.lib.chore_gemm_tn_workspace_bytes(P, m, n), 16), dtype=torch.uint8, device=dev)
-            _lib.check(_lib.lib.chore_gemm_tn_f32(h, a.data_ptr(), lda, b.data_ptr(), ldb, P, m, n, c.data_ptr(),
-                                                  ws.data_ptr(), stream), h, "chore_gemm_tn_f32")
-            return c
-
+        # all 32 parameter gradients from the staged rows in three launches (heads_wgrad.hip)
+        g_c = [t.float().contiguous() for t in g_out]
+        garena = torch.empty(_lib.lib.chore_heads_wgrad_floats(), device=dev)
+        ws = torch.empty(_lib.lib.chore_heads_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.chore_heads_wgrad(h, staging.data_ptr(), B, N, g_c[0].data_ptr(), g_c[2].data_ptr(),
+                                              g_c[1].data_ptr(), g_c[3].data_ptr(), garena.data_ptr(), ws.data_ptr(), stream),
+                   h, "chore_heads_wgrad")
+        o = 0
         for k in range(4):                                            # module order = kernel head order
-            base = k * 8
-            # layer 1: the 328-column X rows in two pieces (the second one runs past column 327 into the next row:
-            # those columns belong to the zero padding of the weight and are cut off)
-            gw1 = torch.cat((gemm_tn(dZ[0, k], HD, X, KP, HD, 256), gemm_tn(dZ[0, k], HD, X[:, 256:], KP, HD, 96)), 1)[:, :323]
-            gw2 = gemm_tn(dZ[1, k], HD, H[0, k], HD, HD, HD)
-            gw3 = gemm_tn(dZ[2, k], HD, H[1, k], HD, HD, HD)
-            gw4 = torch.einsum("bon,bnk->ok", g_out[k], H[2, k].view(B, N, HD))
-            grads[base + 0], grads[base + 1] = gw1.unsqueeze(-1), dZ[0, k].sum(0)
-            grads[base + 2], grads[base + 3] = gw2.unsqueeze(-1), dZ[1, k].sum(0)
-            grads[base + 4], grads[base + 5] = gw3.unsqueeze(-1), dZ[2, k].sum(0)
-            grads[base + 6], grads[base + 7] = gw4.unsqueeze(-1), g_out[k].sum((0, 2))
+            od = g_out[k].shape[1]
+            for j, shape in enumerate(((HD, 323, 1), (HD,), (HD, HD, 1), (HD,), (HD, HD, 1), (HD,), (od, HD, 1), (od,))):
+                n = 1
+                for d in shape:
+                    n *= d
+                grads[k * 8 + j] = garena[o:o + n].view(shape)
+                o += n
         dfeat = dtmpx = None
         if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
             dfe = torch.empty(B, FH, FW, 256, device=dev) if ctx.needs_input_grad[2] else None

@@ -123,8 +123,11 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
  *   H   [3][4][B*N][128]    relu outputs of hidden layers 1..3, heads in the order df, parts, pca, centers
  *   dZ  [3][4][B*N][128]    gradients w.r.t. the pre-activations of layers 1..3
  *   dX  [B*N][328]          gradient w.r.t. the 323-vector, summed over the heads
- * The weight gradients are then plain GEMMs over the point dimension (dW_l = dZ_l^T H_{l-1}, db_l = column sums of
- * dZ_l; the output layer uses the upstream gradients directly) -- the host runs them through chore_gemm_tn_f32.
+ * chore_heads_wgrad turns the staging into the gradients of all 32 head parameters (dW_l = dZ_l^T H_{l-1}, db_l = column
+ * sums of dZ_l; the output layers use the upstream gradients directly -- pass g_df already zeroed where the point is
+ * outside the image, model/chore.py:147-150): `grads` = chore_heads_wgrad_floats() floats, per head in kernel order
+ * (df, parts, pca, centers): W1 (128,323) b1 (128) W2 (128,128) b2 W3 b3 W4 (out,128) b4 (out); ordered partial sums,
+ * bit-reproducible.  workspace: chore_heads_wgrad_workspace_bytes().
  * chore_scatter_features turns dX into the gradients of the two feature maps: dfeat (B,FH,FW,256) and dtmpx
  * (B,TH,TW,64), fp32 NHWC, written (accumulate = 0) or added to (accumulate = 1); tile-gather, no atomics.
  * ------------------------------------------------------------------------------------------- */
@@ -134,6 +137,11 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
                           const void* heads_arena, const float* camera, const float* g_df, const float* g_pca,
                           const float* g_parts, const float* g_centers, void* staging, float* dpoints,
                           chore_stream_t stream);
+size_t chore_heads_wgrad_floats(void);
+size_t chore_heads_wgrad_workspace_bytes(void);
+int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
+                      const float* g_parts, const float* g_centers, float* grads, void* workspace,
+                      chore_stream_t stream);
 int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,
                            int TH, int TW, const float* camera, const void* staging, float* dfeat, float* dtmpx,
                            int accumulate, chore_stream_t stream);

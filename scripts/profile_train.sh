@@ -9,5 +9,5 @@ cd /tmp; rm -rf /tmp/proft_$tag
 rocprofv3 --kernel-trace -d /tmp/proft_$tag -o $tag --output-format csv -- \
     python $repo/bench_train.py --steps 16 --warmup 4 > /dev/null 2> $out/${tag}_train_rocprof.err
 f=$(find /tmp/proft_$tag -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && python $repo/scripts/train_prof_summary.py $f 20 > $out/${tag}_train_kernel_stats.txt
+[ -n "$f" ] && python $repo/scripts/train_prof_summary.py $f > $out/${tag}_train_kernel_stats.txt
 cd $repo

@@ -1,11 +1,13 @@
 """Per-step kernel shares of the training step from a rocprofv3 --kernel-trace csv of bench_train.py.
 
-usage: train_prof_summary.py <kernel_trace.csv> <steps_in_trace>
-Aggregates by kernel name over the SECOND HALF of the trace window (steady state: no library find / first-touch
-work), reports launches and microseconds per step, and the busy / idle split of that window."""
+usage: train_prof_summary.py <kernel_trace.csv> [marker] [marker_launches_per_step]
+Aggregates by kernel name over the SECOND HALF of the trace window (steady state: no first-touch work), counts the
+steps in that window from a marker kernel (default: query_fwd_f32_kernel, 5 launches per step = one per stack),
+reports launches and microseconds per step, and the busy / idle split of that window."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = int(sys.argv[2])
+marker = sys.argv[2] if len(sys.argv) > 2 else "query_fwd_f32_kernel"
+per_step = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
 ev = []
 for r in rows:
     name = r.get("Kernel_Name") or r.get("kernel_name")
@@ -16,7 +18,7 @@ ev.sort()
 t0, t1 = ev[0][0], max(e[1] for e in ev)
 mid = (t0 + t1) // 2
 half = [e for e in ev if e[0] >= mid]
-nsteps = steps / 2.0
+nsteps = sum(1 for e in half if marker in e[2]) / per_step
 agg = collections.defaultdict(lambda: [0, 0.0])
 busy, cur_s, cur_e = 0, None, None
 for s, e, n in half:
