@@ -186,17 +186,169 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     if (a.part_bias && blockIdx.y == 0 && tid < CT32) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient, 64 x 64 channel tiles (Cin, Cout multiples of 64: the layers that carry the FLOPs).
+// The 32x32 kernel above waits for every LDS fragment, loads its tiles one vector at a time and re-stages both
+// tensors once per 32-channel tile pair.  Here a workgroup owns 64 output x 64 input channels x all taps; wave
+// (coh, cih) owns the 32 x 32 channel block (TAPS accumulator tiles = 144 registers at 9 taps) over the WHOLE pixel
+// tile, so there is no cross-wave reduction, and the tensors are staged half as often.  Fragments come from the
+// transposing-read builtin, so the compiler overlaps them with the MFMAs (1 dY + TAPS x fragments per TAPS MFMAs:
+// ~5.1k LDS cycles against 4.6k MFMA cycles per tile).  LDS images are [pixel][64 ch] with a 160-byte pitch: the
+// four 4x16 blocks a transposing read touches fall into disjoint banks.  Staging issues all vector loads of a
+// tensor before the first use.
+// Workgroups that share pixel tiles (same share, different channel pair) are placed on one XCD (id % 8) so the
+// second and later readers of a tile hit that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+constexpr int W64_PITCH = 160;                 // bytes per pixel row of the LDS images (64 bf16 = 128 + 32 pad)
+typedef short tb_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tb_s16x4 lds_s16x4;
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int AW = TW + 2 * PAD, AH = TH + 2 * PAD, AROWS = AH * AW;
+    constexpr int NVX = (AROWS * 8 + 255) / 256, NVY = TH * TW * 8 / 256;      // 16-byte vectors per thread
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* imgA = smem;                                     // [AROWS] x 160 B
+    char* imgY = smem + AROWS * W64_PITCH;                 // [256] x 160 B
+    float* ss = (float*)(imgY + TH * TW * W64_PITCH);      // [64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, cih = wid & 1, coh = wid >> 1;
+    const int nbo = a.Cout / 64, nbc = a.Cin / 64, npairs = nbo * nbc;
+    int share, pair;
+    {
+        const int L = blockIdx.x;
+        if (a.S % 8 == 0) { const int xcd = L & 7, j = L >> 3; share = (j / npairs) * 8 + xcd; pair = j % npairs; }
+        else { share = L / npairs; pair = L % npairs; }
+    }
+    const int co0 = (pair / nbc) * 64, ci0 = (pair % nbc) * 64;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+    const int tiles = a.B * tiles_x * tiles_y;
+    const bool use_gn = a.st != nullptr;
+    const bf16_t* X = (const bf16_t*)a.x;
+    const bf16_t* DY = (const bf16_t*)a.dy;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bias_acc = 0.f;
+    int cur_b = -1;
+    const int h = lane >> 5, g = (lane >> 4) & 1, i16 = lane & 15;
+    const int lane_off = (8 * h + (i16 >> 2)) * W64_PITCH + (g * 16 + (i16 & 3) * 4) * 2;
+    auto frag = [&](const char* p) -> tb_bf16x8 {          // p: image + pixel * pitch + channel * 2 (+ lane_off)
+        const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+        const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(tb_bf16x8, v);
+    };
+
+    for (int tile = share; tile < tiles; tile += a.S) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
+        __syncthreads();                                   // previous tile fully consumed
+        if (use_gn && b != cur_b) {
+            if (tid < 64) gn_scale_shift(a.st, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            __syncthreads();
+        }
+        cur_b = b;
+        {   // ---- dY tile: all loads in flight, then the LDS stores ----
+            u32x4 vy[NVY];
+#pragma unroll
+            for (int q = 0; q < NVY; ++q) {
+                const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+                const int y = min(ty0 + row / TW, a.H - 1), x = min(tx0 + row % TW, a.W - 1);
+                vy[q] = *(const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.ys + co0 + v * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < NVY; ++q) {
+                const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+                u32x4 val = vy[q];
+                if (ty0 + row / TW >= a.H || tx0 + row % TW >= a.W) { val[0] = 0u; val[1] = 0u; val[2] = 0u; val[3] = 0u; }
+                *(u32x4*)(imgY + row * W64_PITCH + v * 16) = val;
+            }
+        }
+        {   // ---- halo tile of the input, GroupNorm + ReLU applied on the way ----
+            u32x4 vx[NVX];
+#pragma unroll
+            for (int q = 0; q < NVX; ++q) {
+                const int i = min(tid + 256 * q, AROWS * 8 - 1), row = i >> 3, v = i & 7;
+                const int y = min(max(ty0 + row / AW - PAD, 0), a.H - 1), x = min(max(tx0 + row % AW - PAD, 0), a.W - 1);
+                vx[q] = *(const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.xs + ci0 + v * 8);
+            }
+#pragma unroll
+            for (int q = 0; q < NVX; ++q) {
+                const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+                const int y = ty0 + row / AW - PAD, x = tx0 + row % AW - PAD;
+                u32x4 val = vx[q];
+                if (use_gn) {
+                    float f[8];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { f[2 * j] = __uint_as_float(val[j] << 16); f[2 * j + 1] = __uint_as_float(val[j] & 0xffff0000u); }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], ss[2 * (v * 8 + j)], ss[2 * (v * 8 + j) + 1]); f[j] = t > 0.f ? t : 0.f; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) val[j] = pack2bf(f[2 * j], f[2 * j + 1]);
+                }
+                if (y < 0 || y >= a.H || x < 0 || x >= a.W) { val[0] = 0u; val[1] = 0u; val[2] = 0u; val[3] = 0u; }
+                if (i < AROWS * 8) *(u32x4*)(imgA + row * W64_PITCH + v * 16) = val;
+            }
+        }
+        __syncthreads();
+        if (a.part_bias && pair % nbc == 0 && tid < 64) {
+            for (int p = 0; p < TH * TW; ++p) bias_acc += bf2f(*(const bf16_t*)(imgY + p * W64_PITCH + tid * 2));
+        }
+        // ---- MFMAs ----
+        const char* baseY = imgY + lane_off + coh * 64;
+        const char* baseA = imgA + lane_off + cih * 64;
+#pragma unroll 1
+        for (int y = 0; y < TH; ++y) {
+#pragma unroll
+            for (int xb = 0; xb < TW; xb += 16) {
+                const tb_bf16x8 fy = frag(baseY + (y * TW + xb) * W64_PITCH);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const tb_bf16x8 fx = frag(baseA + ((y + ky) * AW + xb + kx) * W64_PITCH);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fx, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- this share's partial: [tap][64 co][64 ci] ----
+    const int col = lane & 31;
+    float* out = a.part + ((size_t)share * npairs + pair) * TAPS * 4096;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[(size_t)t * 4096 + (coh * 32 + mfma32_row(r, h)) * 64 + cih * 32 + col] = acc[t][r];
+    if (a.part_bias && pair % nbc == 0 && tid < 64) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc;
+}
+
+static int wgrad64_shares(int B, int H, int W, int Cin, int Cout) {
+    const int tiles = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
+    const int pairs = (Cout / 64) * (Cin / 64);
+    int S = ((256 + pairs - 1) / pairs + 7) / 8 * 8;
+    if (S > tiles) S = tiles;
+    return S;
+}
+static bool wgrad_use64(int dtype, int taps, int Cin, int Cout) {
+    return dtype == CHORE_BF16 && taps == 9 && Cin % 64 == 0 && Cout % 64 == 0;
+}
+
 // dW (O,C,kh,kw) = sum over the shares, in order
 __global__ void wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int S, int Cout,
-                                    int Cin, int taps, float* __restrict__ dw, float* __restrict__ dbias) {
+                                    int Cin, int taps, float* __restrict__ dw, float* __restrict__ dbias, int ct) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = (size_t)Cout * Cin * taps;
     if (i < n) {
         const int t = (int)(i % taps), c = (int)((i / taps) % Cin), o = (int)(i / ((size_t)taps * Cin));
-        const int nbo = Cout / 32, nbc = Cin / 32;
+        const int nbo = Cout / ct, nbc = Cin / ct;      // partial tiles are ct x ct channels
         float s = 0.f;
         for (int k = 0; k < S; ++k)
-            s += part[(((((size_t)k * nbo + o / 32) * nbc + c / 32) * taps + t) * 32 + o % 32) * 32 + c % 32];
+            s += part[(((((size_t)k * nbo + o / ct) * nbc + c / ct) * taps + t) * ct + o % ct) * ct + c % ct];
         dw[i] = s;
     }
     if (dbias && i < (size_t)Cout) {
@@ -427,7 +579,13 @@ static int wgrad_shares(int B, int H, int W, int Cin, int Cout) {
 size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin, int Cout) {
     if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || B <= 0) return 0;
     const int S = wgrad_shares(B, H, W, Cin, Cout);
-    return ((size_t)S * (Cout / 32) * (Cin / 32) * taps * 1024 + (size_t)S * Cout) * sizeof(float);
+    size_t n = (size_t)S * (Cout / 32) * (Cin / 32) * taps * 1024 + (size_t)S * Cout;
+    if (wgrad_use64(CHORE_BF16, taps, Cin, Cout)) {       // the bf16 path of these shapes uses 64-channel tiles
+        const int S64 = wgrad64_shares(B, H, W, Cin, Cout);
+        const size_t n64 = (size_t)S64 * (Cout / 64) * (Cin / 64) * taps * 4096 + (size_t)S64 * Cout;
+        if (n64 > n) n = n64;
+    }
+    return n * sizeof(float);
 }
 
 // dw (Cout,Cin,k,k) fp32 and dbias (Cout, or NULL) of y = conv(a) + bias, a = relu(groupnorm(x)) if stats else x
@@ -444,8 +602,29 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
     a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.xs = Cin; a.ys = Cout; a.npix = (long long)B * H * W;
-    a.S = wgrad_shares(B, H, W, Cin, Cout);
     a.part = (float*)workspace;
+    int ct = 32;
+    if (wgrad_use64(dtype, taps, Cin, Cout)) {
+        ct = 64;
+        a.S = wgrad64_shares(B, H, W, Cin, Cout);
+        const int npairs = (Cout / 64) * (Cin / 64);
+        a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
+        const size_t smem64 = (size_t)(PH * PW + TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
+        static bool attr64 = false;
+        if (!attr64) {
+            CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)smem64));
+            attr64 = true;
+        }
+        hipLaunchKernelGGL(wgrad64_kernel<9>, dim3(a.S * npairs), dim3(256), smem64, s, a);
+        CHORE_LAUNCH_CHECK(h, s);
+        const size_t n = (size_t)Cout * Cin * taps;
+        hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
+                           Cin, taps, dw, dbias, ct);
+        CHORE_LAUNCH_CHECK(h, s);
+        return CHORE_OK;
+    }
+    a.S = wgrad_shares(B, H, W, Cin, Cout);
     a.part_bias = dbias ? a.part + (size_t)a.S * (Cout / 32) * (Cin / 32) * taps * 1024 : nullptr;
     const size_t es = dtype == CHORE_F32 ? 4 : 2;
     const int arows = taps == 9 ? PH * PW : TH * TW;
@@ -467,7 +646,7 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
 #undef LAUNCH_WG
     const size_t n = (size_t)Cout * Cin * taps;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
-                       Cin, taps, dw, dbias);
+                       Cin, taps, dw, dbias, ct);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -506,7 +685,7 @@ int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, 
     hipLaunchKernelGGL((wgrad_kernel<float, 1>), dim3(M / 32, N / 32, a.S), dim3(256), smem, s, a);
     const size_t n = (size_t)M * N;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, nullptr, a.S, M, N, 1, C,
-                       nullptr);
+                       nullptr, 32);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -36,6 +36,9 @@ def check(a, b, dtype, what):
     (1, 64, 128, True, False, (2, 16, 32)),    # downsample path: 1x1 after bn4
     (1, 128, 128, False, True, (3, 8, 32)),    # plain 1x1 with bias (l / al / bl)
     (3, 256, 128, True, False, (1, 32, 32)),
+    (3, 64, 64, True, False, (2, 20, 44)),     # 64-channel-tile weight-gradient kernel, ragged tiles
+    (3, 128, 64, False, True, (3, 24, 96)),    # ... plain conv with bias, several tiles per share
+    (3, 64, 128, True, False, (5, 64, 64)),    # ... more tiles than shares
 ])
 def test_conv_gn_layer(dtype, k, cin, cout, gn, bias, shape):
     from chore_amd import ops
