@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void heads_wgrad_kernel(HeadsWgradArgs a) {
 
 // output layers: dW4[o][c] = sum_p g[o][p] * H3[p][c], db4[o] = sum_p g[o][p]
 __global__ __launch_bounds__(256) void heads_out_wgrad_kernel(HeadsWgradArgs a) {
-    __shared__ float gl[HW_OMAX][64];
+    __shared__ __attribute__((aligned(16))) float gl[HW_OMAX][64];
     __shared__ float red[HW_OMAX][128];
     const int s = blockIdx.x, head = blockIdx.y, od = head_out_dim(head);
     const int P = a.B * a.N, tid = threadIdx.x, c = tid & 127, half = tid >> 7;
@@ -162,13 +162,18 @@ __global__ __launch_bounds__(256) void heads_out_wgrad_kernel(HeadsWgradArgs a) 
         }
         __syncthreads();
         const int p0 = chunk * 64 + half * 32;
-#pragma unroll 4
-        for (int q = 0; q < 32; ++q) {
-            const int p = p0 + q;
-            const float hv = p < P ? H3[(size_t)p * HEAD_HID + c] : 0.f;
+#pragma unroll 2
+        for (int q = 0; q < 32; q += 4) {
+            float hv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hv[e] = p0 + q + e < P ? H3[(size_t)(p0 + q + e) * HEAD_HID + c] : 0.f;
 #pragma unroll
             for (int o = 0; o < HW_OMAX; ++o)
-                if (o < od) acc[o] = fmaf(gl[o][half * 32 + q], hv, acc[o]);
+                if (o < od) {
+                    const f32x4 g4 = *(const f32x4*)&gl[o][half * 32 + q];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[o] = fmaf(g4[e], hv[e], acc[o]);
+                }
         }
         if (tid < od)
             for (int q = 0; q < 64; ++q) bsum += gl[tid][q];

@@ -344,12 +344,12 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ part, const float*
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = (size_t)Cout * Cin * taps;
     if (i < n) {
-        const int t = (int)(i % taps), c = (int)((i / taps) % Cin), o = (int)(i / ((size_t)taps * Cin));
-        const int nbo = Cout / ct, nbc = Cin / ct;      // partial tiles are ct x ct channels
+        // thread index follows the PARTIAL layout [o tile][c tile][tap][o % ct][c % ct]: coalesced reads of every share
+        const int nbc = Cin / ct, cc = (int)(i % ct), oo = (int)((i / ct) % ct), t = (int)((i / ((size_t)ct * ct)) % taps);
+        const int pt = (int)(i / ((size_t)ct * ct * taps)), o = (pt / nbc) * ct + oo, c = (pt % nbc) * ct + cc;
         float s = 0.f;
-        for (int k = 0; k < S; ++k)
-            s += part[(((((size_t)k * nbo + o / ct) * nbc + c / ct) * taps + t) * ct + o % ct) * ct + c % ct];
-        dw[i] = s;
+        for (int k = 0; k < S; ++k) s += part[(size_t)k * n + i];
+        dw[((size_t)o * Cin + c) * taps + t] = s;
     }
     if (dbias && i < (size_t)Cout) {
         float s = 0.f;
@@ -481,12 +481,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     float dgam[4] = {0, 0, 0, 0}, dbet[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
     for (int p = p0 + pl; p < p1; p += P) {
         const size_t o = ((size_t)b * HW + p) * C + cv * 4;
+        const f32x4 xv4 = Vec4<T>::ld(x + o), da4 = Vec4<T>::ld(da + o);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int c = cv * 4 + j;
-            const float xv = ld1<T>(x + o + j);
+            const float xv = xv4[j];
             const float xh = (xv - mr[4 * c]) * mr[4 * c + 1];
-            const float g = fmaf(xv, mr[4 * c + 2], mr[4 * c + 3]) > 0.f ? ld1<T>(da + o + j) : 0.f;
+            const float g = fmaf(xv, mr[4 * c + 2], mr[4 * c + 3]) > 0.f ? da4[j] : 0.f;
             dbet[j] += g;
             dgam[j] += g * xh;
             const float gy = g * gamma[c];
@@ -550,15 +551,21 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         }
     }
     __syncthreads();
-    const size_t total = (size_t)HW * C;
-    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C);
-        const size_t o = (size_t)b * total + i;
-        const float* q = pc + 7 * c;
-        const float xv = ld1<T>(x + o);
-        const float xh = (xv - q[0]) * q[1];
-        const float gy = fmaf(xv, q[5], q[6]) > 0.f ? ld1<T>(da + o) * q[2] : 0.f;
-        st1<T>(dx + o, q[1] * ((gy - q[3]) - xh * q[4]));
+    const size_t total4 = (size_t)HW * C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total4; i += (size_t)gridDim.x * 256) {
+        const int c0 = (int)((i * 4) % C);
+        const size_t o = (size_t)b * total4 * 4 + i * 4;
+        const f32x4 xv4 = Vec4<T>::ld(x + o), da4 = Vec4<T>::ld(da + o);
+        f32x4 r;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float* q = pc + 7 * (c0 + j);
+            const float xv = xv4[j];
+            const float xh = (xv - q[0]) * q[1];
+            const float gy = fmaf(xv, q[5], q[6]) > 0.f ? da4[j] * q[2] : 0.f;
+            r[j] = q[1] * ((gy - q[3]) - xh * q[4]);
+        }
+        Vec4<T>::st(dx + o, r);
     }
 }
 
@@ -741,9 +748,9 @@ int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* sta
     int S = HW / 64;
     if (S < 1) S = 1;
     if (S > GN_SPLITS_MAX) S = GN_SPLITS_MAX;
-    const size_t total = (size_t)HW * C;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
+    const size_t total4 = (size_t)HW * C / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 512) blocks = 512;
     if (dtype == CHORE_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(S, B), dim3(256), 0, s, (const float*)x, (const float*)da,
                            (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
