@@ -335,7 +335,7 @@ static int wgrad64_shares(int B, int H, int W, int Cin, int Cout) {
     return S;
 }
 static bool wgrad_use64(int dtype, int taps, int Cin, int Cout) {
-    return dtype == CHORE_BF16 && taps == 9 && Cin % 64 == 0 && Cout % 64 == 0;
+    return dtype == CHORE_BF16 && (taps == 9 || taps == 1) && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
 // dW (O,C,kh,kw) = sum over the shares, in order
@@ -616,14 +616,17 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
         a.S = wgrad64_shares(B, H, W, Cin, Cout);
         const int npairs = (Cout / 64) * (Cin / 64);
         a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
-        const size_t smem64 = (size_t)(PH * PW + TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
+        const size_t smem64 = (size_t)((taps == 9 ? PH * PW : TH * TW) + TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
         static bool attr64 = false;
         if (!attr64) {
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   (int)smem64));
+                                                   (int)((size_t)(PH * PW + TH * TW) * W64_PITCH + 512)));
+            CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   (int)((size_t)(2 * TH * TW) * W64_PITCH + 512)));
             attr64 = true;
         }
-        hipLaunchKernelGGL(wgrad64_kernel<9>, dim3(a.S * npairs), dim3(256), smem64, s, a);
+        if (taps == 9) hipLaunchKernelGGL(wgrad64_kernel<9>, dim3(a.S * npairs), dim3(256), smem64, s, a);
+        else hipLaunchKernelGGL(wgrad64_kernel<1>, dim3(a.S * npairs), dim3(256), smem64, s, a);
         CHORE_LAUNCH_CHECK(h, s);
         const size_t n = (size_t)Cout * Cin * taps;
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,

@@ -39,6 +39,8 @@ def check(a, b, dtype, what):
     (3, 64, 64, True, False, (2, 20, 44)),     # 64-channel-tile weight-gradient kernel, ragged tiles
     (3, 128, 64, False, True, (3, 24, 96)),    # ... plain conv with bias, several tiles per share
     (3, 64, 128, True, False, (5, 64, 64)),    # ... more tiles than shares
+    (1, 128, 256, True, False, (2, 20, 44)),   # ... 1x1, ragged
+    (1, 256, 256, False, True, (2, 32, 64)),   # ... 1x1 plain with bias
 ])
 def test_conv_gn_layer(dtype, k, cin, cout, gn, bias, shape):
     from chore_amd import ops
