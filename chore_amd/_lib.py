@@ -99,6 +99,10 @@ SIGNATURES = {
     "chore_gn_relu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_gn_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_collision_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p]),
+    "chore_collision_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "chore_silhouette_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_silhouette_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),

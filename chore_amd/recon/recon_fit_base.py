@@ -86,9 +86,53 @@ class _ContactFn(torch.autograd.Function):
         return d_hum, d_obj, None, None, None, None, None
 
 
+class _CollisionFn(torch.autograd.Function):
+    """per-batch interpenetration sums of a triangle mesh (chore_collision_fwd / _bwd, csrc/collision.hip)"""
+
+    @staticmethod
+    def forward(ctx, verts, faces):
+        dev = verts.device
+        if not verts.is_cuda:
+            raise RuntimeError("chore_amd needs device tensors (no CPU path)")
+        h = _lib.handle(dev.index or 0)
+        B, V, _ = verts.shape
+        F_ = faces.shape[0]
+        vc = verts.detach().float().contiguous()
+        ws = torch.empty(_lib.lib.chore_collision_workspace_bytes(B, V, F_), dtype=torch.uint8, device=dev)
+        loss = torch.empty(B, dtype=torch.float32, device=dev)
+        gverts = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
+        counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_collision_fwd(h, vc.data_ptr(), faces.data_ptr(), B, V, F_, loss.data_ptr(),
+                                                gverts.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream), h,
+                   "chore_collision_fwd")
+        ctx.save_for_backward(gverts)
+        ctx.counts = counts            # device tensor; read it only outside captured regions
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (gverts,) = ctx.saved_tensors
+        dev = gverts.device
+        h = _lib.handle(dev.index or 0)
+        B, V, _ = gverts.shape
+        g = g.float().contiguous()
+        dverts = torch.empty_like(gverts)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_collision_bwd(h, gverts.data_ptr(), g.data_ptr(), B, V, dverts.data_ptr(), stream), h,
+                   "chore_collision_bwd")
+        return dverts, None
+
+
 class ReconFitterBase:
     def __init__(self, device="cuda:0", net_in_size=512, crop_size=1200, z_0=2.2, obj_scale=1.0, part_labels=None,
-                 body_prior=None, hand_prior=None, debug=False):
+                 body_prior=None, hand_prior=None, debug=False, scan_verts=None, scan_faces=None):
+        # template mesh of the object (self.scan.v / self.scan.f in the reference, recon_fit_base.py:79): needed by the
+        # interpenetration term only
+        self.scan_verts = None if scan_verts is None else torch.as_tensor(scan_verts, dtype=torch.float32,
+                                                                          device=device)
+        self.scan_faces = None if scan_faces is None else torch.as_tensor(scan_faces, dtype=torch.long, device=device)
+        self._comb_faces = None
         self.device = torch.device(device)
         self.camera = KinectColorCamera(crop_size)
         self.net_in_size = net_in_size
@@ -131,6 +175,24 @@ class ReconFitterBase:
         """rotate, translate, THEN scale (reference order, recon_fit_base.py:367-371)"""
         verts = torch.bmm(verts, obj_R) + obj_t.unsqueeze(1)
         return verts * obj_s.unsqueeze(1).unsqueeze(1)
+
+    # ---- interpenetration (SURVEY a15; parity unpinned, see oracle/collision.py) --------------------
+    def smpl_obj_collision(self, smpl_verts, smpl_faces, obj_verts, obj_faces):
+        """mean over the batch of the penetration loss of the concatenated mesh   [recon_fit_base.py:610-624]"""
+        comb_verts = torch.cat([smpl_verts, obj_verts], 1)
+        key = (smpl_faces.data_ptr(), obj_faces.data_ptr(), smpl_verts.shape[1])
+        if self._comb_faces is None or self._comb_faces[0] != key:
+            comb = torch.cat([smpl_faces.to(self.device).long(), obj_faces.to(self.device).long() + smpl_verts.shape[1]], 0)
+            self._comb_faces = (key, comb.to(torch.int32).contiguous())
+        return torch.mean(_CollisionFn.apply(comb_verts, self._comb_faces[1]))
+
+    def compute_collision_loss(self, smpl_verts, smpl_faces, obj_R, obj_t, obj_s):
+        """collision loss between the SMPL and the object template mesh   [recon_fit_base.py:626-639]"""
+        if self.scan_verts is None or self.scan_faces is None:
+            raise RuntimeError("compute_collision_loss needs the object template mesh (scan_verts / scan_faces)")
+        scan = self.scan_verts.unsqueeze(0).expand(obj_R.shape[0], -1, -1)
+        verts = self.transform_obj_verts(scan, obj_R, obj_t, obj_s)
+        return self.smpl_obj_collision(smpl_verts, smpl_faces, verts, self.scan_faces)
 
     def transform_object(self, object_init, rot, obj_t, obj_s):
         return self.transform_obj_verts(object_init, self.decopose_axis(rot), obj_t, obj_s)

@@ -8,8 +8,8 @@ quirks are kept on purpose because they change the fitted poses (SURVEY Appendix
     over the inner steps;
   * a new Adam at every phase switch; in `optimize_smpl_object` the SMPL parameters are never stepped;
   * `forward_step` queries the object points twice per step (once directly, once in compute_obj_loss).
-Not built yet: the silhouette phase needs the rasteriser ('sil' runs only if the caller
-provides data_dict['silhouette']), the 'collide' term needs the BVH (used only if `self.collision_fn` is set).
+The 'sil' phase runs if the caller provides data_dict['silhouette'] (SilLossROI); the 'collide' term of the joint
+phase (recon_fit_behave.py:213-216) runs if the fitter was given the object template mesh (scan_verts / scan_faces).
 Per-step host synchronisation of the reference (tqdm strings, .item()) is gone: the early-stop test
 reads the loss once per OUTER iteration.
 """
@@ -22,7 +22,6 @@ from .recon_fit_base import ReconFitterBase
 
 
 class ReconFitterBehave(ReconFitterBase):
-    collision_fn = None   # callable(smpl_verts, smpl_faces, R, t, s) -> penetration loss, or None
     use_graphs = False    # True: every inner step is a hipGraph replay (graph_step.py); same update rule
     adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
 
@@ -117,8 +116,8 @@ class ReconFitterBehave(ReconFitterBase):
             model.query(smpl_verts, **data_dict["query_dict"])
             df_hum_o = model.get_preds()[0][:, 1, :]
             self.compute_contact_loss(df_hum_o, df_obj_h, object, smpl_verts, loss_dict, part_o=part_o)
-            if self.collision_fn is not None:
-                loss_dict["collide"] = self.collision_fn(smpl_verts, smpl.faces, R, obj_t, obj_s)
+            if self.scan_faces is not None:
+                loss_dict["collide"] = self.compute_collision_loss(smpl_verts, smpl.faces, R, obj_t, obj_s)
         return loss_dict
 
     def optimize_smpl_object(self, model, data_dict, obj_iter=20, joint_iter=10, steps_per_iter=10, sil_iter=50,

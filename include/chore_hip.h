@@ -247,6 +247,24 @@ int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_in
                          chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Interpenetration term of the joint fit  (replaces ReconFitterBase.smpl_obj_collision recon/recon_fit_base.py:610-624 =
+ * mesh_intersection.BVH(max_collisions=8) + DistanceFieldPenetrationLoss(sigma=0.5, point2plane=False), constructed at
+ * :78-86).  PARITY UNPINNED: that package (github.com/vchoutas/torch-mesh-isect, no revision pinned) is not in the
+ * reference tree; oracle/collision.py states the published method implemented here.
+ *   verts  (B,V,3) fp32: the concatenated mesh (SMPL vertices, then object vertices), faces (F,3) int32 into it.
+ *   loss   (B) per-batch-element sums over all intersecting, non-adjacent triangle pairs (the caller takes the mean,
+ *          like torch.mean(self.pen_distance(...)) :623);  gverts (B,V,3) = d loss[b] / d verts[b], kept for backward;
+ *   counts (B+2 int32, or NULL): pairs found per batch element, then candidates / pairs dropped for lack of list space.
+ * chore_collision_bwd: dverts = gout[b] * gverts.  No host synchronisation, fixed launch grids (hipGraph-capturable),
+ * fixed-point accumulation (bit-reproducible).
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_collision_workspace_bytes(int B, int V, int F);
+int chore_collision_fwd(chore_handle* h, const float* verts, const int* faces, int B, int V, int F, float* loss,
+                        float* gverts, int* counts, void* workspace, chore_stream_t stream);
+int chore_collision_bwd(chore_handle* h, const float* gverts, const float* gout, int B, int V, float* dverts,
+                        chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Encoder layers as differentiable operators (training path).  Replace what torch autograd runs for
  * the reference's encoder modules: nn.Conv2d 3x3 / 1x1 (model/net_util.py:346-349, 356-372,
  * model/HGFilters.py:88-116), nn.GroupNorm(32, C) + F.relu (model/net_util.py:374-396, HGFilters.py:153-176),

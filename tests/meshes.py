@@ -1,0 +1,53 @@
+"""Small closed test meshes (no file I/O)."""
+import numpy as np
+
+
+def icosphere(subdiv=2, radius=1.0, center=(0.0, 0.0, 0.0)):
+    """(V,3) float64 vertices, (F,3) int64 faces of a subdivided icosahedron (F = 20 * 4**subdiv), outward winding"""
+    t = (1.0 + 5.0 ** 0.5) / 2.0
+    v = [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t),
+         (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]
+    f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6),
+         (7, 1, 8), (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7),
+         (9, 8, 1)]
+    v = [np.asarray(p, dtype=np.float64) / np.linalg.norm(p) for p in v]
+    for _ in range(subdiv):
+        cache, nf = {}, []
+
+        def mid(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in cache:
+                m = v[a] + v[b]
+                v.append(m / np.linalg.norm(m))
+                cache[key] = len(v) - 1
+            return cache[key]
+        for a, b, c in f:
+            ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+            nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+        f = nf
+    return np.asarray(v) * radius + np.asarray(center, dtype=np.float64), np.asarray(f, dtype=np.int64)
+
+
+def uv_ellipsoid(rings=82, segments=84, radii=(0.25, 0.85, 0.18), center=(0.0, 0.0, 0.0)):
+    """closed UV ellipsoid: V = 2 + rings * segments, F = 2 * segments * rings.  The defaults give a body-sized blob
+    with exactly the SMPL counts (6 890 vertices, 13 776 faces)."""
+    v = [(0.0, 1.0, 0.0)]
+    for r in range(1, rings + 1):
+        th = np.pi * r / (rings + 1)
+        for s in range(segments):
+            ph = 2 * np.pi * s / segments
+            v.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    v.append((0.0, -1.0, 0.0))
+    f = []
+    last = len(v) - 1
+    for s in range(segments):
+        f.append((0, 1 + (s + 1) % segments, 1 + s))
+        b = 1 + (rings - 1) * segments
+        f.append((last, b + s, b + (s + 1) % segments))
+    for r in range(rings - 1):
+        a, b = 1 + r * segments, 1 + (r + 1) * segments
+        for s in range(segments):
+            s1 = (s + 1) % segments
+            f.append((a + s, a + s1, b + s))
+            f.append((a + s1, b + s1, b + s))
+    return np.asarray(v) * np.asarray(radii) + np.asarray(center, dtype=np.float64), np.asarray(f, dtype=np.int64)
