@@ -101,13 +101,10 @@ class _CollisionFn(torch.autograd.Function):
         ws = torch.empty(_lib.lib.chore_collision_workspace_bytes(B, V, F_), dtype=torch.uint8, device=dev)
         loss = torch.empty(B, dtype=torch.float32, device=dev)
         gverts = torch.empty(B, V, 3, dtype=torch.float32, device=dev)
-        counts = torch.empty(B + 2, dtype=torch.int32, device=dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib.chore_collision_fwd(h, vc.data_ptr(), faces.data_ptr(), B, V, F_, loss.data_ptr(),
-                                                gverts.data_ptr(), counts.data_ptr(), ws.data_ptr(), stream), h,
-                   "chore_collision_fwd")
+                                                gverts.data_ptr(), None, ws.data_ptr(), stream), h, "chore_collision_fwd")
         ctx.save_for_backward(gverts)
-        ctx.counts = counts            # device tensor; read it only outside captured regions
         return loss
 
     @staticmethod

@@ -116,3 +116,72 @@ def test_body_sized_mesh():
     touched = np.zeros(grad.shape[1], bool)
     touched[faces.cpu().numpy()[pairs[0].ravel()].ravel()] = True
     assert (grad[0][~touched] == 0).all() and np.isfinite(grad).all() and np.abs(grad[0][touched]).max() > 0
+
+
+def _joint_fit(opt, use_graphs):
+    """object fit (object-only, then joint WITH the interpenetration term) around a rigid body-sized closed surface"""
+    import copy
+    from chore_amd.lib_smpl.priors import synthetic_priors
+    from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
+    from chore_amd.model import CHORE
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    from meshes import uv_ellipsoid
+    from test_gpu_query import nhwc
+    opt = copy.copy(opt)
+    opt.compute_dtype = "fp32"
+    B = 2
+    net = CHORE(opt).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    rs = np.random.RandomState(9)
+    net.im_feat_list = [nhwc((rs.standard_normal((B, 256, 32, 32)) * 0.5).astype(np.float32))]
+    net.tmpx = nhwc((rs.standard_normal((B, 64, 64, 64)) * 0.5).astype(np.float32))
+    # a synthetic SMPL-H whose template is a closed surface with SMPL's counts; zero pose / shape keep it rigid
+    body_v, body_f = uv_ellipsoid()
+    model = synth.synth_smplh_model(0)
+    model["v_template"] = body_v.astype(np.float32)
+    model["shapedirs"] = np.zeros_like(model["shapedirs"])
+    model["posedirs"] = np.zeros_like(model["posedirs"])
+    trans = np.array([[0.0, 0.3, 2.2], [0.05, 0.25, 2.3]], np.float32)
+    smpl = SMPLPyTorchWrapperBatch(model, B, betas=torch.zeros(B, 10), pose=torch.zeros(B, 156), trans=torch.from_numpy(trans),
+                                   faces=torch.from_numpy(body_f)).cuda()
+    obj_v, obj_f = icosphere(3, 0.3)
+    body_prior, hand_prior = synthetic_priors(0)
+    labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
+    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior,
+                               scan_verts=obj_v, scan_faces=obj_f)
+    fitter.use_graphs = use_graphs
+    fitter.adam_capturable = True
+    cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
+    obj = torch.from_numpy(np.stack([obj_v[rs.randint(0, len(obj_v), 3000)]] * B).astype(np.float32)).cuda()
+    t0 = trans + np.array([0.33, 0.1, 0.02], np.float32)
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1), objects=obj, smpl=smpl,
+                obj_R=torch.eye(3).repeat(B, 1, 1).cuda().requires_grad_(True),
+                obj_t=torch.from_numpy(t0).cuda().requires_grad_(True), obj_s=torch.ones(B).cuda().requires_grad_(True))
+    torch.manual_seed(11)
+    split = fitter.split_smpl(smpl)
+    data["smpl_center"] = fitter.compute_smpl_center_pred(data, net, smpl)
+    ld = fitter.forward_step(net, split, data, data["obj_R"], data["obj_t"], data["obj_s"], "joint",
+                             noise=torch.zeros(B, 3, 3).cuda())
+    collide0 = float(ld["collide"].detach())
+    verts0 = split()[0].detach().cpu().numpy()
+    del ld                                  # the loss dict holds the autograd graph (AccumulateGrad nodes of obj_t, ...)
+    fitter.release_graphs(split, net)()
+    _, R, t = fitter.optimize_smpl_object(net, data, obj_iter=1, joint_iter=2, steps_per_iter=5, max_iter=1)
+    return collide0, verts0, body_f, obj_v, obj_f, t0, [x.detach().cpu().numpy().copy() for x in (R, t, data["obj_s"])]
+
+
+def test_joint_phase_with_collision_graph_equals_eager(opt):
+    c_e, verts, body_f, obj_v, obj_f, t0, eager = _joint_fit(opt, False)
+    c_g, _, _, _, _, _, graph = _joint_fit(opt, True)
+    # the 'collide' entry of the joint phase is the oracle's value for the same meshes
+    ov = (np.stack([obj_v] * 2).astype(np.float32) + t0[:, None, :]).astype(np.float32)
+    want, pairs = oc.smpl_obj_collision(verts, body_f, ov, obj_f)
+    assert want > 0 and min(len(p) for p in pairs) > 10
+    assert abs(c_e - want) <= 2e-4 * want and c_e == c_g
+    for name, a, b in zip(("R", "t", "s"), eager, graph):
+        assert np.isfinite(b).all(), name
+        assert np.abs(a - b).max() < 1e-5, (name, np.abs(a - b).max())
+    assert np.abs(graph[1] - t0).max() > 1e-3
