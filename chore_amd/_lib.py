@@ -69,11 +69,11 @@ SIGNATURES = {
     "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "chore_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "chore_gn_stats_bytes": (c_size_t, [c_int]),
-    "chore_gn_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chore_gn_stats": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "chore_gn_relu_fwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p]),
     "chore_conv2d_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_conv2d_bwd_data": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                       c_void_p, c_void_p, c_void_p]),
     "chore_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
@@ -98,7 +98,7 @@ SIGNATURES = {
                                   c_void_p]),
     "chore_gn_relu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_gn_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
-                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "chore_collision_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -18,11 +18,13 @@ size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout) {
 size_t chore_gn_stats_bytes(int B) { return (size_t)B * GN_GROUPS * sizeof(GroupStat); }
 
 // statistics of x (B,HW,C) for GroupNorm(32, C): stats is zeroed and filled
-int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, chore_stream_t stream) {
+// (zeroed != 0: the caller hands in zeroed accumulators, e.g. a slice of an arena cleared once per pass)
+int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, int zeroed,
+                   chore_stream_t stream) {
     if (!h) return CHORE_EINVAL;
     if (!x || !stats || B <= 0 || HW <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_stats: bad argument");
     hipStream_t s = (hipStream_t)stream;
-    CHORE_HIP_CHECK(h, hipMemsetAsync(stats, 0, chore_gn_stats_bytes(B), s));
+    if (!zeroed) CHORE_HIP_CHECK(h, hipMemsetAsync(stats, 0, chore_gn_stats_bytes(B), s));
     View v; v.p = const_cast<void*>(x); v.cs = C; v.co = 0; v.C = C;
     return launch_gn_stats(h, dtype, v, B, HW, (GroupStat*)stats, s);
 }
@@ -37,10 +39,12 @@ int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* sta
     return launch_gn_apply_relu(h, dtype, vx, (const GroupStat*)stats, gamma, beta, vy, B, HW, (hipStream_t)stream);
 }
 
-// y (B,H,W,Cout) = conv_{taps}(a) + bias, a = relu(groupnorm(x)) if stats != NULL else x; stride 1, zero padding
+// y (B,H,W,Cout) = conv_{taps}(a) + bias, a = relu(groupnorm(x)) if stats != NULL else x; stride 1, zero padding.
+// out_stats (or NULL): ZEROED chore_gn_stats_bytes(B) accumulators that receive the statistics of y (of the values as
+// stored) from the convolution's epilogue -- what a following GroupNorm(32, Cout) needs, without a pass over y
 int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                      const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
-                     int Cout, void* y, void* workspace, chore_stream_t stream) {
+                     int Cout, void* y, void* out_stats, void* workspace, chore_stream_t stream) {
     if (!h) return CHORE_EINVAL;
     if (!x || !w || !y || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: null argument");
     if (stats && (!gamma || !beta)) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: GroupNorm needs gamma and beta");
@@ -53,6 +57,7 @@ int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B,
     a.wpk = workspace; a.bias = bias;
     a.out.p = y; a.out.cs = Cout; a.out.co = 0; a.out.C = Cout;
     a.B = B; a.H = H; a.W = W; a.Cout = Cout;
+    if (out_stats) { a.st_out = (GroupStat*)out_stats; a.st_out_C = Cout; a.st_out_co = 0; }
     return launch_conv(h, dtype, taps, a, s);
 }
 

@@ -738,13 +738,13 @@ size_t chore_gn_relu_bwd_workspace_bytes(int B, int C) { return ((size_t)B * GN_
 // da = gradient w.r.t. relu(groupnorm(x)) -> dx, dgamma (C), dbeta (C)
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                       const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
-                      chore_stream_t stream) {
+                      int workspace_zeroed, chore_stream_t stream) {
     if (!h) return CHORE_EINVAL;
     if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
     if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);
     hipStream_t s = (hipStream_t)stream;
-    CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, chore_gn_relu_bwd_workspace_bytes(B, C), s));
+    if (!workspace_zeroed) CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, chore_gn_relu_bwd_workspace_bytes(B, C), s));
     GnBwdAcc acc;
     acc.grp = (GroupStat*)workspace;
     acc.chan = acc.grp + (size_t)B * GN_GROUPS;

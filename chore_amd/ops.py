@@ -31,49 +31,102 @@ def _env(x):
     return dev, _lib.handle(dev.index or 0), _DT[x.dtype], torch.cuda.current_stream(dev).cuda_stream
 
 
+class ZeroArena:
+    """Zero-filled device memory handed out in slices: the statistics accumulators of the ~180 GroupNorms of a pass and
+    the accumulators of their backward passes have to start at zero; one fill per 4 MB replaces a fill per layer."""
+    CHUNK = 4 << 20
+
+    def __init__(self, dev):
+        self.dev, self.buf, self.off = dev, None, 0
+
+    def take(self, nbytes):
+        n = (int(nbytes) + 255) // 256 * 256
+        if self.buf is None or self.off + n > self.buf.numel():
+            self.buf, self.off = torch.zeros(max(self.CHUNK, n), dtype=torch.uint8, device=self.dev), 0
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+
+_arena = None
+
+
+class zero_arena:
+    """with ops.zero_arena(device): ...   -- the operators inside draw their zeroed accumulators from one arena"""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def __enter__(self):
+        global _arena
+        self.prev, _arena = _arena, ZeroArena(self.dev)
+        return _arena
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self.prev
+        return False
+
+
+def _zeros(nbytes, dev):
+    """(tensor of zero bytes, 1) from the active arena, else (uninitialised tensor, 0): the callee clears it itself"""
+    if _arena is not None and _arena.dev == dev:
+        return _arena.take(nbytes), 1
+    return _u8(nbytes, dev), 0
+
+
 def gn_stats(x):
     dev, h, dt, stream = _env(x)
     B, H, W, C = x.shape
-    st = _u8(_lib.lib.chore_gn_stats_bytes(B), dev)
-    _lib.check(_lib.lib.chore_gn_stats(h, dt, x.data_ptr(), B, H * W, C, st.data_ptr(), stream), h, "chore_gn_stats")
+    st, z = _zeros(_lib.lib.chore_gn_stats_bytes(B), dev)
+    _lib.check(_lib.lib.chore_gn_stats(h, dt, x.data_ptr(), B, H * W, C, st.data_ptr(), z, stream), h, "chore_gn_stats")
     return st
+
+
+def _bwd_acc(B, C, dev):
+    """zeroed accumulators for one GroupNorm backward, reserved at FORWARD time (the arena is live then)"""
+    if _arena is not None and _arena.dev == dev:
+        return _arena.take(_lib.lib.chore_gn_relu_bwd_workspace_bytes(B, C))
+    return None
 
 
 class _GNReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta):
+    def forward(ctx, x, gamma, beta, x_stats):
         dev, h, dt, stream = _env(x)
         B, H, W, C = x.shape
-        st = gn_stats(x)
+        st = gn_stats(x) if x_stats is None else x_stats
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty_like(x)
         _lib.check(_lib.lib.chore_gn_relu_fwd(h, dt, x.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), y.data_ptr(), B,
                                               H * W, C, stream), h, "chore_gn_relu_fwd")
         ctx.save_for_backward(x, st, g, b)
+        ctx.acc = _bwd_acc(B, C, dev)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, st, g, b = ctx.saved_tensors
-        dx, dg, db = _gn_relu_bwd(x, st, g, b, dy.contiguous().to(x.dtype))
-        return dx, dg, db
+        dx, dg, db = _gn_relu_bwd(x, st, g, b, dy.contiguous().to(x.dtype), ctx.acc)
+        ctx.acc = None
+        return dx, dg, db, None
 
 
-def _gn_relu_bwd(x, st, g, b, da):
+def _gn_relu_bwd(x, st, g, b, da, acc=None):
     dev, h, dt, stream = _env(x)
     B, H, W, C = x.shape
     dx = torch.empty_like(x)
     dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
-    ws = _u8(_lib.lib.chore_gn_relu_bwd_workspace_bytes(B, C), dev)
+    ws = acc if acc is not None else _u8(_lib.lib.chore_gn_relu_bwd_workspace_bytes(B, C), dev)
     _lib.check(_lib.lib.chore_gn_relu_bwd(h, dt, x.data_ptr(), st.data_ptr(), g.data_ptr(), b.data_ptr(), da.data_ptr(), B,
-                                          H * W, C, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), stream), h,
-               "chore_gn_relu_bwd")
+                                          H * W, C, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                          1 if acc is not None else 0, stream), h, "chore_gn_relu_bwd")
     return dx, dg, db
 
 
 class _ConvGN(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, w, bias, gamma, beta):
+    def forward(ctx, x, w, bias, gamma, beta, x_stats, want_stats):
         dev, h, dt, stream = _env(x)
         B, H, W, Cin = x.shape
         Cout, taps = w.shape[0], w.shape[2] * w.shape[3]
@@ -81,20 +134,28 @@ class _ConvGN(torch.autograd.Function):
         bf = None if bias is None else bias.detach().float().contiguous()
         st = g = b = None
         if gamma is not None:
-            st = gn_stats(x)
+            st = gn_stats(x) if x_stats is None else x_stats
             g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=dev)
+        # statistics of y from the convolution's epilogue (for the GroupNorm that consumes y): zeroed accumulators
+        st_y = torch.zeros(max(_lib.lib.chore_gn_stats_bytes(B), 16), dtype=torch.uint8, device=dev) \
+            if want_stats and _arena is None else (_arena.take(_lib.lib.chore_gn_stats_bytes(B)) if want_stats else None)
         ws = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cin, Cout), dev)
         _lib.check(_lib.lib.chore_conv2d_fwd(h, dt, taps, x.data_ptr(), B, H, W, Cin, None if st is None else st.data_ptr(),
                                              None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
                                              wf.data_ptr(), None if bf is None else bf.data_ptr(), Cout, y.data_ptr(),
-                                             ws.data_ptr(), stream), h, "chore_conv2d_fwd")
+                                             None if st_y is None else st_y.data_ptr(), ws.data_ptr(), stream), h,
+                   "chore_conv2d_fwd")
         ctx.has_gn, ctx.has_bias = gamma is not None, bias is not None
         ctx.save_for_backward(x, wf, *([st, g, b] if gamma is not None else []))
+        ctx.acc = _bwd_acc(B, Cin, dev) if gamma is not None else None
+        if want_stats:
+            ctx.mark_non_differentiable(st_y)
+            return y, st_y
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         x, wf = ctx.saved_tensors[:2]
         st, g, b = ctx.saved_tensors[2:] if ctx.has_gn else (None, None, None)
         dev, h, dt, stream = _env(x)
@@ -117,10 +178,11 @@ class _ConvGN(torch.autograd.Function):
             _lib.check(_lib.lib.chore_conv2d_bwd_data(h, dt, taps, dy.data_ptr(), B, H, W, Cout, wf.data_ptr(), Cin,
                                                       da.data_ptr(), ws2.data_ptr(), stream), h, "chore_conv2d_bwd_data")
             if ctx.has_gn:
-                dx, dg, db = _gn_relu_bwd(x, st, g, b, da)
+                dx, dg, db = _gn_relu_bwd(x, st, g, b, da, ctx.acc)
+                ctx.acc = None
             else:
                 dx = da
-        return dx, dw, dbias, dg, db
+        return dx, dw, dbias, dg, db, None, None
 
 
 class _UpAdd(torch.autograd.Function):
@@ -214,9 +276,11 @@ def upadd(a, low):
     return _UpAdd.apply(a, low)
 
 
-def conv_gn(x, w, bias=None, gamma=None, beta=None):
-    return _ConvGN.apply(x, w, bias, gamma, beta)
+def conv_gn(x, w, bias=None, gamma=None, beta=None, x_stats=None, want_stats=False):
+    """x_stats: statistics of x if the caller already has them (gn_stats(x), or the st_y of the conv that made x);
+    want_stats: also return the statistics of y, computed in the convolution's epilogue -> (y, st_y)"""
+    return _ConvGN.apply(x, w, bias, gamma, beta, x_stats, want_stats)
 
 
-def gn_relu(x, gamma, beta):
-    return _GNReLU.apply(x, gamma, beta)
+def gn_relu(x, gamma, beta, x_stats=None):
+    return _GNReLU.apply(x, gamma, beta, x_stats)

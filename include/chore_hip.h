@@ -282,14 +282,17 @@ int chore_collision_bwd(chore_handle* h, const float* gverts, const float* gout,
  * ------------------------------------------------------------------------------------------- */
 size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout);
 size_t chore_gn_stats_bytes(int B);
-int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, chore_stream_t stream);
+/* zeroed != 0: `stats` already holds zeros (a slice of an arena cleared once per pass) */
+int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, int zeroed,
+                   chore_stream_t stream);
 /* y = relu(groupnorm(x)) */
 int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
                       const float* beta, void* y, int B, int HW, int C, chore_stream_t stream);
-/* y (B,H,W,Cout) = conv(a) + bias (bias may be NULL) */
+/* y (B,H,W,Cout) = conv(a) + bias (bias may be NULL); out_stats (or NULL): ZEROED statistics accumulators filled with
+ * the statistics of y by the convolution's epilogue (for a GroupNorm(32, Cout) that follows) */
 int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                      const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
-                     int Cout, void* y, void* workspace, chore_stream_t stream);
+                     int Cout, void* y, void* out_stats, void* workspace, chore_stream_t stream);
 /* dx (B,H,W,Cin) = gradient w.r.t. the tensor the convolution saw (a) */
 int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, int B, int H, int W, int Cout,
                           const float* w, int Cin, void* dx, void* workspace, chore_stream_t stream);
@@ -302,7 +305,7 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
 size_t chore_gn_relu_bwd_workspace_bytes(int B, int C);
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
                       const float* beta, const void* da, int B, int HW, int C, void* dx, float* dgamma,
-                      float* dbeta, void* workspace, chore_stream_t stream);
+                      float* dbeta, void* workspace, int workspace_zeroed, chore_stream_t stream);
 /* y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C));  d_low = transpose of the upsampling applied to dy */
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
                     chore_stream_t stream);
