@@ -6,7 +6,7 @@ into a RuntimeError carrying chore_last_error().
 """
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_size_t, c_uint8, c_void_p
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
@@ -99,6 +99,12 @@ SIGNATURES = {
     "chore_gn_relu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_gn_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "chore_gen_compact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_gen_append": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),
+    "chore_gen_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_gen_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_int, c_float, c_void_p, c_void_p]),
     "chore_collision_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

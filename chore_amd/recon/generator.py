@@ -109,8 +109,15 @@ class Generator:
                 for t in ("human", "object")}
 
     def gen_pc_batch(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter=100, mute=False,
-                     rng=None):
-        """rng: optional (randint_fn, randn_fn) hooks so tests can replay recorded resampling draws"""
+                     rng=None, device_loop=True):
+        """device_loop=True (default): masks, per-example lists and resampling stay on the device (csrc/generator.hip),
+        the host reads one scalar per round; the resampling indices are floor(u * k) from DEVICE uniform numbers (the
+        reference draws torch.randint on the CPU: same distribution, different stream).  rng: optional hooks so tests
+        can inject the draws -- (uniform_fn(shape), randn_fn(shape)) here, (randint_fn(high, n), randn_fn(shape)) for the
+        host loop.
+        device_loop=False: the reference's control flow with its per-example host round trips (generator.py:149-188)."""
+        if device_loop:
+            return self._gen_pc_batch_device(model, df_type, samples_init, num_points, batch, num_steps, max_iter, mute, rng)
         query_input = self.prep_query_input(batch)
         k = 0 if df_type == "human" else 1
         bs = samples_init.shape[0]
@@ -150,6 +157,68 @@ class Generator:
             if it == max_iter:
                 raise RuntimeError("point generation failed after 100 iterations")
         self.compose_outdict(bs, out, names, count)
+        return out
+
+    def _gen_pc_batch_device(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter, mute, rng):
+        from .. import _lib
+        query_input = self.prep_query_input(batch)
+        k = 0 if df_type == "human" else 1
+        dev = self.device
+        h = _lib.handle(dev.index or 0)
+        L = _lib.lib
+        bs, sample_num = samples_init.shape[0], 20000
+        uniform = rng[0] if rng else (lambda shape: torch.rand(shape, device=dev))
+        randn = rng[1] if rng else (lambda shape: torch.randn(shape, device=dev))
+        init = samples_init.detach().to(dev).float().contiguous()
+        cap = int(num_points) + max(sample_num, init.shape[1])
+        chans = {"points": 3, "pca_axis": 9, "parts": 14, "centers": 6}
+        # channel-major result buffers (bs, C, cap); entries [offsets[b], ...) are appended every round
+        bufs = {n: torch.empty(bs, c, cap, device=dev) for n, c in chans.items()}
+        offsets = torch.zeros(bs, dtype=torch.int32, device=dev)
+        total = torch.zeros(1, dtype=torch.int32, device=dev)
+        samples = init.clone().requires_grad_(True)
+        it, count = 0, 0
+        while count < num_points:
+            surf, preds = self.approx_surface(model, samples, num_steps, query_input, df_type)
+            N = samples.shape[1]
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            df_t = torch.clamp(preds[0][:, k, :], max=self.threshold).detach()
+            mask = (df_t < self.filter_val).to(torch.uint8).contiguous()
+            order = torch.empty(bs, N, dtype=torch.int32, device=dev)
+            counts = torch.empty(bs, dtype=torch.int32, device=dev)
+            _lib.check(L.chore_gen_compact(h, mask.data_ptr(), bs, N, order.data_ptr(), counts.data_ptr(), stream), h,
+                       "chore_gen_compact")
+            if it > 0:
+                srcs = {"points": (surf.detach().float().contiguous(), (N * 3, 1, 3)),
+                        "pca_axis": (preds[1].detach().float().reshape(bs, 9, N).contiguous(), (9 * N, N, 1)),
+                        "parts": (preds[2].detach().float().contiguous(), (14 * N, N, 1)),
+                        "centers": (preds[3].detach().float().contiguous(), (6 * N, N, 1))}
+                for n, (src, (sb, sc, sn)) in srcs.items():
+                    c = chans[n]
+                    _lib.check(L.chore_gen_append(h, src.data_ptr(), sb, sc, sn, order.data_ptr(), counts.data_ptr(),
+                                                  offsets.data_ptr(), bufs[n].data_ptr(), c * cap, cap, 1, bs, c, N, cap, stream),
+                               h, "chore_gen_append")
+                _lib.check(L.chore_gen_advance(h, counts.data_ptr(), bs, offsets.data_ptr(), total.data_ptr(), stream), h,
+                           "chore_gen_advance")
+            u = uniform((bs, sample_num)).float().contiguous()
+            nz = randn((bs, sample_num, 3)).float().contiguous()
+            new = torch.empty(bs, sample_num, 3, device=dev)
+            cur = samples.detach()
+            _lib.check(L.chore_gen_resample(h, cur.data_ptr(), bs, N, order.data_ptr(), counts.data_ptr(), init.data_ptr(),
+                                            init.shape[1], u.data_ptr(), nz.data_ptr(), sample_num, float(self.threshold / 3),
+                                            new.data_ptr(), stream), h, "chore_gen_resample")
+            samples = new.requires_grad_(True)
+            if it > 0:
+                count = int(total.item())          # the one host read of the round: the loop condition
+                if not mute:
+                    print("{} points".format(count))
+            it += 1
+            if it == max_iter:
+                raise RuntimeError("point generation failed after 100 iterations")
+        out = {"points": bufs["points"][:, :, :count].permute(0, 2, 1).contiguous(),
+               "pca_axis": bufs["pca_axis"][:, :, :count].mean(-1).view(bs, 3, 3),
+               "parts": torch.argmax(bufs["parts"][:, :, :count], 1),
+               "centers": bufs["centers"][:, :, :count].mean(-1)}
         return out
 
     def compose_outdict(self, batch_size, out_dict, out_names, samples_count):

@@ -247,6 +247,28 @@ int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_in
                          chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Device-resident bookkeeping of the surface-point generator  (replaces the boolean-mask indexing, Python lists and CPU
+ * randint of Generator.gen_pc_batch / parse_preds, recon/generator.py:149-188, 190-217).
+ *   chore_gen_compact   order[b][j] = index of the j-th set byte of mask[b][0..N), counts[b] = number of set bytes
+ *                       (the order of x[mask]).
+ *   chore_gen_append    dst[b][c][offsets[b] + j] = src[b][c][order[b][j]] for j < counts[b]; element strides given for
+ *                       (b, c, n) of src and dst, so (B,N,3) and (B,C,N) tensors both fit; entries past `cap` dropped.
+ *   chore_gen_advance   offsets[b] += counts[b]; *total += min_b counts[b]   (generator.py:156-158).
+ *   chore_gen_resample  out (B,M,3): if counts[b] > 1, samples[b][order[b][floor(u * counts[b])]] + sigma * noise, else
+ *                       init[b][floor(u * Ninit)] + 0.5 * noise (generator.py:163-177); u (B,M) uniform in [0,1), noise
+ *                       (B,M,3) standard normal, both drawn by the caller on the device.
+ * ------------------------------------------------------------------------------------------- */
+int chore_gen_compact(chore_handle* h, const unsigned char* mask, int B, int N, int* order, int* counts,
+                      chore_stream_t stream);
+int chore_gen_append(chore_handle* h, const float* src, long long ss_b, long long ss_c, long long ss_n, const int* order,
+                     const int* counts, const int* offsets, float* dst, long long ds_b, long long ds_c, long long ds_n,
+                     int B, int C, int N, int cap, chore_stream_t stream);
+int chore_gen_advance(chore_handle* h, const int* counts, int B, int* offsets, int* total, chore_stream_t stream);
+int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, const int* order, const int* counts,
+                       const float* init, int Ninit, const float* u, const float* noise, int M, float sigma, float* out,
+                       chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Interpenetration term of the joint fit  (replaces ReconFitterBase.smpl_obj_collision recon/recon_fit_base.py:610-624 =
  * mesh_intersection.BVH(max_collisions=8) + DistanceFieldPenetrationLoss(sigma=0.5, point2plane=False), constructed at
  * :78-86).  PARITY UNPINNED: that package (github.com/vchoutas/torch-mesh-isect, no revision pinned) is not in the

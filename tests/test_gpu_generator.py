@@ -68,3 +68,58 @@ def test_gen_pc_batch_end_to_end(gen):
     assert out["parts"].shape == (B, n) and out["parts"].dtype == torch.int64
     assert out["pca_axis"].shape == (B, 3, 3) and out["centers"].shape == (B, 6)
     assert torch.isfinite(out["points"]).all()
+
+
+def test_device_loop_equals_host_loop(gen):
+    """the device-resident loop (csrc/generator.hip: ordered compaction, append, resample) reproduces the reference's
+    host-side control flow (boolean indexing, Python lists) when both consume the same uniform / normal draws"""
+    from chore_amd.utils import synth
+    rs = np.random.RandomState(5)
+    B = 2
+    gen.model.im_feat_list = [nhwc(rs.standard_normal((B, 256, 16, 16)).astype(np.float32))]
+    gen.model.tmpx = nhwc(rs.standard_normal((B, 64, 32, 32)).astype(np.float32))
+    init = torch.from_numpy(synth.synth_points(B, 3000, seed=6)).cuda()
+    batch = {"crop_center": torch.tensor([synth.CROP_CENTER] * B)}
+    g = torch.Generator().manual_seed(77)
+    U = [torch.rand(B, 20000, generator=g).cuda() for _ in range(12)]
+    Z = [torch.randn(B, 20000, 3, generator=g).cuda() for _ in range(12)]
+
+    def device_hooks():
+        st = {"u": 0, "z": 0}
+
+        def uniform(shape):
+            st["u"] += 1
+            return U[st["u"] - 1]
+
+        def randn(shape):
+            st["z"] += 1
+            return Z[st["z"] - 1]
+        return uniform, randn
+
+    def host_hooks():
+        st = {"u": 0, "z": 0}     # the host loop draws per example: example i of round r uses row i of U[r] / Z[r]
+
+        def randint(high, n):
+            r, i = divmod(st["u"], B)
+            st["u"] += 1
+            return torch.clamp(torch.floor(U[r][i] * float(high)), max=high - 1).long()
+
+        def randn(shape):
+            r, i = divmod(st["z"], B)
+            st["z"] += 1
+            return Z[r][i].view(shape)
+        return randint, randn
+
+    old = gen.filter_val
+    gen.filter_val = 1.0
+    try:
+        dev = gen.gen_pc_batch(gen.model, "object", init, 700, batch, num_steps=2, mute=True, rng=device_hooks())
+        host = gen.gen_pc_batch(gen.model, "object", init, 700, batch, num_steps=2, mute=True, rng=host_hooks(),
+                                device_loop=False)
+    finally:
+        gen.filter_val = old
+    assert dev["points"].shape == host["points"].shape and dev["points"].shape[1] >= 700
+    assert torch.equal(dev["points"], host["points"])
+    assert torch.equal(dev["parts"], host["parts"])
+    assert (dev["pca_axis"] - host["pca_axis"]).abs().max() < 1e-6
+    assert (dev["centers"] - host["centers"]).abs().max() < 1e-6
