@@ -99,6 +99,10 @@ SIGNATURES = {
     "chore_gn_relu_bwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_gn_relu_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "chore_eval_chamfer_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "chore_eval_chamfer": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_eval_procrustes": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "chore_eval_apply_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_gen_compact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_gen_append": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),

@@ -247,6 +247,22 @@ int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_in
                          chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Evaluation metrics, fp64  (replace recon/eval/chamfer_distance.py:10-52 = sklearn kd-tree nearest neighbours, and
+ * recon/eval/pose_utils.py compute_transform :145-180 / compute_similarity_transform :103-143).
+ *   chore_eval_chamfer   out[0] = mean_i min_j |x_i - y_j| (direction 'x_to_y'), out[1] = the other direction
+ *                        ('y_to_x'); 'bi' = out[0] + out[1].  Euclidean distances (not squared).  x (Nx,3), y (Ny,3) fp64.
+ *   chore_eval_procrustes  params[13] = R (row-major), t, scale of the similarity that takes S1 closest to S2
+ *                        (R = V Z U^T of K = X1 X2^T, det R = +1); chore_eval_apply_similarity: scale R p + t.
+ * ------------------------------------------------------------------------------------------- */
+size_t chore_eval_chamfer_workspace_bytes(int Nx, int Ny);
+int chore_eval_chamfer(chore_handle* h, const double* x, int Nx, const double* y, int Ny, double* out, void* workspace,
+                       chore_stream_t stream);
+int chore_eval_procrustes(chore_handle* h, const double* S1, const double* S2, int N, double* params,
+                          chore_stream_t stream);
+int chore_eval_apply_similarity(chore_handle* h, const double* pts, int N, const double* params, double* out,
+                                chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Device-resident bookkeeping of the surface-point generator  (replaces the boolean-mask indexing, Python lists and CPU
  * randint of Generator.gen_pc_batch / parse_preds, recon/generator.py:149-188, 190-217).
  *   chore_gen_compact   order[b][j] = index of the j-th set byte of mask[b][0..N), counts[b] = number of set bytes

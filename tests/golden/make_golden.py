@@ -470,7 +470,38 @@ def gen_fit(net):
     np.savez_compressed(os.path.join(HERE, "fit_trajectories.npz"), keys_a=np.array(keys_a), keys_b=np.array(keys_b), **out)
 
 
+def gen_eval():
+    """evaluation metrics: the reference's chamfer_distance (recon/eval/chamfer_distance.py:10-52,
+    sklearn kd-tree, float64) and Procrustes alignment (recon/eval/pose_utils.py:103-180) on seeded clouds"""
+    for m in ("psbody", "psbody.mesh"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    sys.modules["psbody.mesh"].Mesh = object
+    from recon.eval.chamfer_distance import chamfer_distance
+    from recon.eval.pose_utils import compute_transform, compute_similarity_transform, reconstruction_error
+    rs = np.random.RandomState(21)
+    x = rs.standard_normal((3000, 3)) * [0.3, 0.8, 0.2]
+    y = x[rs.permutation(3000)[:2500]] + rs.standard_normal((2500, 3)) * 0.01 + [0.02, -0.01, 0.0]
+    out = dict(x=x, y=y, cd_bi=chamfer_distance(x, y), cd_x_to_y=chamfer_distance(x, y, direction="x_to_y"),
+               cd_y_to_x=chamfer_distance(x, y, direction="y_to_x"))
+    # Procrustes: a rotated, scaled, shifted, noisy copy (one proper and one reflected, which exercises Z[-1,-1] = -1)
+    a = np.linalg.qr(rs.standard_normal((3, 3)))[0]
+    a *= np.sign(np.linalg.det(a))
+    s1 = rs.standard_normal((1500, 3)) * [0.3, 0.8, 0.2]
+    s2 = 1.3 * s1 @ a.T + [0.1, -0.2, 2.2] + rs.standard_normal((1500, 3)) * 0.005
+    refl = s1 * [1, 1, -1]
+    s2b = 0.7 * refl @ a.T + [0.0, 0.3, -0.1] + rs.standard_normal((1500, 3)) * 0.005
+    for tag, (p, q) in {"a": (s1, s2), "b": (s1, s2b)}.items():
+        R, t, scale, transposed = compute_transform(p, q)
+        out.update({f"s1_{tag}": p, f"s2_{tag}": q, f"R_{tag}": R, f"t_{tag}": t, f"scale_{tag}": np.float64(scale),
+                    f"hat_{tag}": compute_similarity_transform(p, q)})
+    out["recon_err"] = reconstruction_error(np.stack([s1, s1]), np.stack([s2, s2b]))
+    np.savez_compressed(os.path.join(HERE, "eval_metrics.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "eval":
+        gen_eval()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     net = ref_model(seed=0)
@@ -488,6 +519,7 @@ def main():
     gen_train_loss(net)
     gen_query_train(net)
     gen_train_grads(net)
+    gen_eval()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 
