@@ -144,8 +144,18 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid % WAVES_N, wm = wid / WAVES_N;
     const int tiles_x = (a.W + TW - 1) / TW;
-    const int ty0 = (blockIdx.x / tiles_x) * TH, tx0 = (blockIdx.x % tiles_x) * TW;
-    const int n_tile = blockIdx.y, b = blockIdx.z;
+    // XCD-aware placement: the dispatcher puts workgroup id on XCD id % 8 (each XCD has its own L2).  The logical order is
+    // (image, pixel tile, channel tile) with the channel tile fastest, and every XCD takes a CONTIGUOUS range of it: the
+    // channel tiles of one pixel tile -- which read the same halo patch -- and neighbouring pixel tiles share an L2
+    // (bijective for any grid size).  dbg bit 2048 switches it off for A/B measurements.
+    const int ntn = a.Cout / NT, tiles = tiles_x * ((a.H + TH - 1) / TH);
+    int lid = blockIdx.x;
+    if (!(a.dbg & 2048)) {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = lid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+    }
+    const int n_tile = lid % ntn, tileb = lid / ntn, tile = tileb % tiles, b = tileb / tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * TW;
     const int Cin = a.in.C;
     const bool use_gn = a.in_st != nullptr;
     const int NKG = Cin / KGE, NB = a.Cout / 32;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const char* a_ptr = patch + ((wm * MB) * PW + px) * ROWB + 16 * half;
     const char* b_ptr = bst + (wn * NBW) * 1024 + lane * 16;
 
-    const int crot = (blockIdx.x * 5 + blockIdx.y * 3) % NCH;
+    const int crot = (tile * 5 + n_tile * 3) % NCH;
     auto chunk_of = [&](int ci) -> int { int x = ci + crot; return x >= NCH ? x - NCH : x; };
 
     // ---- prologue: first chunk's patch and K-step 0 weights (and the next PD-1 chunks) ----
@@ -499,7 +509,7 @@ int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
         attr = true;
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
-    dim3 grid(tiles, a.Cout / NT, a.B);
+    dim3 grid(tiles * (a.Cout / NT) * a.B);
     hipLaunchKernelGGL((conv_lds_kernel<T, TAPS, NT, TPS_>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
