@@ -308,6 +308,12 @@ class CHORE(nn.Module):
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))
         self.intermediate_preds_list = []
+        if pts.shape[1] == 0:     # no points: empty predictions (what the reference's torch ops return), nothing to launch
+            B = pts.shape[0]
+            z = lambda *sh: pts.new_zeros(sh) + pts.sum() * 0     # noqa: E731  (keeps the graph connected)
+            self.intermediate_preds_list = [(z(B, 2, 0), z(B, 3, 3, 0), z(B, 14, 0), z(B, 6, 0)) for _ in self.im_feat_list]
+            self.preds = self.intermediate_preds_list[-1]
+            return
         for feat in self.im_feat_list:
             if train:
                 df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,

@@ -218,3 +218,31 @@ def test_training_backward_heads_and_feature_maps(opt):
                 close(gr.reshape(gr.shape[0], -1)[:16, :24], gg["c_" + name], name + " crop", tol=5e-5)
             n_checked += 1
     assert n_checked == 32
+
+
+@pytest.mark.parametrize("N", [1, 63, 65, 257])
+def test_ragged_point_counts(net, synth_sd, N):
+    """point counts that do not fill the 64-point tiles of the kernels: forward against the oracle, backward finite and
+    equal to the same points' gradients inside a full batch (tile padding must not leak)"""
+    g = golden("query_full.npz")
+    sub = dict(g, points=g["points"][:, :N].copy())
+    pts, (df, pca, parts, centers) = run_query(net, sub, requires_grad=True)
+    o = oq.query(sub["points"], g["crop_center"], g["feat"], g["tmpx"], synth_sd)
+    for k, v in dict(df=df, pca=pca, parts=parts, centers=centers).items():
+        assert v.shape[-1] == N
+        np.testing.assert_allclose(v.detach().cpu().numpy().reshape(o[k].shape), o[k], rtol=1e-5, atol=5e-5, err_msg=k)
+    (torch.clamp(df[:, 1], max=2.0).sum() + parts.sum() * 0.01).backward()
+    full, (df_f, _, parts_f, _) = run_query(net, g, requires_grad=True)
+    (torch.clamp(df_f[:, 1, :N], max=2.0).sum() + parts_f[:, :, :N].sum() * 0.01).backward()
+    assert torch.equal(pts.grad, full.grad[:, :N])
+
+
+def test_empty_query(net):
+    """zero points: empty predictions of the right shapes (what the reference's torch ops return), no launch"""
+    g = golden("query_full.npz")
+    net.im_feat_list = [nhwc(g["feat"])]
+    net.tmpx = nhwc(g["tmpx"])
+    B = g["points"].shape[0]
+    net.query(torch.zeros(B, 0, 3).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
+    df, pca, parts, centers = net.get_preds()
+    assert df.shape == (B, 2, 0) and pca.shape == (B, 3, 3, 0) and parts.shape == (B, 14, 0) and centers.shape == (B, 6, 0)
