@@ -498,9 +498,37 @@ def gen_eval():
     np.savez_compressed(os.path.join(HERE, "eval_metrics.npz"), **out)
 
 
+def gen_coco():
+    """the COCO variant of the fitter (recon/recon_fit_coco.py:32-74): keypoint mapping with the crop centre moved to
+    the mean crop centre, and its loss weights evaluated at (cst, it) = (2.0, 3)"""
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        _install_stub_finder()
+        from recon.recon_fit_coco import ReconFitterCoco
+        from model.camera import KinectColorCamera
+        f = ReconFitterCoco.__new__(ReconFitterCoco)
+        f.device, f.camera, f.net_in_size = "cpu", KinectColorCamera(1200), 512
+        rs = np.random.RandomState(31)
+        kpts = np.concatenate([rs.uniform(100, 1900, (3, 25, 2)), rs.uniform(0, 1, (3, 25, 1))], -1).astype(np.float32)
+        resize, crop = rs.uniform(0.8, 1.3, 3).astype(np.float32), rs.uniform(0.9, 1.4, 3).astype(np.float32)
+        centre = rs.uniform(700, 1300, (3, 2)).astype(np.float32)
+        out = f.scale_body_kpts(torch.from_numpy(kpts), torch.from_numpy(resize), torch.from_numpy(crop), torch.from_numpy(centre))
+        wd = f.get_loss_weights()
+        names = sorted(wd)
+        np.savez_compressed(os.path.join(HERE, "coco_fit.npz"), kpts=kpts, resize_scale=resize, crop_scale=crop,
+                            old_crop_center=centre, kpts_out=out.numpy(), weight_names=np.array(names),
+                            weights_at_2_3=np.array([float(wd[k](2.0, 3)) for k in names]))
+    finally:
+        os.chdir(cwd)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "eval":
         gen_eval()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "coco":
+        gen_coco()
         return
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -520,6 +548,7 @@ def main():
     gen_query_train(net)
     gen_train_grads(net)
     gen_eval()
+    gen_coco()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

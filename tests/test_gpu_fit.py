@@ -301,3 +301,19 @@ def test_fit_trajectories_match_reference(fit_setup):
 
     close([(obj_t.detach().cpu().numpy(), g["obj_t"]), (obj_s.detach().cpu().numpy(), g["obj_s"]),
            (rot(obj_R.detach().cpu().numpy()), rot(g["obj_R"]))], max_tol=1.2e-2)
+
+
+def test_coco_variant_matches_reference():
+    """ReconFitterCoco (recon/recon_fit_coco.py:32-74): keypoint mapping with the mean crop centre and the loss weights,
+    against values of the reference's own class (tests/golden/coco_fit.npz)"""
+    from conftest import golden
+    from chore_amd.recon.recon_fit_coco import ReconFitterCoco
+    g = golden("coco_fit.npz")
+    f = ReconFitterCoco(device="cuda:0")
+    t = lambda k: torch.from_numpy(g[k]).cuda()     # noqa: E731
+    out = f.scale_body_kpts(t("kpts"), t("resize_scale"), t("crop_scale"), t("old_crop_center"))
+    np.testing.assert_allclose(out.cpu().numpy(), g["kpts_out"], rtol=1e-6, atol=1e-3)
+    wd = f.get_loss_weights()
+    assert sorted(wd) == [str(k) for k in g["weight_names"]]
+    for k, v in zip(g["weight_names"], g["weights_at_2_3"]):
+        assert abs(float(wd[str(k)](2.0, 3)) - float(v)) <= 1e-12 * abs(float(v))
