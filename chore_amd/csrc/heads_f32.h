@@ -5,18 +5,18 @@
 
 constexpr int XS = 332;  // LDS row stride of the X tile in floats (332/4 odd -> conflict-free b128)
 
-template <typename T>
-__device__ __forceinline__ void gather_tile(float* X, const PtTable& tab, const T* feat_b,
+template <typename T, int PTS = QT_PTS>
+__device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, const T* feat_b,
                                             const T* tmpx_b, int wid, int lane) {
     using L = MapLoad<T>;
 #pragma unroll 1
-    for (int i = 0; i < QT_PTS / 4; i += 4) {
+    for (int i = 0; i < PTS / 4; i += 4) {
         f32x4 fv[4][4];
         float tv[4][4];
         float fw[4][4], tw[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pt = wid * (QT_PTS / 4) + i + u;
+            const int pt = wid * (PTS / 4) + i + u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int fo = tab.foff[k][pt];
@@ -30,7 +30,7 @@ __device__ __forceinline__ void gather_tile(float* X, const PtTable& tab, const 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pt = wid * (QT_PTS / 4) + i + u;
+            const int pt = wid * (PTS / 4) + i + u;
             f32x4 r;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -62,18 +62,18 @@ __device__ __forceinline__ f32x16 load_bias_frag(const float* arena, int head, i
 }
 
 // hidden layer 1: acc[rb][cb] = b1 + W1 * X^T     (K = 328 in 41 groups of 8)
-__device__ __forceinline__ void heads_layer1(f32x16 (&acc)[4][2], const float* X, const float* arena,
+template <int NCB>
+__device__ __forceinline__ void heads_layer1(f32x16 (&acc)[4][NCB], const float* X, const float* arena,
                                              int head, int lane) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const f32x16 bf = load_bias_frag(arena, head, 0, rb, half);
-        acc[rb][0] = bf;
-        acc[rb][1] = bf;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = bf;
     }
     const f32x4* A = (const f32x4*)(arena + QF_OFF_L1) + ((size_t)head * QF_KG * 4) * 64 + lane;
     const float* x0 = X + col * XS + 4 * half;
-    const float* x1 = X + (32 + col) * XS + 4 * half;
     f32x4 a_cur[4];
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) a_cur[rb] = A[rb * 64];
@@ -83,14 +83,15 @@ __device__ __forceinline__ void heads_layer1(f32x16 (&acc)[4][2], const float* X
         const int qn = (q + 1 < QF_KG) ? q + 1 : q;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb) a_nxt[rb] = A[(qn * 4 + rb) * 64];
-        const f32x4 xb0 = *(const f32x4*)(x0 + q * 8);
-        const f32x4 xb1 = *(const f32x4*)(x1 + q * 8);
+        f32x4 xb[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) xb[cb] = *(const f32x4*)(x0 + cb * 32 * XS + q * 8);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
 #pragma unroll
             for (int rb = 0; rb < 4; ++rb) {
-                acc[rb][0] = MFMA_F32(a_cur[rb][i], xb0[i], acc[rb][0]);
-                acc[rb][1] = MFMA_F32(a_cur[rb][i], xb1[i], acc[rb][1]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = MFMA_F32(a_cur[rb][i], xb[cb][i], acc[rb][cb]);
             }
         }
 #pragma unroll
@@ -99,14 +100,15 @@ __device__ __forceinline__ void heads_layer1(f32x16 (&acc)[4][2], const float* X
 }
 
 // hidden layers 2 and 3: out = b + W * relu(in), activations stay in registers
-__device__ __forceinline__ void heads_layer_hid(f32x16 (&out)[4][2], const f32x16 (&in)[4][2],
+template <int NCB>
+__device__ __forceinline__ void heads_layer_hid(f32x16 (&out)[4][NCB], const f32x16 (&in)[4][NCB],
                                                 const float* arena, int head, int layer /*1|2*/, int lane) {
     const int half = lane >> 5;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const f32x16 bf = load_bias_frag(arena, head, layer, rb, half);
-        out[rb][0] = bf;
-        out[rb][1] = bf;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = bf;
     }
     const f32x4* A = (const f32x4*)(arena + QF_OFF_L23) +
                      (((size_t)head * 2 + (layer - 1)) * 16 * 4) * 64 + lane;
@@ -119,12 +121,13 @@ __device__ __forceinline__ void heads_layer_hid(f32x16 (&out)[4][2], const f32x1
             for (int rb = 0; rb < 4; ++rb) a[rb] = A[((kb * 4 + rg) * 4 + rb) * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float b0 = relu(in[kb][0][rg * 4 + i]);
-                const float b1 = relu(in[kb][1][rg * 4 + i]);
+                float bv[NCB];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) bv[cb] = relu(in[kb][cb][rg * 4 + i]);
 #pragma unroll
                 for (int rb = 0; rb < 4; ++rb) {
-                    out[rb][0] = MFMA_F32(a[rb][i], b0, out[rb][0]);
-                    out[rb][1] = MFMA_F32(a[rb][i], b1, out[rb][1]);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = MFMA_F32(a[rb][i], bv[cb], out[rb][cb]);
                 }
             }
         }
@@ -132,12 +135,13 @@ __device__ __forceinline__ void heads_layer_hid(f32x16 (&out)[4][2], const f32x1
 }
 
 // output layer: out[cb] = b4 + W4 * relu(in)   (rows >= out_dim are zero padding)
-__device__ __forceinline__ void heads_layer_out(f32x16 (&out)[2], const f32x16 (&in)[4][2],
+template <int NCB>
+__device__ __forceinline__ void heads_layer_out(f32x16 (&out)[NCB], const f32x16 (&in)[4][NCB],
                                                 const float* arena, int head, int lane) {
     const int half = lane >> 5;
     const f32x16 bf = load_bias_frag(arena, head, 3, 0, half);
-    out[0] = bf;
-    out[1] = bf;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) out[cb] = bf;
     const f32x4* A = (const f32x4*)(arena + QF_OFF_L4) + ((size_t)head * 16) * 64 + lane;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
@@ -146,8 +150,8 @@ __device__ __forceinline__ void heads_layer_out(f32x16 (&out)[2], const f32x16 (
             const f32x4 a = A[(kb * 4 + rg) * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                out[0] = MFMA_F32(a[i], relu(in[kb][0][rg * 4 + i]), out[0]);
-                out[1] = MFMA_F32(a[i], relu(in[kb][1][rg * 4 + i]), out[1]);
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) out[cb] = MFMA_F32(a[i], relu(in[kb][cb][rg * 4 + i]), out[cb]);
             }
         }
     }

@@ -10,40 +10,43 @@
 // d(323-vector) are reduced through LDS in a fixed order, so the result is deterministic.
 #include "heads_f32.h"
 
-struct QueryBwdSmem {
-    float X[QT_PTS * XS];          // forward: feature tile; backward: d(feature) tile
-    float P[HEAD_NUM][32 * QT_PTS];  // per-head partial of one 32-row block, [row][pt]
-    PtTable tab;
+template <int PTS>
+struct QueryBwdSmemT {
+    float X[PTS * XS];             // forward: feature tile; backward: d(feature) tile
+    float P[HEAD_NUM][32 * PTS];   // per-head partial of one 32-row block, [row][pt]
+    PtTableT<PTS> tab;
 };
 
-__device__ __forceinline__ unsigned sign_mask(const f32x16& c0, const f32x16& c1) {
+template <int NCB>
+__device__ __forceinline__ unsigned sign_mask(const f32x16 (&c)[NCB]) {
     unsigned m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        m |= (c0[r] > 0.f ? 1u : 0u) << r;
-        m |= (c1[r] > 0.f ? 1u : 0u) << (16 + r);
-    }
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= (c[cb][r] > 0.f ? 1u : 0u) << (16 * cb + r);
     return m;
 }
-__device__ __forceinline__ void apply_mask(f32x16 (&d)[4][2], const unsigned (&m)[4]) {
+template <int NCB>
+__device__ __forceinline__ void apply_mask(f32x16 (&d)[4][NCB], const unsigned (&m)[4]) {
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) {
+    for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            d[rb][0][r] = ((m[rb] >> r) & 1u) ? d[rb][0][r] : 0.f;
-            d[rb][1][r] = ((m[rb] >> (16 + r)) & 1u) ? d[rb][1][r] : 0.f;
-        }
-    }
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[rb][cb][r] = ((m[rb] >> (16 * cb + r)) & 1u) ? d[rb][cb][r] : 0.f;
 }
 
 // d_prev = W^T * d_cur for a 128x128 layer; `which` = 0 -> W3 (3rd conv), 1 -> W2
-__device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][2], const f32x16 (&in)[4][2], const float* arena,
+template <int NCB>
+__device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][NCB], const f32x16 (&in)[4][NCB], const float* arena,
                                         int head, int which, int lane) {
     const f32x4* A = (const f32x4*)(arena + QB_OFF_L32T) + (((size_t)head * 2 + which) * 16 * 4) * 64 + lane;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { out[rb][0][r] = 0.f; out[rb][1][r] = 0.f; }
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[rb][cb][r] = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -53,13 +56,10 @@ __device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][2], const f32x16 (&in)[
             for (int rb = 0; rb < 4; ++rb) a[rb] = A[((kb * 4 + rg) * 4 + rb) * 64];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float b0 = in[kb][0][rg * 4 + i];
-                const float b1 = in[kb][1][rg * 4 + i];
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    out[rb][0] = MFMA_F32(a[rb][i], b0, out[rb][0]);
-                    out[rb][1] = MFMA_F32(a[rb][i], b1, out[rb][1]);
-                }
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = MFMA_F32(a[rb][i], in[kb][cb][rg * 4 + i], out[rb][cb]);
             }
         }
     }
@@ -89,23 +89,25 @@ __device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/
     }
 }
 
-template <typename T, bool TRAIN>
+template <typename T, bool TRAIN, int NCB = 2>
 __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
+    static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
+    constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    QueryBwdSmem& sm = *reinterpret_cast<QueryBwdSmem*>(smem_raw);
+    QueryBwdSmemT<PTS>& sm = *reinterpret_cast<QueryBwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
-    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
 
-    if (tid < QT_PTS)
+    if (tid < PTS)
         fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW,
                       nullptr);
     __syncthreads();
     const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
     const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
-    gather_tile<T>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    gather_tile<T, PTS>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
     __syncthreads();
 
     const float* arena = (const float*)a.arena;
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     const size_t row0 = (size_t)b * a.N + n0;                    // first point of the tile in the [B*N] staging rows
     const size_t plane = (size_t)a.B * a.N * HEAD_HID;           // one (layer, head) plane of tH / tdZ
     if constexpr (TRAIN) {
-        for (int i = tid; i < QT_PTS * (QF_KPAD / 4); i += 256) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
             if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
@@ -122,26 +124,26 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
 
     // ---- forward recompute, keep ReLU sign bits only ----
     unsigned m1[4], m2[4], m3[4];
-    f32x16 u[4][2], v[4][2];
-    heads_layer1(u, sm.X, arena, head, lane);
+    f32x16 u[4][NCB], v[4][NCB];
+    heads_layer1<NCB>(u, sm.X, arena, head, lane);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask(u[rb][0], u[rb][1]);
+    for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask<NCB>(u[rb]);
     if constexpr (TRAIN) store_tile(a.tH + (0 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
-    heads_layer_hid(v, u, arena, head, 1, lane);
+    heads_layer_hid<NCB>(v, u, arena, head, 1, lane);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask(v[rb][0], v[rb][1]);
+    for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask<NCB>(v[rb]);
     if constexpr (TRAIN) store_tile(a.tH + (1 * HEAD_NUM + head) * plane, v, true, row0, n0, a.N, lane);
-    heads_layer_hid(u, v, arena, head, 2, lane);
+    heads_layer_hid<NCB>(u, v, arena, head, 2, lane);
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask(u[rb][0], u[rb][1]);
+    for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask<NCB>(u[rb]);
     if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
 
     // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
     {
         const float* g = a.g[head];
-        float gb[2][16];
+        float gb[NCB][16];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
+        for (int cb = 0; cb < NCB; ++cb) {
             const int pt = cb * 32 + col;
             const int n = n0 + pt;
             const bool live = (g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
@@ -155,7 +157,9 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { v[rb][0][r] = 0.f; v[rb][1][r] = 0.f; }
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[rb][cb][r] = 0.f;
 #pragma unroll
         for (int sg = 0; sg < 4; ++sg) {
             f32x4 aw[4];
@@ -164,20 +168,19 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
 #pragma unroll
-                for (int rb = 0; rb < 4; ++rb) {
-                    v[rb][0] = MFMA_F32(aw[rb][i], gb[0][sg * 4 + i], v[rb][0]);
-                    v[rb][1] = MFMA_F32(aw[rb][i], gb[1][sg * 4 + i], v[rb][1]);
-                }
+                for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) v[rb][cb] = MFMA_F32(aw[rb][i], gb[cb][sg * 4 + i], v[rb][cb]);
             }
         }
     }
-    apply_mask(v, m3);
+    apply_mask<NCB>(v, m3);
     if constexpr (TRAIN) store_tile(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
-    bwd_hid(u, v, arena, head, 0, lane);  // d2 = W3^T d3
-    apply_mask(u, m2);
+    bwd_hid<NCB>(u, v, arena, head, 0, lane);  // d2 = W3^T d3
+    apply_mask<NCB>(u, m2);
     if constexpr (TRAIN) store_tile(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane);
-    bwd_hid(v, u, arena, head, 1, lane);  // d1 = W2^T d2
-    apply_mask(v, m1);
+    bwd_hid<NCB>(v, u, arena, head, 1, lane);  // d1 = W2^T d2
+    apply_mask<NCB>(v, m1);
     if constexpr (TRAIN) store_tile(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
 
     // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
@@ -185,9 +188,11 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     const f32x4* A1 = (const f32x4*)(arena + QB_OFF_L1T) + ((size_t)head * 16 * QB_RB1) * 64 + lane;
 #pragma unroll 1
     for (int rb = 0; rb < QB_RB1; ++rb) {
-        f32x16 dx0, dx1;
+        f32x16 dx[NCB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dx0[r] = 0.f; dx1[r] = 0.f; }
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
                 const f32x4 aw = A1[((kb * 4 + rg) * QB_RB1 + rb) * 64];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    dx0 = MFMA_F32(aw[i], v[kb][0][rg * 4 + i], dx0);
-                    dx1 = MFMA_F32(aw[i], v[kb][1][rg * 4 + i], dx1);
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) dx[cb] = MFMA_F32(aw[i], v[kb][cb][rg * 4 + i], dx[cb]);
                 }
             }
         }
@@ -204,14 +209,14 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = mfma32_row(r, half);
-            P[row * QT_PTS + col] = dx0[r];
-            P[row * QT_PTS + 32 + col] = dx1[r];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) P[row * PTS + cb * 32 + col] = dx[cb][r];
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < (32 * QT_PTS) / 256; ++e) {
+        for (int e = 0; e < (32 * PTS) / 256; ++e) {
             const int idx = e * 256 + tid;  // row-major [row][pt]
-            const int row = idx / QT_PTS, pt = idx % QT_PTS;
+            const int row = idx / PTS, pt = idx % PTS;
             const float s = ((sm.P[0][idx] + sm.P[1][idx]) + sm.P[2][idx]) + sm.P[3][idx];
             const int k = rb * 32 + row;
             if (k < QF_KPAD) sm.X[pt * XS + k] = s;
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     }
 
     if constexpr (TRAIN) {   // the d(323-vector) tile, consumed by the feature-map scatter
-        for (int i = tid; i < QT_PTS * (QF_KPAD / 4); i += 256) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
             if (n0 + pt < a.N) *(f32x4*)(a.tdX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
@@ -229,8 +234,8 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     // ---- taps again: d(value)/d(ix,iy), then the projection Jacobian ----
     using L = MapLoad<T>;
 #pragma unroll 1
-    for (int i = 0; i < QT_PTS / 4; ++i) {
-        const int pt = wid * (QT_PTS / 4) + i;
+    for (int i = 0; i < PTS / 4; ++i) {
+        const int pt = wid * (PTS / 4) + i;
         const float* drow = sm.X + pt * XS;
         float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
         {
@@ -284,19 +289,30 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     }
 }
 
-template <typename T, bool TRAIN>
-static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+template <typename T, bool TRAIN, int NCB>
+static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t smem = sizeof(QueryBwdSmem);
+    constexpr int PTS = 32 * NCB;
+    const size_t smem = sizeof(QueryBwdSmemT<PTS>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, NCB>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
-    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN>), grid, dim3(256), smem, s, a);
+    dim3 grid((a.N + PTS - 1) / PTS, a.B);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, NCB>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
+}
+
+bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64-point tiles would not fill the CUs
+
+template <typename T, bool TRAIN>
+static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    if constexpr (!TRAIN) {
+        if (query_small_tiles(a.B, a.N)) return launch_query_bwd_n<T, false, 1>(h, a, s);
+    }
+    return launch_query_bwd_n<T, TRAIN, 2>(h, a, s);
 }
 
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {

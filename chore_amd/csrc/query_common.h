@@ -82,23 +82,26 @@ __device__ __forceinline__ float interp4(float a, float b, float c, float d, con
     return fmaf(d, w[3], fmaf(c, w[2], fmaf(b, w[1], __fmul_rn(a, w[0]))));
 }
 
-// Per-tile point table kept in LDS (structure of arrays, QT_PTS entries each).
-struct PtTable {
-    float xyz[3][QT_PTS];   // x, y, z-2.2
-    int foff[4][QT_PTS];
-    float fw[4][QT_PTS];
-    int toff[4][QT_PTS];
-    float tw[4][QT_PTS];
-    int in_img[QT_PTS];
-    int valid[QT_PTS];
+// Per-tile point table kept in LDS (structure of arrays, PTS entries each).
+template <int PTS>
+struct PtTableT {
+    float xyz[3][PTS];   // x, y, z-2.2
+    int foff[4][PTS];
+    float fw[4][PTS];
+    int toff[4][PTS];
+    float tw[4][PTS];
+    int in_img[PTS];
+    int valid[PTS];
     // backward only: fractional tap coordinates (w, n) of both maps and the raw depth
-    float ffrac[2][QT_PTS];
-    float tfrac[2][QT_PTS];
-    float zraw[QT_PTS];
+    float ffrac[2][PTS];
+    float tfrac[2][PTS];
+    float zraw[PTS];
 };
+using PtTable = PtTableT<QT_PTS>;
 
-// thread `t` (< QT_PTS) fills entry t of the table
-__device__ __forceinline__ void fill_pt_table(PtTable& tab, int t, const float* points,
+// thread `t` (< PTS) fills entry t of the table
+template <typename Tab>
+__device__ __forceinline__ void fill_pt_table(Tab& tab, int t, const float* points,
                                               const float* crop_center, int b, int n, int N,
                                               const Cam& cam, int FH, int FW, int TH, int TW,
                                               float* nxy_out /* optional [2] */) {

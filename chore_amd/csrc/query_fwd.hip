@@ -13,21 +13,27 @@
 // (B,C,N) layout the reference API returns.
 #include "heads_f32.h"
 
-struct QueryFwdSmem {
-    float X[QT_PTS * XS];
-    PtTable tab;
+template <int PTS>
+struct QueryFwdSmemT {
+    float X[PTS * XS];
+    PtTableT<PTS> tab;
 };
+using QueryFwdSmem = QueryFwdSmemT<QT_PTS>;
 
-template <typename T>
+// NCB = 32-point column blocks per workgroup tile: 2 (64 points) for large queries; 1 for the small queries of the fit
+// loop (6 890 / 3 000 points give 108 / 47 tiles of 64: fewer workgroups than CUs, each a serial MFMA chain --
+// halving the tile halves that chain and doubles the workgroups)
+template <typename T, int NCB>
 __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
+    constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    QueryFwdSmem& sm = *reinterpret_cast<QueryFwdSmem*>(smem_raw);
+    QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
 
-    if (tid < QT_PTS) {
+    if (tid < PTS) {
         fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH,
                       a.TW, nullptr);
         if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
@@ -35,23 +41,23 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     __syncthreads();
     const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
     const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
-    gather_tile<T>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    gather_tile<T, PTS>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
     __syncthreads();
 
     const float* arena = (const float*)a.arena;
     const int head = wid;
-    f32x16 h1[4][2], h2[4][2];
-    heads_layer1(h1, sm.X, arena, head, lane);
-    heads_layer_hid(h2, h1, arena, head, 1, lane);
-    heads_layer_hid(h1, h2, arena, head, 2, lane);
-    f32x16 o[2];
-    heads_layer_out(o, h1, arena, head, lane);
+    f32x16 h1[4][NCB], h2[4][NCB];
+    heads_layer1<NCB>(h1, sm.X, arena, head, lane);
+    heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
+    heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
+    f32x16 o[NCB];
+    heads_layer_out<NCB>(o, h1, arena, head, lane);
 
     const int odim = head_out_dim(head);
     float* outp = a.out[head] + (size_t)b * odim * a.N;
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
+    for (int cb = 0; cb < NCB; ++cb) {
         const int pt = cb * 32 + col;
         const int n = n0 + pt;
         const bool inside = sm.tab.in_img[pt] != 0;
@@ -212,19 +218,28 @@ int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hi
     return CHORE_OK;
 }
 
-template <typename T>
-static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+template <typename T, int NCB>
+static int launch_query_fwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     static bool attr_set = false;
-    const size_t smem = sizeof(QueryFwdSmem);
+    constexpr int PTS = 32 * NCB;
+    const size_t smem = sizeof(QueryFwdSmemT<PTS>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, NCB>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
-    dim3 grid((a.N + QT_PTS - 1) / QT_PTS, a.B);
-    hipLaunchKernelGGL(query_fwd_f32_kernel<T>, grid, dim3(256), smem, s, a);
+    dim3 grid((a.N + PTS - 1) / PTS, a.B);
+    hipLaunchKernelGGL((query_fwd_f32_kernel<T, NCB>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
+}
+
+// 64-point tiles unless they would leave CUs without a workgroup
+bool query_small_tiles(int B, int N) { return (size_t)B * ((N + QT_PTS - 1) / QT_PTS) <= 256; }
+
+template <typename T>
+static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return query_small_tiles(a.B, a.N) ? launch_query_fwd_n<T, 1>(h, a, s) : launch_query_fwd_n<T, 2>(h, a, s);
 }
 
 int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
