@@ -25,6 +25,8 @@ Extra objects in the JSON line:
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process RCCL on this driver
 import sys
 import time
 

@@ -14,6 +14,8 @@ only collective is the final gather of the fitted parameters.
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process RCCL on this driver
 import sys
 import time
 

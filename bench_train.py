@@ -14,6 +14,8 @@ Prints ONE JSON line from rank 0 (steps/s of the whole job, weak scaling)."""
 import argparse
 import json
 import os
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process RCCL on this driver
 import sys
 import time
 
