@@ -116,7 +116,8 @@ template <int TAPS, int NT, int TPS_> struct Geo {
     static constexpr int SBYTES = TPS * KGC * (NT / 32) * 1024;     // weight bytes per K-step
     static constexpr int NBW = NT >= 64 ? 2 : 1;
     static constexpr int WAVES_N = (NT / 32) / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
-    static constexpr size_t main_bytes(int Cin) { return (size_t)ROWS * ROWB + 2 * SBYTES + (size_t)Cin * 8; }
+    static constexpr int NPATCH = (TPS_ == 9 && TAPS == 9) ? 2 : 1;   // small grids: double-buffered patch, one barrier per chunk
+    static constexpr size_t main_bytes(int Cin) { return (size_t)NPATCH * ROWS * ROWB + 2 * SBYTES + (size_t)Cin * 8; }
     static constexpr size_t epi_bytes() { return (size_t)4 * 32 * SCR_LD * 4 + (size_t)4 * WAVES_M * NT * 4; }
     static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
 };
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     constexpr int KROWS = TAPS / TPS;                   // K-steps per chunk (3 or 1)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* patch = smem;                                  // [ROWS][ROWB]
-    char* bst = smem + ROWS * ROWB;                      // [2][SBYTES]
+    constexpr int NPATCH = G::NPATCH, PATCHB = ROWS * ROWB;
+    char* patch = smem;                                  // [NPATCH][ROWS][ROWB]
+    char* bst = smem + NPATCH * PATCHB;                  // [2][SBYTES]
     float* ss_lds = (float*)(bst + 2 * SBYTES);          // [Cin][2]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
             pre[j] = *(const u32x4*)(in_b + off + c0 + v * VE);
         }
     };
-    auto write_patch = [&](const u32x4 (&pre)[NVP], int c0) {
+    auto write_patch = [&](const u32x4 (&pre)[NVP], int c0, int pbuf = 0) {
         float sc[VE], sh[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
@@ -201,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
             if (idx < ROWS * VPR) {
                 u32x4 val = {0u, 0u, 0u, 0u};
                 if (row_off[j] >= 0) val = xform<T>(pre[j], sc, sh, use_gn);
-                *(u32x4*)(patch + (idx >> 2) * ROWB + v * 16) = val;
+                *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * ROWB + v * 16) = val;
             }
         }
     };
@@ -268,9 +270,9 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // pair then waits a full LDS round trip (one wave per SIMD: nothing else hides it).
     constexpr int NKS = TPS * KGC;                     // k-steps (one MFMA K each) per K-step
     constexpr int FD = (NT >= 128 || NKS < 3) ? 1 : 2; // fragment prefetch distance
-    auto mfma_step = [&](int slot, int krow) {
+    auto mfma_step = [&](int slot, int krow, int pbuf = 0) {
         const char* bs = b_ptr + slot * SBYTES;
-        const char* ar = a_ptr + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
+        const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
         u32x4 af[FD + 1][MB], bf[FD + 1][NBW];
         auto load_frag = [&](int fs, int ks) {
             const int t = ks / KGC, kg = ks % KGC;
@@ -310,11 +312,17 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 if (!(a.dbg & 2)) load_patch(preq[u], chunk_of(cn) * CC);
                 if (!(a.dbg & 1)) load_w(rbq[u], chunk_of(cn), 0);
                 __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA block
-                if (!(a.dbg & 4)) mfma_step(c & 1, 0);
+                if (!(a.dbg & 4)) mfma_step(c & 1, 0, NPATCH == 2 ? (c & 1) : 0);
                 if (c + 1 < NCH) {
                     write_w(rbq[(u + 1) % PD], (c + 1) & 1);
-                    __syncthreads();   // every wave has finished reading this chunk's patch
-                    if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC);
+                    if constexpr (NPATCH == 2) {
+                        // the other patch buffer and ring slot were last read for chunk c-1, which every wave left
+                        // before the barrier that ended that iteration: no barrier needed before overwriting them
+                        if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC, (c + 1) & 1);
+                    } else {
+                        __syncthreads();   // every wave has finished reading this chunk's patch
+                        if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC);
+                    }
                 }
                 __syncthreads();
             }
@@ -505,7 +513,7 @@ int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     static bool attr = false;
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_lds_kernel<T, TAPS, NT, TPS_>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
         attr = true;
     }
     const int tiles = ((a.W + TW - 1) / TW) * ((a.H + TH - 1) / TH);
