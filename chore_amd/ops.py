@@ -138,8 +138,11 @@ class _ConvGN(torch.autograd.Function):
             g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=dev)
         # statistics of y from the convolution's epilogue (for the GroupNorm that consumes y): zeroed accumulators
-        st_y = torch.zeros(max(_lib.lib.chore_gn_stats_bytes(B), 16), dtype=torch.uint8, device=dev) \
-            if want_stats and _arena is None else (_arena.take(_lib.lib.chore_gn_stats_bytes(B)) if want_stats else None)
+        st_y = None
+        if want_stats:
+            nb = _lib.lib.chore_gn_stats_bytes(B)
+            st_y = _arena.take(nb) if (_arena is not None and _arena.dev == dev) else \
+                torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
         ws = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cin, Cout), dev)
         _lib.check(_lib.lib.chore_conv2d_fwd(h, dt, taps, x.data_ptr(), B, H, W, Cin, None if st is None else st.data_ptr(),
                                              None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),

@@ -57,3 +57,50 @@ def test_no_cpu_fallback(opt):
     m.im_feat_list = [torch.zeros(1, 256, 4, 4)]
     with pytest.raises(RuntimeError):
         m.query(torch.zeros(1, 8, 3), crop_center=torch.zeros(1, 2))
+
+
+def _prototypes():
+    """name -> (return type text, [parameter type texts]) parsed from the header"""
+    hdr = open(os.path.join(REPO, "include", "chore_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\n\s*([A-Za-z_][A-Za-z0-9_ \*]*?)\s*\b(chore_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr):
+        ret, name, params = m.group(1).strip(), m.group(2), m.group(3).strip()
+        ps = [] if params in ("", "void") else [re.sub(r"\s+", " ", p.strip()) for p in params.split(",")]
+        out[name] = (ret, ps)
+    return out
+
+
+def _kind(c_type_text):
+    """'ptr' / 'int' / 'size' / 'float' / 'i64' of a C parameter or return type"""
+    t = re.sub(r"\b[a-zA-Z_][a-zA-Z0-9_]*$", "", c_type_text).strip() if not c_type_text.endswith("*") else c_type_text
+    t = t or c_type_text
+    if "*" in t or "chore_stream_t" in t:
+        return "ptr"
+    if "size_t" in t:
+        return "size"
+    if "long long" in t or "int64_t" in t:
+        return "i64"
+    if "float" in t:
+        return "float"
+    return "int"
+
+
+def test_ctypes_signatures_match_the_header():
+    """argument count and kind (pointer / int / size_t / float / 64-bit) of every ctypes signature in chore_amd/_lib.py
+    against the prototype in include/chore_hip.h: a drifted signature corrupts the call silently"""
+    from chore_amd import _lib
+    kinds = {ctypes.c_int: "int", ctypes.c_size_t: "size", ctypes.c_float: "float", ctypes.c_longlong: "i64",
+             ctypes.c_int64: "i64", ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr"}
+
+    def k(ct):
+        return kinds.get(ct, "ptr")     # POINTER(...) types
+    protos = _prototypes()
+    assert len(protos) >= 60
+    for name, (ret, params) in protos.items():
+        res, args = _lib.SIGNATURES[name]
+        assert len(args) == len(params), (name, len(args), params)
+        got = [k(a) for a in args]
+        want = [_kind(p) for p in params]
+        assert got == want, (name, list(zip(params, got)))
+        assert k(res) == _kind(ret + " x"), (name, ret)
