@@ -43,10 +43,14 @@ SIGNATURES = {
                                        c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p]),
     "chore_query_train_bytes": (c_size_t, [c_int, c_int]),
+    "chore_query_fwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                      c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                      c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_void_p, c_void_p, c_void_p]),
     "chore_query_bwd_train": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                       c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p,
-                                      c_void_p, c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "chore_scatter_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                        POINTER(c_float), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "chore_encoder_arena_bytes": (c_size_t, [POINTER(EncoderCfg), c_int]),

@@ -155,11 +155,29 @@ static void train_staging(QueryArgs& a, void* staging) {
     a.tdX = a.tdZ + P * 3 * HEAD_NUM * HEAD_HID;
 }
 
+// the query forward of a training step: as chore_query_fwd, and the 323-vectors and ReLU outputs of the hidden layers go
+// to `staging` (chore_query_train_bytes) so that chore_query_bwd_train(have_forward = 1) recomputes nothing
+int chore_query_fwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                          const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
+                          float* centers, uint8_t* in_img, void* staging, chore_stream_t stream) {
+    if (!h) return CHORE_EINVAL;
+    if (!df || !pca || !parts || !centers || !staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: null output");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
+                             cam6_host);
+    if (rc) return rc;
+    a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
+    a.in_img = in_img;
+    train_staging(a, staging);
+    return launch_query_fwd_train(h, dtype, a, (hipStream_t)stream);
+}
+
 int chore_query_bwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
                           const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                           const void* heads_arena, const float* cam6_host, const float* g_df, const float* g_pca,
                           const float* g_parts, const float* g_centers, void* staging, float* dpoints,
-                          chore_stream_t stream) {
+                          int have_forward, chore_stream_t stream) {
     if (!h) return CHORE_EINVAL;
     if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
     QueryArgs a;
@@ -169,7 +187,7 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
     a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
     a.dpoints = dpoints;
     train_staging(a, staging);
-    return launch_query_bwd_train(h, dtype, a, (hipStream_t)stream);
+    return launch_query_bwd_train(h, dtype, a, (hipStream_t)stream, have_forward);
 }
 
 int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,

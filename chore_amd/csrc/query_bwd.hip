@@ -65,33 +65,33 @@ __device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][NCB], const f32x16 (&in
     }
 }
 
-// training staging: one wave stores its head's 128 x 64 activation (or gradient) tile as [point][channel] rows.
-// A D fragment holds, per lane, 4 runs of 4 consecutive channels of one point: four 16-byte stores per fragment.
-__device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/, const f32x16 (&f)[4][2], bool relu_it,
-                                           size_t row0, int n0, int N, int lane) {
+// masks of one hidden layer from the staged ReLU outputs ([point][128] rows of this head): bit 16 cb + r of m[rb]
+__device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, size_t row0, int n0, int N, int lane) {
     const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) m[rb] = 0u;
 #pragma unroll
     for (int cb = 0; cb < 2; ++cb) {
         const int pt = cb * 32 + col;
         if (n0 + pt >= N) continue;
-        float* row = base + (row0 + pt) * HEAD_HID;
+        const float* row = base + (row0 + pt) * HEAD_HID;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = {f[rb][cb][4 * j], f[rb][cb][4 * j + 1], f[rb][cb][4 * j + 2], f[rb][cb][4 * j + 3]};
-                if (relu_it) {
+                const f32x4 v = *(const f32x4*)(row + rb * 32 + 8 * j + 4 * half);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-                }
-                *(f32x4*)(row + rb * 32 + 8 * j + 4 * half) = v;
+                for (int e = 0; e < 4; ++e) m[rb] |= (v[e] > 0.f ? 1u : 0u) << (16 * cb + 4 * j + e);
             }
     }
 }
 
-template <typename T, bool TRAIN, int NCB = 2>
+// TRAIN: stage what the parameter gradients need.  STAGED (training only): the forward already staged the 323-vectors
+// and the ReLU outputs (chore_query_fwd_train), so nothing is recomputed -- the ReLU masks are read back instead.
+template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false>
 __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
+    static_assert(!STAGED || TRAIN, "STAGED is a training mode");
     constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryBwdSmemT<PTS>& sm = *reinterpret_cast<QueryBwdSmemT<PTS>*>(smem_raw);
@@ -107,24 +107,31 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     __syncthreads();
     const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
     const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
-    gather_tile<T, PTS>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
-    __syncthreads();
+    if constexpr (!STAGED) {
+        gather_tile<T, PTS>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+        __syncthreads();
+    }
 
     const float* arena = (const float*)a.arena;
     const int head = wid;
     const int odim = head_out_dim(head);
     const size_t row0 = (size_t)b * a.N + n0;                    // first point of the tile in the [B*N] staging rows
     const size_t plane = (size_t)a.B * a.N * HEAD_HID;           // one (layer, head) plane of tH / tdZ
-    if constexpr (TRAIN) {
+    if constexpr (TRAIN && !STAGED) {
         for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
             if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
     }
 
-    // ---- forward recompute, keep ReLU sign bits only ----
+    // ---- forward recompute, keep ReLU sign bits only (STAGED: read them back) ----
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
+    if constexpr (STAGED) {
+        load_masks(m1, a.tH + (0 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
+        load_masks(m2, a.tH + (1 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
+        load_masks(m3, a.tH + (2 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
+    } else {
     heads_layer1<NCB>(u, sm.X, arena, head, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask<NCB>(u[rb]);
@@ -137,6 +144,7 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask<NCB>(u[rb]);
     if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
+    }
 
     // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
     {
@@ -315,6 +323,21 @@ static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     return launch_query_bwd_n<T, TRAIN, 2>(h, a, s);
 }
 
+template <typename T>
+static int launch_query_bwd_staged_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryBwdSmemT<64>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, true, 2, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + 63) / 64, a.B);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, true, 2, true>), grid, dim3(256), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_bwd_t<float, false>(h, a, s);
 }
@@ -322,6 +345,7 @@ int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream
     return launch_query_bwd_t<unsigned short, false>(h, a, s);
 }
 
-int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {
+int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged) {
+    if (staged) return dtype == CHORE_F32 ? launch_query_bwd_staged_t<float>(h, a, s) : launch_query_bwd_staged_t<unsigned short>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_bwd_t<float, true>(h, a, s) : launch_query_bwd_t<unsigned short, true>(h, a, s);
 }

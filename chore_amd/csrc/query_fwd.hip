@@ -23,8 +23,10 @@ using QueryFwdSmem = QueryFwdSmemT<QT_PTS>;
 // NCB = 32-point column blocks per workgroup tile: 2 (64 points) for large queries; 1 for the small queries of the fit
 // loop (6 890 / 3 000 points give 108 / 47 tiles of 64: fewer workgroups than CUs, each a serial MFMA chain --
 // halving the tile halves that chain and doubles the workgroups)
-template <typename T, int NCB>
+// TRAIN: also stage the 323-vectors and the ReLU outputs of the hidden layers (tX, tH) for the backward pass
+template <typename T, int NCB, bool TRAIN = false>
 __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
+    static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
     constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
@@ -47,9 +49,19 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     const float* arena = (const float*)a.arena;
     const int head = wid;
     f32x16 h1[4][NCB], h2[4][NCB];
+    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID;
+    if constexpr (TRAIN) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
+            const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
+            if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
+        }
+    }
     heads_layer1<NCB>(h1, sm.X, arena, head, lane);
+    if constexpr (TRAIN) store_tile(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
     heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
+    if constexpr (TRAIN) store_tile(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
     heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
+    if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
     f32x16 o[NCB];
     heads_layer_out<NCB>(o, h1, arena, head, lane);
 
@@ -240,6 +252,24 @@ bool query_small_tiles(int B, int N) { return (size_t)B * ((N + QT_PTS - 1) / QT
 template <typename T>
 static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return query_small_tiles(a.B, a.N) ? launch_query_fwd_n<T, 1>(h, a, s) : launch_query_fwd_n<T, 2>(h, a, s);
+}
+
+template <typename T>
+static int launch_query_fwd_train_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryFwdSmemT<64>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, 2, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + 63) / 64, a.B);
+    hipLaunchKernelGGL((query_fwd_f32_kernel<T, 2, true>), grid, dim3(256), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {
+    return dtype == CHORE_F32 ? launch_query_fwd_train_t<float>(h, a, s) : launch_query_fwd_train_t<unsigned short>(h, a, s);
 }
 
 int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {

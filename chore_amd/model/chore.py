@@ -86,9 +86,9 @@ class _QueryFn(torch.autograd.Function):
 class _QueryTrainFn(torch.autograd.Function):
     """the query as a TRAINABLE node: gradients w.r.t. the head parameters and the two feature maps (and the points).
 
-    forward = chore_query_fwd; backward = chore_query_bwd_train (recompute + staging of activations / pre-activation
-    gradients), library GEMMs over the point dimension for the weight gradients, chore_scatter_features for the
-    maps.  `params` = 32 tensors: for df, part_predictor, pca_predictor, center_predictor the (weight, bias) of
+    forward = chore_query_fwd_train (stages the 323-vectors and ReLU outputs); backward = chore_query_bwd_train (no
+    recompute: masks read back; stages the pre-activation gradients), chore_heads_wgrad for the 32 parameter gradients,
+    chore_scatter_features for the maps.  `params` = 32 tensors: for df, part_predictor, pca_predictor, center_predictor the (weight, bias) of
     Sequential indices 0, 2, 4, 6 (the reference's make_decoder, model/chore.py:74-85)."""
 
     KORDER = (0, 1, 2, 3)          # module order above -> kernel head order df, parts, pca, centers
@@ -107,17 +107,19 @@ class _QueryTrainFn(torch.autograd.Function):
         centers = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
         in_img = torch.empty(B, N, device=dev, dtype=torch.uint8)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.lib.chore_query_fwd(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
-                                            tp, TH, TW, dtype, arena.data_ptr(), cam6, df.data_ptr(),
-                                            pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), in_img.data_ptr(),
-                                            stream), h, "chore_query_fwd")
-        ctx.save_for_backward(points, crop_center, feat, tmpx, arena, in_img)
+        # the forward stages the 323-vectors and the ReLU outputs for the backward (13.6 KB per point): nothing is recomputed
+        staging = torch.empty(_lib.lib.chore_query_train_bytes(B, N), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.chore_query_fwd_train(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
+                                                  tp, TH, TW, dtype, arena.data_ptr(), cam6, df.data_ptr(),
+                                                  pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), in_img.data_ptr(),
+                                                  staging.data_ptr(), stream), h, "chore_query_fwd_train")
+        ctx.save_for_backward(points, crop_center, feat, tmpx, arena, in_img, staging)
         ctx.cam6, ctx.dtype = cam6, dtype
         return df, pca, parts, centers
 
     @staticmethod
     def backward(ctx, g_df, g_pca, g_parts, g_centers):
-        points, crop_center, feat, tmpx, arena, in_img = ctx.saved_tensors
+        points, crop_center, feat, tmpx, arena, in_img, staging = ctx.saved_tensors
         B, N, _ = points.shape
         P = B * N
         dev = points.device
@@ -129,7 +131,6 @@ class _QueryTrainFn(torch.autograd.Function):
         g_pca = zero(9) if g_pca is None else g_pca.contiguous().float()
         g_parts = zero(14) if g_parts is None else g_parts.contiguous().float()
         g_centers = zero(6) if g_centers is None else g_centers.contiguous().float()
-        staging = torch.empty(_lib.lib.chore_query_train_bytes(B, N), dtype=torch.uint8, device=dev)
         need_pts = ctx.needs_input_grad[0]
         dpoints = torch.empty_like(points) if need_pts else None
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -137,7 +138,7 @@ class _QueryTrainFn(torch.autograd.Function):
                                                   TW, ctx.dtype, arena.data_ptr(), ctx.cam6, g_df.data_ptr(),
                                                   g_pca.data_ptr(), g_parts.data_ptr(), g_centers.data_ptr(),
                                                   staging.data_ptr(), None if dpoints is None else dpoints.data_ptr(),
-                                                  stream), h, "chore_query_bwd_train")
+                                                  1, stream), h, "chore_query_bwd_train")
         HD = 128
         # the df head sees no gradient where the point is outside the image (df is overwritten there, chore.py:147-150)
         g_df = g_df * in_img.unsqueeze(1).float()

@@ -132,11 +132,18 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
  * (B,TH,TW,64), fp32 NHWC, written (accumulate = 0) or added to (accumulate = 1); tile-gather, no atomics.
  * ------------------------------------------------------------------------------------------- */
 size_t chore_query_train_bytes(int B, int N);
+/* training forward: chore_query_fwd that also stages the 323-vectors and the ReLU outputs (X, H of the layout above) */
+int chore_query_fwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                          const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int map_dtype,
+                          const void* heads_arena, const float* camera, float* df, float* pca, float* parts,
+                          float* centers, uint8_t* in_img, void* staging, chore_stream_t stream);
+/* have_forward != 0: `staging` already holds X and H from chore_query_fwd_train of the same inputs; the backward
+ * then recomputes nothing (ReLU masks are read back) and only adds dZ and dX */
 int chore_query_bwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
                           const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int map_dtype,
                           const void* heads_arena, const float* camera, const float* g_df, const float* g_pca,
                           const float* g_parts, const float* g_centers, void* staging, float* dpoints,
-                          chore_stream_t stream);
+                          int have_forward, chore_stream_t stream);
 size_t chore_heads_wgrad_floats(void);
 size_t chore_heads_wgrad_workspace_bytes(void);
 int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
