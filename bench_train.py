@@ -55,6 +55,7 @@ def main():
     net = CHORE(opt).to(dev)
     synth.load_synth_weights(net, seed=0)
     net.train(True)
+    net.losses_on_host = False     # the six separate losses stay on the device: no host synchronisation inside the step
     model = net
     if world > 1:
         model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], find_unused_parameters=True)

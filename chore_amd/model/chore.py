@@ -208,6 +208,7 @@ class CHORE(nn.Module):
         self.loss_weights = [1.0, 1.0, 0.006, 500, 1000, 1000]
         self.camera = KinectColorCamera(opt.loadSize)
         self.OUT_DIST = 5.0
+        self.losses_on_host = True       # False: forward() leaves the 6 separate losses on the device (no sync)
         self._init_weights()
 
         self.im_feat_list = []
@@ -359,7 +360,9 @@ class CHORE(nn.Module):
             losses_all = losses_all + torch.stack([loss_h, loss_o, loss_parts, loss_pca, loss_smpl, loss_obj]).detach()
         n = len(self.intermediate_preds_list)
         error = error / n
-        losses_all = (losses_all / n).cpu()
+        losses_all = losses_all / n
+        if self.losses_on_host:          # the reference returns a CPU tensor (model/chore.py:226): one host sync per call
+            losses_all = losses_all.cpu()
         self.error_buffer = losses_all
         return error, losses_all
 
