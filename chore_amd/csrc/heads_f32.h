@@ -5,18 +5,18 @@
 
 constexpr int XS = 332;  // LDS row stride of the X tile in floats (332/4 odd -> conflict-free b128)
 
-template <typename T, int PTS = QT_PTS>
+template <typename T, int PTS = QT_PTS, int NW = 4>
 __device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, const T* feat_b,
                                             const T* tmpx_b, int wid, int lane) {
     using L = MapLoad<T>;
 #pragma unroll 1
-    for (int i = 0; i < PTS / 4; i += 4) {
+    for (int i = 0; i < PTS / NW; i += 4) {
         f32x4 fv[4][4];
         float tv[4][4];
         float fw[4][4], tw[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pt = wid * (PTS / 4) + i + u;
+            const int pt = wid * (PTS / NW) + i + u;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int fo = tab.foff[k][pt];
@@ -30,7 +30,7 @@ __device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, 
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int pt = wid * (PTS / 4) + i + u;
+            const int pt = wid * (PTS / NW) + i + u;
             f32x4 r;
 #pragma unroll
             for (int c = 0; c < 4; ++c)
@@ -157,14 +157,16 @@ __device__ __forceinline__ void heads_layer_out(f32x16 (&out)[NCB], const f32x16
     }
 }
 
-// training staging: one wave stores its head's 128 x 64 activation (or gradient) tile as [point][channel] rows.
+// training staging: one wave stores its head's 128 x (32 NCB) activation (or gradient) tile as [point][channel] rows;
+// pt0 = first point of this wave's column blocks inside the workgroup tile.
 // A D fragment holds, per lane, 4 runs of 4 consecutive channels of one point: four 16-byte stores per fragment.
-__device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/, const f32x16 (&f)[4][2], bool relu_it,
-                                           size_t row0, int n0, int N, int lane) {
+template <int NCB>
+__device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/, const f32x16 (&f)[4][NCB], bool relu_it,
+                                           size_t row0, int n0, int N, int lane, int pt0 = 0) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int pt = cb * 32 + col;
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int pt = pt0 + cb * 32 + col;
         if (n0 + pt >= N) continue;
         float* row = base + (row0 + pt) * HEAD_HID;
 #pragma unroll
@@ -180,4 +182,3 @@ __device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/
             }
     }
 }
-

@@ -9,6 +9,7 @@
 // MFMA scheme (D fragment of one GEMM = B fragment of the next).  The four heads' contributions to
 // d(323-vector) are reduced through LDS in a fixed order, so the result is deterministic.
 #include "heads_f32.h"
+#include <cstdlib>
 
 template <int PTS>
 struct QueryBwdSmemT {
@@ -66,13 +67,14 @@ __device__ __forceinline__ void bwd_hid(f32x16 (&out)[4][NCB], const f32x16 (&in
 }
 
 // masks of one hidden layer from the staged ReLU outputs ([point][128] rows of this head): bit 16 cb + r of m[rb]
-__device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, size_t row0, int n0, int N, int lane) {
+template <int NCB>
+__device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, size_t row0, int n0, int N, int lane, int pt0) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m[rb] = 0u;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int pt = cb * 32 + col;
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int pt = pt0 + cb * 32 + col;
         if (n0 + pt >= N) continue;
         const float* row = base + (row0 + pt) * HEAD_HID;
 #pragma unroll
@@ -88,11 +90,14 @@ __device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, 
 
 // TRAIN: stage what the parameter gradients need.  STAGED (training only): the forward already staged the 323-vectors
 // and the ReLU outputs (chore_query_fwd_train), so nothing is recomputed -- the ReLU masks are read back instead.
-template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false>
-__global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
-    static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
+// NW = 8 (NCB = 1): two waves per head, one 32-point column block each, of a 64-point tile -- two waves per SIMD hide
+// each other's weight / tap fetches (see query_fwd_f32_w8_kernel)
+template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) {
     static_assert(!STAGED || TRAIN, "STAGED is a training mode");
-    constexpr int PTS = 32 * NCB;
+    static_assert(NW == 4 || (NW == 8 && NCB == 1), "eight waves = two column blocks of one 32-point block each");
+    constexpr int PTS = 32 * NCB * (NW / 4), NT_ = NW * 64;
+    static_assert(!TRAIN || PTS == 64, "the training staging is written for 64-point tiles");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryBwdSmemT<PTS>& sm = *reinterpret_cast<QueryBwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,17 +113,17 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
     const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
     if constexpr (!STAGED) {
-        gather_tile<T, PTS>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+        gather_tile<T, PTS, NW>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
         __syncthreads();
     }
 
     const float* arena = (const float*)a.arena;
-    const int head = wid;
+    const int head = wid & 3, pt0 = (wid >> 2) * 32 * NCB;     // this wave's head and first point of its column blocks
     const int odim = head_out_dim(head);
     const size_t row0 = (size_t)b * a.N + n0;                    // first point of the tile in the [B*N] staging rows
     const size_t plane = (size_t)a.B * a.N * HEAD_HID;           // one (layer, head) plane of tH / tdZ
     if constexpr (TRAIN && !STAGED) {
-        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += NT_) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
             if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
@@ -128,22 +133,22 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
     if constexpr (STAGED) {
-        load_masks(m1, a.tH + (0 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
-        load_masks(m2, a.tH + (1 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
-        load_masks(m3, a.tH + (2 * HEAD_NUM + head) * plane, row0, n0, a.N, lane);
+        load_masks<NCB>(m1, a.tH + (0 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
+        load_masks<NCB>(m2, a.tH + (1 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
+        load_masks<NCB>(m3, a.tH + (2 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
     } else {
-    heads_layer1<NCB>(u, sm.X, arena, head, lane);
+    heads_layer1<NCB>(u, sm.X + pt0 * XS, arena, head, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask<NCB>(u[rb]);
-    if constexpr (TRAIN) store_tile(a.tH + (0 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane, pt0);
     heads_layer_hid<NCB>(v, u, arena, head, 1, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask<NCB>(v[rb]);
-    if constexpr (TRAIN) store_tile(a.tH + (1 * HEAD_NUM + head) * plane, v, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, v, true, row0, n0, a.N, lane, pt0);
     heads_layer_hid<NCB>(u, v, arena, head, 2, lane);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask<NCB>(u[rb]);
-    if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane, pt0);
     }
 
     // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
         float gb[NCB][16];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
-            const int pt = cb * 32 + col;
+            const int pt = pt0 + cb * 32 + col;
             const int n = n0 + pt;
             const bool live = (g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
 #pragma unroll
@@ -183,13 +188,13 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
         }
     }
     apply_mask<NCB>(v, m3);
-    if constexpr (TRAIN) store_tile(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0);
     bwd_hid<NCB>(u, v, arena, head, 0, lane);  // d2 = W3^T d3
     apply_mask<NCB>(u, m2);
-    if constexpr (TRAIN) store_tile(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane, pt0);
     bwd_hid<NCB>(v, u, arena, head, 1, lane);  // d1 = W2^T d2
     apply_mask<NCB>(v, m1);
-    if constexpr (TRAIN) store_tile(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0);
 
     // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
     __syncthreads();  // every wave is done reading X as the forward tile
@@ -218,12 +223,12 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
         for (int r = 0; r < 16; ++r) {
             const int row = mfma32_row(r, half);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) P[row * PTS + cb * 32 + col] = dx[cb][r];
+            for (int cb = 0; cb < NCB; ++cb) P[row * PTS + pt0 + cb * 32 + col] = dx[cb][r];
         }
         __syncthreads();
 #pragma unroll
-        for (int e = 0; e < (32 * PTS) / 256; ++e) {
-            const int idx = e * 256 + tid;  // row-major [row][pt]
+        for (int e = 0; e < (32 * PTS) / NT_; ++e) {
+            const int idx = e * NT_ + tid;  // row-major [row][pt]
             const int row = idx / PTS, pt = idx % PTS;
             const float s = ((sm.P[0][idx] + sm.P[1][idx]) + sm.P[2][idx]) + sm.P[3][idx];
             const int k = rb * 32 + row;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     }
 
     if constexpr (TRAIN) {   // the d(323-vector) tile, consumed by the feature-map scatter
-        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += NT_) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
             if (n0 + pt < a.N) *(f32x4*)(a.tdX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
@@ -242,8 +247,8 @@ __global__ __launch_bounds__(256, 1) void query_bwd_f32_kernel(QueryArgs a) {
     // ---- taps again: d(value)/d(ix,iy), then the projection Jacobian ----
     using L = MapLoad<T>;
 #pragma unroll 1
-    for (int i = 0; i < PTS / 4; ++i) {
-        const int pt = wid * (PTS / 4) + i;
+    for (int i = 0; i < PTS / NW; ++i) {
+        const int pt = wid * (PTS / NW) + i;
         const float* drow = sm.X + pt * XS;
         float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
         {
@@ -315,10 +320,32 @@ static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 
 bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64-point tiles would not fill the CUs
 
+// the eight-wave variants (64-point tile, two waves per head)
+template <typename T, bool TRAIN, bool STAGED>
+static int launch_query_bwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryBwdSmemT<64>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + 63) / 64, a.B);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8>), grid, dim3(512), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+static bool query_w4() { static const bool v = getenv("CHORE_QUERY_W4") != nullptr; return v; }   // A/B switch
+
 template <typename T, bool TRAIN>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if constexpr (!TRAIN) {
         if (query_small_tiles(a.B, a.N)) return launch_query_bwd_n<T, false, 1>(h, a, s);
+    }
+    // the training variants are bound by their staging stores: measured slower with eight waves (39.4 vs 38.6 ms per step)
+    if constexpr (!TRAIN) {
+        if (!query_w4()) return launch_query_bwd_w8<T, false, false>(h, a, s);
     }
     return launch_query_bwd_n<T, TRAIN, 2>(h, a, s);
 }

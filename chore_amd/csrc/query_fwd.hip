@@ -12,6 +12,7 @@
 // heads_pack.  Phase 4: masked (df[~in_img] = 5.0, model/chore.py:147-150) coalesced stores in the
 // (B,C,N) layout the reference API returns.
 #include "heads_f32.h"
+#include <cstdlib>
 
 template <int PTS>
 struct QueryFwdSmemT {
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
         }
     }
     heads_layer1<NCB>(h1, sm.X, arena, head, lane);
-    if constexpr (TRAIN) store_tile(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
     heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
-    if constexpr (TRAIN) store_tile(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
     heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
-    if constexpr (TRAIN) store_tile(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+    if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
     f32x16 o[NCB];
     heads_layer_out<NCB>(o, h1, arena, head, lane);
 
@@ -81,6 +82,55 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
                 if (head == 0 && !inside) v = 5.0f;
                 outp[(size_t)ch * a.N + n] = v;
             }
+        }
+    }
+}
+
+// Eight-wave variant for large queries: the same 64-point tile, but two waves per head, one 32-point column block each.
+// A wave of the four-wave kernel is stalled on weight / tap fetches ~40 % of its life (SQ_WAIT_ANY) with nothing else
+// resident on its SIMD; here every SIMD holds two waves (<= 256 registers each), the second wave of a head finds the
+// weight lines of the first in the L1, and the MFMA pipe stays busy while one of them waits.
+template <typename T>
+__global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
+    constexpr int PTS = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+    if (tid < PTS) {
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH,
+                      a.TW, nullptr);
+        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
+    }
+    __syncthreads();
+    const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
+    const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
+    gather_tile<T, PTS, 8>(sm.X, sm.tab, feat_b, tmpx_b, wid, lane);
+    __syncthreads();
+
+    const float* arena = (const float*)a.arena;
+    const int head = wid & 3, cb0 = wid >> 2;
+    f32x16 h1[4][1], h2[4][1];
+    heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
+    heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
+    heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
+    f32x16 o[1];
+    heads_layer_out<1>(o, h1, arena, head, lane);
+
+    const int odim = head_out_dim(head);
+    float* outp = a.out[head] + (size_t)b * odim * a.N;
+    const int half = lane >> 5, col = lane & 31;
+    const int pt = cb0 * 32 + col, n = n0 + pt;
+    const bool inside = sm.tab.in_img[pt] != 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int ch = mfma32_row(r, half);
+        if (ch < odim && n < a.N) {
+            float v = o[0][r];
+            if (head == 0 && !inside) v = 5.0f;
+            outp[(size_t)ch * a.N + n] = v;
         }
     }
 }
@@ -250,8 +300,25 @@ static int launch_query_fwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 bool query_small_tiles(int B, int N) { return (size_t)B * ((N + QT_PTS - 1) / QT_PTS) <= 256; }
 
 template <typename T>
+static int launch_query_fwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryFwdSmemT<64>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + 63) / 64, a.B);
+    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T>), grid, dim3(512), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+template <typename T>
 static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return query_small_tiles(a.B, a.N) ? launch_query_fwd_n<T, 1>(h, a, s) : launch_query_fwd_n<T, 2>(h, a, s);
+    static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switch: the four-wave kernel for large queries
+    if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1>(h, a, s);
+    return w4 ? launch_query_fwd_n<T, 2>(h, a, s) : launch_query_fwd_w8<T>(h, a, s);
 }
 
 template <typename T>
