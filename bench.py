@@ -170,7 +170,9 @@ def main():
         tpath = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % args.dtype)
         if os.path.exists(tpath):
             traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
-        qname = "query_fwd_f32_kernel<%s>" % tname
+        # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
+        # 32-point tiles when 64-point tiles would not fill the CUs)
+        qname = ("query_fwd_f32_kernel<%s, 1, false>" if B * ((N + 63) // 64) <= 256 else "query_fwd_f32_w8_kernel<%s>") % tname
         kernels[qname] = {"ms_per_step": qry_ms, "launches_per_step": 1,
                           "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
         dom = max((k for k in kernels if kernels[k]["tflops"]), key=lambda k: kernels[k]["ms_per_step"])
