@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
 // A wave of the four-wave kernel is stalled on weight / tap fetches ~40 % of its life (SQ_WAIT_ANY) with nothing else
 // resident on its SIMD; here every SIMD holds two waves (<= 256 registers each), the second wave of a head finds the
 // weight lines of the first in the L1, and the MFMA pipe stays busy while one of them waits.
-template <typename T>
+template <typename T, bool TRAIN = false>
 __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     constexpr int PTS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -113,9 +113,19 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     const float* arena = (const float*)a.arena;
     const int head = wid & 3, cb0 = wid >> 2;
     f32x16 h1[4][1], h2[4][1];
+    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID;
+    if constexpr (TRAIN) {
+        for (int i = tid; i < PTS * (QF_KPAD / 4); i += 512) {
+            const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
+            if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
+        }
+    }
     heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
+    if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
     heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
+    if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32);
     heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
+    if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
     f32x16 o[1];
     heads_layer_out<1>(o, h1, arena, head, lane);
 
@@ -304,12 +314,12 @@ static int launch_query_fwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t 
     static bool attr_set = false;
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, false>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + 63) / 64, a.B);
-    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, false>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -322,7 +332,23 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
 }
 
 template <typename T>
+static int launch_query_fwd_train_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(QueryFwdSmemT<64>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + 63) / 64, a.B);
+    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, true>), grid, dim3(512), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+template <typename T>
 static int launch_query_fwd_train_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    if (!getenv("CHORE_QUERY_W4")) return launch_query_fwd_train_w8<T>(h, a, s);
     static bool attr_set = false;
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
