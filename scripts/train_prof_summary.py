@@ -2,11 +2,11 @@
 
 usage: train_prof_summary.py <kernel_trace.csv> [marker] [marker_launches_per_step]
 Aggregates by kernel name over the SECOND HALF of the trace window (steady state: no first-touch work), counts the
-steps in that window from a marker kernel (default: query_fwd_f32_kernel, 5 launches per step = one per stack),
+steps in that window from a marker kernel (default: query_fwd_f32*, 5 launches per step = one per stack),
 reports launches and microseconds per step, and the busy / idle split of that window."""
 import csv, sys, collections, re
 rows = list(csv.DictReader(open(sys.argv[1])))
-marker = sys.argv[2] if len(sys.argv) > 2 else "query_fwd_f32_kernel"
+marker = sys.argv[2] if len(sys.argv) > 2 else "query_fwd_f32"
 per_step = float(sys.argv[3]) if len(sys.argv) > 3 else 5.0
 ev = []
 for r in rows:
