@@ -1,0 +1,37 @@
+"""Field-value error of a run against the reference's own outputs at BASELINE configs[1].
+
+tests/golden/config2_fields.npz holds what the reference (model/chore.py:87-154, torch fp32 on CPU) returned for the
+benchmark's rank-0 inputs -- the 4 synthetic 512x512 images and the first `n_points` of each image's 20 000 points.
+`field_errors` compares the predictions a `CHORE` holds after filter() + query() on those same inputs.  Used by
+tests/test_gpu_config2.py (where the tolerances are stated) and by bench.py (`config.field_err`): a fixture of numbers,
+no reference code and no oracle is involved.
+"""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden",
+                      "config2_fields.npz")
+
+# stated tolerances (absolute, on field values of magnitude O(1); df is in metres)
+TOL = {
+    "fp32": {"max_abs": 1e-4},                                   # north_star: "field values within 1e-4 of reference"
+    "bf16": {"max_abs": 0.25, "mean_abs": 2e-2, "rel_l2": 2.5e-2},   # bf16 feature maps / MFMA operands: a 1e-2 mode
+}
+
+
+def field_errors(preds, golden=None):
+    """preds: (df, pca, parts, centers) of a query whose first n_points per image are the golden's points.
+    -> {name: {max_abs, mean_abs, rel_l2}} + {"all": ...} over the four outputs"""
+    g = np.load(golden or GOLDEN)
+    K = int(g["n_points"])
+    out, num, den, worst, tot, cnt = {}, 0.0, 0.0, 0.0, 0.0, 0
+    for name, p in zip(("df", "pca", "parts", "centers"), preds):
+        got = p.detach().float().cpu().numpy()[..., :K].astype(np.float64)
+        ref = g[name].astype(np.float64)
+        d = np.abs(got - ref)
+        out[name] = {"max_abs": float(d.max()), "mean_abs": float(d.mean()),
+                     "rel_l2": float(np.sqrt((d ** 2).sum() / (ref ** 2).sum()))}
+        num += (d ** 2).sum(); den += (ref ** 2).sum(); worst = max(worst, d.max()); tot += d.sum(); cnt += d.size
+    out["all"] = {"max_abs": float(worst), "mean_abs": float(tot / cnt), "rel_l2": float(np.sqrt(num / den))}
+    return out

@@ -188,6 +188,23 @@ def gen_encoder(net_eval):
                         tmpx_crop=tmpx[:, :, 128:132, 200:204])
 
 
+def gen_config2(net):
+    """BASELINE configs[1] on the reference itself: CHORE.filter on the 4 synthetic 512x512 images of the benchmark
+    (rank 0 seeds) + CHORE.query at the first 768 of each image's 20 000 benchmark points (model/chore.py:87-154).
+    The field-value tolerance of every precision mode is stated against these values (tests/test_gpu_config2.py)."""
+    B, K = 4, 768
+    img = synth.synth_images(B, 512, 512, seed=0)
+    pts = synth.synth_points(B, 20000, seed=1)[:, :K].copy()
+    cc = np.array([synth.CROP_CENTER] * B, np.float32)
+    with torch.no_grad():
+        net.train(False)
+        net.filter(torch.from_numpy(img))
+        net.query(torch.from_numpy(pts), crop_center=torch.from_numpy(cc))
+        df, pca, parts, centers = [t.numpy() for t in net.get_preds()]
+    np.savez_compressed(os.path.join(HERE, "config2_fields.npz"), n_points=np.int64(K), df=df, pca=pca, parts=parts,
+                        centers=centers)
+
+
 def train_batch(seed=21, B=2, N=512):
     """synthetic training batch with the tensor contract of data/ (SURVEY 3.5); shared with the tests"""
     rs = np.random.RandomState(seed)
@@ -524,15 +541,20 @@ def gen_coco():
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "eval":
-        gen_eval()
-        return
-    if len(sys.argv) > 1 and sys.argv[1] == "coco":
-        gen_coco()
-        return
+    """no arguments: everything; otherwise the named generators (e.g. `make_golden.py config2 fit`)"""
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    todo = sys.argv[1:]
+    if todo == ["eval"]:
+        return gen_eval()
+    if todo == ["coco"]:
+        return gen_coco()
     net = ref_model(seed=0)
+    if todo:
+        for name in todo:
+            fn = globals()["gen_" + name]
+            fn(net) if fn.__code__.co_argcount else fn()
+        return
     # the state-dict contract the synthetic weights (and checkpoints) rely on
     spec = [(k, list(v.shape)) for k, v in net.state_dict().items()]
     json.dump(spec, open(os.path.join(HERE, "state_dict_spec.json"), "w"))
@@ -541,6 +563,7 @@ def main():
     gen_heads(net)
     gen_query(net)
     gen_encoder(net)
+    gen_config2(net)
     gen_surface(net)
     gen_smpl()
     gen_fit(net)
