@@ -70,7 +70,7 @@ def main():
                                    pose=torch.from_numpy(pose), trans=torch.from_numpy(trans)).to(dev)
     body_prior, hand_prior = synthetic_priors(0, device=dev)
     labels = torch.from_numpy(rs.randint(0, 14, 6890)).to(dev)
-    fitter = ReconFitterBehave(device=dev, part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    fitter = ReconFitterBehave.from_parts(device=dev, part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
     cc = torch.tensor([synth.CROP_CENTER] * B, device=dev)
     kpts = torch.from_numpy(np.concatenate([rs.uniform(100, 400, (B, 25, 2)), rs.uniform(0.2, 1, (B, 25, 1))], -1)
                             .astype(np.float32)).to(dev)

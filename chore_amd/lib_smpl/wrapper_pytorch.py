@@ -18,8 +18,21 @@ from .const import BODY_POSE_NUM, GLOBAL_POSE_NUM, HAND_POSE_NUM, SMPL_HAND_POSE
 from .smpl_layer import SMPL_Layer
 
 
-def _as_layer(model):
-    return model if isinstance(model, SMPL_Layer) else SMPL_Layer.from_arrays(model)
+def _as_layer(model, gender="male", num_betas=10):
+    """`model`: a SMPL_Layer, the model arrays (dict), or -- like the reference's `model_root` -- a folder that holds
+    SMPLH_<gender>.pkl / .npz (read by recon/assets.load_smpl_model)"""
+    if isinstance(model, SMPL_Layer):
+        return model
+    if isinstance(model, (str, bytes)) or hasattr(model, "__fspath__"):
+        import os
+        from ..recon.assets import load_smpl_model
+        root = os.fspath(model)
+        for ext in (".npz", ".pkl"):
+            f = os.path.join(root, f"SMPLH_{gender}{ext}")
+            if os.path.isfile(f):
+                return SMPL_Layer.from_arrays(load_smpl_model(f, num_betas), gender=gender)
+        raise FileNotFoundError(f"no SMPLH_{gender}.pkl / .npz under {root}")
+    return SMPL_Layer.from_arrays(model)
 
 
 def synthetic_regressors(V=6890, seed=0):
@@ -69,6 +82,19 @@ class _Landmarks:
         """drop the memo (it holds an autograd graph)"""
         self._memo = None
 
+    @property
+    def faces(self):
+        """(F,3) long triangle list: what the caller handed in, else the model's (the reference reads it from the model
+        file, wrapper_pytorch.py:63); follows the module across devices"""
+        f = self.__dict__.get("_faces")
+        if f is None:
+            return getattr(self.smpl, "th_faces", None)
+        return f.to(self.smpl.th_v_template.device) if torch.is_tensor(f) else f
+
+    @faces.setter
+    def faces(self, f):
+        self.__dict__["_faces"] = f
+
     def get_landmarks(self):
         verts = self.forward()[0]
         # one product for the three regressors (25 + 70 + 42 rows), split afterwards
@@ -82,7 +108,7 @@ class SMPLPyTorchWrapperBatch(nn.Module, _Landmarks):
     def __init__(self, model, batch_sz, betas=None, pose=None, trans=None, offsets=None, faces=None, gender="male",
                  hands=True, num_betas=10, regressors=None):
         super().__init__()
-        self.smpl = _as_layer(model)
+        self.smpl = _as_layer(model, gender, num_betas)
         self.model_root = self.smpl
         J3 = 3 * self.smpl.num_joints
         self.betas = nn.Parameter(torch.zeros(batch_sz, num_betas) if betas is None else betas)
@@ -105,7 +131,7 @@ class SMPLPyTorchWrapperBatchSplitParams(nn.Module, _Landmarks):
                  hand_pose=None, trans=None, offsets=None, faces=None, gender="male", hands=True, num_betas=10,
                  regressors=None):
         super().__init__()
-        self.smpl = _as_layer(model)
+        self.smpl = _as_layer(model, gender, num_betas)
         self.model_root = self.smpl
         hp = HAND_POSE_NUM if hands else SMPL_HAND_POSE_NUM
         z = torch.zeros
@@ -132,11 +158,18 @@ class SMPLPyTorchWrapperBatchSplitParams(nn.Module, _Landmarks):
 
     @staticmethod
     def from_smpl(smpl: SMPLPyTorchWrapperBatch):
+        """split wrapper whose parameters are VIEWS of `smpl`'s parameter storage, like in the reference
+        (wrapper_pytorch.py:199-218 wraps slices of smpl.pose.data / betas.data / trans.data in nn.Parameter; slicing
+        and the same-device .to() copy nothing).  The optimiser's in-place updates of the split parameters therefore
+        write through to `smpl` -- in particular the betas 2..9, which copy_smpl_params never copies back
+        (recon_fit_base.py:682-690), do arrive in the SMPL that optimize_smpl returns.  Writes through these views are
+        invisible to the version counters of `smpl`'s own parameters: call smpl.forget() before evaluating it again
+        (copy_smpl_params does)."""
         B = smpl.pose.shape[0]
         p, b = smpl.pose.data, smpl.betas.data
         g, bp = GLOBAL_POSE_NUM, GLOBAL_POSE_NUM + BODY_POSE_NUM
         return SMPLPyTorchWrapperBatchSplitParams(
-            smpl.smpl, B, trans=smpl.trans.data.clone(), top_betas=b[:, :TOP_BETA_NUM].clone(),
-            other_betas=b[:, TOP_BETA_NUM:].clone(), global_pose=p[:, :g].clone(), body_pose=p[:, g:bp].clone(),
-            hand_pose=p[:, bp:].clone(), faces=smpl.faces, gender=smpl.gender, hands=smpl.hands,
-            num_betas=b.shape[1], regressors=(smpl.body25_reg, smpl.face_reg, smpl.hand_reg)).to(smpl.device)
+            smpl.smpl, B, trans=smpl.trans.data, top_betas=b[:, :TOP_BETA_NUM], other_betas=b[:, TOP_BETA_NUM:],
+            global_pose=p[:, :g], body_pose=p[:, g:bp], hand_pose=p[:, bp:], faces=smpl.faces, gender=smpl.gender,
+            hands=smpl.hands, num_betas=b.shape[1], regressors=(smpl.body25_reg, smpl.face_reg, smpl.hand_reg)
+        ).to(smpl.device)

@@ -279,17 +279,9 @@ class CHORE(nn.Module):
         self.im_feat_list = feats
 
     def project_points(self, points, offsets):
-        """(B,N,3),(B,2) -> (B,3,N) normalised image coordinates + depth, op for op as
-        /root/reference/model/camera.py:44-88 (host-side helper; the query kernel projects itself)"""
-        c = self.camera
-        x, y, z = points[:, :, 0:1], points[:, :, 1:2], points[:, :, 2:3]
-        px = c.fx_px * x / z + c.cx_px
-        py = c.fy_px * y / z + c.cy_px
-        px = c.crop_size / 2 + px - offsets[:, 0].unsqueeze(1).unsqueeze(1)
-        py = c.crop_size / 2 + py - offsets[:, 1].unsqueeze(1).unsqueeze(1)
-        nx = 2 * px / c.crop_size - 1
-        ny = 2 * py / c.crop_size - 1
-        return torch.cat([nx, ny, z], -1).transpose(1, 2)
+        """(B,N,3),(B,2) -> (B,3,N) normalised image coordinates + depth (/root/reference/model/chore.py:98-105;
+        host-side helper -- the query kernel projects itself)"""
+        return self.camera.project_points(points, offsets)
 
     def query(self, points, crop_center=None, **kwargs):
         if crop_center is None:

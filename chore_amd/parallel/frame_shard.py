@@ -29,6 +29,13 @@ def frames_of_rank(num_frames, rank, world):
     return list(range(rank, num_frames, world))
 
 
+def shard_indices(num_items):
+    """the items (frames or loader batches) of THIS process: all of them without torch.distributed, rank::world with it"""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return frames_of_rank(num_items, dist.get_rank(), dist.get_world_size())
+    return list(range(num_items))
+
+
 def gather_fitted(local, num_frames, rank, world, device=None):
     """local: {name: tensor (n_local, ...)} for frames_of_rank(...) in order.  Returns on every rank
     {name: tensor (num_frames, ...)} in frame order.  One all_gather per parameter on padded blocks."""

@@ -1,0 +1,312 @@
+"""What the fitter reads from files, behind one injectable object.
+
+`ReconFitterBase.__init__` of the reference (/root/reference/recon/recon_fit_base.py:48-95) and `prep_smplfit`
+(:398-440) pull data from eight places on disk: the sequence's info.json (behave/seq_utils.py:11-58), the object template
+mesh (recon/opt_utils.py:56-71), assets/smpl_parts_dense.pkl (:277-287), the three landmark regressors
+(lib_smpl/body_landmark.py:16-28), the body / hand priors (lib_smpl/th_smpl_prior.py:41-47, th_hand_prior.py:17-42),
+the licensed SMPL-H pkl (lib_smpl/smplpytorch/.../smpl_layer.py:46-70), and per frame the FrankMocap json (:147-157)
+and the openpose json (:305-320).  The device path needs none of that I/O: the fitter takes a `FitAssets`.
+
+  FileAssets       reads the reference's own file formats from the folders PATHS.yml names (no psbody / trimesh / chumpy:
+                   a small PLY reader, pickles of numpy / scipy objects, and a shim that unpickles the chumpy arrays of
+                   the SMPL-H pkl without chumpy -- that last one cannot be exercised here, the pkl is a licensed
+                   download; an .npz with the same keys is accepted as well)
+  SyntheticAssets  deterministic stand-ins with the real shapes (tests, benchmarks, no files)
+"""
+import json
+import os
+import pickle as pkl
+
+import numpy as np
+
+from ..lib_smpl.priors import BodyPrior, HandPrior
+
+# template file of every BEHAVE object, relative to <BEHAVE_PATH>/../objects  (recon/opt_utils.py:33-54)
+MESH_TEMPLATE = {
+    "backpack": "backpack/backpack_f1000.ply", "basketball": "basketball/basketball_f1000.ply",
+    "boxlarge": "boxlarge/boxlarge_f1000.ply", "boxtiny": "boxtiny/boxtiny_f1000.ply",
+    "boxlong": "boxlong/boxlong_f1000.ply", "boxsmall": "boxsmall/boxsmall_f1000.ply",
+    "boxmedium": "boxmedium/boxmedium_f1000.ply", "chairblack": "chairblack/chairblack_f2500.ply",
+    "chairwood": "chairwood/chairwood_f2500.ply", "monitor": "monitor/monitor_closed_f1000.ply",
+    "keyboard": "keyboard/keyboard_f1000.ply", "plasticcontainer": "plasticcontainer/plasticcontainer_f1000.ply",
+    "stool": "stool/stool_f1000.ply", "tablesquare": "tablesquare/tablesquare_f2000.ply",
+    "toolbox": "toolbox/toolbox_f1000.ply", "suitcase": "suitcase/suitcase_f1000.ply",
+    "tablesmall": "tablesmall/tablesmall_f1000.ply", "yogamat": "yogamat/yogamat_f1000.ply",
+    "yogaball": "yogaball/yogaball_f1000.ply", "trashbin": "trashbin/trashbin_f1000.ply",
+}
+
+
+class FitAssets:
+    """interface; every method returns plain numpy / python values"""
+
+    def seq_info(self, seq_folder):
+        """-> (obj_name, gender) from <seq_folder>/info.json, or None when the file does not exist"""
+        return None
+
+    def template(self, obj_name):
+        """-> (verts (V,3) float64, faces (F,3) int64) of the object template, NOT centred"""
+        raise NotImplementedError
+
+    def part_labels(self):
+        """-> (6890,) int32 part label of every SMPL vertex"""
+        raise NotImplementedError
+
+    def priors(self, device):
+        """-> (body_prior, hand_prior) callables with tensors on `device`"""
+        raise NotImplementedError
+
+    def smpl_model(self, gender):
+        """-> dict(v_template, shapedirs, posedirs, J_regressor, weights, parents, f)"""
+        raise NotImplementedError
+
+    def regressors(self):
+        """-> dense (25,V), (70,V), (42,V) landmark regressors"""
+        raise NotImplementedError
+
+    def mean_hand_pose(self):
+        """-> (90,) mean left + right hand pose"""
+        raise NotImplementedError
+
+    def load_mocap(self, file):
+        """-> (pose (72 or 156,), betas (10,)) predicted by FrankMocap for one frame"""
+        params = json.load(open(file))
+        return np.array(params["pose"]), np.array(params["betas"])
+
+    def load_kpts(self, file):
+        """-> (25,3) openpose body keypoints (x, y, confidence) in the original image"""
+        return np.array(json.load(open(file))["body_joints"]).reshape((-1, 3))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def read_ply(path):
+    """vertices (V,3) float64 and triangle faces (F,3) int64 of an ascii / binary-little-endian PLY"""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a PLY file")
+        fmt, elems, cur = None, [], None
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated header")
+            w = line.decode("ascii").split()
+            if not w:
+                continue
+            if w[0] == "format":
+                fmt = w[1]
+            elif w[0] == "element":
+                cur = {"name": w[1], "count": int(w[2]), "props": []}
+                elems.append(cur)
+            elif w[0] == "property":
+                cur["props"].append(w[1:])
+            elif w[0] == "end_header":
+                break
+        dt = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
+              "double": "f8", "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4",
+              "float32": "f4", "float64": "f8"}
+        verts = faces = None
+        if fmt == "ascii":
+            toks = f.read().decode("ascii").split()
+            pos = 0
+            for e in elems:
+                if e["name"] == "vertex":
+                    n = len(e["props"])
+                    a = np.array(toks[pos:pos + n * e["count"]], np.float64).reshape(e["count"], n)
+                    names = [p[-1] for p in e["props"]]
+                    verts = a[:, [names.index(c) for c in "xyz"]]
+                    pos += n * e["count"]
+                elif e["name"] == "face":
+                    out = []
+                    for _ in range(e["count"]):
+                        k = int(toks[pos])
+                        out.append([int(t) for t in toks[pos + 1:pos + 1 + k]])
+                        pos += 1 + k
+                    faces = np.array(out, np.int64)
+                else:
+                    raise ValueError(f"{path}: unsupported element {e['name']}")
+        elif fmt == "binary_little_endian":
+            for e in elems:
+                if e["name"] == "vertex":
+                    rec = np.dtype([(p[-1], "<" + dt[p[0]]) for p in e["props"]])
+                    a = np.frombuffer(f.read(rec.itemsize * e["count"]), rec)
+                    verts = np.stack([a[c].astype(np.float64) for c in "xyz"], 1)
+                elif e["name"] == "face":
+                    p = e["props"][0]
+                    if p[0] != "list" or len(e["props"]) != 1:
+                        raise ValueError(f"{path}: unsupported face layout")
+                    cdt, idt = np.dtype("<" + dt[p[1]]), np.dtype("<" + dt[p[2]])
+                    raw = f.read()
+                    step = cdt.itemsize + 3 * idt.itemsize
+                    if len(raw) < step * e["count"] or any(raw[i * step] != 3 for i in (0, e["count"] - 1)):
+                        raise ValueError(f"{path}: only triangle meshes are supported")
+                    rec = np.dtype([("n", cdt), ("v", idt, (3,))])
+                    faces = np.frombuffer(raw[:step * e["count"]], rec)["v"].astype(np.int64)
+                else:
+                    raise ValueError(f"{path}: unsupported element {e['name']}")
+        else:
+            raise ValueError(f"{path}: unsupported PLY format {fmt}")
+    return verts, faces
+
+
+class _ChumpyShim:
+    """stands in for any chumpy class while unpickling: keeps the state, exposes the array as `.r`"""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"state": state})
+
+    @property
+    def r(self):
+        for k in ("x", "_x", "a"):
+            v = self.__dict__.get(k)
+            if v is not None:
+                return np.asarray(v.r if isinstance(v, _ChumpyShim) else v)
+        raise AttributeError("chumpy object without array state")
+
+
+class _ShimUnpickler(pkl.Unpickler):
+    def find_class(self, module, name):
+        if module.split(".")[0] == "chumpy":
+            return _ChumpyShim
+        return super().find_class(module, name)
+
+
+def load_smpl_model(path, num_betas=10):
+    """SMPL / SMPL-H model file -> arrays for lib_smpl.SMPL_Layer.from_arrays.  Accepts the licensed pkl (chumpy arrays,
+    unpickled through a shim; fields as in native/webuser/serialization.py:52-85) or an .npz with the same keys."""
+    if path.endswith(".npz"):
+        d = dict(np.load(path, allow_pickle=True))
+    else:
+        with open(path, "rb") as f:
+            d = _ShimUnpickler(f, encoding="latin1").load()
+    arr = lambda v: np.asarray(v.r if isinstance(v, _ChumpyShim) else (v.toarray() if hasattr(v, "toarray") else v))  # noqa: E731
+    kt = arr(d["kintree_table"])
+    return dict(v_template=arr(d["v_template"]).astype(np.float32),
+                shapedirs=arr(d["shapedirs"])[:, :, :num_betas].astype(np.float32),
+                posedirs=arr(d["posedirs"]).astype(np.float32), J_regressor=arr(d["J_regressor"]).astype(np.float32),
+                weights=arr(d["weights"]).astype(np.float32), parents=kt[0].astype(np.int64).tolist(),
+                f=arr(d["f"]).astype(np.int64))
+
+
+class FileAssets(FitAssets):
+    def __init__(self, smpl_assets_root, smpl_model_root=None, behave_path=None):
+        self.assets_root, self.model_root, self.behave_path = smpl_assets_root, smpl_model_root, behave_path
+
+    @classmethod
+    def from_paths_yml(cls, file="PATHS.yml"):
+        import yaml
+        p = yaml.safe_load(open(file))
+        return cls(p["SMPL_ASSETS_ROOT"], p.get("SMPL_MODEL_ROOT"), p.get("BEHAVE_PATH"))
+
+    def seq_info(self, seq_folder):
+        f = os.path.join(seq_folder, "info.json")
+        if not os.path.isfile(f):
+            return None
+        info = json.load(open(f))
+        return info["cat"], info["gender"]
+
+    def template(self, obj_name):
+        return read_ply(os.path.join(self.behave_path + "/../objects", MESH_TEMPLATE[obj_name]))
+
+    def part_labels(self):
+        parts = pkl.load(open(os.path.join(self.assets_root, "smpl_parts_dense.pkl"), "rb"))
+        labels = np.zeros((6890,), dtype="int32")
+        for n, k in enumerate(parts):
+            labels[parts[k]] = n
+        return labels
+
+    def priors(self, device):
+        return BodyPrior.from_assets(self.assets_root, device), HandPrior.from_assets(self.assets_root, device)
+
+    def regressors(self):
+        out = []
+        for n in ("body25", "face", "hand"):
+            r = pkl.load(open(os.path.join(self.assets_root, n + "_regressor.pkl"), "rb"), encoding="latin1").T
+            out.append(np.asarray(r.todense(), np.float32))
+        return out
+
+    def mean_hand_pose(self):
+        lh = pkl.load(open(os.path.join(self.assets_root, "priors", "lh_prior.pkl"), "rb"))
+        rh = pkl.load(open(os.path.join(self.assets_root, "priors", "rh_prior.pkl"), "rb"))
+        return np.concatenate([np.array(lh["mean"]), np.array(rh["mean"])])
+
+    def smpl_model(self, gender):
+        for ext in (".npz", ".pkl"):
+            p = os.path.join(self.model_root, f"SMPLH_{gender}{ext}")
+            if os.path.isfile(p):
+                return load_smpl_model(p)
+        raise FileNotFoundError(f"no SMPLH_{gender}.pkl / .npz under {self.model_root}")
+
+
+class SyntheticAssets(FitAssets):
+    """no files: the synthetic SMPL-H model / regressors / priors of chore_amd.utils.synth, a closed template mesh,
+    per-frame mocap / keypoint values drawn from the frame's path"""
+
+    def __init__(self, seed=0, template=None, obj_name="synthetic", gender="male", mocap=None, kpts=None,
+                 mean_hand_pose=None, part_labels=None):
+        self.seed, self.obj_name, self.gender = seed, obj_name, gender
+        self._template, self._mocap, self._kpts = template, mocap or {}, kpts or {}
+        self._mhp, self._labels = mean_hand_pose, part_labels
+
+    def seq_info(self, seq_folder):
+        return self.obj_name, self.gender
+
+    def template(self, obj_name):
+        if self._template is not None:
+            return self._template
+        # a closed box-like blob: octahedron subdivided three times, stretched
+        v = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], np.float64)
+        f = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+        v = [p for p in v]
+        for _ in range(3):
+            cache, nf = {}, []
+
+            def mid(a, b):
+                key = (min(a, b), max(a, b))
+                if key not in cache:
+                    m = v[a] + v[b]
+                    v.append(m / np.linalg.norm(m))
+                    cache[key] = len(v) - 1
+                return cache[key]
+            for a, b, c in f:
+                ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+                nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+            f = nf
+        return np.asarray(v) * np.array([0.35, 0.2, 0.12]) + 0.05, np.asarray(f, np.int64)
+
+    def part_labels(self):
+        if self._labels is not None:
+            return np.asarray(self._labels, np.int32)
+        return np.random.RandomState(8100 + self.seed).randint(0, 14, 6890).astype(np.int32)
+
+    def priors(self, device):
+        from ..lib_smpl.priors import synthetic_priors
+        return synthetic_priors(self.seed, device)
+
+    def smpl_model(self, gender):
+        from ..utils import synth
+        m = synth.synth_smplh_model(self.seed)
+        m["f"] = np.random.RandomState(8000 + self.seed).randint(0, 6890, (13776, 3)).astype(np.int64)
+        return m
+
+    def regressors(self):
+        from ..lib_smpl.wrapper_pytorch import synthetic_regressors
+        return synthetic_regressors(6890, self.seed)
+
+    def mean_hand_pose(self):
+        if self._mhp is not None:
+            return np.asarray(self._mhp)
+        return np.random.RandomState(8200 + self.seed).standard_normal(90) * 0.1
+
+    def load_mocap(self, file):
+        if file in self._mocap:
+            return self._mocap[file]
+        rs = np.random.RandomState(abs(hash(os.path.basename(os.path.dirname(file)))) % (2 ** 31))
+        return rs.standard_normal(72) * 0.2, rs.standard_normal(10) * 0.5
+
+    def load_kpts(self, file):
+        if file in self._kpts:
+            return self._kpts[file]
+        rs = np.random.RandomState(abs(hash(file)) % (2 ** 31))
+        return np.concatenate([rs.uniform(300, 1700, (25, 2)), rs.uniform(0, 1, (25, 1))], -1)

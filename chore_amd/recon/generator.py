@@ -124,8 +124,9 @@ class Generator:
         names = ["points", "pca_axis", "parts", "centers"]
         out = {n: [[] for _ in range(bs)] for n in names}
         sample_num = 20000
-        randint = rng[0] if rng else (lambda high, n: torch.randint(high, (n,), device=self.device))
-        randn = rng[1] if rng else (lambda shape: torch.randn(shape, device=self.device))
+        # the reference draws on the CPU (torch.randint / torch.randn, generator.py:168-177): same calls, same stream
+        randint = rng[0] if rng else (lambda high, n: torch.randint(high, (1, n))[0].to(self.device))
+        randn = rng[1] if rng else (lambda shape: torch.randn(shape).to(self.device))
         it, count = 0, 0
         samples = samples_init.clone().to(self.device).requires_grad_(True)
         while count < num_points:

@@ -9,7 +9,8 @@ with torch.cuda.graph (hipGraph on ROCm) and replayed.  What changes between rep
 the loss-weight decay, the previous loss, the stop flag, the index of the SO(3) perturbation noise.
 
 Both steppers implement the reference's update rule exactly (gradients accumulate over the inner steps of an
-outer iteration; the caller zeroes them through `begin_outer`).  Adam runs with capturable=True in the graph
+outer iteration; the caller zeroes them through `begin_outer`; the early-stop rule is tested after every inner step and
+everything after the step that meets it is a no-op, which equals the reference's immediate return).  Adam runs with capturable=True in the graph
 stepper (same formulas evaluated on the device).
 """
 import torch
@@ -32,30 +33,55 @@ class _OnePlusDecay:
 
 class EagerStep:
     def __init__(self, params, lr, loss_fn, tol, prev, betas=(0.9, 0.999), state=(), opt=None, release=None,
-                 capturable=False):
+                 capturable=False, carry=()):
         """opt: continue with an existing optimiser (a phase that only changes the loss, recon_fit_behave.py:252-254);
-        capturable: evaluate Adam's bias corrections on the device like the graph stepper does (bit-comparable runs)"""
+        capturable: evaluate Adam's bias corrections on the device like the graph stepper does (bit-comparable runs);
+        carry: parameters this phase does not step but whose .grad keeps accumulating (every leaf the loss reaches does in
+        the reference, and a later phase's new Adam starts from those sums, recon_fit_behave.py:243-259)"""
         self.params = list(params)
         self.opt = opt if opt is not None else optim.Adam(self.params, lr=lr, betas=betas, capturable=capturable)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
-        dev = self.params[0].device
+        self._init_flags(self.params[0].device)
+
+    def _init_flags(self, dev):
         self.denom = torch.ones((), device=dev)           # 1 + decay
-        self.stop = torch.zeros((), dtype=torch.bool, device=dev)
+        self.armed = torch.zeros((), dtype=torch.bool, device=dev)   # the early-stop rule is live in this outer iteration
+        self.stop = torch.zeros((), dtype=torch.bool, device=dev)    # latched: the reference has returned
         self.loss = torch.zeros((), device=dev)
 
-    def begin_outer(self, decay):
-        self.opt.zero_grad()
-        self.stop.zero_()
+    def zero_grads(self):
+        """what optimizer.zero_grad() did in the reference's torch (zero in place; the tensors stay: a recorded graph
+        accumulates into them)"""
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    def begin_outer(self, decay, armed=False, zero=True):
+        """top of an outer iteration (recon_fit_behave.py:117-118, 242-243).  zero=False: the first iteration of a phase
+        whose optimiser was re-created -- the reference zeroed through the PREVIOUS optimiser there"""
+        if zero:
+            self.zero_grads()
+        self.armed.fill_(bool(armed))
         self.denom.fill_(1 + decay)
 
     def _one(self):
+        # The reference returns from INSIDE the inner loop at the step that meets the stop rule, after that step's
+        # update (recon_fit_behave.py:158-160, 278-285).  Here the host looks at the flag once per outer iteration, so
+        # the remaining inner steps still run -- as no-ops: once `stop` is latched every later step leaves the
+        # parameters and the previous loss as they were.
+        frozen = self.stop.clone()
+        saved = [p.detach().clone() for p in self.params]
         loss = self.loss_fn(_OnePlusDecay(self.denom))
         loss.backward()
         self.opt.step()
-        lv = loss.detach()
-        self.stop.logical_or_(torch.abs(self.prev - lv) / self.prev < self.prev * self.tol)
-        self.prev.copy_(lv)
-        self.loss.copy_(lv)
+        with torch.no_grad():
+            for p, s in zip(self.params, saved):
+                p.copy_(torch.where(frozen, s, p))
+            lv = loss.detach()
+            hit = torch.abs(self.prev - lv) / self.prev < self.prev * self.tol
+            self.stop.logical_or_(hit & self.armed)
+            self.prev.copy_(torch.where(frozen, self.prev, lv))
+            self.loss.copy_(lv)
 
     def step(self):
         self._one()
@@ -69,21 +95,20 @@ class GraphedStep(EagerStep):
     noise index) -- they are snapshotted around the warm-up runs, which must not leave a trace in the fit."""
 
     def __init__(self, params, lr, loss_fn, tol, prev, betas=(0.9, 0.999), state=(), opt=None, release=None,
-                 capturable=True, warmup=2):
+                 capturable=True, warmup=2, carry=()):
         """release: drops every reference to autograd graphs of earlier steps (cached predictions, concatenated
         parameters).  The gradient accumulators of the parameters live as long as such a graph does and stay bound
         to the stream they were created on; recording needs them re-created on the capture stream."""
         self.params = list(params)
         dev = self.params[0].device
-        for p in self.params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
+        carry = [p for p in carry if all(p is not q for q in self.params)]
+        for p in self.params + carry:
+            if p.grad is None:       # a recorded backward must ADD into a tensor that exists (a missing .grad would be
+                p.grad = torch.zeros_like(p)   # replaced by a graph-private tensor and overwritten on every replay)
         self.opt = opt if opt is not None else optim.Adam(self.params, lr=lr, betas=betas, capturable=True)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
-        self.denom = torch.ones((), device=dev)
-        self.stop = torch.zeros((), dtype=torch.bool, device=dev)
-        self.loss = torch.zeros((), device=dev)
-        mutable = [p.data for p in self.params] + [p.grad for p in self.params] + [self.prev, self.stop, self.loss]
+        self._init_flags(dev)
+        mutable = [p.data for p in self.params] + [p.grad for p in self.params + carry] + [self.prev, self.stop, self.loss]
         mutable += list(state)
         mutable += [v for st in self.opt.state.values() for v in st.values() if torch.is_tensor(v)]   # continued Adam
         snap = [t.clone() for t in mutable]
@@ -114,12 +139,6 @@ class GraphedStep(EagerStep):
                         v.zero_()
         if self.release is not None:
             self.release()   # results memoised during the warm-up are stale now (.data writes bump no version)
-
-    def begin_outer(self, decay):
-        for p in self.params:
-            p.grad.zero_()   # in place: the graph accumulates into these tensors
-        self.stop.zero_()
-        self.denom.fill_(1 + decay)
 
     def step(self):
         self.graph.replay()

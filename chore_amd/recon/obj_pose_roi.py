@@ -133,12 +133,14 @@ def crop_and_resize(masks, boxes_xyxy, size):
 class SilLossROI(nn.Module):
     net_input_size = 512
 
-    def __init__(self, person_masks, obj_masks, temp_verts, temp_faces, crop_centers, rend_size=256, kernel_size=7,
+    def __init__(self, person_masks, obj_masks, temp_mesh, crop_centers, rend_size=256, kernel_size=7,
                  bbox_expansion=0.3, device="cuda:0", crop_size=1200):
-        """person_masks / obj_masks: (B,512,512) network-input masks; temp_verts (V,3) centred template,
-        temp_faces (F,3); crop_centers (B,2) in original-image pixels"""
+        """the reference's argument list (obj_pose_roi.py:21-29).  person_masks / obj_masks: (B,512,512) network-input
+        masks; temp_mesh: the centred template, an object with .v (V,3) and .f (F,3) or a (verts, faces) pair;
+        crop_centers (B,2) in original-image pixels"""
         super().__init__()
         dev = torch.device(device)
+        temp_verts, temp_faces = (temp_mesh.v, temp_mesh.f) if hasattr(temp_mesh, "v") else temp_mesh
         person_masks, obj_masks = torch.as_tensor(person_masks).to(dev), torch.as_tensor(obj_masks).to(dev)
         boxes = np.stack([mask2bbox(m.cpu().numpy()) for m in obj_masks])                       # xyxy
         xywh = np.concatenate([boxes[:, :2], boxes[:, 2:] - boxes[:, :2]], 1)

@@ -7,6 +7,10 @@ the same.  Heavy steps run in libchore_hip.so: the field queries (chore_query_fw
 (chore_smpl_lbs_*) and the SO(3) projection (chore_so3_project_*); the remaining terms are a few
 reductions over (B,N) tensors expressed with torch ops on the device.
 """
+import os
+import pickle as pkl
+
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -14,6 +18,28 @@ from .. import _lib
 from ..lib_smpl.const import SMPL_PARTS_NUM, SMPL_POSE_PRAMS_NUM  # noqa: F401
 from ..lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatchSplitParams
 from ..model.camera import KinectColorCamera
+
+
+# 14 body-part colours of the visualisations (recon/opt_utils.py:13-28)
+MTURK_COLORS = np.array([44, 160, 44, 31, 119, 180, 255, 127, 14, 214, 39, 40, 148, 103, 189, 140, 86, 75, 227, 119, 194,
+                         127, 127, 127, 189, 189, 34, 255, 152, 150, 23, 190, 207, 174, 199, 232, 255, 187, 120, 152, 223,
+                         138]).reshape((-1, 3)) / 255.
+
+
+def write_ply(path, verts, faces=None):
+    """binary little-endian PLY (float32 vertices, int32 triangle lists)"""
+    verts = np.asarray(verts, "<f4")
+    with open(path, "wb") as f:
+        hdr = ["ply", "format binary_little_endian 1.0", f"element vertex {len(verts)}", "property float x",
+               "property float y", "property float z"]
+        if faces is not None:
+            hdr += [f"element face {len(faces)}", "property list uchar int vertex_indices"]
+        f.write(("\n".join(hdr) + "\nend_header\n").encode("ascii"))
+        f.write(verts.tobytes())
+        if faces is not None:
+            rec = np.zeros(len(faces), np.dtype([("n", "u1"), ("v", "<i4", (3,))]))
+            rec["n"], rec["v"] = 3, np.asarray(faces)
+            f.write(rec.tobytes())
 
 
 class _SO3Fn(torch.autograd.Function):
@@ -121,23 +147,220 @@ class _CollisionFn(torch.autograd.Function):
         return dverts, None
 
 
+class _Scan:
+    """object template: .v (V,3) float64 centred vertices, .f (F,3) int64 faces (the two attributes of psbody's Mesh
+    the reference uses)"""
+
+    def __init__(self, v, f):
+        self.v, self.f = np.asarray(v, np.float64), np.asarray(f, np.int64)
+
+
+def sample_surface(verts, faces, count, rs):
+    """`count` points uniformly on the triangle mesh (area-weighted triangle choice + uniform barycentric point) -- what
+    trimesh.Trimesh.sample does (recon_fit_base.py:120-121), drawn from the numpy RandomState `rs`"""
+    tri = verts[faces]
+    area = 0.5 * np.linalg.norm(np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]), axis=1)
+    idx = np.searchsorted(np.cumsum(area), rs.random_sample(count) * area.sum())
+    idx = np.minimum(idx, len(faces) - 1)
+    u, v = rs.random_sample(count), rs.random_sample(count)
+    flip = u + v > 1
+    u, v = np.where(flip, 1 - u, u), np.where(flip, 1 - v, v)
+    t = tri[idx]
+    return t[:, 0] + u[:, None] * (t[:, 1] - t[:, 0]) + v[:, None] * (t[:, 2] - t[:, 0])
+
+
 class ReconFitterBase:
-    def __init__(self, device="cuda:0", net_in_size=512, crop_size=1200, z_0=2.2, obj_scale=1.0, part_labels=None,
-                 body_prior=None, hand_prior=None, debug=False, scan_verts=None, scan_faces=None):
-        # template mesh of the object (self.scan.v / self.scan.f in the reference, recon_fit_base.py:79): needed by the
-        # interpenetration term only
-        self.scan_verts = None if scan_verts is None else torch.as_tensor(scan_verts, dtype=torch.float32,
-                                                                          device=device)
-        self.scan_faces = None if scan_faces is None else torch.as_tensor(scan_faces, dtype=torch.long, device=device)
-        self._comb_faces = None
+    def __init__(self, seq_folder=None, device="cuda:0", debug=False, obj_name=None, outpath=None, args=None,
+                 assets=None):
+        """the reference's argument list (recon_fit_base.py:48-52) + `assets`: where the files it reads come from
+        (recon/assets.py; default: the folders of ./PATHS.yml like the reference).  Everything loaded here -- template
+        PCA axes and surface samples, part labels, priors -- lands on the device once."""
+        from .assets import FileAssets
+        self.seq_folder, self.outpath = seq_folder, outpath
+        self.assets = assets if assets is not None else FileAssets.from_paths_yml()
+        info = self.assets.seq_info(seq_folder) if seq_folder is not None else None
+        if info is None:
+            if obj_name is None:
+                raise AssertionError("must provide the name of the object to be reconstructed!")
+            self.gender = "male"
+        else:
+            obj_name, self.gender = info
+        self._init_common(device, debug)
+        pca_init, obj_points = self.compute_pca_init(obj_name)
+        self.pca_init = torch.tensor(pca_init, dtype=torch.float32).to(self.device)
+        self.obj_points = torch.tensor(obj_points, dtype=torch.float32).to(self.device)
+        self.part_labels = self.load_part_labels()
+        crop = args.loadSize if args is not None else 1200
+        self.camera = KinectColorCamera(crop)
+        self.net_in_size = args.net_img_size[0] if args is not None else 512
+        self.z_0 = 2.2 if args is None or "z_0" not in args else args.z_0
+        self.scan_verts = torch.as_tensor(self.scan.v, dtype=torch.float32, device=self.device)
+        self.scan_faces = torch.as_tensor(self.scan.f, dtype=torch.long, device=self.device)
+        self.body_prior, self.hand_prior = self.assets.priors(self.device)
+
+    def _init_common(self, device, debug):
         self.device = torch.device(device)
-        self.camera = KinectColorCamera(crop_size)
-        self.net_in_size = net_in_size
-        self.z_0 = z_0
-        self.obj_scale = obj_scale
         self.debug = debug
+        self.obj_scale = 1.0
+        self.scan = None
+        self.scan_verts = self.scan_faces = None
+        self._comb_faces = None
+        self._layers = {}
+        self.part_names = {0: "head", 1: "left foot", 2: "left hand", 3: "left leg", 4: "left midarm",
+                           5: "left upper arm", 6: "right foot", 7: "right hand", 8: "right leg", 9: "right midarm",
+                           10: "right right upper arm", 11: "torso", 12: "upper left leg", 13: "upper right leg"}
+
+    @classmethod
+    def from_parts(cls, device="cuda:0", net_in_size=512, crop_size=1200, z_0=2.2, obj_scale=1.0, part_labels=None,
+                   body_prior=None, hand_prior=None, debug=False, scan_verts=None, scan_faces=None, assets=None):
+        """a fitter from values already in memory (tests, benchmarks): no sequence folder, no files"""
+        self = cls.__new__(cls)
+        self.seq_folder = self.outpath = None
+        self.assets, self.gender = assets, "male"
+        self._init_common(device, debug)
+        if scan_verts is not None:
+            self.scan = _Scan(np.asarray(torch.as_tensor(scan_verts).cpu()), np.asarray(torch.as_tensor(scan_faces).cpu()))
+            self.scan_verts = torch.as_tensor(scan_verts, dtype=torch.float32, device=device)
+            self.scan_faces = torch.as_tensor(scan_faces, dtype=torch.long, device=device)
+        self.camera = KinectColorCamera(crop_size)
+        self.net_in_size, self.z_0, self.obj_scale = net_in_size, z_0, obj_scale
         self.part_labels = part_labels          # (6890,) long: assets/smpl_parts_dense.pkl in the reference
         self.body_prior, self.hand_prior = body_prior, hand_prior
+        return self
+
+    # ---- what the reference loads from files ---------------------------------------------------------
+    def compute_pca_init(self, obj_name, n_samples=3000, seed=0):
+        """template -> centred mesh (self.scan), its PCA axes (3,3) and 3 000 surface samples  [recon_fit_base.py:108-122]
+        PCA = sklearn's, like the reference (its sign convention fixes which of the +-axes the object starts from)"""
+        from sklearn.decomposition import PCA
+        v, f = self.assets.template(obj_name)
+        v = np.asarray(v, np.float64)
+        v = v - np.mean(v, 0)          # load_scan_centered
+        v = v - np.mean(v, 0)          # and once more in compute_pca_init (:115)
+        self.scan = _Scan(v, f)
+        pca = PCA(n_components=3)
+        pca.fit(v)
+        return pca.components_, sample_surface(self.scan.v, self.scan.f, n_samples, np.random.RandomState(seed))
+
+    def load_part_labels(self):
+        return torch.tensor(np.asarray(self.assets.part_labels(), np.int32)).to(self.device)
+
+    def load_part_labels_batch(self, batch_size):
+        return self.load_part_labels().repeat(batch_size, 1).to(self.device).long()
+
+    def load_mocap(self, file):
+        return self.assets.load_mocap(file)
+
+    def smpl_layer(self, gender):
+        """one packed body model per gender, kept on the device"""
+        if gender not in self._layers:
+            from ..lib_smpl.smpl_layer import SMPL_Layer
+            self._layers[gender] = SMPL_Layer.from_arrays(self.assets.smpl_model(gender), gender=gender).to(self.device)
+        return self._layers[gender]
+
+    def get_smpl_init(self, image_paths, trans):
+        """SMPL-H initialised from the FrankMocap prediction next to every image  [recon_fit_base.py:124-140]"""
+        from ..lib_smpl.smpl_generator import SMPLHGenerator
+        poses, betas = [], []
+        for x in image_paths:
+            p, b = self.load_mocap(x.replace(".color.jpg", ".mocap.json"))
+            poses.append(p)
+            betas.append(b)
+        return SMPLHGenerator.get_smplh(np.stack(poses, 0), np.stack(betas, 0), trans, self.gender, device=self.device,
+                                        assets=self.assets, layer=self.smpl_layer(self.gender))
+
+    def get_kpt_paths(self, image_paths):
+        return [x.replace(".color.jpg", ".color.json") for x in image_paths]
+
+    def load_kpts(self, json_paths, tol):
+        """(B,25,3) 2-D body keypoints in the original image, confidences below `tol` zeroed  [:305-320]"""
+        kpts = []
+        for file in json_paths:
+            J2d = np.array(self.assets.load_kpts(file), np.float64).reshape((-1, 3))
+            J2d[:, 2][J2d[:, 2] < tol] = 0
+            kpts.append(J2d)
+        return torch.tensor(np.stack(kpts, 0), dtype=torch.float32).to(self.device)
+
+    def get_body_kpts2d(self, traindata_paths, tol=0.3):
+        return self.load_kpts(self.get_kpt_paths(traindata_paths), tol)
+
+    def get_parts_colors(self, part):
+        """(B,N) labels -> (B,N,3) colours, visualisation only  [:652-659]"""
+        part = part.cpu().numpy() if torch.is_tensor(part) else np.asarray(part)
+        return MTURK_COLORS[np.clip(part, 0, 13)]
+
+    def prepare_query_dict(self, batch):
+        return {"crop_center": batch.get("crop_center").to(self.device)}
+
+    def prep_smplfit(self, data, generator, pc_generated):
+        """everything optimize_smpl needs, from a loader batch and the generated point clouds  [recon_fit_base.py:398-440]"""
+        batch_size = data["images"].shape[0]
+        human_points = pc_generated["human"]["points"].clone().detach().to(self.device)
+        obj_points = pc_generated["object"]["points"].clone().detach().to(self.device)
+        human_parts = pc_generated["human"]["parts"].clone().detach().to(self.device)
+        human_t = pc_generated["human"]["centers"][:, :3]
+        human_t[:, 2] = self.z_0                                   # in place, like the reference: fixed SMPL depth
+        smpl = self.get_smpl_init(data.get("path"), human_t)
+        part_labels = self.load_part_labels_batch(batch_size)
+        part_colors = self.get_parts_colors(pc_generated["human"]["parts"])
+        body_kpts = self.get_body_kpts2d(data.get("path"))
+        body_kpts = self.scale_body_kpts(body_kpts, data.get("resize_scale").to(self.device),
+                                         data.get("crop_scale").to(self.device), data.get("old_crop_center").to(self.device))
+        body_kpts = body_kpts.clone().float().to(self.device)
+        query_dict = self.prepare_query_dict(data)
+        betas_dict = {"images": data.get("images").to(self.device), "human_init": human_points, "human_parts": human_parts,
+                      "part_labels": part_labels, "part_colors": part_colors, "body_kpts": body_kpts,
+                      "query_dict": query_dict, "net": generator.model,
+                      "pose_init": smpl.pose[:, 3:SMPL_POSE_PRAMS_NUM].clone().detach().to(self.device)}
+        return (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
+                smpl)
+
+    def init_obj_fit_data(self, batch_size, human_t, pc_generated, scale):
+        """object translation from the predicted centres (relative to the SMPL centre), rotation from the predicted PCA
+        axes against the template's, scale from the SMPL height ratio  [recon_fit_base.py:720-747]"""
+        obj_t = pc_generated["object"]["centers"][:, 3:].to(self.device) + human_t.to(self.device)
+        obj_t = obj_t.clone().detach().to(self.device).requires_grad_(True)
+        pca_axis = pc_generated["object"]["pca_axis"].to(self.device)
+        pca_axis_init = torch.stack([self.pca_init for _ in range(batch_size)], 0)
+        obj_R = self.init_object_orientation(pca_axis, pca_axis_init).detach().requires_grad_(True)
+        obj_s = scale.clone().detach().to(self.device).requires_grad_(True)
+        object_init = torch.stack([self.obj_points for _ in range(batch_size)], 0)
+        return obj_R, obj_s, obj_t, object_init
+
+    # ---- results on disk (recon_fit_base.py:233-275) ---------------------------------------------------
+    def get_output_paths(self, image_paths, save_name, test_id):
+        seq_names = [x.split(os.sep)[-3] for x in image_paths]
+        frame_times = [x.split(os.sep)[-2] for x in image_paths]
+        smpl_files, obj_files = [], []
+        for seq, frame in zip(seq_names, frame_times):
+            folder = os.path.join(self.outpath, seq, frame, save_name)
+            os.makedirs(folder, exist_ok=True)
+            smpl_files.append(os.path.join(folder, f"k{test_id}.smpl.ply"))
+            obj_files.append(os.path.join(folder, f"k{test_id}.object.ply"))
+        return smpl_files, obj_files
+
+    def is_done(self, image_paths, save_name, test_id):
+        smpl_files, obj_files = self.get_output_paths(image_paths, save_name, test_id)
+        return all(os.path.isfile(sf) and os.path.isfile(of) for sf, of in zip(smpl_files, obj_files))
+
+    def save_outputs(self, smpl, obj_R, obj_t, traindata_paths, save_name, test_id, obj_s=None):
+        """fitted SMPL mesh + parameters and object mesh + parameters next to each other  [:258-275, opt_utils.py:73-101]"""
+        smpl_files, obj_files = self.get_output_paths(traindata_paths, save_name, test_id)
+        smpl.forget()
+        with torch.no_grad():
+            verts = smpl()[0].cpu().numpy()
+            faces = None if smpl.faces is None else smpl.faces.cpu().numpy()
+            B = len(obj_files)
+            obj_verts = self.scan_verts.unsqueeze(0).repeat(B, 1, 1)
+            obj_verts = self.transform_object(obj_verts, obj_R, obj_t, obj_s).cpu().numpy()
+            rot = self.decopose_axis(obj_R, no_rand=True).cpu().numpy()
+        for i, (sf, of) in enumerate(zip(smpl_files, obj_files)):
+            write_ply(sf, verts[i], faces)
+            pkl.dump({"pose": smpl.pose[i].detach().cpu().numpy(), "betas": smpl.betas[i].detach().cpu().numpy(),
+                      "trans": smpl.trans[i].detach().cpu().numpy(), "score": 0.0}, open(sf.replace(".ply", ".pkl"), "wb"))
+            write_ply(of, obj_verts[i], self.scan.f)
+            pkl.dump({"rot": rot[i], "trans": obj_t[i].detach().cpu().numpy(), "scale": obj_s[i].detach().cpu().numpy()},
+                     open(of.replace(".ply", ".pkl"), "wb"))
 
     # ---- SO(3) ------------------------------------------------------------------------------------
     @staticmethod
@@ -228,14 +451,9 @@ class ReconFitterBase:
         loss_dict["smplz"] = torch.mean((J[:, 8, 2] - self.z_0) ** 2)
 
     def project_points(self, joints3d, crop_center=None):
-        c = self.camera
-        x, y, z = joints3d[..., 0:1], joints3d[..., 1:2], joints3d[..., 2:3]
-        px = c.fx_px * x / z + c.cx_px
-        py = c.fy_px * y / z + c.cy_px
-        if crop_center is not None:
-            px = c.crop_size / 2 + px - crop_center[:, 0].unsqueeze(1).unsqueeze(1)
-            py = c.crop_size / 2 + py - crop_center[:, 1].unsqueeze(1).unsqueeze(1)
-        return torch.cat([px, py], -1) * self.net_in_size / c.crop_size
+        """3-D keypoints -> pixels of the network input image  [recon_fit_base.py:661-670]"""
+        px, py = self.camera.project_screen(joints3d, crop_center)
+        return torch.cat([px, py], -1) * self.net_in_size / self.camera.crop_size
 
     def projection_loss(self, joints3d, joints2d, crop_center):
         proj = self.project_points(joints3d, crop_center)
@@ -269,7 +487,11 @@ class ReconFitterBase:
         smpl.pose.data[:, :3] = split_smpl.global_pose.data
         smpl.pose.data[:, 3:66] = split_smpl.body_pose.data
         smpl.pose.data[:, 66:] = split_smpl.hand_pose.data
-        smpl.betas.data[:, :2] = split_smpl.top_betas.data   # (other_betas are not copied back: reference quirk, :682-690)
+        smpl.betas.data[:, :2] = split_smpl.top_betas.data
+        # the reference copies no other_betas here (:682-690) and does not need to: the split parameters are views of
+        # smpl's storage (wrapper_pytorch.from_smpl), the optimised betas 2..9 are in smpl.betas already.  For a split
+        # that owns its storage the line below keeps that outcome; for views it copies a tensor onto itself.
+        smpl.betas.data[:, 2:] = split_smpl.other_betas.data
         smpl.trans.data = split_smpl.trans.data
         smpl.forget()   # writes through .data are invisible to the version counters the LBS memo is keyed on
         return smpl

@@ -10,8 +10,9 @@ quirks are kept on purpose because they change the fitted poses (SURVEY Appendix
   * `forward_step` queries the object points twice per step (once directly, once in compute_obj_loss).
 The 'sil' phase runs if the caller provides data_dict['silhouette'] (SilLossROI); the 'collide' term of the joint
 phase (recon_fit_behave.py:213-216) runs if the fitter was given the object template mesh (scan_verts / scan_faces).
-Per-step host synchronisation of the reference (tqdm strings, .item()) is gone: the early-stop test
-reads the loss once per OUTER iteration.
+Per-step host synchronisation of the reference (tqdm strings, .item()) is gone: the early-stop rule is evaluated on the
+device after every inner step and the host reads the latched flag once per OUTER iteration (graph_step.py).
+`fit_recon` (:29-76) chains the stages; `recon_fit(args)` (:361-365) is the command-line entry.
 """
 import torch
 import torch.nn.functional as F
@@ -47,6 +48,75 @@ class ReconFitterBehave(ReconFitterBase):
              "ocent": 15 ** 2, "collide": 3 ** 2, "pinit": 5 ** 2, "rot": 10.0 ** 2, "trans": 10.0 ** 2}
         return {k: (lambda cst, it, c=c: c * cst / (1 + it)) for k, c in w.items()}
 
+    # ---- the whole chain ------------------------------------------------------------------------------
+    def fit_recon(self, args, loader=None, model=None, generator=None, save=True):
+        """[recon_fit_behave.py:29-76] for every batch of the loader: dense point clouds from the two UDFs -> SMPL-H
+        initialisation -> optimize_smpl -> object initialisation -> optimize_smpl_object -> results on disk.
+        `loader` / `model` / `generator` default to what the reference builds from `args` (TestData loader of the
+        sequence, CHORE(args), Generator with the experiment's checkpoint).  Under torch.distributed every rank takes the
+        batches rank::world_size (frames are independent: BASELINE configs[4]); returns this rank's fitted parameters."""
+        from ..model import CHORE
+        from ..parallel.frame_shard import shard_indices
+        from .generator import Generator
+        loader = self.init_dataloader(args) if loader is None else loader
+        if generator is None:
+            model = CHORE(args) if model is None else model
+            generator = Generator(model, getattr(args, "exp_name", None), threshold=2.0,
+                                  sparse_thres=getattr(args, "sparse_thres", 0.03),
+                                  filter_val=getattr(args, "filter_val", 0.004), device=self.device,
+                                  checkpoint=getattr(args, "checkpoint", None))
+        batches = list(loader) if not hasattr(loader, "__len__") else loader
+        mine = set(shard_indices(len(batches)))
+        results = []
+        for i, data in enumerate(batches):
+            if i not in mine:
+                continue
+            if save and self.outpath is not None and not getattr(args, "redo", False) and \
+                    self.is_done(data["path"], args.save_name, args.test_kid):
+                print(data["path"], args.save_name, "already done, skipped")
+                continue
+            smpl, obj_R, obj_t, obj_s = self.fit_batch(data, generator)
+            if save and self.outpath is not None:
+                self.save_outputs(smpl, obj_R, obj_t, data["path"], args.save_name, args.test_kid, obj_s)
+            results.append(dict(index=i, pose=smpl.pose.detach(), betas=smpl.betas.detach(), trans=smpl.trans.detach(),
+                                obj_R=self.decopose_axis(obj_R, no_rand=True).detach(), obj_t=obj_t.detach(),
+                                obj_s=obj_s.detach()))
+        return results
+
+    def fit_batch(self, data, generator, smpl_iters=None, object_iters=None):
+        """one batch through the chain of fit_recon (:46-74); the iteration counts are the reference's"""
+        batch_size = data["images"].shape[0]
+        pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True)
+        (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
+         smpl) = self.prep_smplfit(data, generator, pc_generated)
+        smpl, scale = self.optimize_smpl(smpl, betas_dict, **(smpl_iters or dict(iter_for_kpts=1, iter_for_pose=1,
+                                                                                 iter_for_betas=1)))
+        obj_R, obj_s, obj_t, object_init = self.init_obj_fit_data(batch_size, human_t, pc_generated, scale)
+        data_dict = {"obj_R": obj_R, "obj_t": obj_t, "obj_s": obj_s, "objects": object_init, "smpl": smpl,
+                     "images": data.get("images").to(self.device), "human_init": human_points, "obj_init": obj_points,
+                     "human_parts": human_parts, "part_labels": part_labels, "part_colors": part_colors,
+                     "body_kpts": body_kpts, "query_dict": query_dict, "obj_t_init": obj_t.clone().detach().to(self.device)}
+        smpl, obj_R, obj_t = self.optimize_smpl_object(generator.model, data_dict, **(object_iters or {}))
+        return smpl, obj_R, obj_t, obj_s
+
+    def init_dataloader(self, args):
+        """[recon_fit_behave.py:78-88] the image loader is the reference's own host-side code (data/test_data.py, cv2
+        JPEG decoding -- out of scope of the device path): it is imported from the reference tree when this module
+        runs inside one (python -m chore_amd.dropin recon/recon_fit_behave.py ...), otherwise pass `loader=`"""
+        try:
+            from data.data_paths import DataPaths
+            from data.test_data import TestData
+        except ImportError as e:
+            raise RuntimeError("fit_recon needs a loader: run from the reference tree (its data/ package provides "
+                               "TestData) or pass loader= with batches of the data/test_data.py contract") from e
+        image_files = DataPaths.get_image_paths_seq(self.seq_folder, check_occlusion=False)
+        batch_end = args.end if args.end is not None else len(image_files)
+        image_files = image_files[args.start:batch_end]
+        dataset = TestData(image_files, args.batch_size, args.batch_size, image_size=args.net_img_size,
+                           crop_size=args.loadSize)
+        print(f"In total {len(image_files)} test examples")
+        return dataset.get_loader(shuffle=False)
+
     # ---- SMPL ---------------------------------------------------------------------------------------
     def forward_smpl(self, smpl, data_dict, phase):
         loss_dict = {}
@@ -65,6 +135,11 @@ class ReconFitterBehave(ReconFitterBase):
 
     def optimize_smpl(self, smpl, data_dict, iter_for_betas=10, iter_for_pose=10, iter_for_kpts=5, steps_per_iter=10,
                       max_iter=150):
+        """[recon_fit_behave.py:224-291] global (betas 0-1 + translation, lr 0.02) -> all pose (new Adam, lr 0.006) ->
+        + keypoints (same Adam), until the stop rule fires.  Reference details that change the result and are kept:
+        the split parameters alias `smpl`'s storage; at the switch to 'smpl all pose' the OLD optimiser is zeroed, so
+        global_pose / body_pose / other_betas enter the new Adam with the gradients summed over the whole 'global' phase
+        (:243-259); the stop rule is tested after every inner step."""
         split = self.split_smpl(smpl)
         height_init = self.get_smpl_height(smpl)
         wd = self.get_loss_weights()
@@ -75,21 +150,27 @@ class ReconFitterBehave(ReconFitterBase):
 
         phase = "global"
         rel = self.release_graphs(split, data_dict["net"])
-        st = self._stepper([split.top_betas, split.trans], 0.02, loss_of(phase), 0.001, prev, release=rel)
+        carry = [split.global_pose, split.body_pose, split.other_betas, split.hand_pose]
+        st = self._stepper([split.top_betas, split.trans], 0.02, loss_of(phase), 0.001, prev, release=rel, carry=carry)
         for it in range(iter_for_betas + iter_for_kpts + iter_for_pose + max_iter):
+            zero = True
             if it == iter_for_betas:
-                phase = "smpl all pose"   # new Adam
+                phase = "smpl all pose"
+                st.zero_grads()            # the reference's zero_grad() of this iteration still goes through the old Adam
                 st = self._stepper([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas],
-                                   0.006, loss_of(phase), 0.001, prev, release=rel)
+                                   0.006, loss_of(phase), 0.001, prev, release=rel, carry=carry)
+                zero = False
             elif it == iter_for_betas + iter_for_pose:
                 phase = "kpts"            # same Adam, the loss gains the keypoint term
-                st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel)
-            st.begin_outer(1 if phase != "kpts" else it / 3)
+                st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel, carry=carry)
+            armed = it > 0.25 * max_iter + iter_for_betas + iter_for_pose
+            st.begin_outer(1 if phase != "kpts" else it / 3, armed=armed, zero=zero)
             for _ in range(steps_per_iter):
                 st.step()
-            if it > 0.25 * max_iter + iter_for_betas + iter_for_pose and st.stopped():
+            if armed and st.stopped():
                 break
         rel()   # graph replays change the parameters without touching their version counters: drop memoised results
+        smpl.forget()
         scale = self.get_smpl_height(split) / height_init
         return self.copy_smpl_params(split, smpl), scale
 
@@ -122,21 +203,40 @@ class ReconFitterBehave(ReconFitterBase):
 
     def optimize_smpl_object(self, model, data_dict, obj_iter=20, joint_iter=10, steps_per_iter=10, sil_iter=50,
                              max_iter=100):
+        """[recon_fit_behave.py:90-163] object only (Adam on t, R, s, lr 0.006) -> silhouette (new Adam, same
+        parameters) -> joint (new Adam on t, s, lr 0.002) until the stop rule fires; the SMPL parameters are never
+        stepped.  `sil_iter` / `max_iter` are the reference's hard-coded 50 / 100.  The silhouette term is built from
+        the two masks of data_dict['images'] like the reference does (:94-96) unless the caller put one into
+        data_dict['silhouette']; without masks and template the phase is skipped."""
         smpl = data_dict["smpl"]
         split = self.split_smpl(smpl)
         data_dict["smpl"] = split
         obj_R, obj_t, obj_s = data_dict["obj_R"], data_dict["obj_t"], data_dict["obj_s"]
         wd = self.get_loss_weights()
+        if "silhouette" not in data_dict and self.scan is not None and "images" in data_dict:
+            from .obj_pose_roi import SilLossROI
+            images = data_dict["images"]
+            data_dict["silhouette"] = SilLossROI(images[:, 3, :, :], images[:, 4, :, :], self.scan,
+                                                 data_dict["query_dict"]["crop_center"], device=self.device,
+                                                 crop_size=self.camera.crop_size).to(self.device)
         if "silhouette" not in data_dict:
             sil_iter = 0
         data_dict["smpl_center"] = self.compute_smpl_center_pred(data_dict, model, smpl)
+        # no optimiser of this function owns a SMPL parameter (reference quirk, :102,126,134): their gradients would be
+        # computed (LBS backward, the 6 890-point query backward of the joint phase) and never read -- switched off
+        for p in split.parameters():
+            p.requires_grad_(False)
         prev = torch.tensor(300.0, device=self.device)
         n_outer = joint_iter + obj_iter + max_iter + sil_iter
-        # the SO(3) perturbation of every step (recon_fit_base.py:384) is drawn from the CPU generator like the
-        # reference does, but for all steps at once (one call yields the same stream as one call per step) so that
-        # a step only reads noise[k] on the device
+        # The SO(3) perturbation (recon_fit_base.py:384) comes from the CPU generator in the order the reference
+        # consumes it -- one (B,3,3) draw per step, and between the last 'object only' step and the first silhouette
+        # step the draw of rot_init's decopose_axis (:127) -- but up front, so that a step only reads noise[k] on the
+        # device (consecutive torch.rand calls continue one stream: n calls = one call of n times the size).
         B = obj_R.shape[0]
-        noise = torch.rand(n_outer * steps_per_iter, B, 3, 3).to(self.device)
+        n_obj = obj_iter * steps_per_iter
+        noise_obj = torch.rand(n_obj, B, 3, 3)
+        noise_rot = torch.rand(B, 3, 3) if sil_iter > 0 else None
+        noise = torch.cat([noise_obj, torch.rand((n_outer - obj_iter) * steps_per_iter, B, 3, 3)]).to(self.device)
         k = torch.zeros(1, dtype=torch.long, device=self.device)
 
         def loss_of(phase):
@@ -150,23 +250,34 @@ class ReconFitterBehave(ReconFitterBase):
         rel = self.release_graphs(split, model)
         st = self._stepper([obj_t, obj_R, obj_s], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
         for it in range(n_outer):
+            # zero_grad() of the reference runs at the top of the iteration through the optimiser of the PREVIOUS
+            # phase (:118): identical here, every new Adam owns a subset of the previous one's parameters
+            st.zero_grads()
             if it == obj_iter and sil_iter > 0:
                 phase = "sil"
-                st = self._stepper([obj_R, obj_s, obj_t], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
-                data_dict["rot_init"] = self.decopose_axis(obj_R).detach().clone()
+                data_dict["rot_init"] = self.decopose_axis(obj_R, noise=noise_rot).detach().clone()
                 data_dict["trans_init"] = obj_t.detach().clone()
+                st = self._stepper([obj_R, obj_s, obj_t], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
             if it == obj_iter + sil_iter:
                 phase = "joint"
-                st = self._stepper([obj_t, obj_s], 0.002, loss_of(phase), 0.0001, prev, state=[k], release=rel)
+                st = self._stepper([obj_t, obj_s], 0.002, loss_of(phase), 0.0001, prev, state=[k], release=rel, carry=[obj_R])
             decay = 1 if phase == "object only" else it
             if phase == "sil":
                 decay = it - obj_iter + 1
             elif phase == "joint":
                 decay = (it - obj_iter + 1) / 5
-            st.begin_outer(decay)
+            armed = phase == "joint" and it > 0.25 * max_iter
+            st.begin_outer(decay, armed=armed, zero=False)
             for _ in range(steps_per_iter):
                 st.step()
-            if phase == "joint" and it > 0.25 * max_iter and st.stopped():
+            if armed and st.stopped():
                 break
         rel()
         return smpl, data_dict["obj_R"], data_dict["obj_t"]
+
+
+def recon_fit(args):
+    """[recon_fit_behave.py:361-365]"""
+    fitter = ReconFitterBehave(args.seq_folder, debug=getattr(args, "display", False), outpath=args.outpath, args=args)
+    fitter.fit_recon(args)
+    print("all done")

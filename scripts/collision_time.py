@@ -8,7 +8,7 @@ from chore_amd.recon.recon_fit_base import ReconFitterBase, _CollisionFn
 va, fa = uv_ellipsoid()
 vb, fb = icosphere(4, 0.3, (0.33, 0.2, 0.05))
 for B in (1, 8):
-    fit = ReconFitterBase(device="cuda:0")
+    fit = ReconFitterBase.from_parts(device="cuda:0")
     sv = torch.tensor(np.stack([va] * B), dtype=torch.float32, device="cuda")
     ov = torch.tensor(np.stack([vb + 0.01 * i for i in range(B)]), dtype=torch.float32, device="cuda").requires_grad_(True)
     sf, of = torch.tensor(fa, device="cuda"), torch.tensor(fb, device="cuda")

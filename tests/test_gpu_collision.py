@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 
 def _fitter(**kw):
     from chore_amd.recon.recon_fit_base import ReconFitterBase
-    return ReconFitterBase(device="cuda:0", **kw)
+    return ReconFitterBase.from_parts(device="cuda:0", **kw)
 
 
 def _run(va, fa, vb, fb):
@@ -150,7 +150,7 @@ def _joint_fit(opt, use_graphs):
     obj_v, obj_f = icosphere(3, 0.3)
     body_prior, hand_prior = synthetic_priors(0)
     labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
-    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior,
+    fitter = ReconFitterBehave.from_parts(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior,
                                scan_verts=obj_v, scan_faces=obj_f)
     fitter.use_graphs = use_graphs
     fitter.adam_capturable = True

@@ -40,30 +40,7 @@ def test_project_so3_forward_and_backward():
     assert (gc - gg).abs().max() < 5e-4 * gc.abs().max()
 
 
-def ref_contact_loss(df_hum_o, df_obj_h, obj, hum, part_logits, part_labels, n_parts=14):
-    """restatement of compute_contact_loss (recon/recon_fit_base.py:553-608) with pytorch3d.loss.chamfer_distance's
-    documented defaults (squared L2 nearest neighbour, mean over the points of a cloud, mean over clouds, both
-    directions added) on ragged clouds, torch ops with autograd; returns None where the reference omits the term"""
-    mask_o, mask_h = df_obj_h < 0.08, df_hum_o < 0.08
-    part_o = torch.argmax(part_logits, 1)
-    da, db = [], []
-    for hv, ov, mh, mo, po in zip(hum, obj, mask_h, mask_o, part_o):
-        ch, co = int(mh.sum()), int(mo.sum())
-        if ch + co == 0:
-            continue
-        obj_v, label_o = (ov[mo], po[mo]) if co > 0 else (ov, po)
-        hum_v, label_h = (hv[mh], part_labels[mh]) if ch > 0 else (hv, part_labels)
-        for i in range(n_parts):
-            hi, oi = torch.where(label_h == i)[0], torch.where(label_o == i)[0]
-            if hi.numel() == 0 or oi.numel() == 0:
-                continue
-            a, b = hum_v[hi], obj_v[oi]
-            d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
-            da.append(d.min(1)[0].mean())
-            db.append(d.min(0)[0].mean())
-    if not da:
-        return None
-    return torch.stack(da).mean() + torch.stack(db).mean()
+from oracle.contact import contact_loss as ref_contact_loss  # noqa: E402  (restatement of recon_fit_base.py:553-608)
 
 
 def test_contact_term_matches_restatement():
@@ -122,7 +99,7 @@ def fit_setup(opt):   # function scope: the tests optimise the parameters in pla
                                    pose=torch.from_numpy(pose), trans=torch.from_numpy(trans)).cuda()
     body_prior, hand_prior = synthetic_priors(0)
     labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
-    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    fitter = ReconFitterBehave.from_parts(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
     cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
     kpts = torch.from_numpy(np.concatenate([rs.uniform(100, 400, (B, 25, 2)), rs.uniform(0.2, 1, (B, 25, 1))], -1)
                             .astype(np.float32)).cuda()
@@ -208,7 +185,7 @@ def run_fit_with(opt, use_graphs, silhouette=None, obj_iter=2, sil_iter=0, joint
                                    pose=torch.from_numpy(pose), trans=torch.from_numpy(trans)).cuda()
     body_prior, hand_prior = synthetic_priors(0)
     labels = torch.from_numpy(rs.randint(0, 14, 6890)).cuda()
-    fitter = ReconFitterBehave(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    fitter = ReconFitterBehave.from_parts(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
     fitter.use_graphs = use_graphs
     fitter.adam_capturable = True   # the same Adam arithmetic in both runs
     cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
@@ -309,7 +286,7 @@ def test_coco_variant_matches_reference():
     from conftest import golden
     from chore_amd.recon.recon_fit_coco import ReconFitterCoco
     g = golden("coco_fit.npz")
-    f = ReconFitterCoco(device="cuda:0")
+    f = ReconFitterCoco.from_parts(device="cuda:0")
     t = lambda k: torch.from_numpy(g[k]).cuda()     # noqa: E731
     out = f.scale_body_kpts(t("kpts"), t("resize_scale"), t("crop_scale"), t("old_crop_center"))
     np.testing.assert_allclose(out.cpu().numpy(), g["kpts_out"], rtol=1e-6, atol=1e-3)

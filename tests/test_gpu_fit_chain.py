@@ -1,0 +1,317 @@
+"""GPU: the drivers around the kernels -- Generator loop, the two optimisation schedules, the glue of fit_recon -- against
+what THE REFERENCE's own drivers produced on the same synthetic inputs (tests/golden/generator_loop.npz,
+fit_schedule.npz, fit_init.npz; written by tests/golden/make_golden.py, inputs shared through tests/fit_harness.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+from fit_harness import AnalyticField, SilStub, fit_case, rot_of, smplh_faces
+
+pytestmark = pytest.mark.gpu
+
+
+# ---- Generator --------------------------------------------------------------------------------------------------------
+def _generator():
+    from chore_amd.recon.generator import Generator
+    return Generator(AnalyticField().cuda(), None, threshold=2.0, sparse_thres=0.03, filter_val=0.004,
+                     device=torch.device("cuda"))
+
+
+def _check_clouds(res, g):
+    for t in ("human", "object"):
+        pts = res[t]["points"].cpu().numpy()
+        assert pts.shape == g[t + "_points"].shape, (t, pts.shape)
+        # Alg. 1 on a smooth field: the only differences are fp32 round-off of the field evaluation (1e-6 of a metre)
+        assert np.abs(pts - g[t + "_points"]).max() < 2e-5, (t, np.abs(pts - g[t + "_points"]).max())
+        assert np.array_equal(res[t]["parts"].cpu().numpy(), g[t + "_parts"]), t
+        assert np.abs(res[t]["pca_axis"].cpu().numpy() - g[t + "_pca_axis"]).max() < 1e-5
+        assert np.abs(res[t]["centers"].cpu().numpy() - g[t + "_centers"]).max() < 1e-5
+
+
+def test_generator_host_loop_matches_reference():
+    """generate_pclouds_batch with the reference's control flow (device_loop=False) and its CPU random stream: the
+    same rounds, the same per-example counts (one of them 0 in the first round: the fallback branch of the
+    resampling), the same clouds / argmax parts / mean axes / mean centres"""
+    g = golden("generator_loop.npz")
+    gen = _generator()
+    B = 2
+    data = {"images": torch.zeros(B, 5, 8, 8), "crop_center": torch.tensor([[1008.0, 995.0]] * B)}
+    torch.manual_seed(int(g["seed"]))
+    gen.filter(data)
+    samples = gen.get_grid_samples(30000, batch_size=B)
+    res = {t: gen.gen_pc_batch(gen.model, t, samples, 2000, data, 10, mute=True, device_loop=False)
+           for t in ("human", "object")}
+    _check_clouds(res, g)
+
+
+def test_generator_device_loop_matches_reference():
+    """the same through the default device-resident loop (csrc/generator.hip); its resampling indices are floor(u k) of
+    uniform numbers, so the test turns the reference's CPU randint draws into u = (idx + 0.5) / k with k from the
+    golden's per-round counts.  Also pins init_samples (only example 0 is rescaled) through generate_pclouds_batch."""
+    g = golden("generator_loop.npz")
+    gen = _generator()
+    B, M, NI = 2, 20000, 30000
+    state = {"t": None, "round": 0, "nz": None}
+
+    def uniform(shape):
+        counts = g["counts_" + state["t"]][state["round"]]
+        us, nzs = [], []
+        for i in range(B):                      # the reference's order: randint, randn of example 0, then of example 1
+            k = int(counts[i])
+            hi = k if k > 1 else NI
+            idx = torch.randint(hi, (1, M))[0]
+            us.append((idx.double() + 0.5) / hi)
+            nzs.append(torch.randn(1, M, 3)[0])
+        state["nz"] = torch.stack(nzs).cuda()
+        state["round"] += 1
+        return torch.stack(us).float().cuda()
+
+    def randn(shape):
+        return state["nz"]
+
+    data = {"images": torch.zeros(B, 5, 8, 8), "crop_center": torch.tensor([[1008.0, 995.0]] * B)}
+    torch.manual_seed(int(g["seed"]))
+    gen.filter(data)
+    samples = gen.get_grid_samples(30000, batch_size=B)
+    res = {}
+    for t in ("human", "object"):
+        state["t"], state["round"] = t, 0
+        res[t] = gen.gen_pc_batch(gen.model, t, samples, 2000, data, 10, mute=True, rng=(uniform, randn))
+        assert state["round"] == len(g["counts_" + t])
+    _check_clouds(res, g)
+
+
+# ---- fitting schedules ------------------------------------------------------------------------------------------------
+def _fit_objects(opt, use_graphs=False, analytic=False):
+    """analytic: the closed-form field instead of the network (what fit_schedule.npz was recorded with, see
+    make_golden.gen_fit_schedule for why)"""
+    import copy
+    from chore_amd.lib_smpl.priors import synthetic_priors
+    from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
+    from chore_amd.model import CHORE
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    from test_gpu_query import nhwc
+    o = copy.copy(opt)
+    o.compute_dtype = "fp32"
+    B = 2
+    c = fit_case(B)
+    if analytic:
+        net = AnalyticField().cuda()
+    else:
+        net = CHORE(o).cuda().eval()
+        synth.load_synth_weights(net, seed=0)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        net.im_feat_list = [nhwc(c["feat"])]
+        net.tmpx = nhwc(c["tmpx"])
+    model = synth.synth_smplh_model(0)
+    model["f"] = smplh_faces()
+    t = lambda a: torch.from_numpy(a.copy())      # noqa: E731
+    smpl = SMPLPyTorchWrapperBatch(model, B, betas=t(c["betas"]), pose=t(c["pose"]), trans=t(c["trans"])).cuda()
+    body_prior, hand_prior = synthetic_priors(0)
+    labels = torch.from_numpy(c["labels"]).cuda()
+    fitter = ReconFitterBehave.from_parts(device="cuda:0", part_labels=labels, body_prior=body_prior, hand_prior=hand_prior)
+    fitter.use_graphs = use_graphs
+    cc = t(c["crop_center"]).cuda()
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1),
+                pose_init=t(c["pose"][:, 3:72]).cuda(), body_kpts=t(c["kpts"]).cuda())
+    data2 = dict(obj_R=t(c["obj_R"]).cuda().requires_grad_(True), obj_t=t(c["obj_t"]).cuda().requires_grad_(True),
+                 obj_s=t(c["obj_s"]).cuda().requires_grad_(True), objects=t(c["obj"]).cuda(), images=t(c["images"]).cuda(),
+                 query_dict={"crop_center": cc}, silhouette=SilStub(B).cuda())
+    return fitter, net, smpl, data, data2
+
+
+def _log_losses(fitter, name, log):
+    orig = getattr(fitter, name)
+
+    def f(*a, **k):
+        ld = orig(*a, **k)
+        log.append({k_: v.detach() for k_, v in ld.items()})
+        return ld
+    setattr(fitter, name, f)
+
+
+def _loss_table(log, keys):
+    return np.array([[float(ld[k]) if k in ld else np.nan for k in keys] for ld in log], np.float64)
+
+
+def _compare_losses(got, ref, rtol, atol, what):
+    n = len(ref)
+    assert len(got) >= n, (what, len(got), n)
+    assert np.array_equal(np.isnan(got[:n]), np.isnan(ref)), what + ": different loss terms per step"
+    m = ~np.isnan(ref)
+    err = np.abs(got[:n][m] - ref[m]) / (atol + rtol * np.abs(ref[m]))
+    assert err.max() < 1.0, (what, float(err.max()), np.argwhere(np.abs(got[:n] - ref) > atol + rtol * np.abs(ref))[:5])
+
+
+def test_optimize_schedules_match_reference(opt):
+    """(on the closed-form field: see make_golden.gen_fit_schedule)  the COMPLETE optimize_smpl (2 + 2 + 2 + up to 8 outer iterations of 5 steps) and optimize_smpl_object (3 + 50 +
+    up to 102 outer iterations of 3 steps) against the reference's runs: the per-step loss terms of every step up to the
+    step at which the reference's stop rule returned (36 and 161 steps), the number of steps that changed the
+    parameters, and the fitted parameters.  What this pins beyond round 1's single-phase trajectories: the phase
+    switches and optimiser re-creation, the gradients carried into the second Adam, the decay formulas, the aliasing
+    of the split parameters (betas 2..9 arrive in the returned SMPL), the stop rule tested at every inner step with
+    nothing applied after it, rot_init's place in the random stream."""
+    g = golden("fit_schedule.npz")
+    fitter, net, smpl, data, data2 = _fit_objects(opt, analytic=True)
+    log = []
+    _log_losses(fitter, "forward_smpl", log)
+    betas0 = smpl.betas.detach().clone()
+    torch.manual_seed(11)
+    smpl2, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5,
+                                        max_iter=8)
+    keys = [str(k) for k in g["keys_a"]]
+    ref = g["smpl_losses"]
+    got = _loss_table(log, keys)
+    _compare_losses(got, ref, 2e-4, 1e-6, "optimize_smpl")       # measured: 1e-5 relative over all 36 steps
+    # the reference returned inside outer iteration 7 after its first step (36 steps); the remaining 4 inner steps of
+    # that iteration ran here as no-ops and no further outer iteration was started
+    assert len(ref) == 36 and len(got) == 40
+    assert smpl2 is smpl
+    assert float((smpl.betas.detach() - betas0)[:, 2:].abs().max()) > 1e-2      # other_betas were optimised AND returned
+    for k in ("pose", "betas", "trans"):
+        d = np.abs(getattr(smpl, k).detach().cpu().numpy() - g["smpl_" + k])
+        assert d.max() < 2e-4 and np.median(d) < 2e-5, (k, d.max(), np.median(d))
+    assert np.abs(scale.cpu().numpy() - g["smpl_scale"]).max() < 1e-4
+    # ---- object ----
+    log.clear()
+    _log_losses(fitter, "forward_step", log)
+    data2["smpl"] = smpl2
+    torch.manual_seed(12)
+    _, obj_R, obj_t = fitter.optimize_smpl_object(net, data2, obj_iter=3, joint_iter=2, steps_per_iter=3)
+    keys = [str(k) for k in g["keys_b"] if str(k) != "collide"]      # left out on both sides (zero in the reference run)
+    ref = g["obj_losses"][:, :len(keys)]
+    got = _loss_table(log, keys)
+    assert len(ref) == 161 and len(got) == 162       # the reference returned after the 2nd of 3 steps of iteration 53
+    _compare_losses(got, ref, 1e-3, 1e-6, "optimize_smpl_object")
+    assert np.abs(data2["rot_init"].cpu().numpy() - g["rot_init"]).max() < 5e-4
+    assert np.abs(data2["smpl_center"].cpu().numpy() - g["smpl_center"]).max() < 1e-4
+    assert np.abs(obj_t.detach().cpu().numpy() - g["obj_t"]).max() < 1e-3
+    assert np.abs(data2["obj_s"].detach().cpu().numpy() - g["obj_s"]).max() < 1e-3
+    assert np.abs(rot_of(obj_R.detach().cpu().numpy()) - rot_of(g["obj_R"])).max() < 2e-3
+
+
+def test_graph_replay_follows_the_same_schedule(opt):
+    """config 5: the same two schedules with every inner step a hipGraph replay end where the eager run ends (same
+    number of executed steps -- the stop flag is latched on the device -- and the same parameters to Adam round-off)"""
+    out = []
+    for use_graphs in (False, True):
+        fitter, net, smpl, data, data2 = _fit_objects(opt, use_graphs)
+        fitter.adam_capturable = True
+        torch.manual_seed(11)
+        smpl2, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5,
+                                            max_iter=8)
+        data2["smpl"] = smpl2
+        torch.manual_seed(12)
+        _, obj_R, obj_t = fitter.optimize_smpl_object(net, data2, obj_iter=3, joint_iter=2, steps_per_iter=3, sil_iter=6)
+        out.append([x.detach().cpu().numpy().copy() for x in (smpl2.pose, smpl2.betas, smpl2.trans, scale, obj_t,
+                                                               data2["obj_s"])] + [rot_of(obj_R.detach().cpu().numpy())])
+    for name, a, b in zip(("pose", "betas", "trans", "scale", "t", "s", "R"), *out):
+        assert np.isfinite(b).all(), name
+        assert np.abs(a - b).max() < 2e-4, (name, np.abs(a - b).max())
+
+
+# ---- glue of fit_recon ------------------------------------------------------------------------------------------------
+def _assets_for_golden(g, tmp):
+    """SyntheticAssets carrying the DATA the reference read from its files in make_golden.gen_fit_init"""
+    from chore_amd.recon.assets import SyntheticAssets
+    paths, mocap, kpts = [], {}, {}
+    for i in range(2):
+        p = os.path.join(tmp, "seq", f"t000{i}.000", "k1.color.jpg")
+        paths.append(p)
+        mocap[p.replace(".color.jpg", ".mocap.json")] = (g["mocap_pose"][i], g["mocap_betas"][i])
+        kpts[p.replace(".color.jpg", ".color.json")] = g["kpts_raw"][i]
+    return SyntheticAssets(0, mocap=mocap, kpts=kpts, mean_hand_pose=g["mean_hand_pose"],
+                           part_labels=g["part_labels"].astype(np.int32)), paths
+
+
+def test_prep_smplfit_and_init_obj_fit_data_match_reference(opt, tmp_path):
+    g = golden("fit_init.npz")
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    assets, paths = _assets_for_golden(g, str(tmp_path))
+    args = opt
+    fitter = ReconFitterBehave(None, device="cuda:0", obj_name="synthetic", outpath=str(tmp_path), args=args, assets=assets)
+    t = lambda k: torch.from_numpy(g[k].copy())     # noqa: E731
+    pc = {"human": {"points": t("human_points"), "parts": t("human_parts"), "centers": t("human_centers")},
+          "object": {"points": t("object_points"), "pca_axis": t("object_pca_axis"), "centers": t("object_centers")}}
+    data = dict(images=torch.zeros(2, 5, 8, 8), path=paths, resize_scale=t("resize_scale"), crop_scale=t("crop_scale"),
+                old_crop_center=t("old_crop_center"), crop_center=torch.tensor([[1008.0, 995.0]] * 2))
+    import argparse
+    gen = argparse.Namespace(model=None)
+    (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
+     smpl) = fitter.prep_smplfit(data, gen, pc)
+    assert np.abs(smpl.pose.detach().cpu().numpy() - g["smpl_pose"]).max() < 1e-6
+    assert np.abs(smpl.betas.detach().cpu().numpy() - g["smpl_betas"]).max() < 1e-6
+    assert np.abs(smpl.trans.detach().cpu().numpy() - g["smpl_trans"]).max() < 1e-6
+    np.testing.assert_allclose(body_kpts.cpu().numpy(), g["body_kpts"], rtol=1e-5, atol=1e-3)
+    assert np.array_equal(part_labels.cpu().numpy(), np.stack([g["part_labels"]] * 2).astype(np.int64))
+    assert np.abs(betas_dict["pose_init"].cpu().numpy() - g["pose_init"]).max() < 1e-6
+    assert np.abs(human_t.cpu().numpy() - g["human_t"]).max() == 0 and float(human_t[0, 2]) == np.float32(2.2)
+    assert part_colors.shape == (2, 50, 3) and human_points.is_cuda and obj_points.is_cuda
+    # ---- object initialisation (PCA-axis alignment through init_object_orientation -> SO(3) projection kernel) ----
+    fitter.pca_init = t("pca_init").cuda()
+    torch.manual_seed(int(g["init_seed"]))
+    obj_R, obj_s, obj_t, object_init = fitter.init_obj_fit_data(2, human_t, pc, t("scale"))
+    assert obj_R.requires_grad and obj_s.requires_grad and obj_t.requires_grad and obj_R.is_leaf
+    assert np.abs(obj_R.detach().cpu().numpy() - g["init_obj_R"]).max() < 5e-5
+    assert np.abs(obj_t.detach().cpu().numpy() - g["init_obj_t"]).max() < 1e-6
+    assert np.abs(obj_s.detach().cpu().numpy() - g["init_obj_s"]).max() == 0
+    assert object_init.shape == (2, 3000, 3)
+
+
+def test_fit_recon_chain_end_to_end(opt, tmp_path):
+    """fit_recon on a synthetic 'sequence' (two batches of one frame): generator -> prep_smplfit -> optimize_smpl ->
+    init_obj_fit_data -> optimize_smpl_object (with the real silhouette term built from the image masks) -> files;
+    a second call finds the results and skips"""
+    import argparse
+    import copy
+    from chore_amd.model import CHORE
+    from chore_amd.recon.assets import SyntheticAssets
+    from chore_amd.recon.generator import Generator
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    o = copy.copy(opt)
+    o.compute_dtype = "fp32"
+    args = argparse.Namespace(**vars(o), save_name="test", test_kid=1, redo=False)
+    net = CHORE(o).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    gen = Generator(net, None, threshold=2.0, sparse_thres=0.03, filter_val=1.0, device=torch.device("cuda"))
+    fitter = ReconFitterBehave(None, device="cuda:0", obj_name="synthetic", outpath=str(tmp_path), args=args,
+                               assets=SyntheticAssets(0))
+    calls = []
+    orig = fitter.fit_batch
+    fitter.fit_batch = lambda data, g_: (calls.append(1), orig(
+        data, g_, smpl_iters=dict(iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, steps_per_iter=2, max_iter=1),
+        object_iters=dict(obj_iter=1, joint_iter=1, steps_per_iter=2, sil_iter=1, max_iter=1)))[1]
+    # a field whose 'surface' is reachable with random weights: collect with a loose filter, few points
+    orig_gen = gen.generate_pclouds_batch
+    gen.generate_pclouds_batch = lambda data, num_points=5000, num_steps=10, mute=True: orig_gen(
+        data, num_steps=3, num_points=300, mute=True)
+    loader = []
+    for i in range(2):
+        img = synth.synth_images(1, 128, 128, seed=i)
+        img[:, 3:] = 0
+        img[:, 3, 30:100, 40:70] = 1          # person mask
+        img[:, 4, 60:90, 60:100] = 1          # object mask
+        loader.append(dict(images=torch.from_numpy(img), path=[os.path.join(str(tmp_path), "in", "seq0", f"t{i}", "k1.color.jpg")],
+                           crop_center=torch.tensor([[1008.0, 995.0]]), old_crop_center=torch.tensor([[1008.0, 995.0]]),
+                           resize_scale=torch.ones(1), crop_scale=torch.ones(1)))
+    res = fitter.fit_recon(args, loader=loader, generator=gen)
+    assert len(res) == 2 and len(calls) == 2
+    for r in res:
+        for k in ("pose", "betas", "trans", "obj_R", "obj_t", "obj_s"):
+            assert torch.isfinite(r[k]).all(), k
+        assert torch.allclose(torch.bmm(r["obj_R"], r["obj_R"].transpose(1, 2)), torch.eye(3, device="cuda").unsqueeze(0), atol=1e-4)
+    for i in range(2):
+        folder = os.path.join(str(tmp_path), "seq0", f"t{i}", "test")
+        for f in ("k1.smpl.ply", "k1.smpl.pkl", "k1.object.ply", "k1.object.pkl"):
+            assert os.path.getsize(os.path.join(folder, f)) > 0
+    from chore_amd.recon.assets import read_ply
+    v, f = read_ply(os.path.join(str(tmp_path), "seq0", "t0", "test", "k1.object.ply"))
+    assert v.shape == (fitter.scan.v.shape[0], 3) and f.shape == fitter.scan.f.shape
+    res2 = fitter.fit_recon(args, loader=loader, generator=gen)      # is_done: nothing to do
+    assert res2 == [] and len(calls) == 2
