@@ -1,32 +1,43 @@
 #!/usr/bin/env python
-"""bench.py -- headline benchmark of the CHORE field-query hot path on MI355X.
+"""bench.py -- the benchmarks of the CHORE field-query / fitting hot path on MI355X, one JSON line each.
 
-Workload (BASELINE.json configs[1]): per GPU, ONE STEP = HGFilters encode of a batch of 4 synthetic
-512x512 5-channel images + one 20 000-point MLP field query per image (80 000 points), i.e.
-`CHORE.filter(images); CHORE.query(points, crop_center)` through libchore_hip.so.  Inputs are
-resident in HBM before the timed region.  metric = query points per second (whole job, all GPUs).
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode query|fit|train]
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+--mode query (default; BASELINE.json metric 1, configs[1]): per GPU ONE STEP = HGFilters encode of 4 synthetic 512x512
+    5-channel images + one 20 000-point MLP field query per image = `CHORE.filter(images); CHORE.query(points, crop_center)`
+    through libchore_hip.so, bf16 mode.  value = query points per second, whole job.
+--mode fit (metric 2, configs[2]; with N > 1 configs[4]): ONE STEP = the whole fit_recon chain for one batch of frames --
+    encode, point-cloud generation, SMPL-H initialisation, optimize_smpl, object initialisation, optimize_smpl_object
+    with the silhouette, contact and collision terms -- run with schedules of exactly 100 + 200 = 300 Adam iterations
+    (stop rule off), every inner iteration a hipGraph replay.  value = ms per fit iteration.
+--mode train (metric 3, configs[3]): ONE STEP = CHORE.forward (5 stacks) + backward + Adam on 4 images x 20 000 points
+    per GPU, gradients all-reduced by torch DDP over RCCL when N > 1.  value = training steps per second.
 
-Multi-GPU: the path shards by image (frames are independent); every rank runs the same
-per-GPU workload on its own seeded inputs, no data-path collective ("scaling": "weak").  Timing is
-bracketed by barrier + synchronize on both sides and the MAX over ranks is reported.
+With --gpus N > 1 and no launcher environment the script re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+(one process per GPU); the driver's own launch line does the same.  Every mode: W untimed warm-up steps, then exactly K
+steps bracketed by barrier + synchronize on both sides, MAX over ranks, rank 0 prints the line.  The work shards by
+image / frame: every rank runs the same per-GPU workload on its own seeded inputs ("scaling": "weak"); the
+only collectives are the barriers, the MAX-reduce of the time and, in train mode, DDP's gradient all-reduce.
 
-Extra objects in the JSON line:
-  roofline      -- the dominant kernel of the step (by measured time), its ALGORITHMIC FLOPs
-                   per launch / average launch duration measured live with hipEvents on the launch
-                   stream (chore_profile_enable; that pass runs the encoder on ONE stream so kernels do not
-                   overlap), against the dense MFMA peak of the dtype.  Kernel names are the rocprofv3 names.
-  cpu_baseline  -- the numpy oracle ("port") timed on this host on a bounded sample of the same
-                   workload (1 image encode + 20 000-point query = 1/4 step), rank 0, N=1 only.
+Extra objects in the line:
+  roofline            query: the kernel class with the largest measured time per step -- ALGORITHMIC FLOPs per launch /
+                      average launch duration measured live with hipEvents on the launch stream (chore_profile_enable;
+                      that pass runs the encoder on ONE stream so kernels do not overlap) against the dense MFMA peak of
+                      its dtype; kernel names are the rocprofv3 names.  fit / train: the whole step against the same
+                      peak (named so in `kernel`).
+  config.field_err    query: measured error of df / pca / parts / centers against the values THE REFERENCE produced for the
+                      same images and points (tests/golden/config2_fields.npz) in the timed mode, and the same for the
+                      fp32 parity mode with its own timing beside (`fp32_mode`).
+  cpu_baseline        the numpy oracle ("port") and `cpu_baseline_torch` the same graph as stock PyTorch CPU operators
+                      (oracle/torch_graph.py), timed on this host on a bounded sample, rank 0, N = 1 only.
 """
 import argparse
 import json
 import os
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for multi-process RCCL on this driver
+import socket
 import sys
 import time
 
@@ -47,13 +58,24 @@ def chore_opt(dtype):
                               loadSize=1200, net_img_size=[512, 512], gpu_id=0, compute_dtype=dtype)
 
 
-def cpu_baseline():
+def _spec():
+    return [(k, tuple(s)) for k, s in json.load(open(os.path.join(REPO, "tests", "golden", "state_dict_spec.json")))]
+
+
+def _host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        return os.cpu_count() or 1
+
+
+# ---- CPU baselines (rank 0, N = 1 only; bounded samples) ---------------------------------------------------------------
+def cpu_baseline_query():
     """numpy oracle on the host cores: 1 image encode + 20 000-point query (a quarter of one step)"""
     from chore_amd.utils import synth
     from oracle import encoder as oe, query as oq
-    from chore_amd.model import CHORE
-    spec = [(k, tuple(v.shape)) for k, v in CHORE(chore_opt("fp32")).state_dict().items()]
-    sd = synth.synth_state_dict(spec, seed=0)
+    sd = synth.synth_state_dict(_spec(), seed=0)
     img = synth.synth_images(1, 512, 512, seed=0)
     pts = synth.synth_points(1, 20000, seed=1)
     cc = np.array([synth.CROP_CENTER], np.float32)
@@ -62,79 +84,185 @@ def cpu_baseline():
     t1 = time.perf_counter()
     oq.query(pts, cc, outs[-1], tmpx, sd)
     t2 = time.perf_counter()
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
-    except Exception:
-        threads = os.cpu_count() or 1
-    return {"value": 20000.0 / (t2 - t0), "unit": "points/s", "cores": int(threads), "kind": "port",
+    return {"value": 20000.0 / (t2 - t0), "unit": "points/s", "cores": int(_host_threads()), "kind": "port",
             "sample": "numpy oracle: 1 image 512x512 encode (%.2f s) + 20000-point query (%.3f s) = 1/4 step"
                       % (t1 - t0, t2 - t1),
             "host_cpus": os.cpu_count()}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--points", type=int, default=20000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def cpu_baseline_query_torch(reps=3):
+    """the same graph as stock PyTorch CPU operators (what the reference executes): 1 image + 20 000 points, best of reps"""
+    from chore_amd.utils import synth
+    from oracle import torch_graph as tg
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(_spec(), seed=0).items()}
+    img = torch.from_numpy(synth.synth_images(1, 512, 512, seed=0))
+    pts = torch.from_numpy(synth.synth_points(1, 20000, seed=1))
+    cc = torch.tensor([synth.CROP_CENTER])
+    best = None
+    with torch.no_grad():
+        for _ in range(reps + 1):          # first pass warms the thread pool / allocator
+            t0 = time.perf_counter()
+            outs, tmpx, _ = tg.encoder(img, sd)
+            t1 = time.perf_counter()
+            tg.query(pts, cc, outs[-1], tmpx, sd)
+            t2 = time.perf_counter()
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+    return {"value": 20000.0 / best[0], "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "stock torch CPU ops of the same graph (oracle/torch_graph.py): 1 image 512x512 encode (%.3f s) + "
+                      "20000-point query (%.3f s) = 1/4 step, best of %d" % (best[1], best[2], reps)}
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=dev)
 
+def cpu_baseline_fit(reps=3):
+    """the field part of ONE fit iteration as stock torch CPU ops: forward + backward-to-points of the 6 890 SMPL vertices
+    and twice the 3 000 object points (recon_fit_behave.py:179,196,204) on one image's maps -- a lower bound of the
+    reference's CPU time per iteration (LBS, priors, contact and Adam come on top)"""
+    from chore_amd.utils import synth
+    from oracle import torch_graph as tg
+    sd = {k: torch.from_numpy(v) for k, v in synth.synth_state_dict(_spec(), seed=0).items()}
+    rs = np.random.RandomState(3)
+    feat = torch.from_numpy(rs.standard_normal((1, 256, 128, 128)).astype(np.float32))
+    tmpx = torch.from_numpy(rs.standard_normal((1, 64, 256, 256)).astype(np.float32))
+    cc = torch.tensor([synth.CROP_CENTER])
+    best = None
+    for _ in range(reps + 1):
+        t0 = time.perf_counter()
+        for n in (6890, 3000, 3000):
+            p = torch.from_numpy(synth.synth_points(1, n, seed=n)).requires_grad_(True)
+            df = tg.query(p, cc, feat, tmpx, sd)[0]
+            df.clamp(max=0.8).mean().backward()
+        t = time.perf_counter() - t0
+        best = t if best is None or t < best else best
+    return {"value": best * 1e3, "unit": "ms", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "stock torch CPU ops: field queries of one fit iteration (6890 + 2 x 3000 points, forward + "
+                      "backward to the points), 1 frame, best of %d; LBS / priors / contact / Adam not included" % reps}
+
+
+def cpu_baseline_train():
+    """forward + backward of the training loss as stock torch CPU ops on 1 image x 20 000 points (1/4 of a GPU's batch)"""
+    from chore_amd.utils import synth
+    from oracle import torch_graph as tg
+    sd = {k: torch.from_numpy(v).requires_grad_(True) for k, v in synth.synth_state_dict(_spec(), seed=0).items()}
+    img = torch.from_numpy(synth.synth_images(1, 512, 512, seed=0))
+    pts = torch.from_numpy(synth.synth_points(1, 20000, seed=1))
+    cc = torch.tensor([synth.CROP_CENTER])
+    t0 = time.perf_counter()
+    outs, tmpx, _ = tg.encoder(img, sd)
+    loss = 0
+    for o in outs:
+        df, pca, parts, centers = tg.query(pts, cc, o, tmpx, sd)
+        loss = loss + df.clamp(max=5.0).abs().sum(-1).mean() + parts.square().mean() + pca.square().mean() + centers.square().mean()
+    loss.backward()
+    t = time.perf_counter() - t0
+    return {"value": 1.0 / (4 * t), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "stock torch CPU ops: encoder + 5 field queries + a loss of the same shape, forward + backward, 1 image x "
+                      "20000 points (%.2f s) = 1/4 of a per-GPU step; no optimiser" % t}
+
+
+# ---- launch -----------------------------------------------------------------------------------------------------------
+def self_launch(n):
+    """re-run this script as one process per GPU (the line the driver uses for N > 1)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.execv(sys.executable, cmd)
+
+
+class Ctx:
+    """rank / device / collectives of this process"""
+
+    def __init__(self, gpus, backend=None):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
+        self.cuda = torch.cuda.is_available()
+        self.dist = None
+        if self.cuda:
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+        else:
+            self.dev = torch.device("cpu")
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.cuda:
+                dist.init_process_group(backend=backend or "nccl", init_method="env://", device_id=self.dev)
+            else:
+                dist.init_process_group(backend=backend or "gloo", init_method="env://")
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def sync(self):
+        if self.cuda:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup):
+        """the contract's timing: W untimed steps, then exactly K between barrier + synchronize, MAX over ranks"""
+        for _ in range(warmup):
+            step()
+        self.barrier()
+        self.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        self.sync()
+        self.barrier()
+        return self.max_over_ranks(time.perf_counter() - t0)
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def base_line(args, ctx, metric, value, unit, elapsed, higher, dtype, config):
+    return {"metric": metric, "value": value, "unit": unit, "n_gpus": ctx.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": higher, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic", "config": config}
+
+
+# ---- mode: query ------------------------------------------------------------------------------------------------------
+def mode_query(args, ctx):
     from chore_amd import _lib
     from chore_amd.model import CHORE
     from chore_amd.utils import synth
-
-    opt = chore_opt(args.dtype)
-    opt.gpu_id = local
-    net = CHORE(opt).to(dev).eval()
-    synth.load_synth_weights(net, seed=0)
-    for p in net.parameters():
-        p.requires_grad_(False)
+    from chore_amd.utils.field_check import field_errors
+    dev, rank, local = ctx.dev, ctx.rank, ctx.local
     B, N = args.batch, args.points
-    images = torch.from_numpy(synth.synth_images(B, 512, 512, seed=rank)).to(dev)
-    points = torch.from_numpy(synth.synth_points(B, N, seed=1 + rank)).to(dev)
-    cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev)
 
-    def step():
-        net.filter(images)
-        net.query(points, crop_center=cc)
+    def make(dtype, seed_rank):
+        opt = chore_opt(dtype)
+        opt.gpu_id = local
+        net = CHORE(opt).to(dev).eval()
+        synth.load_synth_weights(net, seed=0)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        images = torch.from_numpy(synth.synth_images(B, 512, 512, seed=seed_rank)).to(dev)
+        points = torch.from_numpy(synth.synth_points(B, N, seed=1 + seed_rank)).to(dev)
+        cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
+        def step():
+            net.filter(images)
+            net.query(points, crop_center=cc)
+        return net, images, points, cc, step
 
+    net, images, points, cc, step = make(args.dtype, rank)
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        elapsed = ctx.timed(step, args.steps, args.warmup)
 
         # ---- component timings + live roofline measurement (outside the timed region) ----
         def timed(fn, n):
@@ -154,7 +282,20 @@ def main():
             net.filter(images)
         prof = _lib.profile_read(local)
         _lib.profile_enable(local, False)
-
+        # ---- field values against the reference's (rank 0 inputs are the golden's) ----
+        field_err = fp32_mode = None
+        if rank == 0 and B == 4 and N == 20000:
+            step()
+            field_err = field_errors(net.get_preds())
+            if args.dtype != "fp32":
+                net32, _, _, _, step32 = make("fp32", 0)
+                for _ in range(2):
+                    step32()
+                t32 = timed(step32, 5)
+                fp32_mode = {"ms_per_step": t32, "value": B * N / t32 * 1e3, "unit": "points/s",
+                             "field_err": field_errors(net32.get_preds())["all"]}
+                del net32
+    out = None
     if rank == 0:
         kernels = {}
         for k, v in prof.items():
@@ -184,35 +325,217 @@ def main():
                                   % args.dtype if dom in traffic else None,
                 "avg_launch_ms": dv["ms_per_step"] / dv["launches_per_step"],
                 "flops_per_launch": dv["tflops"] * 1e9 * dv["ms_per_step"] / dv["launches_per_step"]}
-        out = {
-            "metric": "query-points/sec (HGFilters encode + 20k-pt MLP field query per 512x512 image)",
-            "value": world * B * N * args.steps / elapsed,
-            "unit": "points/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: encode %dx(5,512,512) + query %dx%d points per GPU per step"
-                                   % (B, B, N),
-                       "images_per_gpu": B, "points_per_image": N, "image": "512x512x5",
-                       "heads_dtype": "fp32 (exact-fp32 MFMA)", "sharding": "images across ranks, no collective"},
-            "roofline": roof,
-            "encode_ms": enc_ms,
-            "query_ms": qry_ms,
-            "query_only_points_per_s": B * N / qry_ms * 1e3,
-            "encode_tflops": B * ENCODER_FLOP_PER_IMAGE / enc_ms / 1e9,
-            "kernels": kernels,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        out = base_line(args, ctx, "query-points/sec (HGFilters encode + 20k-pt MLP field query per 512x512 image)",
+                        ctx.world * B * N * args.steps / elapsed, "points/s", elapsed, True, args.dtype,
+                        {"workload": "BASELINE configs[1]: encode %dx(5,512,512) + query %dx%d points per GPU per step"
+                                     % (B, B, N),
+                         "images_per_gpu": B, "points_per_image": N, "image": "512x512x5",
+                         "heads_dtype": "fp32 (exact-fp32 MFMA)", "sharding": "images across ranks, no collective",
+                         "field_err": field_err,
+                         "field_err_note": "max / mean absolute and relative-L2 difference to the values THE REFERENCE "
+                                           "produced for the same images and points (tests/golden/config2_fields.npz, "
+                                           "4 x 768 points); stated tolerances: chore_amd/utils/field_check.py"})
+        out.update({"roofline": roof, "fp32_mode": fp32_mode, "encode_ms": enc_ms, "query_ms": qry_ms,
+                    "query_only_points_per_s": B * N / qry_ms * 1e3,
+                    "encode_tflops": B * ENCODER_FLOP_PER_IMAGE / enc_ms / 1e9, "kernels": kernels})
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_query()
+            out["cpu_baseline_torch"] = cpu_baseline_query_torch()
+    return out
+
+
+# ---- mode: fit --------------------------------------------------------------------------------------------------------
+def fit_batch_inputs(B, seed, dev):
+    """one loader batch of the data/test_data.py contract: 512x512 RGB + a person and an object mask, crop metadata"""
+    from chore_amd.utils import synth
+    img = synth.synth_images(B, 512, 512, seed=seed)
+    img[:, 3:] = 0
+    img[:, 3, 120:420, 180:300] = 1          # person mask
+    img[:, 4, 250:380, 280:420] = 1          # object mask
+    img[:, :3] *= np.maximum(img[:, 3:4], img[:, 4:5])      # background zeroed like data/base_data.py:179-192
+    cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32)
+    return dict(images=torch.from_numpy(img).to(dev), path=[f"/synthetic/seq{seed}/t{i:04d}.000/k1.color.jpg" for i in range(B)],
+                crop_center=cc.to(dev), old_crop_center=cc.clone(), resize_scale=torch.ones(B), crop_scale=torch.ones(B))
+
+
+SMPL_ITERS = dict(iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, steps_per_iter=10, max_iter=7)      # 10 x 10 = 100
+OBJECT_ITERS = dict(obj_iter=5, sil_iter=5, joint_iter=5, max_iter=5, steps_per_iter=10)                    # 20 x 10 = 200
+
+
+def mode_fit(args, ctx):
+    from chore_amd.model import CHORE
+    from chore_amd.parallel.frame_shard import gather_fitted
+    from chore_amd.recon.assets import SyntheticAssets
+    from chore_amd.recon.generator import Generator
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    dev, rank = ctx.dev, ctx.rank
+    B = args.frames_per_gpu or (1 if ctx.world == 1 else 8)     # configs[2]: one frame; configs[4]: 64 frames on 8 GPUs
+    opt = chore_opt(args.dtype)
+    opt.gpu_id = ctx.local
+    net = CHORE(opt).to(dev).eval()
+    synth.load_synth_weights(net, seed=0)
+    fitter = ReconFitterBehave(None, device=dev, obj_name="synthetic", outpath=None, args=opt, assets=SyntheticAssets(0))
+    fitter.use_graphs = not args.eager
+    fitter.early_stop = False      # time exactly 300 iterations (with random weights the rule fires at once)
+    fitter.timer = []
+    # random weights have no thin zero level set: a loose filter collects the 5 000 points in the first rounds
+    gen = Generator(net, None, threshold=2.0, sparse_thres=0.03, filter_val=1.0, device=dev)
+    data = fit_batch_inputs(B, rank, dev)
+    stages = {}
+
+    def clock(name, fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        stages[name] = stages.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return out
+
+    result = {}
+
+    def step():
+        pc = clock("generate_pclouds", lambda: gen.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True))
+        (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
+         smpl) = clock("prep_smplfit", lambda: fitter.prep_smplfit(data, gen, pc))
+        smpl, scale = clock("optimize_smpl", lambda: fitter.optimize_smpl(smpl, betas_dict, **SMPL_ITERS))
+        obj_R, obj_s, obj_t, object_init = clock("init_obj_fit_data", lambda: fitter.init_obj_fit_data(B, human_t, pc, scale))
+        dd = {"obj_R": obj_R, "obj_t": obj_t, "obj_s": obj_s, "objects": object_init, "smpl": smpl, "images": data["images"],
+              "body_kpts": body_kpts, "query_dict": query_dict, "part_labels": part_labels}
+        clock("optimize_smpl_object", lambda: fitter.optimize_smpl_object(net, dd, **OBJECT_ITERS))
+        result.update(trans=smpl.trans.detach(), obj_t=obj_t.detach(), obj_s=obj_s.detach())
+
+    for _ in range(args.warmup):
+        step()
+    stages.clear()
+    fitter.timer.clear()
+    elapsed = ctx.timed(step, args.steps, 0)
+    iters = sum(n for _, _, n in fitter.timer)
+    iter_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in fitter.timer) / iters
+    iter_ms = ctx.max_over_ranks(iter_ms)
+    fitted = gather_fitted(result, B * ctx.world, rank, ctx.world, device=dev)
+    out = None
+    if rank == 0:
+        per_step = {k: v / args.steps for k, v in stages.items()}
+        # points through the heads in the 300 iterations (recon_fit_behave.py:293-337, 165-222): optimize_smpl queries the 6 890
+        # vertices (forward + backward) 100 times; object-only 2 x 3 000 points (fwd + bwd) 50 times; silhouette 3 000
+        # (fwd) 50 times; joint 2 x 3 000 (fwd + bwd) + 6 890 (fwd) 100 times
+        fwd_pts = 100 * 6890 + 50 * 6000 + 50 * 3000 + 100 * (6000 + 6890)
+        bwd_pts = 100 * 6890 + 50 * 6000 + 100 * 6000
+        flops = B * (fwd_pts + bwd_pts) * HEADS_FLOP_PER_POINT / 300
+        out = base_line(args, ctx, "ms per fit iteration (SMPL-H LBS + field queries + loss terms + Adam; whole fit_recon chain run)",
+                        iter_ms, "ms", elapsed, False, args.dtype,
+                        {"workload": "BASELINE configs[%d]: fit_recon chain on %d frame(s) per GPU, 300 Adam iterations = optimize_smpl "
+                                     "%s + optimize_smpl_object %s" % (2 if ctx.world == 1 else 4, B, SMPL_ITERS, OBJECT_ITERS),
+                         "frames_per_gpu": B, "frames": B * ctx.world, "adam_iterations_per_step": iters // max(args.steps, 1),
+                         "inner_iteration": "eager" if args.eager else "hipGraph replay (chore_amd/recon/graph_step.py)",
+                         "early_stop": "off (a fixed 300 iterations are timed)",
+                         "terms": "df_h, part, pose/hand priors, smplz, pinit, j2d | object, scale, ocent | silhouette (HIP "
+                                  "rasteriser), trans | contact, collision",
+                         "value_is": "device time between events around the inner iterations / number of iterations; "
+                                     "chain_ms_per_step holds the wall time of every stage incl. graph capture",
+                         "sharding": "frames across ranks, no collective in the loop; one gather of the fitted parameters"})
+        out.update({"chain_ms_per_step": per_step, "frame_iterations_per_s": ctx.world * B * 1e3 / iter_ms,
+                    "frames_per_s_whole_chain": ctx.world * B * args.steps / elapsed,
+                    "roofline": {"kernel": "whole fit iteration (field queries dominate: query_fwd_f32_kernel / query_bwd_f32_kernel, "
+                                           "32-point tiles)", "bound": "mfma", "achieved": flops / iter_ms / 1e9,
+                                 "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": flops / iter_ms / 1e9 / PEAK_TFLOPS["fp32"],
+                                 "traffic": None, "flops_per_iteration": flops,
+                                 "note": "algorithmic FLOPs of the heads only (600 832 per point forward, the same again backward)"},
+                    "gathered": {k: list(v.shape) for k, v in fitted.items()}})
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_fit()
+    return out
+
+
+# ---- mode: train ------------------------------------------------------------------------------------------------------
+def mode_train(args, ctx):
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    dev, rank, local = ctx.dev, ctx.rank, ctx.local
+    opt = chore_opt(args.dtype)
+    opt.gpu_id = local
+    net = CHORE(opt).to(dev)
+    synth.load_synth_weights(net, seed=0)
+    net.train(True)
+    net.losses_on_host = False     # the six separate losses stay on the device: no host synchronisation inside the step
+    model = net
+    if ctx.world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], find_unused_parameters=True)
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    B, N = args.batch, args.points
+    rs = np.random.RandomState(50 + rank)
+    t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
+    batch = dict(images=t(synth.synth_images(B, 512, 512, seed=rank)), points=t(synth.synth_points(B, N, seed=1 + rank)),
+                 df_h=t(rs.uniform(0, 0.3, (B, N)).astype(np.float32)), df_o=t(rs.uniform(0, 0.3, (B, N)).astype(np.float32)),
+                 parts_gt=t(rs.randint(0, 14, (B, N))), pca_gt=t(rs.standard_normal((B, 3, 3, N)).astype(np.float32)),
+                 body_center=t((rs.standard_normal((B, 3)) * 0.3).astype(np.float32)),
+                 obj_center=t((rs.standard_normal((B, 3, N)) * 0.3).astype(np.float32)),
+                 crop_center=torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev))
+    last = {}
+
+    def step():
+        optim.zero_grad(set_to_none=True)
+        error, _ = model(**batch)
+        error.backward()
+        optim.step()
+        last["err"] = error
+
+    elapsed = ctx.timed(step, args.steps, args.warmup)
+    out = None
+    if rank == 0:
+        flops = 3.0 * (B * ENCODER_FLOP_PER_IMAGE + 5 * B * N * HEADS_FLOP_PER_POINT)     # SURVEY 8(d): 3.82 TFLOP at B=4
+        ms = elapsed / args.steps * 1e3
+        out = base_line(args, ctx, "training steps/s (CHORE.forward + backward + Adam, B=4 x 512x512 images, 20k points/image per GPU)",
+                        args.steps / elapsed, "steps/s", elapsed, True, args.dtype,
+                        {"workload": "BASELINE configs[3]: DDP training, batch %d/GPU, %d points/image, 5 stacks" % (B, N),
+                         "images_per_gpu": B, "points_per_image": N,
+                         "grad_allreduce": "torch DDP over RCCL (backend nccl), find_unused_parameters=True" if ctx.world > 1
+                                           else "none (1 GPU)"})
+        out.update({"images_per_s": ctx.world * B * args.steps / elapsed, "final_loss": float(last["err"].detach()),
+                    "parameters": sum(p.numel() for p in net.parameters()),
+                    "roofline": {"kernel": "whole training step (all kernels)", "bound": "mfma", "achieved": flops / ms / 1e9,
+                                 "peak": PEAK_TFLOPS[args.dtype], "unit": "TFLOP/s", "frac": flops / ms / 1e9 / PEAK_TFLOPS[args.dtype],
+                                 "traffic": None, "flops_per_step": flops}})
+        if ctx.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_train()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", default="query", choices=["query", "fit", "train"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--points", type=int, default=20000)
+    ap.add_argument("--frames-per-gpu", type=int, default=0, help="fit mode: frames fitted as one batch per GPU (default 1, or 8 when N > 1)")
+    ap.add_argument("--eager", action="store_true", help="fit mode: issue the inner iterations from Python instead of replaying hipGraphs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
+    args = ap.parse_args()
+    defaults = {"query": (20, 5), "fit": (3, 1), "train": (10, 3)}[args.mode]
+    args.steps = defaults[0] if args.steps is None else args.steps
+    args.warmup = defaults[1] if args.warmup is None else args.warmup
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)
+    ctx = Ctx(args.gpus)
+    if args.dry_run:
+        # the distributed skeleton without the device work: used by the CPU test of the N > 1 launch path
+        elapsed = ctx.timed(lambda: time.sleep(0.001 * (1 + ctx.rank)), args.steps, args.warmup)
+        if ctx.rank == 0:
+            print(json.dumps(base_line(args, ctx, "dry run", args.steps / elapsed, "steps/s", elapsed, True, "none",
+                                       {"workload": "dry run (no device work)"})), flush=True)
+        ctx.close()
+        return
+    if not ctx.cuda:
+        raise SystemExit("bench.py needs a GPU (there is no CPU path); --dry-run exercises the launch skeleton only")
+    out = {"query": mode_query, "fit": mode_fit, "train": mode_train}[args.mode](args, ctx)
+    if ctx.rank == 0:
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    ctx.close()
 
 
 if __name__ == "__main__":

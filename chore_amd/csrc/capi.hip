@@ -44,7 +44,7 @@ int chore_create(chore_handle** out, int device_ordinal) {
 void chore_encoder_cache_free(chore_handle* h);
 
 int chore_destroy(chore_handle* h) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     chore_encoder_cache_free(h);
     delete h;
     return CHORE_OK;
@@ -59,7 +59,8 @@ size_t chore_heads_arena_bytes(int dtype) {
 
 int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_descs, int dtype, void* arena,
                      chore_stream_t stream) {
-    if (!h || !descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_pack: null argument");
+    CHORE_ENTER(h);
+    if (!descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_pack: null argument");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_pack: bad dtype");
     static const char* names[HEAD_NUM] = {"df", "part_predictor", "pca_predictor", "center_predictor"};
     HeadsRaw raw;
@@ -98,7 +99,7 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
                     const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                     const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
                     float* centers, uint8_t* in_img, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: null output");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
@@ -114,7 +115,7 @@ int chore_sample_features(chore_handle* h, const float* points, const float* cro
                           const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                           const float* cam6_host, float* features, float* nxy, uint8_t* in_img,
                           chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!features) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: null output");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, feat /*unused*/,
@@ -129,7 +130,7 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
                            const void* heads_arena, const float* cam6_host, const float* g_df,
                            const float* g_pca, const float* g_parts, const float* g_centers, float* dpoints,
                            chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!dpoints) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_points: null dpoints");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
@@ -161,7 +162,7 @@ int chore_query_fwd_train(chore_handle* h, const float* points, const float* cro
                           const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                           const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
                           float* centers, uint8_t* in_img, void* staging, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers || !staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: null output");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
@@ -178,7 +179,7 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
                           const void* heads_arena, const float* cam6_host, const float* g_df, const float* g_pca,
                           const float* g_parts, const float* g_centers, void* staging, float* dpoints,
                           int have_forward, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
@@ -193,7 +194,7 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
 int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,
                            int TH, int TW, const float* cam6_host, const void* staging, float* dfeat, float* dtmpx,
                            int accumulate, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!staging || (!dfeat && !dtmpx)) CHORE_FAIL(h, CHORE_EINVAL, "chore_scatter_features: null argument");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, staging /*unused*/, FH, FW, staging /*unused*/, TH, TW,

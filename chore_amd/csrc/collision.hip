@@ -437,7 +437,7 @@ size_t chore_collision_workspace_bytes(int B, int V, int F) {
 
 int chore_collision_fwd(chore_handle* h, const float* verts, const int* faces, int B, int V, int F, float* loss, float* gverts,
                         int* counts, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!verts || !faces || !loss || !gverts || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_collision_fwd: null argument");
     if (B <= 0 || V <= 0 || F <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_collision_fwd: B, V, F must be positive");
     hipStream_t s = (hipStream_t)stream;
@@ -466,7 +466,7 @@ int chore_collision_fwd(chore_handle* h, const float* verts, const int* faces, i
 
 int chore_collision_bwd(chore_handle* h, const float* gverts, const float* gout, int B, int V, float* dverts,
                         chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!gverts || !gout || !dverts || B <= 0 || V <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_collision_bwd: bad argument");
     const size_t m = (size_t)B * V * 3;
     hipLaunchKernelGGL(coll_scale_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gverts, gout, V * 3, m,

@@ -14,7 +14,30 @@ struct chore_handle {
     std::string err;
     // cached encoder programs keyed by shape (see encoder.cpp)
     void* enc_cache = nullptr;
+    // one-off per-device setup that has been done for THIS handle's device (kernel attributes such as the dynamic LDS
+    // limit are per device): keyed by the address of a marker that is unique per call site / template instantiation
+    std::unordered_map<const void*, bool> once;
 };
+
+// every entry point runs with the handle's device current (a caller whose current device is another GPU -- e.g. the
+// reference's model.to(torch.device(opt.gpu_id)) without torch.cuda.set_device -- would otherwise create the encoder's
+// auxiliary streams and set kernel attributes on the wrong device) and restores the caller's device on return
+struct ChoreDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit ChoreDeviceGuard(const chore_handle* h) {
+        if (h && hipGetDevice(&prev) == hipSuccess && prev != h->device) switched = hipSetDevice(h->device) == hipSuccess;
+    }
+    ~ChoreDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    ChoreDeviceGuard(const ChoreDeviceGuard&) = delete;
+    ChoreDeviceGuard& operator=(const ChoreDeviceGuard&) = delete;
+};
+#define CHORE_ENTER(h)                  \
+    if (!(h)) return CHORE_EINVAL;      \
+    ChoreDeviceGuard _chore_guard(h)
+#define CHORE_ONCE_FLAG(h) ([&]() -> bool& { static char _site; return (h)->once[(const void*)&_site]; }())
 
 #define CHORE_FAIL(h, code, ...)                         \
     do {                                                 \

@@ -321,7 +321,7 @@ extern "C" size_t chore_contact_workspace_bytes(int B, int Nh, int No, int P) {
 extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float* obj, const float* df_hum_o,
                                  const float* df_obj_h, const int* label_h, const float* part_logits, int B, int Nh,
                                  int No, int P, float thres, float* loss, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!hum || !obj || !df_hum_o || !df_obj_h || !label_h || !part_logits || !loss || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_fwd: null argument");
     if (B <= 0 || Nh <= 0 || No <= 0 || P <= 0 || P > CP_MAX)
@@ -361,7 +361,7 @@ extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float*
 extern "C" int chore_contact_bwd(chore_handle* h, const float* hum, const float* obj, const int* label_h, int B, int Nh,
                                  int No, int P, const float* g_loss, const void* workspace, float* d_hum, float* d_obj,
                                  chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!hum || !obj || !label_h || !g_loss || !workspace || !d_hum || !d_obj)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: null argument");
     if (B <= 0 || Nh <= 0 || No <= 0 || P <= 0 || P > CP_MAX)

@@ -27,6 +27,17 @@
 //     stored values are reduced in a fixed order.
 #include "enc_common.h"
 
+// Ablation switches for kernel experiments (scripts/conv_ablate.sh) exist only in builds with -DCHORE_CONV_ABLATE=1; in
+// the shipped library DBG(a) is the constant 0 and every switch below folds away.
+#ifndef CHORE_CONV_ABLATE
+#define CHORE_CONV_ABLATE 0
+#endif
+#if CHORE_CONV_ABLATE
+#define DBG(a) ((a).dbg)
+#else
+#define DBG(a) 0
+#endif
+
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
 namespace {
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // (bijective for any grid size).  dbg bit 2048 switches it off for A/B measurements.
     const int ntn = a.Cout / NT, tiles = tiles_x * ((a.H + TH - 1) / TH);
     int lid = blockIdx.x;
-    if (!(a.dbg & 2048)) {
+    if (!(DBG(a) & 2048)) {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = lid & 7;
         lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
     }
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         load_patch(preq[q], chunk_of(cq) * CC);
         load_w(rbq[q], chunk_of(cq), 0);
     }
-    if (use_gn && !(a.dbg & 64)) {
+    if (use_gn && !(DBG(a) & 64)) {
         // GroupNorm affine of this image's input channels from the producers' exact group totals
         for (int ci = tid; ci < Cin; ci += 256)
             gn_scale_shift(a.in_st, b, Cin, ci, a.H * a.W, a.gamma, a.beta, ss_lds[2 * ci], ss_lds[2 * ci + 1]);
@@ -304,24 +315,24 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         // sets are named statically; the loads are unconditional (the tail re-fetches the last chunk) so that the
         // wait before a publish counts only the loads issued after the ones it needs.  NCH % PD == 0 (launcher).
 #pragma unroll 1
-        for (int c0 = 0; c0 < ((a.dbg & 128) ? 0 : NCH); c0 += PD) {
+        for (int c0 = 0; c0 < ((DBG(a) & 128) ? 0 : NCH); c0 += PD) {
 #pragma unroll
             for (int u = 0; u < PD; ++u) {
                 const int c = c0 + u;
                 const int cn = c + PD < NCH ? c + PD : NCH - 1;
-                if (!(a.dbg & 2)) load_patch(preq[u], chunk_of(cn) * CC);
-                if (!(a.dbg & 1)) load_w(rbq[u], chunk_of(cn), 0);
+                if (!(DBG(a) & 2)) load_patch(preq[u], chunk_of(cn) * CC);
+                if (!(DBG(a) & 1)) load_w(rbq[u], chunk_of(cn), 0);
                 __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMA block
-                if (!(a.dbg & 4)) mfma_step(c & 1, 0, NPATCH == 2 ? (c & 1) : 0);
+                if (!(DBG(a) & 4)) mfma_step(c & 1, 0, NPATCH == 2 ? (c & 1) : 0);
                 if (c + 1 < NCH) {
                     write_w(rbq[(u + 1) % PD], (c + 1) & 1);
                     if constexpr (NPATCH == 2) {
                         // the other patch buffer and ring slot were last read for chunk c-1, which every wave left
                         // before the barrier that ended that iteration: no barrier needed before overwriting them
-                        if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC, (c + 1) & 1);
+                        if (!(DBG(a) & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC, (c + 1) & 1);
                     } else {
                         __syncthreads();   // every wave has finished reading this chunk's patch
-                        if (!(a.dbg & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC);
+                        if (!(DBG(a) & 32)) write_patch(preq[(u + 1) % PD], chunk_of(c + 1) * CC);
                     }
                 }
                 __syncthreads();
@@ -330,15 +341,15 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     } else {
         int c = 0, krow = 0;   // c counts chunks in visiting order
 #pragma unroll 1
-        for (int s = 0; s < ((a.dbg & 128) ? 0 : S); ++s) {
+        for (int s = 0; s < ((DBG(a) & 128) ? 0 : S); ++s) {
             const bool last_row = (krow == KROWS - 1);
             const bool more_chunks = (c + 1 < NCH);
             // (a) prefetch the next K-step's weights (and the next chunk's patch) into registers; they have
             //     the whole MFMA block below to land
-            if (s + 1 < S && !(a.dbg & 1)) load_w(rbq[0], chunk_of(last_row ? c + 1 : c), last_row ? 0 : krow + 1);
-            if (krow == 0 && more_chunks && !(a.dbg & 2)) load_patch(preq[0], chunk_of(c + 1) * CC);
+            if (s + 1 < S && !(DBG(a) & 1)) load_w(rbq[0], chunk_of(last_row ? c + 1 : c), last_row ? 0 : krow + 1);
+            if (krow == 0 && more_chunks && !(DBG(a) & 2)) load_patch(preq[0], chunk_of(c + 1) * CC);
             // (b) the MFMAs of this K-step
-            if (!(a.dbg & 4)) mfma_step(s & 1, krow);
+            if (!(DBG(a) & 4)) mfma_step(s & 1, krow);
             // (c) publish the next step's operands
             if (s + 1 < S) write_w(rbq[0], (s + 1) & 1);
             if (last_row && more_chunks) {
@@ -349,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
             if (last_row) { krow = 0; ++c; } else ++krow;
         }
     }
-    if (a.dbg & 8) return;
+    if (DBG(a) & 8) return;
 
     // ---- epilogue (the loop ended with a barrier: patch and ring are dead, reuse them) ----
     float* scr = (float*)smem + wid * (32 * SCR_LD);          // wave-private [32 pixels][SCR_LD]
@@ -366,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const size_t img = (size_t)b * a.H * a.W;
     T* out_p = (T*)a.out.p + img * a.out.cs + a.out.co + nv;
     T* raw_p = a.raw.p ? (T*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
-    const T* res_p = (a.res.p && !(a.dbg & 1024)) ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
-    const T* res2_p = (a.res2.p && !(a.dbg & 1024)) ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
-    const bool want_stats = (a.st_raw || a.st_out) && !(a.dbg & 256);
+    const T* res_p = (a.res.p && !(DBG(a) & 1024)) ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    const T* res2_p = (a.res2.p && !(DBG(a) & 1024)) ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
+    const bool want_stats = (a.st_raw || a.st_out) && !(DBG(a) & 256);
     float sr[8], qr[8], so[8], qo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 const f32x4 lo = *(const f32x4*)(scr + p * SCR_LD + g8 * 8), hi = *(const f32x4*)(scr + p * SCR_LD + g8 * 8 + 4);
                 f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
             }
-            if (y < a.H && x < a.W && !(a.dbg & 512)) {
+            if (y < a.H && x < a.W && !(DBG(a) & 512)) {
                 const size_t pix = (size_t)y * a.W + x;
                 if (raw_p) {
                     float g[8];
@@ -482,7 +493,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
                 for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
             const int cg = n_tile * NT + tid;
-            if (a.dbg & 16) return;
+            if (DBG(a) & 16) return;
             // channels -> GroupNorm groups of the tensor the slice belongs to (gs consecutive lanes), one lane adds
             if (a.st_raw) {
                 const int gs = a.st_raw_C / GN_GROUPS;
@@ -510,7 +521,7 @@ template <typename T, int TAPS, int NT, int TPS_>
 int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     using G = Geo<TAPS, NT, TPS_>;
     const size_t smem = G::smem_bytes(a.in.C);
-    static bool attr = false;
+    bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_lds_kernel<T, TAPS, NT, TPS_>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024));
@@ -586,9 +597,11 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
-    static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
     ConvArgs a = a_in;
+#if CHORE_CONV_ABLATE
+    static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
     a.dbg = dbg;
+#endif
     const int nt = choose_nt(dtype, a.B, a.H, a.W, a.Cout);
     const bool small_grid = is_small_grid(dtype, a.B, a.H, a.W, a.in.C, a.Cout, nt);
     if (dtype == CHORE_F32)

@@ -90,19 +90,19 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
     const int OH = H / 2, OW = W / 2;
     dim3 grid((OW + STEM_T - 1) / STEM_T, (OH + STEM_T - 1) / STEM_T, B);
     const size_t smem = ((size_t)Cin * 49 * 64 + (size_t)Cin * STEM_P * STEM_P) * sizeof(float);
-    static bool attr[2] = {false, false};
+    bool* attr[2] = {&CHORE_ONCE_FLAG(h), &CHORE_ONCE_FLAG(h)};
     if (dtype == CHORE_F32) {
-        if (!attr[0]) {
+        if (!*attr[0]) {
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)stem_kernel<float>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr[0] = true;
+            *attr[0] = true;
         }
         hipLaunchKernelGGL(stem_kernel<float>, grid, dim3(256), smem, s, images, B, Cin, H, W, wk, bias, (float*)out);
     } else {
-        if (!attr[1]) {
+        if (!*attr[1]) {
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)stem_kernel<bf16_t>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            attr[1] = true;
+            *attr[1] = true;
         }
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), smem, s, images, B, Cin, H, W, wk, bias,
                            (bf16_t*)out);
@@ -394,7 +394,7 @@ template <typename T, int C, typename Op>
 static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int OH, int OW, GroupStat* st,
                         hipStream_t s) {
     dim3 grid(((OH + MAP_T - 1) / MAP_T) * ((OW + MAP_T - 1) / MAP_T), B);
-    static bool attr = false;   // per instantiation
+    bool& attr = CHORE_ONCE_FLAG(h);   // per instantiation
     if (!attr && Op::SMEM > 32 * 1024) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)map_stats_kernel<T, C, Op>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)Op::SMEM));

@@ -595,7 +595,7 @@ size_t chore_encoder_arena_bytes(const chore_encoder_cfg* cfg, int dtype) {
 
 int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chore_weight_desc* descs, int n_descs,
                        int dtype, void* arena, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (int rc = check_cfg(h, cfg)) return rc;
     if (!descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: null argument");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: bad dtype");
@@ -639,7 +639,7 @@ size_t chore_encoder_workspace_bytes(const chore_encoder_cfg* cfg, int B, int H,
 int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float* images, int B, int H, int W,
                      int dtype, const void* arena, void* workspace, size_t workspace_bytes, void* const* feat_out,
                      int n_stack_out, void* tmpx, void* normx, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (int rc = check_cfg(h, cfg)) return rc;
     if (!images || !arena || !workspace || !tmpx) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: null argument");
     if (B <= 0 || B > 65535 || H % 16 || W % 16 || H < 16 || W < 16)
@@ -723,7 +723,7 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
 }
 
 int chore_profile_enable(chore_handle* h, int on) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!h->enc_cache) h->enc_cache = new EncCache();
     Profile& p = ((EncCache*)h->enc_cache)->prof;
     p.on = on != 0;

@@ -109,7 +109,7 @@ size_t chore_eval_chamfer_workspace_bytes(int Nx, int Ny) { return (size_t)(Nx >
 // out[0] = mean_i min_j |x_i - y_j| ('x_to_y'), out[1] = mean_j min_i |x_i - y_j| ('y_to_x'); 'bi' is their sum
 int chore_eval_chamfer(chore_handle* h, const double* x, int Nx, const double* y, int Ny, double* out, void* workspace,
                        chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !y || !out || !workspace || Nx <= 0 || Ny <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_eval_chamfer: bad argument");
     hipStream_t s = (hipStream_t)stream;
     double* d2 = (double*)workspace;
@@ -123,7 +123,7 @@ int chore_eval_chamfer(chore_handle* h, const double* x, int Nx, const double* y
 
 // params[13] = R (9, row-major), t (3), scale: S2 ~ scale R S1 + t   (pose_utils.py compute_transform)
 int chore_eval_procrustes(chore_handle* h, const double* S1, const double* S2, int N, double* params, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!S1 || !S2 || !params || N <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_eval_procrustes: bad argument");
     hipLaunchKernelGGL(procrustes_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, S1, S2, N, params);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
@@ -131,7 +131,7 @@ int chore_eval_procrustes(chore_handle* h, const double* S1, const double* S2, i
 }
 
 int chore_eval_apply_similarity(chore_handle* h, const double* pts, int N, const double* params, double* out, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!pts || !params || !out || N <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_eval_apply_similarity: bad argument");
     hipLaunchKernelGGL(apply_similarity_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, pts, N, params, out);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);

@@ -94,7 +94,7 @@ __global__ void gen_resample_kernel(const float* __restrict__ samples, int N, co
 extern "C" {
 
 int chore_gen_compact(chore_handle* h, const unsigned char* mask, int B, int N, int* order, int* counts, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!mask || !order || !counts || B <= 0 || N <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_compact: bad argument");
     hipLaunchKernelGGL(gen_compact_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, N, order, counts);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
@@ -104,7 +104,7 @@ int chore_gen_compact(chore_handle* h, const unsigned char* mask, int B, int N, 
 int chore_gen_append(chore_handle* h, const float* src, long long ss_b, long long ss_c, long long ss_n, const int* order,
                      const int* counts, const int* offsets, float* dst, long long ds_b, long long ds_c, long long ds_n, int B,
                      int C, int N, int cap, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!src || !order || !counts || !offsets || !dst || B <= 0 || C <= 0 || N <= 0 || cap <= 0)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_append: bad argument");
     hipLaunchKernelGGL(gen_append_kernel, dim3((N + 255) / 256, C, B), dim3(256), 0, (hipStream_t)stream, src, ss_b, ss_c, ss_n, order,
@@ -114,7 +114,7 @@ int chore_gen_append(chore_handle* h, const float* src, long long ss_b, long lon
 }
 
 int chore_gen_advance(chore_handle* h, const int* counts, int B, int* offsets, int* total, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!counts || !offsets || !total || B <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_advance: bad argument");
     hipLaunchKernelGGL(gen_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counts, B, offsets, total);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
@@ -123,7 +123,7 @@ int chore_gen_advance(chore_handle* h, const int* counts, int B, int* offsets, i
 
 int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, const int* order, const int* counts, const float* init,
                        int Ninit, const float* u, const float* noise, int M, float sigma, float* out, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!samples || !order || !counts || !init || !u || !noise || !out || B <= 0 || N <= 0 || Ninit <= 0 || M <= 0)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_resample: bad argument");
     hipLaunchKernelGGL(gen_resample_kernel, dim3((M + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, samples, N, order, counts, init,

@@ -243,7 +243,7 @@ size_t chore_heads_wgrad_workspace_bytes(void) { return (HW_PART + HW_PART_B + H
 
 int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
                       const float* g_parts, const float* g_centers, float* grads, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!staging || !g_df || !g_pca || !g_parts || !g_centers || !grads || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_wgrad: null argument");
     if (B <= 0 || N <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_wgrad: B, N must be positive");
@@ -261,7 +261,7 @@ int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const 
     a.part_b4 = a.part4 + HW_PART4;
     a.out = grads;
     const size_t smem = (size_t)2 * HW_KT * 256 * sizeof(float);
-    static bool attr = false;
+    bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)heads_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;

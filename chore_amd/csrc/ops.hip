@@ -21,7 +21,7 @@ size_t chore_gn_stats_bytes(int B) { return (size_t)B * GN_GROUPS * sizeof(Group
 // (zeroed != 0: the caller hands in zeroed accumulators, e.g. a slice of an arena cleared once per pass)
 int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, int zeroed,
                    chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !stats || B <= 0 || HW <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_stats: bad argument");
     hipStream_t s = (hipStream_t)stream;
     if (!zeroed) CHORE_HIP_CHECK(h, hipMemsetAsync(stats, 0, chore_gn_stats_bytes(B), s));
@@ -32,7 +32,7 @@ int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int
 // y = relu(groupnorm(x))
 int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                       void* y, int B, int HW, int C, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !stats || !gamma || !beta || !y) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_fwd: null argument");
     View vx; vx.p = const_cast<void*>(x); vx.cs = C; vx.co = 0; vx.C = C;
     View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
@@ -45,7 +45,7 @@ int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* sta
 int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                      const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
                      int Cout, void* y, void* out_stats, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !w || !y || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: null argument");
     if (stats && (!gamma || !beta)) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_fwd: GroupNorm needs gamma and beta");
     hipStream_t s = (hipStream_t)stream;
@@ -65,7 +65,7 @@ int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B,
 // the same kernel on the transposed, spatially flipped weights
 int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, int B, int H, int W, int Cout,
                           const float* w, int Cin, void* dx, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!dy || !w || !dx || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_data: null argument");
     hipStream_t s = (hipStream_t)stream;
     int rc = launch_pack_conv(h, dtype, taps, /*Cin of this conv*/ Cout, /*Cout of this conv*/ Cin, w, workspace, s, 1);
@@ -84,7 +84,7 @@ size_t chore_stem_workspace_bytes(int Cin) { return Cin > 0 ? (size_t)Cin * 49 *
 
 int chore_stem_fwd(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const float* w,
                    const float* bias, void* y, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!images || !w || !bias || !y || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: null argument");
     if (B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: bad shape");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_fwd: dtype");
@@ -96,7 +96,7 @@ int chore_stem_fwd(chore_handle* h, int dtype, const float* images, int B, int C
 
 // y (B,H/2,W/2,C) = 2x2 average pooling of x (B,H,W,C), C in {64,128,256}; dx = its transpose applied to dy
 int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: bad argument");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: dtype");
     View vx; vx.p = const_cast<void*>(x); vx.cs = C; vx.co = 0; vx.C = C;
@@ -105,7 +105,7 @@ int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B
 }
 
 int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!dy || !dx || B <= 0 || H <= 0 || W <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_bwd: bad argument");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_bwd: dtype");
     return launch_pool2_bwd(h, dtype, dy, dx, B, H, W, C, (hipStream_t)stream);
@@ -114,7 +114,7 @@ int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int
 // y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C)), align_corners=True  (HourGlass._forward, HGFilters.py:47-50); y may be a
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
                     chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!a || !low || !y) CHORE_FAIL(h, CHORE_EINVAL, "chore_upadd_fwd: null argument");
     View va; va.p = const_cast<void*>(a); va.cs = C; va.co = 0; va.C = C;
     View vl; vl.p = const_cast<void*>(low); vl.cs = C; vl.co = 0; vl.C = C;
@@ -124,7 +124,7 @@ int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, 
 
 // d_low (B,H,W,C) = transpose of the bicubic x2 upsampling applied to dy (B,2H,2W,C)
 int chore_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!dy || !dlow) CHORE_FAIL(h, CHORE_EINVAL, "chore_up2_bwd: null argument");
     return launch_up2_bwd(h, dtype, dy, dlow, B, H, W, C, (hipStream_t)stream);
 }

@@ -304,7 +304,7 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
 
 template <typename T, bool TRAIN, int NCB>
 static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     constexpr int PTS = 32 * NCB;
     const size_t smem = sizeof(QueryBwdSmemT<PTS>);
     if (!attr_set) {
@@ -323,7 +323,7 @@ bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64
 // the eight-wave variants (64-point tile, two waves per head)
 template <typename T, bool TRAIN, bool STAGED>
 static int launch_query_bwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryBwdSmemT<64>);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8>,
@@ -352,7 +352,7 @@ static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
 
 template <typename T>
 static int launch_query_bwd_staged_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryBwdSmemT<64>);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, true, 2, true>,

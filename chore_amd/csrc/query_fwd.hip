@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void sample_features_kernel(QueryArgs a, float
 
 template <typename T>
 static int launch_sample_features_t(chore_handle* h, const QueryArgs& a, float* features, float* nxy, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmem);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)sample_features_kernel<T>,
@@ -292,7 +292,7 @@ int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hi
 
 template <typename T, int NCB>
 static int launch_query_fwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     constexpr int PTS = 32 * NCB;
     const size_t smem = sizeof(QueryFwdSmemT<PTS>);
     if (!attr_set) {
@@ -311,7 +311,7 @@ bool query_small_tiles(int B, int N) { return (size_t)B * ((N + QT_PTS - 1) / QT
 
 template <typename T>
 static int launch_query_fwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, false>,
@@ -333,7 +333,7 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
 
 template <typename T>
 static int launch_query_fwd_train_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, true>,
@@ -349,7 +349,7 @@ static int launch_query_fwd_train_w8(chore_handle* h, const QueryArgs& a, hipStr
 template <typename T>
 static int launch_query_fwd_train_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if (!getenv("CHORE_QUERY_W4")) return launch_query_fwd_train_w8<T>(h, a, s);
-    static bool attr_set = false;
+    bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, 2, true>,

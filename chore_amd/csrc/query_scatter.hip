@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void scatter_kernel(QueryArgs a, const float* 
 
 int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX, float* dfeat, float* dtmpx,
                             int accumulate, hipStream_t s) {
-    static bool attr = false;
+    bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_kernel<FEAT_C, 8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));

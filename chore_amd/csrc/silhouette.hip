@@ -148,8 +148,9 @@ struct Img {
     }
 };
 
+// The 64 lanes of a wave share one walk: lane l takes the positions d0_from + l, + 64, ... along the edge.
 __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v0, float u1, float v1, float u2, float v2,
-                              float eps, float& g0, float& g1) {
+                              float eps, int lane, float& g0, float& g1) {
     const int size = im.size;
     const float S = (float)size;
     int direction;
@@ -157,7 +158,7 @@ __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v
     else direction = (u0 < u1) ? 1 : -1;
     const int d0_from = (int)fmaxf(ceilf(fminf(u0, u1)), 0.f);
     const int d0_to = (int)fminf(fmaxf(u0, u1), S - 1.f);
-    for (int d0 = d0_from; d0 <= d0_to; ++d0) {
+    for (int d0 = d0_from + lane; d0 <= d0_to; d0 += 64) {
         const float fd0 = (float)d0;
         const float cross = (v1 - v0) / (u1 - u0) * (fd0 - u0) + v0;
         if (!(fabsf(cross) <= 3.0e38f)) continue;          // non-finite: degenerate edge
@@ -201,16 +202,24 @@ __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v
     }
 }
 
-__global__ void sil_bwd_kernel(const float* __restrict__ faces, const int* __restrict__ face_index,
-                               const float* __restrict__ alpha, const float* __restrict__ grad_alpha, int B, int F,
-                               int size, float eps, float* __restrict__ grad_faces) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * F) return;
+// One workgroup per triangle, one wave per walk (3 edges x 2 axes), one lane per position along the edge: the reference
+// (rasterize_cuda_kernel.cu:290-549) gives a whole triangle to ONE thread, whose six walks of up to `size` positions x up
+// to `size` pixels each are a serial chain of tens of thousands of dependent loads -- 5.4 ms for a 1 024-triangle
+// template that fills the 256-px ROI.  The per-lane partial sums are combined with a fixed butterfly and the six walks
+// in the reference's order, so the result is deterministic; it differs from the serial sum by fp32 round-off only.
+__global__ __launch_bounds__(384) void sil_bwd_kernel(const float* __restrict__ faces, const int* __restrict__ face_index,
+                                                      const float* __restrict__ alpha, const float* __restrict__ grad_alpha,
+                                                      int B, int F, int size, float eps, float* __restrict__ grad_faces) {
+    const int i = blockIdx.x;
     const int b = i / F, fn = i % F;
-    float f[9], g[9];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ float part[6][2];
+    float f[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) { f[k] = faces[(size_t)i * 9 + k]; g[k] = 0.f; }
-    if (!tri_backside(f)) {
+    for (int k = 0; k < 9; ++k) f[k] = faces[(size_t)i * 9 + k];
+    const bool back = tri_backside(f);
+    float g0 = 0.f, g1 = 0.f;
+    if (!back) {
         const size_t img = (size_t)b * size * size;
         const Img im{face_index + img, alpha + img, grad_alpha + img, size};
         const float S = (float)size;
@@ -220,15 +229,33 @@ __global__ void sil_bwd_kernel(const float* __restrict__ faces, const int* __res
             px[v] = 0.5f * ((f[3 * v] * S + S) - 1.0f);
             py[v] = 0.5f * ((f[3 * v + 1] * S + S) - 1.0f);
         }
-        for (int e = 0; e < 3; ++e) {
-            const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
-            // axis 0: walk x, the gradient goes to y; axis 1: walk y, the gradient goes to x
-            sil_edge_walk(im, fn, 0, px[i0], py[i0], px[i1], py[i1], px[i2], py[i2], eps, g[3 * i0 + 1], g[3 * i1 + 1]);
-            sil_edge_walk(im, fn, 1, py[i0], px[i0], py[i1], px[i1], py[i2], px[i2], eps, g[3 * i0 + 0], g[3 * i1 + 0]);
+        const int e = wave >> 1, axis = wave & 1;
+        const int i0 = e, i1 = (e + 1) % 3, i2 = (e + 2) % 3;
+        // axis 0: walk x, the gradient goes to y; axis 1: walk y, the gradient goes to x
+        if (axis == 0) sil_edge_walk(im, fn, 0, px[i0], py[i0], px[i1], py[i1], px[i2], py[i2], eps, lane, g0, g1);
+        else sil_edge_walk(im, fn, 1, py[i0], px[i0], py[i1], px[i1], py[i2], px[i2], eps, lane, g0, g1);
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            g0 += __shfl_xor(g0, o);
+            g1 += __shfl_xor(g1, o);
         }
     }
+    if (lane == 0) { part[wave][0] = g0; part[wave][1] = g1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float g[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) grad_faces[(size_t)i * 9 + k] = g[k];
+        for (int k = 0; k < 9; ++k) g[k] = 0.f;
+        for (int e = 0; e < 3; ++e) {           // the reference's order: edges 0, 1, 2, axis 0 before axis 1
+            const int i0 = e, i1 = (e + 1) % 3;
+            g[3 * i0 + 1] += part[2 * e][0];
+            g[3 * i1 + 1] += part[2 * e][1];
+            g[3 * i0 + 0] += part[2 * e + 1][0];
+            g[3 * i1 + 0] += part[2 * e + 1][1];
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) grad_faces[(size_t)i * 9 + k] = g[k];
+    }
 }
 
 }  // namespace
@@ -238,7 +265,7 @@ extern "C" size_t chore_silhouette_workspace_bytes(int B, int F) { return (size_
 extern "C" int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, int F, int size, float near_z,
                                     float far_z, int* face_index, float* alpha, void* workspace,
                                     chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!faces || !face_index || !alpha || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_fwd: null argument");
     if (B <= 0 || F <= 0 || size <= 0 || size > 4096 || B > 65535)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_fwd: bad sizes B=%d F=%d size=%d", B, F, size);
@@ -256,14 +283,14 @@ extern "C" int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, 
 extern "C" int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_index, const float* alpha,
                                     const float* grad_alpha, int B, int F, int size, float eps, float* grad_faces,
                                     chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!faces || !face_index || !alpha || !grad_alpha || !grad_faces)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_bwd: null argument");
     if (B <= 0 || F <= 0 || size <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_silhouette_bwd: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     const int n = B * F;
-    hipLaunchKernelGGL(sil_bwd_kernel, dim3((n + 63) / 64), dim3(64), 0, s, faces, face_index, alpha, grad_alpha, B, F,
-                       size, eps, grad_faces);
+    hipLaunchKernelGGL(sil_bwd_kernel, dim3(n), dim3(384), 0, s, faces, face_index, alpha, grad_alpha, B, F, size, eps,
+                       grad_faces);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

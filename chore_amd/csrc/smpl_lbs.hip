@@ -559,7 +559,7 @@ size_t chore_smpl_workspace_bytes(int V, int J, int num_betas, int B) {
 int chore_smpl_pack(chore_handle* h, int V, int J, int num_betas, const float* v_template, const float* shapedirs,
                     const float* posedirs, const float* J_regressor, const float* weights, const int* parents_host,
                     void* arena, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     const Dims d{V, J, num_betas, 9 * (J - 1)};
     if (int rc = check_dims(h, d, 1)) return rc;
     if (!v_template || !shapedirs || !posedirs || !J_regressor || !weights || !parents_host || !arena)
@@ -586,7 +586,7 @@ int chore_smpl_pack(chore_handle* h, int V, int J, int num_betas, const float* v
 int chore_smpl_lbs_fwd(chore_handle* h, const void* arena, int V, int J, int num_betas, const float* pose,
                        const float* betas, const float* trans, const float* offsets, float scale, int B, float* verts,
                        float* joints, float* v_posed, float* naked, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     const Dims d{V, J, num_betas, 9 * (J - 1)};
     if (int rc = check_dims(h, d, B)) return rc;
     if (!arena || !pose || !betas || !trans || !verts || !joints || !v_posed || !naked || !workspace)
@@ -606,7 +606,7 @@ int chore_smpl_lbs_fwd(chore_handle* h, const void* arena, int V, int J, int num
 int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num_betas, const float* pose, float scale,
                        int B, const float* v_posed, const float* g_verts, const float* g_joints, float* dpose,
                        float* dbetas, float* dtrans, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     const Dims d{V, J, num_betas, 9 * (J - 1)};
     if (int rc = check_dims(h, d, B)) return rc;
     if (!arena || !pose || !v_posed || !dpose || !dbetas || !dtrans || !workspace)

@@ -82,7 +82,7 @@ extern "C" {
 size_t chore_so3_aux_bytes(int B) { return (size_t)B * 22 * sizeof(double); }
 
 int chore_so3_project_fwd(chore_handle* h, const float* M, int B, float* R, void* aux, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!M || !R || B < 1) CHORE_FAIL(h, CHORE_EINVAL, "chore_so3_project_fwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(so3_fwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, M, B, R, (double*)aux);
@@ -91,7 +91,7 @@ int chore_so3_project_fwd(chore_handle* h, const float* M, int B, float* R, void
 }
 
 int chore_so3_project_bwd(chore_handle* h, const void* aux, const float* G, int B, float* dM, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!aux || !G || !dM || B < 1) CHORE_FAIL(h, CHORE_EINVAL, "chore_so3_project_bwd: bad argument");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(so3_bwd_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const double*)aux, G, B, dM);

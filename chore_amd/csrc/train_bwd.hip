@@ -599,7 +599,7 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
 int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                             const void* stats, const float* gamma, const float* beta, const void* dy, int Cout, float* dw,
                             float* dbias, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: null argument");
     if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || Cin > 256)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: unsupported taps=%d Cin=%d Cout=%d", taps, Cin, Cout);
@@ -617,7 +617,7 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
         const int npairs = (Cout / 64) * (Cin / 64);
         a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
         const size_t smem64 = (size_t)((taps == 9 ? PH * PW : TH * TW) + TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
-        static bool attr64 = false;
+        bool& attr64 = CHORE_ONCE_FLAG(h);
         if (!attr64) {
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                    (int)((size_t)(PH * PW + TH * TW) * W64_PITCH + 512)));
@@ -643,7 +643,7 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
     dim3 grid(Cout / 32, Cin / 32, a.S);
 #define LAUNCH_WG(T, TP)                                                                                              \
     do {                                                                                                              \
-        static bool attr = false;                                                                                     \
+        bool& attr = CHORE_ONCE_FLAG(h);                                                                                     \
         if (!attr) {                                                                                                  \
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad_kernel<T, TP>,                                 \
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));          \
@@ -674,7 +674,7 @@ size_t chore_gemm_tn_workspace_bytes(int P, int M, int N) {
 
 int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, int ldb, int P, int M, int N, float* C,
                       void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!A || !B || !C || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_gemm_tn_f32: null argument");
     if (P <= 0 || M % 32 || N % 32 || lda % 4 || ldb % 4)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gemm_tn_f32: M, N must be multiples of 32 (P=%d M=%d N=%d)", P, M, N);
@@ -686,7 +686,7 @@ int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, 
     a.part = (float*)workspace;
     a.part_bias = nullptr;
     size_t smem = (size_t)(2 * TH * TW) * CT32 * 4 + 256;
-    static bool attr = false;
+    bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad_kernel<float, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                96 * 1024));
@@ -713,7 +713,7 @@ size_t chore_stem_wgrad_workspace_bytes(int B, int Cin, int H, int W) {
 // dw (64,Cin,7,7), dbias (64, or NULL) of the stem convolution y = conv7x7/2(images) + bias; dy is (B,H/2,W/2,64)
 int chore_stem_bwd_weight(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W, const void* dy,
                           float* dw, float* dbias, void* workspace, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!images || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: null argument");
     if (B <= 0 || Cin <= 0 || Cin > SW_MAXC || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: Cin <= %d and even H, W (Cin=%d H=%d W=%d)", SW_MAXC, Cin, H, W);
@@ -739,7 +739,7 @@ size_t chore_gn_relu_bwd_workspace_bytes(int B, int C) { return ((size_t)B * GN_
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                       const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
                       int workspace_zeroed, chore_stream_t stream) {
-    if (!h) return CHORE_EINVAL;
+    CHORE_ENTER(h);
     if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
     if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);

@@ -243,7 +243,7 @@ class CHORE(nn.Module):
 
     def _heads_arena(self, device):
         params = [p for _, m in self._head_modules() for p in m.parameters()]
-        key = (str(device), sum(p._version for p in params), params[0].data_ptr())
+        key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self._heads_packed is not None and self._heads_packed[0] == key:
             return self._heads_packed[1]
         dtype = _DT[self.compute_dtype]
@@ -262,6 +262,23 @@ class CHORE(nn.Module):
                    "chore_heads_pack")
         self._heads_packed = (key, arena)
         return arena
+
+    def invalidate_packed(self):
+        """drop the packed copies of the head and encoder weights.  The caches are keyed on (address, version) of every
+        parameter, which sees optimiser steps, load_state_dict and .to(); a write through `p.data` is invisible to the
+        version counters -- call this after one."""
+        self._heads_packed = None
+        self.image_filter.invalidate_packed()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self._heads_packed = None
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_packed()
+        return out
 
     # ---- reference API ----------------------------------------------------------------------
     def filter(self, images):

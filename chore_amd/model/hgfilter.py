@@ -100,6 +100,7 @@ class HGFilter(_Params):
                 self.add_module(f"bl{i}", _conv(256, 256, 1, True))
                 self.add_module(f"al{i}", _conv(hd, 256, 1, True))
         self._packed = {}  # dtype -> (version key, arena tensor)
+        self._plist = None
         self._work = {}    # (B,H,W,dtype) -> workspace tensor
 
     # ---------------------------------------------------------------------------------------
@@ -108,7 +109,27 @@ class HGFilter(_Params):
                                self.opt.hourglass_dim)
 
     def _version_key(self, device):
-        return (str(device), sum(p._version for p in self.parameters()), tuple(p.data_ptr() for p in (self.conv1.weight,)))
+        """(storage address, version counter) of every parameter: an in-place update, a swapped tensor or a moved module
+        all change it.  A write through `p.data` (EMA / averaging code, nn.init on .data) bumps no version counter and
+        is invisible here -- call invalidate_packed() after such writes (load_state_dict and .to() do it themselves)."""
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
+
+    def invalidate_packed(self):
+        """forget the repacked (MFMA-fragment order) copies of the weights; the next forward packs again"""
+        self._packed = {}
+        self._plist = None
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        self.invalidate_packed()
+        return out
+
+    def load_state_dict(self, *a, **k):
+        out = super().load_state_dict(*a, **k)
+        self.invalidate_packed()
+        return out
 
     def packed_arena(self, dtype, device):
         key = self._version_key(device)

@@ -286,9 +286,7 @@ class SyntheticAssets(FitAssets):
 
     def smpl_model(self, gender):
         from ..utils import synth
-        m = synth.synth_smplh_model(self.seed)
-        m["f"] = np.random.RandomState(8000 + self.seed).randint(0, 6890, (13776, 3)).astype(np.int64)
-        return m
+        return synth.synth_smplh_surface_model(self.seed)
 
     def regressors(self):
         from ..lib_smpl.wrapper_pytorch import synthetic_regressors

@@ -24,12 +24,27 @@ from .recon_fit_base import ReconFitterBase
 
 class ReconFitterBehave(ReconFitterBase):
     use_graphs = False    # True: every inner step is a hipGraph replay (graph_step.py); same update rule
+    early_stop = True     # False: never arm the stop rule (benchmarks that time a fixed number of iterations)
+    timer = None          # a list: per outer iteration (start event, end event, number of inner steps) is appended
     adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
 
     def _stepper(self, *a, **k):
         if self.use_graphs:
             return GraphedStep(*a, **k)
         return EagerStep(*a, capturable=self.adam_capturable, **k)
+
+    def _inner(self, st, n):
+        """the inner steps of one outer iteration"""
+        if self.timer is None:
+            for _ in range(n):
+                st.step()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            st.step()
+        e1.record()
+        self.timer.append((e0, e1, n))
 
     @staticmethod
     def release_graphs(split, model):
@@ -163,10 +178,9 @@ class ReconFitterBehave(ReconFitterBase):
             elif it == iter_for_betas + iter_for_pose:
                 phase = "kpts"            # same Adam, the loss gains the keypoint term
                 st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel, carry=carry)
-            armed = it > 0.25 * max_iter + iter_for_betas + iter_for_pose
+            armed = self.early_stop and it > 0.25 * max_iter + iter_for_betas + iter_for_pose
             st.begin_outer(1 if phase != "kpts" else it / 3, armed=armed, zero=zero)
-            for _ in range(steps_per_iter):
-                st.step()
+            self._inner(st, steps_per_iter)
             if armed and st.stopped():
                 break
         rel()   # graph replays change the parameters without touching their version counters: drop memoised results
@@ -266,10 +280,9 @@ class ReconFitterBehave(ReconFitterBase):
                 decay = it - obj_iter + 1
             elif phase == "joint":
                 decay = (it - obj_iter + 1) / 5
-            armed = phase == "joint" and it > 0.25 * max_iter
+            armed = self.early_stop and phase == "joint" and it > 0.25 * max_iter
             st.begin_outer(decay, armed=armed, zero=False)
-            for _ in range(steps_per_iter):
-                st.step()
+            self._inner(st, steps_per_iter)
             if armed and st.stopped():
                 break
         rel()

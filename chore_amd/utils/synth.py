@@ -107,3 +107,58 @@ def synth_smpl_params(B, seed=0):
     betas = (rs.standard_normal((B, 10)) * 0.8).astype(np.float32)
     trans = (rs.standard_normal((B, 3)) * 0.1 + np.array([0.0, 0.3, 2.2])).astype(np.float32)
     return pose, betas, trans
+
+
+def uv_ellipsoid(rings=82, segments=84, radii=(0.25, 0.85, 0.18), center=(0.0, 0.0, 0.0)):
+    """closed UV ellipsoid: V = 2 + rings * segments, F = 2 * segments * rings.  The defaults give a body-sized blob
+    with exactly the SMPL counts (6 890 vertices, 13 776 faces)."""
+    v = [(0.0, 1.0, 0.0)]
+    for r in range(1, rings + 1):
+        th = np.pi * r / (rings + 1)
+        for s in range(segments):
+            ph = 2 * np.pi * s / segments
+            v.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
+    v.append((0.0, -1.0, 0.0))
+    f = []
+    last = len(v) - 1
+    for s in range(segments):
+        f.append((0, 1 + (s + 1) % segments, 1 + s))
+        b = 1 + (rings - 1) * segments
+        f.append((last, b + s, b + (s + 1) % segments))
+    for r in range(rings - 1):
+        a, b = 1 + r * segments, 1 + (r + 1) * segments
+        for s in range(segments):
+            s1 = (s + 1) % segments
+            f.append((a + s, a + s1, b + s))
+            f.append((a + s1, b + s1, b + s))
+    return np.asarray(v) * np.asarray(radii) + np.asarray(center, dtype=np.float64), np.asarray(f, dtype=np.int64)
+
+
+def synth_smplh_surface_model(seed: int = 0, num_betas: int = 10):
+    """Like synth_smplh_model, but a SURFACE: the template is a closed body-sized blob with SMPL's vertex / face counts
+    and the blend shapes and skinning weights vary smoothly over it, so posed bodies stay free of self-intersections.
+    (A random vertex cloud with random faces is fine for the arithmetic, but every other triangle pair of it
+    'collides': the interpenetration term then does 60x the work it does on a body.)  Returns the model dict + 'f'."""
+    rs = np.random.RandomState(4500 + seed)
+    J = len(SMPLH_PARENTS)
+    vt, faces = uv_ellipsoid()
+    V = vt.shape[0]
+    jc = np.stack([0.12 * np.cos(2.4 * np.arange(J)), 0.8 - 1.6 * np.arange(J) / (J - 1), 0.08 * np.sin(2.4 * np.arange(J))], 1)
+    d2 = ((vt[:, None, :] - jc[None, :, :]) ** 2).sum(-1)                        # (V,J)
+    w = np.exp(-d2 / (2 * 0.15 ** 2))
+    cut = np.sort(w, 1)[:, -4][:, None]                                          # four joints per vertex
+    w = np.where(w >= cut, w, 0.0)
+    weights = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    jr = np.zeros((J, V), np.float32)
+    for j in range(J):
+        idx = np.argsort(d2[:, j])[:24]
+        jr[j, idx] = 1.0 / 24
+    # smooth blend shapes: low-frequency functions of the template position
+    k = rs.standard_normal((num_betas, 3, 3)) * 2.0
+    ph = rs.uniform(0, 6.28, (num_betas, 3))
+    shapedirs = np.stack([0.02 * np.sin(vt @ k[b].T + ph[b]) for b in range(num_betas)], -1).astype(np.float32)   # (V,3,nb)
+    kp = rs.standard_normal(((J - 1) * 9, 3, 3)) * 2.0
+    php = rs.uniform(0, 6.28, ((J - 1) * 9, 3))
+    posedirs = np.stack([0.001 * np.sin(vt @ kp[i].T + php[i]) for i in range((J - 1) * 9)], -1).astype(np.float32)
+    return dict(v_template=vt.astype(np.float32), shapedirs=shapedirs, posedirs=posedirs, J_regressor=jr, weights=weights,
+                parents=np.array(SMPLH_PARENTS, np.int32), f=faces)

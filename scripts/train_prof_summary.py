@@ -1,4 +1,4 @@
-"""Per-step kernel shares of the training step from a rocprofv3 --kernel-trace csv of bench_train.py.
+"""Per-step kernel shares of the training step from a rocprofv3 --kernel-trace csv of bench.py --mode train.
 
 usage: train_prof_summary.py <kernel_trace.csv> [marker] [marker_launches_per_step]
 Aggregates by kernel name over the SECOND HALF of the trace window (steady state: no first-touch work), counts the

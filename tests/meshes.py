@@ -28,26 +28,4 @@ def icosphere(subdiv=2, radius=1.0, center=(0.0, 0.0, 0.0)):
     return np.asarray(v) * radius + np.asarray(center, dtype=np.float64), np.asarray(f, dtype=np.int64)
 
 
-def uv_ellipsoid(rings=82, segments=84, radii=(0.25, 0.85, 0.18), center=(0.0, 0.0, 0.0)):
-    """closed UV ellipsoid: V = 2 + rings * segments, F = 2 * segments * rings.  The defaults give a body-sized blob
-    with exactly the SMPL counts (6 890 vertices, 13 776 faces)."""
-    v = [(0.0, 1.0, 0.0)]
-    for r in range(1, rings + 1):
-        th = np.pi * r / (rings + 1)
-        for s in range(segments):
-            ph = 2 * np.pi * s / segments
-            v.append((np.sin(th) * np.cos(ph), np.cos(th), np.sin(th) * np.sin(ph)))
-    v.append((0.0, -1.0, 0.0))
-    f = []
-    last = len(v) - 1
-    for s in range(segments):
-        f.append((0, 1 + (s + 1) % segments, 1 + s))
-        b = 1 + (rings - 1) * segments
-        f.append((last, b + s, b + (s + 1) % segments))
-    for r in range(rings - 1):
-        a, b = 1 + r * segments, 1 + (r + 1) * segments
-        for s in range(segments):
-            s1 = (s + 1) % segments
-            f.append((a + s, a + s1, b + s))
-            f.append((a + s1, b + s1, b + s))
-    return np.asarray(v) * np.asarray(radii) + np.asarray(center, dtype=np.float64), np.asarray(f, dtype=np.int64)
+from chore_amd.utils.synth import uv_ellipsoid  # noqa: E402,F401  (shared with the synthetic body model)

@@ -1,0 +1,24 @@
+"""CPU: `bench.py --gpus 2` launches itself as one process per rank when no launcher set the environment
+(torch.distributed.run, 127.0.0.1 rendezvous), runs the barrier-bracketed timing skeleton over gloo and prints ONE JSON
+line from rank 0 with the contract's keys.  --dry-run replaces the device work (there is no CPU path to bench)."""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launch_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 2.0       # MAX over ranks: rank 1 sleeps 2 ms per step

@@ -1,7 +1,7 @@
 """GPU: the DDP training step (train_launch.py:30 + trainer/trainer.py:76-131) with two ranks.
 
 The box has one GPU, so both ranks share cuda:0 and the gradient all-reduce goes over gloo (the production launch,
-bench_train.py, uses backend "nccl" = RCCL with one GPU per rank); what is checked is that torch's DDP reducer sees
+bench.py --mode train, uses backend "nccl" = RCCL with one GPU per rank); what is checked is that torch's DDP reducer sees
 the gradients our HIP autograd nodes produce -- find_unused_parameters=True like the reference, because the bn4
 affines of the blocks without downsample never receive one -- and that what it leaves in .grad is the average of the
 two ranks' own gradients (each recomputed here in one process on that rank's sample).  It is NOT compared with the

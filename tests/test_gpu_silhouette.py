@@ -119,8 +119,12 @@ def test_sil_loss_roi_end_to_end():
     (pr * torch.from_numpy(gpv).cuda()).sum().backward()
     R2, t2, s2 = (x.detach().clone().requires_grad_(True) for x in (R, t, s))
     (sil.apply_transformation(R2, t2, s2) * vt.grad).sum().backward()
+    # t / s / R gradients are sums over all vertices of terms that nearly cancel (the edge terms carry 1 / (dist + 1e-4)
+    # factors): the bound is relative to the sum of the magnitudes that enter, not to the cancelled result.  (The kernel
+    # adds a triangle's contributions lane-parallel with a fixed butterfly; the restatement adds them serially.)
+    scale = float(vt.grad.abs().sum()) * 4.0
     for a, b in ((t.grad, t2.grad), (s.grad, s2.grad), (R.grad, R2.grad)):
-        assert (a - b).abs().max() < 1e-3 * max(1e-6, float(b.abs().max()))
+        assert (a - b).abs().max() < 2e-6 * scale + 1e-3 * float(b.abs().max()), ((a - b).abs().max(), scale)
 
 
 def test_sil_phase_runs_in_the_fit_loop(opt):
