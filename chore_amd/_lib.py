@@ -113,6 +113,10 @@ SIGNATURES = {
     "chore_gen_advance": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_gen_resample": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                    c_int, c_float, c_void_p, c_void_p]),
+    "chore_prep_masks2bbox": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chore_prep_resize_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "chore_prep_crop_compose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                        c_int, c_void_p, c_void_p]),
     "chore_collision_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -1,0 +1,92 @@
+"""Network input from the decoded images, on the device.
+
+Counterpart of TestData.prepare_image_crop (/root/reference/data/test_data.py:59-125) from the point where the RGB
+image and the two masks are decoded uint8 arrays: bounding box of the masks -> crop centre, resize to the 2048-px space,
+crop of `scale * 1200` px around the centre (zero padded), resize to the network input, /255, background masking,
+channel stacking.  All pixel work runs in libchore_hip.so (csrc/image_prep.hip: chore_prep_masks2bbox / _resize_u8 /
+_crop_compose); the host does the few scalar steps in numpy with the reference's expressions.  JPEG decoding, the
+keypoint / mocap based `fullbody_crop` scale (:167-200) and the use_mean_center variant of the COCO loader (float64
+canvas, :127-160) stay with the reference's host code.
+
+    prep = ImagePrep(image_size=(512, 512), crop_size=1200)
+    images, crop_center, resize_scale, old_center = prep.prepare(rgb_u8, person_u8, obj_u8, scale)
+
+cv2's resize arithmetic is restated (oracle/image_prep.py): parity with cv2 itself is UNPINNED -- OpenCV is not in this
+image; against the restatement the kernels are bit-exact (tests/test_gpu_image_prep.py).
+"""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class ImagePrep:
+    def __init__(self, image_size=(512, 512), crop_size=1200, use_mean_center=False, device="cuda:0"):
+        if use_mean_center:
+            raise NotImplementedError("use_mean_center (COCO loader) pads on a float64 canvas: host code of the reference")
+        if image_size[0] != image_size[1]:
+            raise ValueError("the crop is square: image_size must be (S, S)")
+        self.img_size, self.crop_size = tuple(image_size), float(crop_size)
+        self.device = torch.device(device)
+
+    def _u8(self, a, ndim):
+        t = torch.as_tensor(a)
+        if t.dtype != torch.uint8 or t.dim() != ndim:
+            raise ValueError(f"expected a uint8 array with {ndim} dimensions")
+        return t.to(self.device).contiguous()
+
+    def masks2bbox(self, masks, thres=127):
+        """[data/base_data.py:92-112] -> (bmin, bmax) numpy int arrays (one host read)"""
+        m = [self._u8(x, 2) for x in masks]
+        if len(m) not in (1, 2):
+            raise ValueError("one or two masks")
+        H, W = m[0].shape
+        h = _lib.handle(self.device.index or 0)
+        out = torch.empty(4, dtype=torch.int32, device=self.device)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib.chore_prep_masks2bbox(h, m[0].data_ptr(), m[1].data_ptr() if len(m) == 2 else None, H, W, thres,
+                                                  out.data_ptr(), s), h, "chore_prep_masks2bbox")
+        b = out.cpu().numpy()
+        return b[:2].astype(np.int64), b[2:].astype(np.int64)
+
+    def resize(self, img, dsize):
+        """cv2.resize(img, dsize=(width, height)) on a uint8 (H,W) or (H,W,C) image, INTER_LINEAR"""
+        t = torch.as_tensor(img)
+        x = self._u8(t, t.dim())
+        sh, sw = x.shape[:2]
+        C = 1 if x.dim() == 2 else x.shape[2]
+        dw, dh = int(dsize[0]), int(dsize[1])
+        out = torch.empty((dh, dw) + tuple(x.shape[2:]), dtype=torch.uint8, device=self.device)
+        h = _lib.handle(self.device.index or 0)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(_lib.lib.chore_prep_resize_u8(h, x.data_ptr(), sh, sw, C, out.data_ptr(), dh, dw, s), h, "chore_prep_resize_u8")
+        return out
+
+    def prepare(self, rgb, person_mask, obj_mask, scale=1.0):
+        """-> images (5,S,S) fp32 on the device, crop_center (2,), resize_scale, old_center   [test_data.py:59-125]"""
+        rgb, pm, om = self._u8(rgb, 3), self._u8(person_mask, 2), self._u8(obj_mask, 2)
+        bmin, bmax = self.masks2bbox([pm, om])
+        width = bmax - bmin
+        if width[0] > self.crop_size or width[1] > self.crop_size:
+            raise AssertionError("crop too small for the bounding box of the masks: {}".format(width))
+        crop_center = (bmin + bmax) // 2
+        rh, rw = rgb.shape[:2]
+        if rw > rh:
+            resize_scale = 2048 / rw
+            newsize = (2048, int(rh * resize_scale))
+        else:
+            resize_scale = 1536 / rh
+            newsize = (int(rw * resize_scale), 1536)
+        crop_center = np.round(resize_scale * crop_center)
+        rgb, pm, om = self.resize(rgb, newsize), self.resize(pm, newsize), self.resize(om, newsize)
+        size = scale * np.array([self.crop_size, self.crop_size])
+        tl = np.round(crop_center - size / 2).astype(int)
+        br = np.round(crop_center + size / 2).astype(int)
+        S = self.img_size[0]
+        images = torch.empty(5, S, S, dtype=torch.float32, device=self.device)
+        h = _lib.handle(self.device.index or 0)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        H, W = rgb.shape[:2]
+        _lib.check(_lib.lib.chore_prep_crop_compose(h, rgb.data_ptr(), pm.data_ptr(), om.data_ptr(), H, W, int(tl[0]), int(tl[1]),
+                                                    int(br[0]), int(br[1]), S, images.data_ptr(), s), h, "chore_prep_crop_compose")
+        return images, crop_center, resize_scale, crop_center.copy()

@@ -292,6 +292,29 @@ int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, cons
                        chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Image preparation of the test loader on the device  (replaces, from the decoded uint8 images on,
+ * TestData.prepare_image_crop data/test_data.py:59-125 with use_mean_center=False = BaseDataset.masks2bbox
+ * data/base_data.py:92-112 + cv2.resize + BaseDataset.crop :131-162 + BaseDataset.resize :164-176 + compose_images
+ * :178-192).  Integer arithmetic; cv2's 8-bit INTER_LINEAR algorithm is restated (oracle/image_prep.py): PARITY
+ * UNPINNED at cv2, which the reference neither vendors nor pins.
+ *   chore_prep_masks2bbox    bbox4 = {xmin, ymin, xmax + 1, ymax + 1} (int32, device) of the pixels where the uint8
+ *                            wrap-around sum mask0 + mask1 exceeds thres; {50000, 50000, -100, -100} when there is none.
+ *                            mask1 may be NULL.
+ *   chore_prep_resize_u8     (sh, sw, C) uint8 -> (dh, dw, C) uint8, C <= 4.
+ *   chore_prep_crop_compose  crop of the (H, W) images with corners tl = round(center - size / 2), br = round(center +
+ *                            size / 2) (zero padded, base_data.py's clipping), resized to S x S, / 255, RGB zeroed where
+ *                            neither mask exceeds 0.5, stacked as images (5, S, S) fp32 = [R, G, B, person, object].
+ *                            rgb (H, W, 3), masks (H, W) uint8.
+ * ------------------------------------------------------------------------------------------- */
+int chore_prep_masks2bbox(chore_handle* h, const unsigned char* mask0, const unsigned char* mask1, int H, int W, int thres,
+                          int* bbox4, chore_stream_t stream);
+int chore_prep_resize_u8(chore_handle* h, const unsigned char* src, int sh, int sw, int C, unsigned char* dst, int dh, int dw,
+                         chore_stream_t stream);
+int chore_prep_crop_compose(chore_handle* h, const unsigned char* rgb, const unsigned char* person_mask,
+                            const unsigned char* obj_mask, int H, int W, int tl_x, int tl_y, int br_x, int br_y, int S,
+                            float* images, chore_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Interpenetration term of the joint fit  (replaces ReconFitterBase.smpl_obj_collision recon/recon_fit_base.py:610-624 =
  * mesh_intersection.BVH(max_collisions=8) + DistanceFieldPenetrationLoss(sigma=0.5, point2plane=False), constructed at
  * :78-86).  PARITY UNPINNED: that package (github.com/vchoutas/torch-mesh-isect, no revision pinned) is not in the
