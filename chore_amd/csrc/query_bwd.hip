@@ -103,7 +103,9 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, col = lane & 31;
-    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
+    int b, tile_;
+    query_block(b, tile_);
+    const int n0 = tile_ * PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
 
     if (tid < PTS)

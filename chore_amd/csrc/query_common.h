@@ -132,3 +132,16 @@ __device__ __forceinline__ void fill_pt_table(Tab& tab, int t, const float* poin
         tab.tw[k][t] = tt.w[k];
     }
 }
+
+// Workgroup -> (image, point tile).  The dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, each with
+// its own L2; in launch order every image's tiles would land on all 8 of them and every L2 would pull its own copy of
+// that image's feature maps (measured: 3.1x the compulsory bytes).  Here XCD x takes the x-th CONTIGUOUS eighth of the
+// (image-major) tile order instead, so an image is read through ceil(8 / B) L2s only (bijective for any grid size).
+__device__ __forceinline__ void query_block(int& b, int& tile) {
+    const int tiles = gridDim.x, nwg = gridDim.x * gridDim.y;
+    const int L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
+    const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    b = lid / tiles;
+    tile = lid - b * tiles;
+}

@@ -33,7 +33,9 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
+    int b, tile_;
+    query_block(b, tile_);
+    const int n0 = tile_ * PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
 
     if (tid < PTS) {
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, n0 = blockIdx.x * PTS;
+    int b, tile_;
+    query_block(b, tile_);
+    const int n0 = tile_ * PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
     if (tid < PTS) {
         fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH,
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(256) void sample_features_kernel(QueryArgs a, float
     QueryFwdSmem& sm = *reinterpret_cast<QueryFwdSmem*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.y, n0 = blockIdx.x * QT_PTS;
+    int b, tile_;
+    query_block(b, tile_);
+    const int n0 = tile_ * QT_PTS;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
     if (tid < QT_PTS) {
         float nn[2];

@@ -173,12 +173,16 @@ class HGFilter(_Params):
         arena = self.packed_arena(dtype, dev)
         cfg = self.cfg()
         h = _lib.handle(dev.index or 0)
-        wkey = (B, H, W, dtype, str(dev))
+        # one workspace per (shape, stream): encodes issued on different streams (two batches in flight) must not share
+        # the activation arena; the newest shape replaces the older ones
+        stream_id = torch.cuda.current_stream(dev).cuda_stream
+        wkey = (B, H, W, dtype, str(dev), stream_id)
         work = self._work.get(wkey)
         if work is None:
             nbytes = _lib.lib.chore_encoder_workspace_bytes(ctypes.byref(cfg), B, H, W, dtype)
             work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._work = {wkey: work}
+            self._work = {k: v for k, v in self._work.items() if k[:5] == wkey[:5]}
+            self._work[wkey] = work
         feats = [torch.empty(B, H // 4, W // 4, 256, dtype=tdt, device=dev) for _ in range(n_out)]
         tmpx = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
         normx = torch.empty(B, H // 4, W // 4, 128, dtype=tdt, device=dev)
