@@ -27,8 +27,9 @@ Extra objects in the line:
                       its dtype; kernel names are the rocprofv3 names.  fit / train: the whole step against the same
                       peak (named so in `kernel`).
   config.field_err    query: measured error of df / pca / parts / centers against the values THE REFERENCE produced for the
-                      same images and points (tests/golden/config2_fields.npz) in the timed mode, and the same for the
-                      fp32 parity mode with its own timing beside (`fp32_mode`).
+                      same images and points (tests/golden/config2_fields.npz) in the timed mode; `other_modes` holds the
+                      same step in the two fp32-grade modes with their own timing and error: "fp16x3" (fp32 tensors,
+                      convolutions as three fp16 MFMAs per product on hi/lo split operands) and "fp32" (native fp32 MFMA).
   cpu_baseline        the numpy oracle ("port") and `cpu_baseline_torch` the same graph as stock PyTorch CPU operators
                       (oracle/torch_graph.py), timed on this host on a bounded sample, rank 0, N = 1 only.
 """
@@ -47,7 +48,10 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md
+# dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp16x3 issues three fp16 MFMAs per algorithmic product: its
+# algorithmic FLOPs are priced against the full fp16 peak (a kernel doing nothing but MFMAs would show frac = 1/3)
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0}
+TNAME = {"bf16": "unsigned short", "fp32": "float", "fp16x3": "x3_t"}
 HEADS_FLOP_PER_POINT = 600832.0
 ENCODER_FLOP_PER_IMAGE = 258.25e9
 
@@ -283,18 +287,20 @@ def mode_query(args, ctx):
         prof = _lib.profile_read(local)
         _lib.profile_enable(local, False)
         # ---- field values against the reference's (rank 0 inputs are the golden's) ----
-        field_err = fp32_mode = None
+        field_err, other_modes = None, {}
         if rank == 0 and B == 4 and N == 20000:
             step()
             field_err = field_errors(net.get_preds())
-            if args.dtype != "fp32":
-                net32, _, _, _, step32 = make("fp32", 0)
+            for mode in ("fp16x3", "fp32"):
+                if mode == args.dtype:
+                    continue
+                net2, _, _, _, step2 = make(mode, 0)
                 for _ in range(2):
-                    step32()
-                t32 = timed(step32, 5)
-                fp32_mode = {"ms_per_step": t32, "value": B * N / t32 * 1e3, "unit": "points/s",
-                             "field_err": field_errors(net32.get_preds())["all"]}
-                del net32
+                    step2()
+                t2 = timed(step2, 5)
+                other_modes[mode] = {"ms_per_step": t2, "value": B * N / t2 * 1e3, "unit": "points/s",
+                                     "field_err": field_errors(net2.get_preds())["all"]}
+                del net2
     out = None
     if rank == 0:
         kernels = {}
@@ -303,7 +309,7 @@ def mode_query(args, ctx):
                 kernels[k] = {"ms_per_step": v["ms"] / 3, "launches_per_step": v["launches"] // 3,
                               "tflops": v["flops"] / v["ms"] / 1e9 if v["flops"] else None,
                               "gbps": v["bytes"] / v["ms"] / 1e6}
-        tname = "unsigned short" if args.dtype == "bf16" else "float"
+        tname = TNAME[args.dtype]
         kernels = {k.replace("<T,", "<%s, " % tname).replace(",", ", ").replace(",  ", ", "): v for k, v in kernels.items()}
         # HBM-side bytes per launch of each kernel from the committed rocprofv3 counter passes (FETCH_SIZE x2 +
         # WRITE_SIZE, scripts/pmc_traffic.py) -- counters cannot be read live, so this is the last profiled build
@@ -313,7 +319,8 @@ def mode_query(args, ctx):
             traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
         # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
         # 32-point tiles when 64-point tiles would not fill the CUs)
-        qname = ("query_fwd_f32_kernel<%s, 1, false>" if B * ((N + 63) // 64) <= 256 else "query_fwd_f32_w8_kernel<%s>") % tname
+        qname = ("query_fwd_f32_kernel<%s, 1, false>" if B * ((N + 63) // 64) <= 256 else "query_fwd_f32_w8_kernel<%s>") % \
+            ("float" if args.dtype == "fp16x3" else tname)
         kernels[qname] = {"ms_per_step": qry_ms, "launches_per_step": 1,
                           "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
         dom = max((k for k in kernels if kernels[k]["tflops"]), key=lambda k: kernels[k]["ms_per_step"])
@@ -335,7 +342,7 @@ def mode_query(args, ctx):
                          "field_err_note": "max / mean absolute and relative-L2 difference to the values THE REFERENCE "
                                            "produced for the same images and points (tests/golden/config2_fields.npz, "
                                            "4 x 768 points); stated tolerances: chore_amd/utils/field_check.py"})
-        out.update({"roofline": roof, "fp32_mode": fp32_mode, "encode_ms": enc_ms, "query_ms": qry_ms,
+        out.update({"roofline": roof, "other_modes": other_modes, "encode_ms": enc_ms, "query_ms": qry_ms,
                     "query_only_points_per_s": B * N / qry_ms * 1e3,
                     "encode_tflops": B * ENCODER_FLOP_PER_IMAGE / enc_ms / 1e9, "kernels": kernels})
         if ctx.world == 1 and not args.no_cpu_baseline:
@@ -508,7 +515,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="query", choices=["query", "fit", "train"])
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp16x3"])
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="fit mode: frames fitted as one batch per GPU (default 1, or 8 when N > 1)")

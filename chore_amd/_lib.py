@@ -11,7 +11,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, F16X3 = 0, 1, 2
 
 
 class WeightDesc(ctypes.Structure):
@@ -184,7 +184,7 @@ def profile_enable(device_index: int, on: bool):
 def profile_read(device_index: int):
     """-> {class: dict(ms, flops, bytes, launches)} accumulated since profile_enable"""
     h = handle(device_index)
-    n = 16
+    n = 24
     names = (c_char_p * n)()
     ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
     la = (c_int64 * n)()

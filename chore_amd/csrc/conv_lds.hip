@@ -39,6 +39,7 @@
 #endif
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 namespace {
 
@@ -50,6 +51,8 @@ constexpr int SCR_LD = 68;       // scratch row stride in floats (64 channels + 
 template <typename T> struct CT;
 template <> struct CT<float> { static constexpr int VE = 4, KGE = 8; };
 template <> struct CT<bf16_t> { static constexpr int VE = 8, KGE = 16; };
+template <> struct CT<x3_t> { static constexpr int VE = 8, KGE = 16; };   // VE: channels per staging slot (two 16-byte loads)
+
 
 template <typename T>
 __device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* sh, bool use_gn) {
@@ -72,6 +75,37 @@ __device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* 
         }
     }
     return o;
+}
+
+// fp16 x 3 staging: 8 fp32 channels (two vectors) -> GroupNorm + ReLU -> fp16 hi and lo vectors
+__device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
+                                         u32x4& lo) {
+    float t[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { t[j] = __uint_as_float(r0[j]); t[4 + j] = __uint_as_float(r1[j]); }
+    if (use_gn) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float y = fmaf(t[j], sc[j], sh[j]);
+            t[j] = y > 0.f ? y : 0.f;
+        }
+    }
+    f16x8_t h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h[j] = (_Float16)t[j];
+        l[j] = (_Float16)(t[j] - (float)h[j]);
+    }
+    hi = __builtin_bit_cast(u32x4, h);
+    lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
+    const f16x8_t a0 = __builtin_bit_cast(f16x8_t, ah), a1 = __builtin_bit_cast(f16x8_t, al);
+    const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bh), b1 = __builtin_bit_cast(f16x8_t, bl);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);   // small terms first
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
 }
 
 template <typename T>
@@ -120,15 +154,17 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)
 
 // TPS = taps per K-step: 3 (one kernel row) for large grids; 9 (the whole chunk) for the small maps, where a
 // workgroup's time is a chain of dependent weight fetches and fewer, longer steps mean fewer round trips
-template <int TAPS, int NT, int TPS_> struct Geo {
+template <int TAPS, int NT, int TPS_, bool X3 = false> struct Geo {
     static constexpr int PAD = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = TW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
     static constexpr int TPS = TPS_;                                // taps per K-step
-    static constexpr int SBYTES = TPS * KGC * (NT / 32) * 1024;     // weight bytes per K-step
+    static constexpr int RB = X3 ? 144 : ROWB;                      // LDS patch row: x3 = 64 B hi + 64 B lo + 16 B pad (9 slots: odd)
+    static constexpr int SB1 = TPS * KGC * (NT / 32) * 1024;        // bytes of one operand plane of a K-step
+    static constexpr int SBYTES = (X3 ? 2 : 1) * SB1;               // weight bytes per K-step (x3: hi plane, then lo plane)
     static constexpr int NBW = NT >= 64 ? 2 : 1;
     static constexpr int WAVES_N = (NT / 32) / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
     static constexpr int NPATCH = (TPS_ == 9 && TAPS == 9) ? 2 : 1;   // small grids: double-buffered patch, one barrier per chunk
-    static constexpr size_t main_bytes(int Cin) { return (size_t)NPATCH * ROWS * ROWB + 2 * SBYTES + (size_t)Cin * 8; }
+    static constexpr size_t main_bytes(int Cin) { return (size_t)NPATCH * ROWS * RB + 2 * SBYTES + (size_t)Cin * 8; }
     static constexpr size_t epi_bytes() { return (size_t)4 * 32 * SCR_LD * 4 + (size_t)4 * WAVES_M * NT * 4; }
     static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
 };
@@ -137,18 +173,22 @@ constexpr int PD_SMALL = 2;
 
 template <typename T, int TAPS, int NT, int TPS_>
 __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
-    using G = Geo<TAPS, NT, TPS_>;
+    constexpr bool X3 = IS_X3<T>;
+    using ST = typename Store<T>::type;                 // element type in memory
+    using G = Geo<TAPS, NT, TPS_, X3>;
     constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
-    constexpr int CC = KGC * KGE;                       // channels per chunk (32 bf16 / 16 fp32)
+    constexpr int CC = KGC * KGE;                       // channels per chunk (32 bf16 / 16 fp32 / 32 x3)
+    constexpr int LV = X3 ? 2 : 1;                      // 16-byte loads per staging slot
+    constexpr int RB = G::RB, SB1 = G::SB1;
     constexpr int PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, TPS = G::TPS, SBYTES = G::SBYTES;
     constexpr int NBW = G::NBW, WAVES_N = G::WAVES_N, WAVES_M = G::WAVES_M, MB = G::MB;
     constexpr int VPR = 4;                              // 16-byte vectors per patch row
     constexpr int NVP = (ROWS * VPR + 255) / 256;       // patch vectors per thread
-    constexpr int SVEC = SBYTES / 16, SBV = (SVEC + 255) / 256;
+    constexpr int SVEC = SBYTES / 16, SBV = (SVEC + 255) / 256, SV1 = G::SB1 / 16;   // SV1: vectors of one operand plane
     constexpr int KROWS = TAPS / TPS;                   // K-steps per chunk (3 or 1)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NPATCH = G::NPATCH, PATCHB = ROWS * ROWB;
+    constexpr int NPATCH = G::NPATCH, PATCHB = ROWS * RB;
     char* patch = smem;                                  // [NPATCH][ROWS][ROWB]
     char* bst = smem + NPATCH * PATCHB;                  // [2][SBYTES]
     float* ss_lds = (float*)(bst + 2 * SBYTES);          // [Cin][2]
@@ -178,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 
     // ---- staging coordinates ----
     const int v = tid & 3;
-    const T* in_b = (const T*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
+    const ST* in_b = (const ST*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
     int row_off[NVP];
 #pragma unroll
     for (int j = 0; j < NVP; ++j) {
@@ -191,17 +231,18 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // global round trip (~2 us) but the workgroup's own MFMA block (~0.5 us per chunk), so the loads of PD chunks are
     // kept in flight; large grids rely on the co-resident workgroups instead and keep the registers for the tile.
     constexpr int PD = (TPS == 9) ? PD_SMALL : 1;
-    u32x4 preq[PD][NVP];
+    u32x4 preq[PD][NVP * LV];
     // loads are unconditional (invalid rows re-read the tile's first pixel and are zeroed at publish time): a
     // branch around a load makes the compiler's vmcnt bookkeeping give up and wait for everything in flight
-    auto load_patch = [&](u32x4 (&pre)[NVP], int c0) {
+    auto load_patch = [&](u32x4 (&pre)[NVP * LV], int c0) {
 #pragma unroll
         for (int j = 0; j < NVP; ++j) {
             const int off = row_off[j] >= 0 ? row_off[j] : 0;
-            pre[j] = *(const u32x4*)(in_b + off + c0 + v * VE);
+#pragma unroll
+            for (int k = 0; k < LV; ++k) pre[j * LV + k] = *((const u32x4*)(in_b + off + c0 + v * VE) + k);
         }
     };
-    auto write_patch = [&](const u32x4 (&pre)[NVP], int c0, int pbuf = 0) {
+    auto write_patch = [&](const u32x4 (&pre)[NVP * LV], int c0, int pbuf = 0) {
         float sc[VE], sh[VE];
 #pragma unroll
         for (int j = 0; j < VE; ++j) {
@@ -213,8 +254,15 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
             const int idx = tid + j * 256;
             if (idx < ROWS * VPR) {
                 u32x4 val = {0u, 0u, 0u, 0u};
-                if (row_off[j] >= 0) val = xform<T>(pre[j], sc, sh, use_gn);
-                *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * ROWB + v * 16) = val;
+                if constexpr (X3) {
+                    u32x4 lo = {0u, 0u, 0u, 0u};
+                    if (row_off[j] >= 0) xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo);
+                    *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + v * 16) = val;
+                    *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + 64 + v * 16) = lo;
+                } else {
+                    if (row_off[j] >= 0) val = xform<T>(pre[j], sc, sh, use_gn);
+                    *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + v * 16) = val;
+                }
             }
         }
     };
@@ -225,10 +273,12 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     int woff[SBV];   // per-thread vector offsets inside a K-step slice (step-independent)
 #pragma unroll
     for (int j = 0; j < SBV; ++j) {
-        const int i = (tid + j * 256 < SVEC) ? tid + j * 256 : SVEC - 1;
+        const int i0 = (tid + j * 256 < SVEC) ? tid + j * 256 : SVEC - 1;
+        const int i = i0 % SV1;                 // position inside the operand plane
         constexpr int PER_KG = (NT / 32) * 64;
         const int t = i / (KGC * PER_KG), kg = (i / PER_KG) % KGC, r = i % PER_KG;
         woff[j] = (t * NKG + kg) * (int)wkg + r;
+        if (X3 && i0 >= SV1) woff[j] += TAPS * NKG * (int)wkg;   // the lo plane follows the complete hi plane in memory
     }
     auto load_w = [&](u32x4 (&rb)[SBV], int c, int krow) {
         const u32x4* wb = wbase + (size_t)(krow * TPS * NKG + c * KGC) * wkg;   // wave-uniform
@@ -252,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
 
     const int half = lane >> 5, px = lane & 31;
-    const char* a_ptr = patch + ((wm * MB) * PW + px) * ROWB + 16 * half;
+    const char* a_ptr = patch + ((wm * MB) * PW + px) * RB + 16 * half;
     const char* b_ptr = bst + (wn * NBW) * 1024 + lane * 16;
 
     const int crot = (tile * 5 + n_tile * 3) % NCH;
@@ -280,20 +330,25 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     // so that it keeps that order: left alone it sinks the ds_reads to just before their use and every other MFMA
     // pair then waits a full LDS round trip (one wave per SIMD: nothing else hides it).
     constexpr int NKS = TPS * KGC;                     // k-steps (one MFMA K each) per K-step
-    constexpr int FD = (NT >= 128 || NKS < 3) ? 1 : 2; // fragment prefetch distance
+    constexpr int FD = (NT >= 128 || NKS < 3 || X3) ? 1 : 2; // fragment prefetch distance
     auto mfma_step = [&](int slot, int krow, int pbuf = 0) {
         const char* bs = b_ptr + slot * SBYTES;
-        const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 9) ? 0 : (krow * PW) * ROWB);
+        const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 9) ? 0 : (krow * PW) * RB);
         u32x4 af[FD + 1][MB], bf[FD + 1][NBW];
+        u32x4 afl[X3 ? FD + 1 : 1][MB], bfl[X3 ? FD + 1 : 1][NBW];     // fp16 x 3: the lo planes
         auto load_frag = [&](int fs, int ks) {
             const int t = ks / KGC, kg = ks % KGC;
             const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
 #pragma unroll
-            for (int q = 0; q < NBW; ++q)
+            for (int q = 0; q < NBW; ++q) {
                 bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+                if constexpr (X3) bfl[fs][q] = *(const u32x4*)(bs + SB1 + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+            }
 #pragma unroll
-            for (int m = 0; m < MB; ++m)
-                af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * ROWB + kg * 32);
+            for (int m = 0; m < MB; ++m) {
+                af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + kg * 32);
+                if constexpr (X3) afl[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + 64 + kg * 32);
+            }
         };
 #pragma unroll
         for (int d = 0; d < FD; ++d)
@@ -305,7 +360,12 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MB; ++m)
 #pragma unroll
-                for (int q = 0; q < NBW; ++q) mfma<T>(acc[m][q], af[ks % (FD + 1)][m], bf[ks % (FD + 1)][q]);
+                for (int q = 0; q < NBW; ++q) {
+                    if constexpr (X3)
+                        mfma_x3(acc[m][q], af[ks % (FD + 1)][m], afl[ks % (FD + 1)][m], bf[ks % (FD + 1)][q], bfl[ks % (FD + 1)][q]);
+                    else
+                        mfma<T>(acc[m][q], af[ks % (FD + 1)][m], bf[ks % (FD + 1)][q]);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -363,6 +423,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     if (DBG(a) & 8) return;
 
     // ---- epilogue (the loop ended with a barrier: patch and ring are dead, reuse them) ----
+    constexpr float ASCALE = X3 ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;   // undoes the weight scaling of the fp16 x 3 packing
     float* scr = (float*)smem + wid * (32 * SCR_LD);          // wave-private [32 pixels][SCR_LD]
     float* red = (float*)smem + 4 * 32 * SCR_LD;              // [4][WAVES_M][NT]
     constexpr int CW = NBW * 32;                              // channels of this wave
@@ -375,17 +436,17 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 #pragma unroll
     for (int q = 0; q < NBW; ++q) bias[q] = a.bias ? a.bias[nw0 + q * 32 + px] : 0.f;
     const size_t img = (size_t)b * a.H * a.W;
-    T* out_p = (T*)a.out.p + img * a.out.cs + a.out.co + nv;
-    T* raw_p = a.raw.p ? (T*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
-    const T* res_p = (a.res.p && !(DBG(a) & 1024)) ? (const T*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
-    const T* res2_p = (a.res2.p && !(DBG(a) & 1024)) ? (const T*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
+    ST* out_p = (ST*)a.out.p + img * a.out.cs + a.out.co + nv;
+    ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
+    const ST* res_p = (a.res.p && !(DBG(a) & 1024)) ? (const ST*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    const ST* res2_p = (a.res2.p && !(DBG(a) & 1024)) ? (const ST*)a.res2.p + img * a.res2.cs + a.res2.co + nv : nullptr;
     const bool want_stats = (a.st_raw || a.st_out) && !(DBG(a) & 256);
     float sr[8], qr[8], so[8], qo[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
 
     // residual vectors of pixel row m are fetched one row ahead of their use (raw 16/32-byte loads)
-    constexpr int RV = sizeof(T) == 2 ? 1 : 2;               // u32x4 per 8 channels
+    constexpr int RV = sizeof(ST) == 2 ? 1 : 2;               // u32x4 per 8 channels
     u32x4 rq[2][NVE][RV], rq2[2][NVE][RV];
     auto fetch_res = [&](int m, int slot) {
         const int y = ty0 + wm * MB + m;
@@ -403,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         }
     };
     auto add_res = [&](float (&f)[8], const u32x4 (&v)[RV]) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (sizeof(ST) == 2) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 f[2 * k] += __uint_as_float(v[0][k] << 16);
@@ -426,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
         for (int q = 0; q < NBW; ++q)
 #pragma clang loop unroll(full)
             for (int r = 0; r < 16; ++r)
-                scr[mfma32_row(r, half) * SCR_LD + q * 32 + px] = acc[m][q][r] + bias[q];
+                scr[mfma32_row(r, half) * SCR_LD + q * 32 + px] = acc[m][q][r] * ASCALE + bias[q];
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int y = ty0 + wm * MB + m;
@@ -445,7 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                     float g[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) g[e] = f[e];
-                    store8<T>(raw_p + pix * a.raw.cs, g);
+                    store8<ST>(raw_p + pix * a.raw.cs, g);
                     if (want_stats) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
@@ -453,7 +514,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 }
                 if (res_p) add_res(f, rq[m & 1][j]);
                 if (res2_p) add_res(f, rq2[m & 1][j]);
-                store8<T>(out_p + pix * a.out.cs, f);
+                store8<ST>(out_p + pix * a.out.cs, f);
                 if (want_stats) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { so[e] += f[e]; qo[e] += f[e] * f[e]; }
@@ -519,7 +580,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
 
 template <typename T, int TAPS, int NT, int TPS_>
 int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = Geo<TAPS, NT, TPS_>;
+    using G = Geo<TAPS, NT, TPS_, IS_X3<T>>;
     const size_t smem = G::smem_bytes(a.in.C);
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
@@ -537,8 +598,10 @@ int launch_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 template <typename T, int TAPS>
 int launch_nt(chore_handle* h, int nt, bool small_grid, const ConvArgs& a, hipStream_t s) {
     if constexpr (TAPS == 9) {
-        if (small_grid && nt == 64) return launch_t<T, 9, 64, 9>(h, a, s);
-        if (small_grid && nt == 32) return launch_t<T, 9, 32, 9>(h, a, s);
+        if constexpr (!IS_X3<T>) {        // fp16 x 3: two LDS planes per operand, the whole-chunk variant would not fit
+            if (small_grid && nt == 64) return launch_t<T, 9, 64, 9>(h, a, s);
+            if (small_grid && nt == 32) return launch_t<T, 9, 32, 9>(h, a, s);
+        }
         if constexpr (sizeof(T) == 2) {   // the 4x2 register tile is bf16-only (choose_nt never picks it for fp32)
             if (nt == 128) return launch_t<T, 9, 128, 3>(h, a, s);
         }
@@ -563,7 +626,7 @@ int choose_nt(int dtype, int B, int H, int W, int Cout) {
     for (int i = 0; i < 3; ++i) {
         const int nt = nts[i];
         if (Cout % nt) continue;
-        if (nt == 128 && dtype == CHORE_F32) continue;   // the 4x2 fp32 register tile does not fit 256 VGPRs
+        if (nt == 128 && dtype != CHORE_BF16) continue;  // the 4x2 register tile fits 256 VGPRs with bf16 operands only
         const long wgs = (long)B * tiles_of(H, W) * (Cout / nt);
         if (wgs >= 448) return nt;
         if (wgs > best_wgs) { best_wgs = wgs; best = nt; }
@@ -577,17 +640,20 @@ int choose_nt(int dtype, int B, int H, int W, int Cout) {
 // count to be a multiple of the prefetch distance)
 static bool is_small_grid(int dtype, int B, int H, int W, int Cin, int Cout, int nt) {
     const int nch = Cin / (dtype == CHORE_F32 ? 16 : 32);
+    if (dtype == CHORE_F16X3) return false;
     return nt <= 64 && nch % PD_SMALL == 0 && (long)B * tiles_of(H, W) * (Cout / nt) < 384;
 }
 
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+    if (conv_small_eligible(dtype, taps, H, W, Cin, Cout)) return ConvPlan{32, 1, H * (W / 32), 0, Cin};
     const int nt = choose_nt(dtype, B, H, W, Cout);
     const int tps = taps == 1 ? 1 : (is_small_grid(dtype, B, H, W, Cin, Cout, nt) ? 9 : 3);
-    return ConvPlan{nt, TH, tiles_of(H, W), tps};
+    return ConvPlan{nt, TH, tiles_of(H, W), tps, 0};
 }
 
 int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipStream_t s) {
     const int cc = dtype == CHORE_F32 ? 16 : 32;
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "conv: bad dtype");
     if (a_in.in.C % cc || a_in.in.C > 256) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cin=%d", a_in.in.C);
     if (a_in.Cout % 32) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cout=%d", a_in.Cout);
     if (a_in.B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "conv: B too large");
@@ -597,6 +663,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
+    if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
     ConvArgs a = a_in;
 #if CHORE_CONV_ABLATE
     static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
@@ -606,6 +673,8 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     const bool small_grid = is_small_grid(dtype, a.B, a.H, a.W, a.in.C, a.Cout, nt);
     if (dtype == CHORE_F32)
         return taps == 9 ? launch_nt<float, 9>(h, nt, small_grid, a, s) : launch_nt<float, 1>(h, nt, small_grid, a, s);
+    if (dtype == CHORE_F16X3)
+        return taps == 9 ? launch_nt<x3_t, 9>(h, nt, false, a, s) : launch_nt<x3_t, 1>(h, nt, false, a, s);
     return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, small_grid, a, s) : launch_nt<bf16_t, 1>(h, nt, small_grid, a, s);
 }
 
@@ -616,7 +685,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
 // ------------------------------------------------------------------------------------------------
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout) {
     const int kge = dtype == CHORE_F32 ? 8 : 16;
-    return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024;
+    return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024 * (dtype == CHORE_F16X3 ? 2 : 1);   // fp16 x 3: hi plane + lo plane
 }
 
 // transposed = 1 packs the weights of the DATA-GRADIENT convolution of a layer whose forward weights are
@@ -641,7 +710,19 @@ __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __res
         vals[j] = transposed ? w[((size_t)(c0 + j) * Cout + n) * taps + (taps - 1 - tap)]
                              : w[((size_t)n * Cin + c0 + j) * taps + tap];
     u32x4 o;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (IS_X3<T>) {
+        // fp16 x 3: hi plane at i, lo plane `nvec` vectors further; weights scaled by 2^X3_WSHIFT (exact)
+        f16x8_t hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float ws = vals[j] * (float)(1 << X3_WSHIFT);
+            hh[j] = (_Float16)ws;
+            ll[j] = (_Float16)(ws - (float)hh[j]);
+        }
+        dst[i] = __builtin_bit_cast(u32x4, hh);
+        dst[i + nvec] = __builtin_bit_cast(u32x4, ll);
+        return;
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = (unsigned)f2bf(vals[2 * j]) | ((unsigned)f2bf(vals[2 * j + 1]) << 16);
     } else {
@@ -653,9 +734,12 @@ __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __res
 
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w, void* dst,
                      hipStream_t s, int transposed) {
-    const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16;
+    const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16 / (dtype == CHORE_F16X3 ? 2 : 1);   // per plane
     const unsigned blocks = (unsigned)((nvec + 255) / 256);
-    if (dtype == CHORE_F32)
+    if (dtype == CHORE_F16X3)
+        hipLaunchKernelGGL(pack_conv_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec,
+                           transposed);
+    else if (dtype == CHORE_F32)
         hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec,
                            transposed);
     else

@@ -8,6 +8,20 @@
 
 typedef unsigned short bf16_t;
 
+// "fp16 x 3" element type (CHORE_F16X3): fp32 tensors in memory, every product a*w of a convolution evaluated on the fp16
+// matrix cores as hi(a) hi(w) + lo(a) hi(w) + hi(a) lo(w) with hi = fp16(x), lo = fp16(x - hi) and fp32 accumulation.
+// hi + lo carries 22 mantissa bits and fp16 x fp16 products are exact in fp32, so the result is fp32-grade (the dropped
+// lo*lo term is 2^-22 relative) at a third of the fp16 MFMA rate = 5x the rate of the native fp32 MFMA.  The matrix
+// cores keep fp16 subnormals (scripts/probes/f16_denorm_probe.hip), so small lo parts are not lost.  Weights are scaled
+// by 2^X3_WSHIFT before the split (their lo parts stay normal numbers), the accumulators by 2^-X3_WSHIFT afterwards.
+struct x3_t { float v; };
+constexpr int X3_WSHIFT = 8;
+template <typename T> struct Store { using type = T; };
+template <> struct Store<x3_t> { using type = float; };
+template <typename T> struct IsX3 { static constexpr bool value = false; };
+template <> struct IsX3<x3_t> { static constexpr bool value = true; };
+template <typename T> constexpr bool IS_X3 = IsX3<T>::value;
+
 struct View {
     void* p = nullptr;
     int cs = 0;   // channel stride (channels of the underlying buffer)
@@ -116,7 +130,10 @@ template <> struct Vec4<bf16_t> {
 };
 #endif
 
-struct ConvPlan { int nt, th, ntiles, tps; };   // N tile, tile height, tiles per image, taps per K-step
+struct ConvPlan { int nt, th, ntiles, tps, small_cin; };   // N tile, tile height, tiles per image, taps per K-step (tps 0: conv_small_kernel)
+// small maps (conv_small.hip): one workgroup = 32 pixels of a row x 32 output channels, K split over its four waves
+bool conv_small_eligible(int dtype, int taps, int H, int W, int Cin, int Cout);
+int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s);
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // tile configuration launch_conv will use
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);

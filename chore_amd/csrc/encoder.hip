@@ -14,7 +14,9 @@
 namespace {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-size_t esize(int dtype) { return dtype == CHORE_F32 ? 4 : 2; }
+size_t esize(int dtype) { return dtype == CHORE_BF16 ? 2 : 4; }
+// element type the non-convolution kernels see: fp16 x 3 keeps fp32 tensors, only the convolutions split their operands
+int sdt(int dtype) { return dtype == CHORE_F16X3 ? CHORE_F32 : dtype; }
 
 // ------------------------------------------------------------------------------------------------
 // weight arena: name -> (offset, bytes), deterministic traversal shared by pack and run
@@ -150,13 +152,15 @@ struct RunCtx {
 
 // one class per kernel instantiation, named like the kernel in a rocprofv3 trace so that bench.py's live
 // hipEvent numbers can be checked against profiles/*_kernel_stats.csv line by line
-enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_NUM = K_CONV_FIRST + 8 };
+enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_NUM = K_CONV_FIRST + 11 };
 const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "map_stats_kernel<T,C,PoolOp>",
                                          "map_stats_kernel<T,C,UpAddOp>", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
                                          "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
                                          "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
-                                         "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>"};
+                                         "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>", "conv_small_kernel<T,64>",
+                                         "conv_small_kernel<T,128>", "conv_small_kernel<T,256>"};
 inline int conv_class(const ConvPlan& p, int taps) {
+    if (p.tps == 0) return K_CONV_FIRST + 8 + (p.small_cin == 64 ? 0 : (p.small_cin == 128 ? 1 : 2));
     const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
     if (taps == 1) return K_CONV_FIRST + 5 + ni;
     if (p.tps == 9) return K_CONV_FIRST + 3 + (ni - 1);
@@ -289,7 +293,7 @@ struct Builder {
         cur_class = K_GN_STATS; cur_flops = 0.0; cur_bytes = (double)B * HW * x.C * es();
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_gn_stats(r.h, r.dtype, view(r, xb), Bn, HW, (GroupStat*)(r.stats + xb.st_off), r.s);
+            r.rc = launch_gn_stats(r.h, sdt(r.dtype), view(r, xb), Bn, HW, (GroupStat*)(r.stats + xb.st_off), r.s);
         });
     }
 
@@ -392,7 +396,7 @@ struct Builder {
         const int Bn = B;
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_avgpool2(r.h, r.dtype, view(r, x), view(r, y), Bn, x.H, x.W,
+            r.rc = launch_avgpool2(r.h, sdt(r.dtype), view(r, x), view(r, y), Bn, x.H, x.W,
                                    (GroupStat*)(r.stats + y.st_off), r.s);
         });
         return y;
@@ -405,7 +409,7 @@ struct Builder {
         const int Bn = B;
         push([=](RunCtx& r) {
             if (r.rc) return;
-            r.rc = launch_upadd(r.h, r.dtype, view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W,
+            r.rc = launch_upadd(r.h, sdt(r.dtype), view(r, ab), view(r, low), view(r, ab), Bn, low.H, low.W,
                                 (GroupStat*)(r.stats + ab.st_off), r.s);
         });
     }
@@ -455,7 +459,7 @@ struct Builder {
             cur_bytes = (double)B * H * W * Cin * 4 + (double)B * (H / 2) * (W / 2) * 64 * es();
             push([=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_stem(r.h, r.dtype, r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
+                r.rc = launch_stem(r.h, sdt(r.dtype), r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
                                    (const float*)(r.arena + be.off), ptr(r, c1), r.s);
             });
         }
@@ -468,7 +472,7 @@ struct Builder {
             cur_class = K_GN_APPLY; cur_flops = 0.0; cur_bytes = 2.0 * B * H2 * W2 * 64 * es();
             push([=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_gn_apply_relu(r.h, r.dtype, view(r, c1b), (const GroupStat*)(r.stats + c1b.st_off),
+                r.rc = launch_gn_apply_relu(r.h, sdt(r.dtype), view(r, c1b), (const GroupStat*)(r.stats + c1b.st_off),
                                             (const float*)(r.arena + ge.off), (const float*)(r.arena + bte.off),
                                             view(r, tmpx), Bn, H2 * W2, r.s);
             });
@@ -589,7 +593,7 @@ void chore_encoder_cache_free(chore_handle* h) {
 }
 
 size_t chore_encoder_arena_bytes(const chore_encoder_cfg* cfg, int dtype) {
-    if (!cfg || (dtype != CHORE_F32 && dtype != CHORE_BF16)) return 0;
+    if (!cfg || (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3)) return 0;
     return make_layout(*cfg, dtype).total;
 }
 
@@ -598,7 +602,7 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
     CHORE_ENTER(h);
     if (int rc = check_cfg(h, cfg)) return rc;
     if (!descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: null argument");
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: bad dtype");
     const WLayout L = make_layout(*cfg, dtype);
     std::unordered_map<std::string, const chore_weight_desc*> by_name;
     for (int i = 0; i < n_descs; ++i)
@@ -632,7 +636,7 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
 
 size_t chore_encoder_workspace_bytes(const chore_encoder_cfg* cfg, int B, int H, int W, int dtype) {
     if (!cfg || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return 0;
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16) return 0;
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) return 0;
     return plan_workspace(*cfg, B, H, W, dtype);
 }
 
@@ -644,7 +648,7 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     if (!images || !arena || !workspace || !tmpx) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: null argument");
     if (B <= 0 || B > 65535 || H % 16 || W % 16 || H < 16 || W < 16)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad shape B=%d H=%d W=%d (H, W multiples of 16)", B, H, W);
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad dtype");
     if (n_stack_out < 0 || n_stack_out > cfg->num_stack || (n_stack_out > 0 && !feat_out))
         CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad n_stack_out");
     for (int i = 0; i < n_stack_out; ++i)

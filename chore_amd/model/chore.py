@@ -9,8 +9,10 @@ attributes (`im_feat_list, tmpx, normx, intermediate_preds_list, preds, camera, 
 loss_weights, error_buffer`).  Everything runs on the GPU through libchore_hip.so; CPU tensors are
 rejected (no fallback).
 
-Precision: `compute_dtype` "fp32" (exact-fp32 matrix-core path, parity mode) or "bf16"
-(bf16 feature maps / MFMA operands with fp32 accumulation; heads stay fp32).  Selected by
+Precision: `compute_dtype` "fp32" (exact-fp32 matrix-core path, parity mode), "bf16" (bf16 feature maps / MFMA
+operands with fp32 accumulation; heads stay fp32) or "fp16x3" (fp32 feature maps; the encoder's convolutions run on the
+fp16 matrix cores with every operand split into an fp16 hi + lo pair, three MFMAs per product: fp32-grade results at
+5x the native fp32 MFMA rate).  Selected by
 `opt.compute_dtype`, else the CHORE_AMD_DTYPE environment variable, else "fp32".
 """
 import ctypes
@@ -24,7 +26,9 @@ from .. import _lib
 from .camera import KinectColorCamera
 from .hgfilter import HGFilter
 
-_DT = {"fp32": _lib.F32, "bf16": _lib.BF16}
+_DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
+# what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps
+_QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32}
 
 
 def _nhwc_ptr(t, C):
@@ -246,7 +250,7 @@ class CHORE(nn.Module):
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self._heads_packed is not None and self._heads_packed[0] == key:
             return self._heads_packed[1]
-        dtype = _DT[self.compute_dtype]
+        dtype = _QDT[self.compute_dtype]
         h = _lib.handle(device.index or 0)
         arena = torch.empty(_lib.lib.chore_heads_arena_bytes(dtype), dtype=torch.uint8, device=device)
         named = []
@@ -288,6 +292,8 @@ class CHORE(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
             # training: the layer-by-layer differentiable forward (model/hgfilter_train.py)
             from .hgfilter_train import forward_train
+            if self.compute_dtype == "fp16x3":
+                raise NotImplementedError("compute_dtype 'fp16x3' is an inference mode (train in 'fp32' or 'bf16')")
             tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
             feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt)
             feats = feats[-n_out:]
@@ -314,7 +320,7 @@ class CHORE(nn.Module):
         if pts.dim() != 3 or pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
             raise ValueError("points must be (B,N,3) and crop_center (B,2)")
         arena = self._heads_arena(points.device)
-        dtype = _DT[self.compute_dtype]
+        dtype = _QDT[self.compute_dtype]
         head_params = [p for _, m in self._head_modules() for p in m.parameters()]
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))

@@ -169,7 +169,7 @@ class HGFilter(_Params):
         dev = images.device
         images = images.contiguous().float()
         n_out = self.num_modules if n_stack_out is None else n_stack_out
-        tdt = torch.float32 if dtype == _lib.F32 else torch.bfloat16
+        tdt = torch.bfloat16 if dtype == _lib.BF16 else torch.float32
         arena = self.packed_arena(dtype, dev)
         cfg = self.cfg()
         h = _lib.handle(dev.index or 0)

@@ -16,6 +16,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.ab
 # stated tolerances (absolute, on field values of magnitude O(1); df is in metres)
 TOL = {
     "fp32": {"max_abs": 1e-4},                                   # north_star: "field values within 1e-4 of reference"
+    "fp16x3": {"max_abs": 1e-4},                                 # same bound: fp16 hi/lo split operands, fp32 accumulation
     "bf16": {"max_abs": 0.25, "mean_abs": 2e-2, "rel_l2": 2.5e-2},   # bf16 feature maps / MFMA operands: a 1e-2 mode
 }
 

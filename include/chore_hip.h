@@ -40,7 +40,7 @@ enum {
 };
 
 /* storage / MFMA-operand type of feature maps and packed weights */
-enum { CHORE_F32 = 0, CHORE_BF16 = 1 };
+enum { CHORE_F32 = 0, CHORE_BF16 = 1, CHORE_F16X3 = 2 };
 
 /* one tensor of a reference state_dict (Appendix D of SURVEY.md): name, device pointer to its
  * contiguous fp32 data in the reference layout, element count */

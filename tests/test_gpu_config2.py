@@ -4,6 +4,7 @@ precision modes, against the field values the reference itself produced for the 
 
 Stated tolerances (chore_amd/utils/field_check.py::TOL), absolute on outputs of magnitude O(1):
   fp32 mode : every df / pca / parts / centers value within 1e-4 of the reference (the north-star bound)
+  fp16x3    : the same 1e-4 bound (fp32 tensors; convolutions as three fp16 MFMAs per product on hi/lo split operands)
   bf16 mode : max 0.25, mean 2e-2, relative L2 2.5e-2 -- bf16 feature maps carry 8 mantissa bits, so this mode is a 1e-2
               mode by construction; the benchmark prints the measured numbers (config.field_err)
 """
@@ -48,6 +49,20 @@ def test_fp32_mode_fields_within_1e4_of_reference(preds32):
     K = int(g["n_points"])
     df = preds32[0].cpu().numpy()[..., :K]
     assert np.array_equal(df == 5.0, g["df"] == 5.0)
+
+
+def test_fp16x3_mode_fields_within_1e4_of_reference(opt, preds32):
+    """the fp16 x 3 mode (fp32 tensors, convolutions on the fp16 matrix cores with hi/lo split operands) meets the same
+    1e-4 bound as the native-fp32 mode -- on the golden points against the reference, and on all 4 x 20 000 points
+    against the fp32 mode"""
+    from chore_amd.utils.field_check import TOL, field_errors
+    preds = run_mode(opt, "fp16x3")
+    err = field_errors(preds)
+    for name in ("df", "pca", "parts", "centers"):
+        assert err[name]["max_abs"] < TOL["fp16x3"]["max_abs"], (name, err[name])
+    for name, a, b in zip(("df", "pca", "parts", "centers"), preds, preds32):
+        assert float((a.double() - b.double()).abs().max()) < 1e-4, name
+    assert torch.equal(preds[0] == 5.0, preds32[0] == 5.0)
 
 
 def test_bf16_mode_fields_within_stated_tolerance(opt, preds32):
