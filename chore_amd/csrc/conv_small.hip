@@ -24,18 +24,27 @@ typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int PW = 34, NPX = 3 * PW;      // patch: 3 rows x 34 pixels
+constexpr int PW = 34;                    // patch row: 32 pixels + halo
 constexpr int RED_LD = 33;                // pitch of a partial tile row in floats
+constexpr int RED_BYTES = 4 * 32 * RED_LD * 4;
 
-template <typename T, int CIN> struct SGeo {
+// ROWS = image rows per workgroup (1, 2 or 4); the four waves are ROWS rows x KS = 4 / ROWS parts of the K dimension.
+// More rows: the weight fragments a workgroup pulls from L2 serve ROWS tiles (the waves of different rows read the same
+// fragment within a few cycles: one L2 fetch, L1 hits for the others) and the halo shrinks from 3-for-1 to
+// (ROWS + 2)-for-ROWS; fewer rows: more workgroups.
+template <typename T, int CIN, int ROWS> struct SGeo {
     static constexpr bool X3 = IS_X3<T>;
+    static constexpr int KS = 4 / ROWS;
+    static constexpr int NPX = (ROWS + 2) * PW;
     static constexpr int PB = CIN * 2 + 16;                 // bytes per pixel per operand plane (16-byte slots: odd count)
     static constexpr int PLANE = NPX * PB;
     static constexpr int NPL = X3 ? 2 : 1;
     static constexpr int VPP = CIN / 8;                     // 8-channel slots per pixel
     static constexpr int NSLOT = (NPX * VPP + 255) / 256;   // slots per thread
     static constexpr int U = (CIN / 32) * 3;                // K units: (32-channel chunk, kernel row)
-    static constexpr size_t smem = (size_t)NPL * PLANE + (size_t)CIN * 8 + (size_t)4 * 32 * RED_LD * 4 + (size_t)4 * 4 * 32 * 4;
+    // the partial tiles of the reduction reuse the patch (dead after the K loop)
+    static constexpr size_t MAIN = (size_t)NPL * PLANE > RED_BYTES ? (size_t)NPL * PLANE : RED_BYTES;
+    static constexpr size_t smem = MAIN + (size_t)CIN * 8 + (size_t)4 * 4 * 32 * 4;
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 acc) {
@@ -45,18 +54,18 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, f32x1
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), acc, 0, 0, 0);
 }
 
-template <typename T, int CIN>
+template <typename T, int CIN, int ROWS>
 __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
-    using G = SGeo<T, CIN>;
+    using G = SGeo<T, CIN, ROWS>;
     constexpr bool X3 = G::X3;
     using ST = typename Store<T>::type;
-    constexpr int PB = G::PB, PLANE = G::PLANE, VPP = G::VPP, NSLOT = G::NSLOT, U = G::U;
+    constexpr int PB = G::PB, PLANE = G::PLANE, VPP = G::VPP, NSLOT = G::NSLOT, U = G::U, KS = G::KS, NPX = G::NPX;
     constexpr int LV = X3 ? 2 : 1;                          // 16-byte loads per 8-channel slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                                     // [NPL][NPX][PB]
-    float* ss = (float*)(smem + G::NPL * PLANE);            // [CIN][2] GroupNorm affine
-    float* red = ss + 2 * CIN;                              // [4 waves][32 pixels][RED_LD]
-    float* sred = red + 4 * 32 * RED_LD;                    // [4 kinds][4 waves][32 channels]
+    float* red = (float*)smem;                              // [4 waves][32 pixels][RED_LD], over the patch once it is dead
+    float* ss = (float*)(smem + G::MAIN);                   // [CIN][2] GroupNorm affine
+    float* sred = ss + 2 * CIN;                             // [4 kinds][4 waves][32 channels]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -71,7 +80,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     const int n_tile = lid % ntn;
     int t = lid / ntn;
     const int seg = t % segs; t /= segs;
-    const int y = t % a.H, b = t / a.H;
+    const int rgs = a.H / ROWS;
+    const int y = (t % rgs) * ROWS, b = t / rgs;            // first row of this workgroup
     const int x0 = seg * 32;
     const bool use_gn = a.in_st != nullptr;
 
@@ -148,6 +158,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int wrow_ = wid / G::KS;
     u32x4 b0[6], b1[6], l0[X3 ? 6 : 1], l1[X3 ? 6 : 1];       // two fragment sets, named statically (no indexed registers)
     auto load_b = [&](u32x4 (&bq)[6], u32x4 (&bl)[X3 ? 6 : 1], int u) {
         const int c = u / 3, ky = u % 3;
@@ -160,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     };
     auto unit = [&](const u32x4 (&bq)[6], const u32x4 (&bl)[X3 ? 6 : 1], int u) {
         const int c = u / 3, ky = u % 3;
-        const char* ap = patch + ((ky * PW + px) * PB) + (c * 32 + 8 * half) * 2;
+        const char* ap = patch + (((wrow_ + ky) * PW + px) * PB) + (c * 32 + 8 * half) * 2;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const int kx = k / 2, kg = k & 1;
@@ -175,81 +186,89 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
             }
         }
     };
-    if (wid < U) load_b(b0, l0, wid);
+    const int kp = wid % KS;                                // this wave: image row y + wrow_, K part kp
+    if (kp < U) load_b(b0, l0, kp);
 #pragma unroll 1
-    for (int u = wid; u < U; u += 8) {
-        if (u + 4 < U) load_b(b1, l1, u + 4);
+    for (int u = kp; u < U; u += 2 * KS) {
+        if (u + KS < U) load_b(b1, l1, u + KS);
         unit(b0, l0, u);
-        if (u + 4 < U) {
-            if (u + 8 < U) load_b(b0, l0, u + 8);
-            unit(b1, l1, u + 4);
+        if (u + KS < U) {
+            if (u + 2 * KS < U) load_b(b0, l0, u + 2 * KS);
+            unit(b1, l1, u + KS);
         }
     }
 
-    // ---- add the four partial tiles in wave order ----
+    // ---- add the KS partial tiles of every row in wave order, then the epilogue row by row ----
+    __syncthreads();                                        // every wave is done with the patch: reuse it
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wid * 32 + mfma32_row(r, half)) * RED_LD + px] = acc[r];
     __syncthreads();
     constexpr float ASCALE = X3 ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;
     const int p = tid >> 3, g4 = (tid & 7) * 4;              // this thread: pixel p, channels g4 .. g4+3 of the tile
     const int cg = n_tile * 32 + g4;
-    float f[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        float sacc = red[(0 * 32 + p) * RED_LD + g4 + k];
-#pragma unroll
-        for (int w = 1; w < 4; ++w) sacc += red[(w * 32 + p) * RED_LD + g4 + k];
-        f[k] = sacc * ASCALE + (a.bias ? a.bias[cg + k] : 0.f);
-    }
-    const size_t pix = ((size_t)b * a.H + y) * a.W + x0 + p;
-    auto ld4 = [&](const View& v, float (&o)[4]) {
-        const ST* q = (const ST*)v.p + pix * v.cs + v.co + cg;
-        if constexpr (sizeof(ST) == 2) {
-            const unsigned long long raw = *(const unsigned long long*)q;
-            o[0] = __uint_as_float((unsigned)(raw & 0xffffu) << 16);
-            o[1] = __uint_as_float((unsigned)(raw & 0xffff0000u));
-            o[2] = __uint_as_float((unsigned)((raw >> 32) & 0xffffu) << 16);
-            o[3] = __uint_as_float((unsigned)((raw >> 32) & 0xffff0000u));
-        } else {
-            const f32x4 r4 = *(const f32x4*)q;
-            o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3];
-        }
-    };
-    auto st4 = [&](const View& v, float (&o)[4]) {            // stores; o is replaced by the values as stored
-        ST* q = (ST*)v.p + pix * v.cs + v.co + cg;
-        if constexpr (sizeof(ST) == 2) {
-            const unsigned lo = pack2bf(o[0], o[1]), hi = pack2bf(o[2], o[3]);
-            *(unsigned long long*)q = (unsigned long long)lo | ((unsigned long long)hi << 32);
-            o[0] = __uint_as_float(lo << 16); o[1] = __uint_as_float(lo & 0xffff0000u);
-            o[2] = __uint_as_float(hi << 16); o[3] = __uint_as_float(hi & 0xffff0000u);
-        } else {
-            const f32x4 r4 = {o[0], o[1], o[2], o[3]};
-            *(f32x4*)q = r4;
-        }
-    };
     const bool want_stats = a.st_raw || a.st_out;
     float sr[4] = {0.f, 0.f, 0.f, 0.f}, qr[4] = {0.f, 0.f, 0.f, 0.f}, so[4] = {0.f, 0.f, 0.f, 0.f}, qo[4] = {0.f, 0.f, 0.f, 0.f};
-    if (a.raw.p) {
-        float g[4] = {f[0], f[1], f[2], f[3]};
-        st4(a.raw, g);
+    float bias4[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { sr[k] = g[k]; qr[k] = g[k] * g[k]; }
+    for (int k = 0; k < 4; ++k) bias4[k] = a.bias ? a.bias[cg + k] : 0.f;
+#pragma unroll
+    for (int row = 0; row < ROWS; ++row) {
+        float f[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float sacc = red[((row * KS + 0) * 32 + p) * RED_LD + g4 + k];
+#pragma unroll
+            for (int w = 1; w < KS; ++w) sacc += red[((row * KS + w) * 32 + p) * RED_LD + g4 + k];
+            f[k] = sacc * ASCALE + bias4[k];
+        }
+        const size_t pix = ((size_t)b * a.H + y + row) * a.W + x0 + p;
+        auto ld4 = [&](const View& v, float (&o)[4]) {
+            const ST* q = (const ST*)v.p + pix * v.cs + v.co + cg;
+            if constexpr (sizeof(ST) == 2) {
+                const unsigned long long raw = *(const unsigned long long*)q;
+                o[0] = __uint_as_float((unsigned)(raw & 0xffffu) << 16);
+                o[1] = __uint_as_float((unsigned)(raw & 0xffff0000u));
+                o[2] = __uint_as_float((unsigned)((raw >> 32) & 0xffffu) << 16);
+                o[3] = __uint_as_float((unsigned)((raw >> 32) & 0xffff0000u));
+            } else {
+                const f32x4 r4 = *(const f32x4*)q;
+                o[0] = r4[0]; o[1] = r4[1]; o[2] = r4[2]; o[3] = r4[3];
+            }
+        };
+        auto st4 = [&](const View& v, float (&o)[4]) {        // stores; o is replaced by the values as stored
+            ST* q = (ST*)v.p + pix * v.cs + v.co + cg;
+            if constexpr (sizeof(ST) == 2) {
+                const unsigned lo = pack2bf(o[0], o[1]), hi = pack2bf(o[2], o[3]);
+                *(unsigned long long*)q = (unsigned long long)lo | ((unsigned long long)hi << 32);
+                o[0] = __uint_as_float(lo << 16); o[1] = __uint_as_float(lo & 0xffff0000u);
+                o[2] = __uint_as_float(hi << 16); o[3] = __uint_as_float(hi & 0xffff0000u);
+            } else {
+                const f32x4 r4 = {o[0], o[1], o[2], o[3]};
+                *(f32x4*)q = r4;
+            }
+        };
+        if (a.raw.p) {
+            float g[4] = {f[0], f[1], f[2], f[3]};
+            st4(a.raw, g);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sr[k] += g[k]; qr[k] += g[k] * g[k]; }
+        }
+        if (a.res.p) {
+            float r4[4];
+            ld4(a.res, r4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] += r4[k];
+        }
+        if (a.res2.p) {
+            float r4[4];
+            ld4(a.res2, r4);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) f[k] += r4[k];
+        }
+        st4(a.out, f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { so[k] += f[k]; qo[k] += f[k] * f[k]; }
     }
-    if (a.res.p) {
-        float r4[4];
-        ld4(a.res, r4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f[k] += r4[k];
-    }
-    if (a.res2.p) {
-        float r4[4];
-        ld4(a.res2, r4);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) f[k] += r4[k];
-    }
-    st4(a.out, f);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { so[k] = f[k]; qo[k] = f[k] * f[k]; }
 
     if (want_stats) {   // uniform over the grid
         // a wave holds 8 pixels x 8 channel quads: fixed butterfly over the pixel bits, then the four waves in order
@@ -302,47 +321,80 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int CIN>
+template <typename T, int CIN, int ROWS>
 int launch_small_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = SGeo<T, CIN>;
-    bool& attr = CHORE_ONCE_FLAG(h);
-    if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_small_kernel<T, CIN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)G::smem));
-        attr = true;
+    using G = SGeo<T, CIN, ROWS>;
+    if constexpr (G::smem > 160 * 1024) {
+        CHORE_FAIL(h, CHORE_EINVAL, "conv_small: %d rows x %d channels do not fit the LDS", ROWS, CIN);
+    } else {
+        bool& attr = CHORE_ONCE_FLAG(h);
+        if (!attr) {
+            CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_small_kernel<T, CIN, ROWS>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::smem));
+            attr = true;
+        }
+        const unsigned grid = (unsigned)((size_t)a.B * (a.H / ROWS) * (a.W / 32) * (a.Cout / 32));
+        hipLaunchKernelGGL((conv_small_kernel<T, CIN, ROWS>), dim3(grid), dim3(256), G::smem, s, a);
+        CHORE_LAUNCH_CHECK(h, s);
+        return CHORE_OK;
     }
-    const unsigned grid = (unsigned)((size_t)a.B * a.H * (a.W / 32) * (a.Cout / 32));
-    hipLaunchKernelGGL((conv_small_kernel<T, CIN>), dim3(grid), dim3(256), G::smem, s, a);
-    CHORE_LAUNCH_CHECK(h, s);
-    return CHORE_OK;
+}
+
+template <typename T, int CIN>
+int launch_small_r(chore_handle* h, int rows, const ConvArgs& a, hipStream_t s) {
+    switch (rows) {
+        case 1: return launch_small_t<T, CIN, 1>(h, a, s);
+        case 2: return launch_small_t<T, CIN, 2>(h, a, s);
+        case 4: return launch_small_t<T, CIN, 4>(h, a, s);
+    }
+    CHORE_FAIL(h, CHORE_EINVAL, "conv_small: rows must be 1, 2 or 4");
 }
 
 template <typename T>
-int launch_small_c(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+int launch_small_c(chore_handle* h, int rows, const ConvArgs& a, hipStream_t s) {
     switch (a.in.C) {
-        case 64: return launch_small_t<T, 64>(h, a, s);
-        case 128: return launch_small_t<T, 128>(h, a, s);
-        case 256: return launch_small_t<T, 256>(h, a, s);
+        case 64: return launch_small_r<T, 64>(h, rows, a, s);
+        case 128: return launch_small_r<T, 128>(h, rows, a, s);
+        case 256: return launch_small_r<T, 256>(h, rows, a, s);
     }
     CHORE_FAIL(h, CHORE_EINVAL, "conv_small: unsupported Cin=%d", a.in.C);
 }
 
+// rows per workgroup; 0 = use conv_lds_kernel.  Environment overrides for A/B measurements.
+int small_rows(int dtype, int H, int W, int Cin) {
+    static const int r32 = getenv("CHORE_CONV_SMALL_ROWS32") ? atoi(getenv("CHORE_CONV_SMALL_ROWS32")) : -1;
+    static const int r64 = getenv("CHORE_CONV_SMALL_ROWS64") ? atoi(getenv("CHORE_CONV_SMALL_ROWS64")) : -1;
+    static const int r64c = getenv("CHORE_CONV_SMALL_ROWS64_C256") ? atoi(getenv("CHORE_CONV_SMALL_ROWS64_C256")) : -1;
+    const bool x3 = dtype == CHORE_F16X3;
+    int rows;
+    if (H * W <= 32 * 32) rows = r32 >= 0 ? r32 : (x3 ? 2 : 1);
+    else if (Cin == 256) rows = r64c >= 0 ? r64c : 0;
+    else rows = r64 >= 0 ? r64 : 0;
+    // LDS: (rows + 2) x 34 pixels x (2 Cin + 16) bytes per plane, two planes for fp16 x 3
+    while (rows > 0 && (size_t)(x3 ? 2 : 1) * (rows + 2) * PW * (Cin * 2 + 16) + (size_t)Cin * 8 + 2048 > 160 * 1024) rows >>= 1;
+    if (rows && H % rows) rows = 0;
+    return rows;
+}
+
 }  // namespace
 
-// Where it is used (measured, bench.py encode time, B = 4: bf16 4.06 -> 3.79 ms, fp16 x 3 6.55 -> 6.26 ms).  Every
-// workgroup fetches its whole K slice of the weights and a patch with a 3-rows-for-1 halo from L2, so the kernel trades
-// L2 traffic for parallelism: it wins on the 32 x 32 maps, where the big kernel has 16-64 workgroups for 256 CUs; on the
-// 64 x 64 maps it is level with it up to 128 input channels and slower for 256 (2 048 workgroups x 200 KB of L2 reads),
-// so those stay with conv_lds_kernel.  bf16 and fp16 x 3 only: the native-fp32 parity mode keeps
-// the one kernel it was validated with.
+// Where it is used (measured, bench.py encode time, B = 4: bf16 4.06 -> 3.79 ms, fp16 x 3 6.55 -> 6.1 ms).  A workgroup
+// fetches its K slice of the weights (147 KB for 256 -> 128 channels) and its halo patch from L2 on its own, so the
+// kernel trades L2 traffic for parallelism.  It wins on the 32 x 32 maps, where conv_lds_kernel has 16-64 workgroups for
+// 256 CUs.  On the 64 x 64 maps it loses in every variant tried (1, 2 or 4 rows per workgroup, CHORE_CONV_SMALL_ROWS64*):
+// 1 024-2 048 workgroups x 200 KB is L2-bandwidth bound (53 us against 26 us for the 256-channel convolution), and with
+// several rows per workgroup the waves drift apart and each pulls the weight fragments through the 32 KB L1 again --
+// sharing them takes the LDS ring and barriers of conv_lds_kernel, which therefore keeps those maps.  bf16 and
+// fp16 x 3 only: the native-fp32 parity mode keeps the one kernel it was validated with.
 bool conv_small_eligible(int dtype, int taps, int H, int W, int Cin, int Cout) {
     static const bool off = getenv("CHORE_NO_CONV_SMALL") != nullptr;      // A/B switch
     if (off || taps != 9 || (dtype != CHORE_BF16 && dtype != CHORE_F16X3)) return false;
-    if (W % 32 || Cout % 32 || (Cin != 64 && Cin != 128 && Cin != 256)) return false;
-    return H * W <= 32 * 32;
+    if (W % 32 || Cout % 32 || (Cin != 64 && Cin != 128 && Cin != 256) || H * W > 64 * 64) return false;
+    return small_rows(dtype, H, W, Cin) > 0;
 }
 
 int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s) {
     if ((size_t)a.B * a.H * (a.W / 32) * (a.Cout / 32) > 0x7fffffffull) CHORE_FAIL(h, CHORE_EINVAL, "conv_small: grid too large");
-    return dtype == CHORE_F16X3 ? launch_small_c<x3_t>(h, a, s) : launch_small_c<bf16_t>(h, a, s);
+    const int rows = small_rows(dtype, a.H, a.W, a.in.C);
+    return dtype == CHORE_F16X3 ? launch_small_c<x3_t>(h, rows, a, s) : launch_small_c<bf16_t>(h, rows, a, s);
 }

@@ -85,10 +85,32 @@ WLayout make_layout(const chore_encoder_cfg& cfg, int dtype) {
         if (i < cfg.num_stack - 1) {
             layout_conv(L, dtype, p + "bl" + s, 1, 256, 256, true);
             layout_conv(L, dtype, p + "al" + s, 1, cfg.hourglass_dim, 256, true);
+            // merged l / bl / al (see Builder::build): derived at pack time, not a tensor of the state dict
+            L.add(p + "ml" + s + ".wf32", (size_t)256 * 256 * 4, 3, 1, 256, 256);
+            L.add(p + "ml" + s + ".weight", packed_conv_bytes(dtype, 1, 256, 256), 4, 1, 256, 256);
+            L.add(p + "ml" + s + ".bias", 256 * 4, 5, 0, 0, 256);
         }
     }
     L.total = align_up(L.total, 256);
     return L;
+}
+
+// previous' = previous + bl(ll) + al(l(ll)) (HGFilters.py:176-183) is ONE 1x1 convolution of ll when out_i = l(ll) itself is
+// not asked for: W = W_bl + W_al W_l, b = b_bl + b_al + W_al b_l.  One thread per element of W, fp64 accumulation.
+__global__ void compose_1x1_kernel(const float* __restrict__ wl, const float* __restrict__ bl_l, const float* __restrict__ wbl,
+                                   const float* __restrict__ bbl, const float* __restrict__ wal, const float* __restrict__ bal,
+                                   int C, float* __restrict__ wout, float* __restrict__ bout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // output channel o = i / C, input channel c = i % C
+    if (i >= C * C) return;
+    const int o = i / C, c = i % C;
+    double acc = (double)wbl[(size_t)o * C + c];
+    for (int k = 0; k < C; ++k) acc += (double)wal[(size_t)o * C + k] * (double)wl[(size_t)k * C + c];
+    wout[i] = (float)acc;
+    if (c == 0) {
+        double b = (double)bbl[o] + (double)bal[o];
+        for (int k = 0; k < C; ++k) b += (double)wal[(size_t)o * C + k] * (double)bl_l[k];
+        bout[o] = (float)b;
+    }
 }
 
 int check_cfg(chore_handle* h, const chore_encoder_cfg* cfg) {
@@ -157,8 +179,8 @@ const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_a
                                          "map_stats_kernel<T,C,UpAddOp>", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
                                          "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
                                          "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
-                                         "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>", "conv_small_kernel<T,64>",
-                                         "conv_small_kernel<T,128>", "conv_small_kernel<T,256>"};
+                                         "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>", "conv_small_kernel<T,64,ROWS>",
+                                         "conv_small_kernel<T,128,ROWS>", "conv_small_kernel<T,256,ROWS>"};
 inline int conv_class(const ConvPlan& p, int taps) {
     if (p.tps == 0) return K_CONV_FIRST + 8 + (p.small_cin == 64 ? 0 : (p.small_cin == 128 ? 1 : 2));
     const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
@@ -212,7 +234,11 @@ struct Builder {
     double cur_flops = 0.0, cur_bytes = 0.0;
     double es() const { return (double)esize(dtype); }
 
-    explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) { concurrent = getenv("CHORE_ENC_SERIAL") == nullptr; }
+    bool no_merge = false;   // CHORE_ENC_NO_MERGE: keep l / bl / al separate in eval too (A/B and bit-comparison with training mode)
+    explicit Builder(Program& p) : P(p), B(p.B), dtype(p.dtype) {
+        concurrent = getenv("CHORE_ENC_SERIAL") == nullptr;
+        no_merge = getenv("CHORE_ENC_NO_MERGE") != nullptr;
+    }
 
     Buf alloc(int H, int W, int C) {
         Buf b;
@@ -499,6 +525,20 @@ struct Builder {
             conv(cl);
             release(t1);
             const int oi = i - (cfg.num_stack - P.n_out);
+            if (oi < 0 && i < cfg.num_stack - 1 && !no_merge) {
+                // out_i = l(ll) is not an output of this call (eval keeps the last stack only, model/chore.py:95-96) and
+                // its only reader is al: l, bl and al collapse into the single 1x1 convolution packed as "ml<i>"
+                Buf nprev = alloc(H4, W4, 256);
+                new_stats(nprev);
+                ConvSpec ml;
+                ml.in = t2; ml.in_C = 256; ml.gn = p + "bn_end" + s; ml.wname = p + "ml" + s; ml.bias = true;
+                ml.out = nprev; ml.has_res = true; ml.res = previous; ml.taps = 1; ml.cout = 256; ml.stat_out = true;
+                conv(ml);
+                release(previous);
+                previous = nprev;
+                release(t2);
+                continue;
+            }
             Buf out_i = (oi >= 0) ? external(oi, H4, W4, 256) : alloc(H4, W4, 256);
             ConvSpec l;
             l.in = t2; l.in_C = 256; l.gn = p + "bn_end" + s; l.wname = p + "l" + s; l.bias = true; l.out = out_i;
@@ -610,6 +650,29 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
     hipStream_t s = (hipStream_t)stream;
     for (const std::string& name : L.order) {
         const WEntry& e = L.e.at(name);
+        if (e.kind >= 3) {
+            if (e.kind != 3) continue;                         // .weight / .bias of a merged conv are written with its .wf32
+            const std::string base = name.substr(0, name.size() - 5);                     // "...ml<i>"
+            const std::string idx = base.substr(base.rfind("ml") + 2), pre = base.substr(0, base.rfind("ml"));
+            const float* src[6];
+            const char* leaf[6] = {"l%s.weight", "l%s.bias", "bl%s.weight", "bl%s.bias", "al%s.weight", "al%s.bias"};
+            for (int k = 0; k < 6; ++k) {
+                char buf[64];
+                snprintf(buf, sizeof(buf), leaf[k], idx.c_str());
+                auto f = by_name.find(pre + buf);
+                const int64_t want = (k & 1) ? 256 : 256 * 256;
+                if (f == by_name.end() || f->second->numel != want)
+                    CHORE_FAIL(h, CHORE_ESTATE, "chore_encoder_pack: tensor '%s%s' missing or of the wrong size", pre.c_str(), buf);
+                src[k] = (const float*)f->second->ptr;
+            }
+            float* wf = (float*)((char*)arena + e.off);
+            float* bf = (float*)((char*)arena + L.e.at(base + ".bias").off);
+            hipLaunchKernelGGL(compose_1x1_kernel, dim3(256), dim3(256), 0, s, src[0], src[1], src[2], src[3], src[4], src[5], 256,
+                               wf, bf);
+            CHORE_LAUNCH_CHECK(h, s);
+            if (int rc = launch_pack_conv(h, dtype, 1, 256, 256, wf, (char*)arena + L.e.at(base + ".weight").off, s)) return rc;
+            continue;
+        }
         auto it = by_name.find(name);
         if (it == by_name.end()) CHORE_FAIL(h, CHORE_ESTATE, "chore_encoder_pack: tensor '%s' missing", name.c_str());
         const chore_weight_desc* d = it->second;

@@ -72,9 +72,11 @@ def test_encoder_fp32_matches_reference(net32, synth_sd):
     o_outs, o_tmpx, o_normx = oe.Encoder(synth_sd).forward(g["images"])
     for a, b in zip(outs, o_outs):
         assert rel_max(a, b) < 2e-4
-    # eval mode keeps only the last stack and gives the same tensor
+    # eval mode keeps only the last stack and gives the same tensor -- to fp32 round-off: the outputs of stacks 0-3 are
+    # not produced there, and their l / bl / al 1x1 convolutions run merged into one (W_bl + W_al W_l, composed in fp64)
     outs_e, _, _ = encode(net32, g["images"], train=False)
-    assert len(outs_e) == 1 and np.array_equal(outs_e[0], outs[-1])
+    assert len(outs_e) == 1 and rel_max(outs_e[0], outs[-1]) < 2e-5
+    assert rel_max(outs_e[0], g["out_last"]) < 2e-4
 
 
 def test_encoder_bf16_within_stated_tolerance(net16):
