@@ -6,6 +6,10 @@ into a RuntimeError carrying chore_last_error().
 """
 import ctypes
 import os
+
+import torch  # noqa: F401  -- FIRST: PyTorch ships its own libamdhip64; loading libchore_hip.so before it would bind the
+#                              library to the system ROCm's copy and the process would hold two HIP runtimes (the second one
+#                              finds no device).  With torch loaded the dlopen below resolves to the runtime torch uses.
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
