@@ -1,0 +1,86 @@
+"""GPU: the PER-GPU workloads of BASELINE configs[3] and [4] at their full sizes on one GPU (the multi-GPU part -- DDP's
+all-reduce, the final gather -- is covered by the 2-rank tests; no multi-GPU box exists for the tests).
+
+  configs[3]  DDP training: batch 4 x 512x512 images, 20 000 points per image, 5 stacks, bf16 -- one full training step
+              (forward, backward to all 475 trained tensors, Adam) with finite loss / gradients and a loss that moves
+  configs[4]  frame-sharded fitting: 8 frames per GPU fitted as one batch, every inner iteration a hipGraph replay --
+              the whole fit_recon chain (point clouds, SMPL-H init, both optimisation loops with silhouette, contact and
+              collision terms), compared with the same chain issued eagerly
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config3_training_step_at_full_per_gpu_size(opt):
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    o = copy.copy(opt)
+    o.compute_dtype = "bf16"
+    net = CHORE(o).cuda()
+    synth.load_synth_weights(net, seed=0)
+    net.train(True)
+    net.losses_on_host = False
+    B, N = 4, 20000
+    rs = np.random.RandomState(50)
+    t = lambda a: torch.from_numpy(a).cuda()     # noqa: E731
+    batch = dict(images=t(synth.synth_images(B, 512, 512, seed=0)), points=t(synth.synth_points(B, N, seed=1)),
+                 df_h=t(rs.uniform(0, 0.3, (B, N)).astype(np.float32)), df_o=t(rs.uniform(0, 0.3, (B, N)).astype(np.float32)),
+                 parts_gt=t(rs.randint(0, 14, (B, N))), pca_gt=t(rs.standard_normal((B, 3, 3, N)).astype(np.float32)),
+                 body_center=t((rs.standard_normal((B, 3)) * 0.3).astype(np.float32)),
+                 obj_center=t((rs.standard_normal((B, 3, N)) * 0.3).astype(np.float32)),
+                 crop_center=torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32).cuda())
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for _ in range(3):
+        optim.zero_grad(set_to_none=True)
+        error, sep = net(**batch)
+        error.backward()
+        optim.step()
+        losses.append(float(error.detach()))
+    assert len(net.intermediate_preds_list) == 5 and net.intermediate_preds_list[0][0].shape == (B, 2, N)
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    n_grad = sum(1 for p in net.parameters() if p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0)
+    assert n_grad == 475          # every trained tensor; the 82 never-used bn4 affines get none, like in the reference
+    assert sep.is_cuda            # losses_on_host = False: no host synchronisation inside the step
+
+
+def _fit8(opt, use_graphs):
+    import bench
+    from chore_amd.model import CHORE
+    from chore_amd.recon.assets import SyntheticAssets
+    from chore_amd.recon.generator import Generator
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    o = copy.copy(opt)
+    o.compute_dtype = "fp16x3"
+    dev = torch.device("cuda", 0)
+    net = CHORE(o).to(dev).eval()
+    synth.load_synth_weights(net, seed=0)
+    fitter = ReconFitterBehave(None, device=dev, obj_name="synthetic", outpath=None, args=o, assets=SyntheticAssets(0))
+    fitter.use_graphs, fitter.early_stop, fitter.adam_capturable = use_graphs, False, True
+    gen = Generator(net, None, threshold=2.0, sparse_thres=0.03, filter_val=1.0, device=dev)
+    data = bench.fit_batch_inputs(8, 0, dev)
+    torch.manual_seed(5)
+    with torch.random.fork_rng(devices=[dev]):
+        torch.cuda.manual_seed(5)
+        smpl, obj_R, obj_t, obj_s = fitter.fit_batch(
+            data, gen, smpl_iters=dict(iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, steps_per_iter=5, max_iter=1),
+            object_iters=dict(obj_iter=2, sil_iter=2, joint_iter=2, max_iter=1, steps_per_iter=5))
+    return [x.detach().cpu().numpy().copy() for x in (smpl.pose, smpl.betas, smpl.trans, obj_t, obj_s,
+                                                      fitter.decopose_axis(obj_R, no_rand=True))]
+
+
+def test_config4_eight_frames_per_gpu_graph_replay(opt):
+    eager = _fit8(opt, False)
+    graph = _fit8(opt, True)
+    for name, a, b in zip(("pose", "betas", "trans", "obj_t", "obj_s", "R"), eager, graph):
+        assert a.shape[0] == 8 and np.isfinite(b).all(), name
+        assert np.abs(a - b).max() < 5e-4, (name, np.abs(a - b).max())
+    R = graph[5]
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-4
+    assert np.abs(graph[3] - eager[3]).max() < 5e-4 and np.abs(graph[2].std(0)).max() > 0      # frames differ, fits differ
