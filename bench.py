@@ -334,6 +334,8 @@ def mode_query(args, ctx):
                                   % args.dtype if dom in traffic else None,
                 "avg_launch_ms": dv["ms_per_step"] / dv["launches_per_step"],
                 "flops_per_launch": dv["tflops"] * 1e9 * dv["ms_per_step"] / dv["launches_per_step"]}
+        if dom_dtype == "fp16x3":     # every algorithmic product is three fp16 MFMAs: the share of the matrix cores' issue rate
+            roof["mfma_issue_frac"] = 3.0 * roof["frac"]
         out = base_line(args, ctx, "query-points/sec (HGFilters encode + 20k-pt MLP field query per 512x512 image)",
                         ctx.world * B * N * args.steps / elapsed, "points/s", elapsed, True, args.dtype,
                         {"workload": "BASELINE configs[1]: encode %dx(5,512,512) + query %dx%d points per GPU per step"
