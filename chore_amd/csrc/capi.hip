@@ -3,6 +3,8 @@
 #include <cstring>
 
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_fwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s);
+size_t heads_arena_bytes();
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s);
 
@@ -53,8 +55,8 @@ int chore_destroy(chore_handle* h) {
 const char* chore_last_error(const chore_handle* h) { return h ? h->err.c_str() : g_noh_err.c_str(); }
 
 size_t chore_heads_arena_bytes(int dtype) {
-    (void)dtype;  // the exact-fp32 heads use the same arena for fp32 and bf16 feature maps
-    return QF_TOTAL_FLOATS * sizeof(float);
+    (void)dtype;  // one arena for every mode: the fp32 MFMA fragments, then the fp16 x 3 fragments (heads_x3.h)
+    return heads_arena_bytes();
 }
 
 int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_descs, int dtype, void* arena,
@@ -102,11 +104,14 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
     CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: null output");
     QueryArgs a;
-    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
-                             cam6_host);
+    // CHORE_F16X3: fp32 feature maps (what the fp16 x 3 encoder writes) and the heads on the fp16 matrix cores
+    const bool x3 = dtype == CHORE_F16X3;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, x3 ? CHORE_F32 : dtype,
+                             heads_arena, cam6_host);
     if (rc) return rc;
     a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
     a.in_img = in_img;
+    if (x3) return launch_query_fwd_x3(h, a, (hipStream_t)stream);
     return dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream)
                               : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream);
 }

@@ -11,7 +11,7 @@
 // never leave registers; weights stream from the L2-resident fragment-ordered arena written by
 // heads_pack.  Phase 4: masked (df[~in_img] = 5.0, model/chore.py:147-150) coalesced stores in the
 // (B,C,N) layout the reference API returns.
-#include "heads_f32.h"
+#include "heads_x3.h"
 #include <cstdlib>
 
 template <int PTS>
@@ -25,9 +25,11 @@ using QueryFwdSmem = QueryFwdSmemT<QT_PTS>;
 // loop (6 890 / 3 000 points give 108 / 47 tiles of 64: fewer workgroups than CUs, each a serial MFMA chain --
 // halving the tile halves that chain and doubles the workgroups)
 // TRAIN: also stage the 323-vectors and the ReLU outputs of the hidden layers (tX, tH) for the backward pass
-template <typename T, int NCB, bool TRAIN = false>
+// X3: the heads on the fp16 matrix cores with hi/lo split operands (heads_x3.h) instead of the native fp32 MFMA
+template <typename T, int NCB, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
+    static_assert(!(TRAIN && X3), "the training path stages fp32-MFMA activations");
     constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
@@ -59,14 +61,21 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
             if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
     }
-    heads_layer1<NCB>(h1, sm.X, arena, head, lane);
-    if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
-    heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
-    if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
-    heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
-    if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
     f32x16 o[NCB];
-    heads_layer_out<NCB>(o, h1, arena, head, lane);
+    if constexpr (X3) {
+        heads_layer1_x3<NCB>(h1, sm.X, arena, head, lane);
+        heads_layer_hid_x3<NCB>(h2, h1, arena, head, 1, lane);
+        heads_layer_hid_x3<NCB>(h1, h2, arena, head, 2, lane);
+        heads_layer_out_x3<NCB>(o, h1, arena, head, lane);
+    } else {
+        heads_layer1<NCB>(h1, sm.X, arena, head, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+        heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
+        heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+        heads_layer_out<NCB>(o, h1, arena, head, lane);
+    }
 
     const int odim = head_out_dim(head);
     float* outp = a.out[head] + (size_t)b * odim * a.N;
@@ -92,8 +101,9 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
 // A wave of the four-wave kernel is stalled on weight / tap fetches ~40 % of its life (SQ_WAIT_ANY) with nothing else
 // resident on its SIMD; here every SIMD holds two waves (<= 256 registers each), the second wave of a head finds the
 // weight lines of the first in the L1, and the MFMA pipe stays busy while one of them waits.
-template <typename T, bool TRAIN = false>
+template <typename T, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
+    static_assert(!(TRAIN && X3), "the training path stages fp32-MFMA activations");
     constexpr int PTS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
@@ -124,14 +134,21 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
             if (n0 + pt < a.N) *(f32x4*)(a.tX + (row0 + pt) * QF_KPAD + 4 * q) = *(const f32x4*)(sm.X + pt * XS + 4 * q);
         }
     }
-    heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
-    if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
-    heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
-    if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32);
-    heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
-    if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
     f32x16 o[1];
-    heads_layer_out<1>(o, h1, arena, head, lane);
+    if constexpr (X3) {
+        heads_layer1_x3<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
+        heads_layer_hid_x3<1>(h2, h1, arena, head, 1, lane);
+        heads_layer_hid_x3<1>(h1, h2, arena, head, 2, lane);
+        heads_layer_out_x3<1>(o, h1, arena, head, lane);
+    } else {
+        heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32);
+        heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        heads_layer_out<1>(o, h1, arena, head, lane);
+    }
 
     const int odim = head_out_dim(head);
     float* outp = a.out[head] + (size_t)b * odim * a.N;
@@ -288,26 +305,84 @@ __global__ void heads_pack_f32_kernel(HeadsRaw raw, float* arena) {
     arena[idx] = v;
 }
 
+// fp16 x 3 fragments (heads_x3.h): one thread per 16-byte vector of a hi plane, writes the hi and the lo vector
+__global__ void heads_pack_x3_kernel(HeadsRaw raw, u32x4* dst) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n1 = QX_L1_VEC / 2, n23 = QX_L23_VEC / 2, n4 = QX_L4_VEC / 2;
+    if (idx >= n1 + n23 + n4) return;
+    float v[8];
+    size_t out;                                   // index of the hi vector; the lo vector follows 64 vectors later
+    if (idx < n1) {                               // [head][ks][rb][lane]
+        size_t t = idx;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int ks = (int)(t % QX_KS1);
+        const int hd = (int)(t / QX_KS1);
+        const int row = rb * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = ks * 16 + 8 * (lane >> 5) + j;
+            v[j] = k < HEAD_IN ? raw.w[hd][0][(size_t)row * HEAD_IN + k] : 0.f;
+        }
+        out = (((size_t)hd * QX_KS1 + ks) * 4 + rb) * 2 * 64 + lane;
+    } else if (idx < n1 + n23) {                  // [head][l][kb][s][rb][lane]
+        size_t t = idx - n1;
+        const int lane = t & 63; t >>= 6;
+        const int rb = t & 3; t >>= 2;
+        const int s = t & 1; t >>= 1;
+        const int kb = t & 3; t >>= 2;
+        const int l = t & 1; t >>= 1;
+        const int hd = (int)t;
+        const int row = rb * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw.w[hd][1 + l][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, lane >> 5)];
+        out = QX_L1_VEC + ((((((size_t)hd * 2 + l) * 4 + kb) * 2 + s) * 4 + rb) * 2) * 64 + lane;
+    } else {                                      // [head][kb][s][lane]
+        size_t t = idx - n1 - n23;
+        const int lane = t & 63; t >>= 6;
+        const int s = t & 1; t >>= 1;
+        const int kb = t & 3; t >>= 2;
+        const int hd = (int)t;
+        const int row = lane & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = row < head_out_dim(hd) ? raw.w[hd][3][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, lane >> 5)] : 0.f;
+        out = QX_L1_VEC + QX_L23_VEC + ((((size_t)hd * 4 + kb) * 2 + s) * 2) * 64 + lane;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= QX_SCALE;
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    dst[out] = hi;
+    dst[out + 64] = lo;
+}
+
 int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s) {
     const int threads = 256;
     const int blocks = (int)((QF_TOTAL_FLOATS + threads - 1) / threads);
     hipLaunchKernelGGL(heads_pack_f32_kernel, dim3(blocks), dim3(threads), 0, s, raw, arena);
     CHORE_LAUNCH_CHECK(h, s);
+    const size_t nx = QX_TOTAL_VEC / 2;
+    hipLaunchKernelGGL(heads_pack_x3_kernel, dim3((unsigned)((nx + threads - 1) / threads)), dim3(threads), 0, s, raw,
+                       (u32x4*)((char*)arena + QX_OFF_BYTES));
+    CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
-template <typename T, int NCB>
+size_t heads_arena_bytes() { return QX_ARENA_BYTES; }
+
+template <typename T, int NCB, bool X3 = false>
 static int launch_query_fwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     constexpr int PTS = 32 * NCB;
     const size_t smem = sizeof(QueryFwdSmemT<PTS>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, NCB>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, NCB, false, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + PTS - 1) / PTS, a.B);
-    hipLaunchKernelGGL((query_fwd_f32_kernel<T, NCB>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((query_fwd_f32_kernel<T, NCB, false, X3>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -315,26 +390,26 @@ static int launch_query_fwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 // 64-point tiles unless they would leave CUs without a workgroup
 bool query_small_tiles(int B, int N) { return (size_t)B * ((N + QT_PTS - 1) / QT_PTS) <= 256; }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_query_fwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, false>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, false, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + 63) / 64, a.B);
-    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, false>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, false, X3>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switch: the four-wave kernel for large queries
-    if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1>(h, a, s);
-    return w4 ? launch_query_fwd_n<T, 2>(h, a, s) : launch_query_fwd_w8<T>(h, a, s);
+    if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1, X3>(h, a, s);
+    return w4 ? launch_query_fwd_n<T, 2, X3>(h, a, s) : launch_query_fwd_w8<T, X3>(h, a, s);
 }
 
 template <typename T>
@@ -376,4 +451,7 @@ int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
 }
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_fwd_t<unsigned short>(h, a, s);
+}
+int launch_query_fwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_fwd_t<float, true>(h, a, s);
 }

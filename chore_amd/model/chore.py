@@ -27,8 +27,10 @@ from .camera import KinectColorCamera
 from .hgfilter import HGFilter
 
 _DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
-# what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps
+# what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps; its query FORWARD runs the heads on the
+# fp16 matrix cores with split operands too (csrc/heads_x3.h), the backward kernels take the native fp32 MFMA
 _QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32}
+_QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
 
 
 def _nhwc_ptr(t, C):
@@ -45,7 +47,7 @@ class _QueryFn(torch.autograd.Function):
     """chore_query_fwd / chore_query_bwd_points as one autograd node (gradient w.r.t. points)."""
 
     @staticmethod
-    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype):
+    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype, fwd_dtype):
         B, N, _ = points.shape
         dev = points.device
         h = _lib.handle(dev.index or 0)
@@ -57,7 +59,7 @@ class _QueryFn(torch.autograd.Function):
         centers = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib.chore_query_fwd(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
-                                            tp, TH, TW, dtype, arena.data_ptr(), cam6, df.data_ptr(),
+                                            tp, TH, TW, fwd_dtype, arena.data_ptr(), cam6, df.data_ptr(),
                                             pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), None,
                                             stream), h, "chore_query_fwd")
         ctx.save_for_backward(points, crop_center, feat, tmpx, arena)
@@ -84,7 +86,7 @@ class _QueryFn(torch.autograd.Function):
                                                    FW, tp, TH, TW, ctx.dtype, arena.data_ptr(), ctx.cam6,
                                                    ptr[0], ptr[1], ptr[2], ptr[3], dpoints.data_ptr(),
                                                    stream), h, "chore_query_bwd_points")
-        return dpoints, None, None, None, None, None, None
+        return dpoints, None, None, None, None, None, None, None
 
 
 class _QueryTrainFn(torch.autograd.Function):
@@ -336,7 +338,8 @@ class CHORE(nn.Module):
                 df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
                                                               *head_params)
             else:
-                df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype)
+                df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
+                                                         _QDT_FWD[self.compute_dtype])
             B, _, N = df.shape
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]

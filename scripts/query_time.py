@@ -4,7 +4,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 from bench import chore_opt
 from chore_amd.model import CHORE
 from chore_amd.utils import synth
-for dt in ("bf16", "fp32"):
+for dt in ("bf16", "fp32", "fp16x3"):
     net = CHORE(chore_opt(dt)).cuda().eval(); synth.load_synth_weights(net, 0)
     for p in net.parameters(): p.requires_grad_(False)
     B, N = 4, 20000

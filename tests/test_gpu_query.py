@@ -153,6 +153,31 @@ def test_bf16_maps_query(net, synth_sd):
         np.testing.assert_allclose(v.cpu().numpy(), o[k], rtol=1e-5, atol=3e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("B,N", [(1, 2048), (2, 333), (4, 20000)])
+def test_fp16x3_heads_forward(net, synth_sd, B, N):
+    """the fp16 x 3 mode's query forward -- fp32 maps, the heads as three fp16 MFMAs per product on hi/lo split operands
+    (csrc/heads_x3.h) -- against the oracle on seeded maps: 5e-5 absolute (the north-star bound is 1e-4), the OUT_DIST
+    mask identical, for the 32-point-tile, the ragged and the 64-point-tile kernels"""
+    from chore_amd.utils import synth
+    rs = np.random.RandomState(22)
+    feat = rs.standard_normal((B, 256, 128, 128)).astype(np.float32)
+    tmpx = rs.standard_normal((B, 64, 256, 256)).astype(np.float32)
+    pts = synth.synth_points(B, N, seed=3)
+    cc = np.tile(np.array([synth.CROP_CENTER], np.float32), (B, 1))
+    g = dict(feat=feat, tmpx=tmpx, points=pts, crop_center=cc)
+    _, ref = run_query(net, g)
+    net.compute_dtype = "fp16x3"
+    try:
+        _, out = run_query(net, g)
+    finally:
+        net.compute_dtype = "fp32"
+    o = oq.query(pts, cc, feat, tmpx, synth_sd)
+    for k, v, r in zip(("df", "pca", "parts", "centers"), out, ref):
+        np.testing.assert_allclose(v.cpu().numpy().reshape(o[k].shape), o[k], rtol=1e-5, atol=5e-5, err_msg=k)
+        assert float((v - r).abs().max()) < 5e-5, k
+    assert torch.equal(out[0] == 5.0, ref[0] == 5.0)
+
+
 def test_rejects_bad_inputs(net):
     g = golden("query_full.npz")
     net.im_feat_list = [torch.from_numpy(g["feat"]).cuda()]  # NCHW-contiguous, not NHWC
