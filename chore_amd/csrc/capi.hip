@@ -4,6 +4,7 @@
 
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_query_fwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s);
 size_t heads_arena_bytes();
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s);
@@ -138,11 +139,13 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
     CHORE_ENTER(h);
     if (!dpoints) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_points: null dpoints");
     QueryArgs a;
-    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
-                             cam6_host);
+    const bool x3 = dtype == CHORE_F16X3;       // fp32 maps, the chain on the fp16 matrix cores (see chore_query_fwd)
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, x3 ? CHORE_F32 : dtype,
+                             heads_arena, cam6_host);
     if (rc) return rc;
     a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
     a.dpoints = dpoints;
+    if (x3) return launch_query_bwd_x3(h, a, (hipStream_t)stream);
     return dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream)
                               : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);
 }

@@ -160,20 +160,26 @@ __device__ __forceinline__ void heads_layer_out(f32x16 (&out)[NCB], const f32x16
 // training staging: one wave stores its head's 128 x (32 NCB) activation (or gradient) tile as [point][channel] rows;
 // pt0 = first point of this wave's column blocks inside the workgroup tile.
 // A D fragment holds, per lane, 4 runs of 4 consecutive channels of one point: four 16-byte stores per fragment.
+// mul: per column block factor applied on the way out (the fp16 x 3 chains keep scaled accumulators), nullptr = none
 template <int NCB>
 __device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/, const f32x16 (&f)[4][NCB], bool relu_it,
-                                           size_t row0, int n0, int N, int lane, int pt0 = 0) {
+                                           size_t row0, int n0, int N, int lane, int pt0 = 0, const float* mul = nullptr) {
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
         const int pt = pt0 + cb * 32 + col;
         if (n0 + pt >= N) continue;
         float* row = base + (row0 + pt) * HEAD_HID;
+        const float m = mul ? mul[cb] : 1.f;
 #pragma unroll
         for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 f32x4 v = {f[rb][cb][4 * j], f[rb][cb][4 * j + 1], f[rb][cb][4 * j + 2], f[rb][cb][4 * j + 3]};
+                if (mul) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= m;
+                }
                 if (relu_it) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;

@@ -17,8 +17,15 @@ constexpr int QX_KS1 = 21;                                            // layer 1
 constexpr size_t QX_L1_VEC = (size_t)HEAD_NUM * QX_KS1 * 4 * 2 * 64;   // [head][ks][rb][plane][lane] u32x4
 constexpr size_t QX_L23_VEC = (size_t)HEAD_NUM * 2 * 4 * 2 * 4 * 2 * 64;   // [head][l][kb][s][rb][plane][lane]
 constexpr size_t QX_L4_VEC = (size_t)HEAD_NUM * 4 * 2 * 2 * 64;        // [head][kb][s][plane][lane]
+// transposed fragments of the backward chain (d_prev = W^T d_cur), same k order
+constexpr size_t QX_L4T_VEC = (size_t)HEAD_NUM * 4 * 2 * 64;           // [head][rb][plane][lane]      K = 16 outputs
+constexpr size_t QX_L32T_VEC = (size_t)HEAD_NUM * 2 * 4 * 2 * 4 * 2 * 64;  // [head][j][kb][s][rb][plane][lane]  j=0: W3^T, 1: W2^T
+constexpr size_t QX_L1T_VEC = (size_t)HEAD_NUM * 4 * 2 * QB_RB1 * 2 * 64;  // [head][kb][s][rb(11)][plane][lane]
+constexpr size_t QX_OFF_L4T = QX_L1_VEC + QX_L23_VEC + QX_L4_VEC;       // in vectors from the start of the x3 region
+constexpr size_t QX_OFF_L32T = QX_OFF_L4T + QX_L4T_VEC;
+constexpr size_t QX_OFF_L1T = QX_OFF_L32T + QX_L32T_VEC;
 constexpr size_t QX_OFF_BYTES = (QF_TOTAL_FLOATS * sizeof(float) + 255) / 256 * 256;   // after the fp32 fragments
-constexpr size_t QX_TOTAL_VEC = QX_L1_VEC + QX_L23_VEC + QX_L4_VEC;
+constexpr size_t QX_TOTAL_VEC = QX_OFF_L1T + QX_L1T_VEC;
 constexpr size_t QX_ARENA_BYTES = QX_OFF_BYTES + QX_TOTAL_VEC * 16;
 constexpr float QX_SCALE = (float)(1 << X3_WSHIFT), QX_INV = 1.0f / (float)(1 << X3_WSHIFT);
 
@@ -44,9 +51,19 @@ __device__ __forceinline__ f32x16 scaled_bias(const float* arena, int head, int 
     return b;
 }
 
+// The weight fragments come from the L2 (1.3 MB of them per tile, far beyond the L1): a k-step of 12 MFMAs lasts 0.16 us,
+// an L2 round trip several times that, so the loads run QX_PF k-steps ahead of the MFMAs in a register ring.
+constexpr int QX_PF = 3;
+struct AFrag { u32x4 h[4], l[4]; };
+__device__ __forceinline__ void load_afrag(AFrag& f, const u32x4* A /*[rb][plane][lane], lane applied*/) {
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) { f.h[rb] = A[(rb * 2) * 64]; f.l[rb] = A[(rb * 2 + 1) * 64]; }
+}
+
 // hidden layer 1: acc[rb][cb] = 2^s (b1 + W1 X^T)
-template <int NCB>
+template <int NCB, int PF = QX_PF>
 __device__ __forceinline__ void heads_layer1_x3(f32x16 (&acc)[4][NCB], const float* X, const float* arena, int head, int lane) {
+    static_assert(QX_KS1 % PF == 0, "the k loop is unrolled by the prefetch depth");
     const int half = lane >> 5, col = lane & 31;
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
@@ -56,33 +73,34 @@ __device__ __forceinline__ void heads_layer1_x3(f32x16 (&acc)[4][NCB], const flo
     }
     const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + (size_t)head * QX_KS1 * 4 * 2 * 64 + lane;
     const float* x0 = X + col * XS + 8 * half;
-    u32x4 ah[4], al[4];
+    AFrag ring[PF];
 #pragma unroll
-    for (int rb = 0; rb < 4; ++rb) { ah[rb] = A[(rb * 2) * 64]; al[rb] = A[(rb * 2 + 1) * 64]; }
+    for (int p = 0; p < PF; ++p) load_afrag(ring[p], A + (size_t)p * 4 * 2 * 64);
 #pragma unroll 1
-    for (int ks = 0; ks < QX_KS1; ++ks) {
-        u32x4 nh[4], nl[4];
-        const int kn = ks + 1 < QX_KS1 ? ks + 1 : ks;
+    for (int k0 = 0; k0 < QX_KS1; k0 += PF) {
 #pragma unroll
-        for (int rb = 0; rb < 4; ++rb) { nh[rb] = A[((kn * 4 + rb) * 2) * 64]; nl[rb] = A[((kn * 4 + rb) * 2 + 1) * 64]; }
-        u32x4 bh[NCB], bl[NCB];
-        // the X rows are zero-filled up to QF_KPAD = 328: the upper half of the last k-step (k = 328..335) lies beyond
-        const bool beyond = (ks == QX_KS1 - 1) && half;
+        for (int p = 0; p < PF; ++p) {
+            const int ks = k0 + p;
+            u32x4 bh[NCB], bl[NCB];
+            // the X rows are zero-filled up to QF_KPAD = 328: the upper half of the last k-step (k = 328..335) lies beyond
+            const bool beyond = (ks == QX_KS1 - 1) && half;
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) {
-            float v[8];
-            const float* src = x0 + cb * 32 * XS + (beyond ? 0 : ks * 16);       // never read past the row
-            const f32x4 p = *(const f32x4*)src, q = *(const f32x4*)(src + 4);
+            for (int cb = 0; cb < NCB; ++cb) {
+                float v[8];
+                const float* src = x0 + cb * 32 * XS + (beyond ? 0 : ks * 16);       // never read past the row
+                const f32x4 p4 = *(const f32x4*)src, q4 = *(const f32x4*)(src + 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] = beyond ? 0.f : p[j]; v[4 + j] = beyond ? 0.f : q[j]; }
-            split8(v, bh[cb], bl[cb]);
+                for (int j = 0; j < 4; ++j) { v[j] = beyond ? 0.f : p4[j]; v[4 + j] = beyond ? 0.f : q4[j]; }
+                split8(v, bh[cb], bl[cb]);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma3(ring[p].h[rb], ring[p].l[rb], bh[cb], bl[cb], acc[rb][cb]);
+            const int kn = ks + PF < QX_KS1 ? ks + PF : QX_KS1 - 1;     // the tail reloads the last step (in bounds)
+            load_afrag(ring[p], A + (size_t)kn * 4 * 2 * 64);
+            __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks the loads to their use, three steps later
         }
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma3(ah[rb], al[rb], bh[cb], bl[cb], acc[rb][cb]);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) { ah[rb] = nh[rb]; al[rb] = nl[rb]; }
     }
 }
 
@@ -96,32 +114,34 @@ __device__ __forceinline__ void act_frag(const f32x16 (&in)[4][NCB], int kb, int
 }
 
 // hidden layers 2 and 3
-template <int NCB>
+template <int NCB, int PF = QX_PF>
 __device__ __forceinline__ void heads_layer_hid_x3(f32x16 (&out)[4][NCB], const f32x16 (&in)[4][NCB], const float* arena, int head,
                                                    int layer /*1|2*/, int lane) {
     const int half = lane >> 5;
+    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_L1_VEC +
+                     ((size_t)head * 2 + (layer - 1)) * 4 * 2 * 4 * 2 * 64 + lane;
+    AFrag ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_afrag(ring[p], A + (size_t)p * 4 * 2 * 64);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const f32x16 bf = scaled_bias(arena, head, layer, rb, half);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = bf;
     }
-    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_L1_VEC +
-                     ((size_t)head * 2 + (layer - 1)) * 4 * 2 * 4 * 2 * 64 + lane;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int t = 0; t < 8; ++t) {          // k-step t = (kb, s)
+        u32x4 bh[NCB], bl[NCB];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 bh[NCB], bl[NCB];
+        for (int cb = 0; cb < NCB; ++cb) act_frag<NCB>(in, t >> 1, t & 1, cb, bh[cb], bl[cb]);
+        AFrag& f = ring[t % PF];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) act_frag<NCB>(in, kb, s, cb, bh[cb], bl[cb]);
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const u32x4 ah = A[(((kb * 2 + s) * 4 + rb) * 2) * 64], al = A[(((kb * 2 + s) * 4 + rb) * 2 + 1) * 64];
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(ah, al, bh[cb], bl[cb], out[rb][cb]);
-            }
-        }
+            for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(f.h[rb], f.l[rb], bh[cb], bl[cb], out[rb][cb]);
+        if (t + PF < 8) load_afrag(f, A + (size_t)(t + PF) * 4 * 2 * 64);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -151,4 +171,123 @@ __device__ __forceinline__ void heads_layer_out_x3(f32x16 (&out)[NCB], const f32
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[cb][r] *= QX_INV;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward chain.  Gradients have no fixed magnitude (a mean over 80 000 points puts them at 1e-5, where an fp16 hi / lo
+// pair has a handful of bits), so every point's column carries its own power-of-two scale: chosen from max |dOut| of
+// the column, renewed after every layer from the column's max, divided out exactly where the column leaves the chain.
+// Columns are independent (one point each), so this changes nothing but the rounding.
+
+// 2^(4 - floor(log2 m)): brings a column of max magnitude m to [16, 32).  1 for m = 0 / inf / nan.
+__device__ __forceinline__ float col_scale_for(float m) {
+    int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 127;
+    if (m == 0.f || e == 128) return 1.f;
+    e = e < -24 ? -24 : (e > 24 ? 24 : e);
+    return __uint_as_float((unsigned)(127 + 4 - e) << 23);
+}
+// max |.| of a lane's D registers of one column block, over both halves of the wave (the 128 rows of the column)
+template <int NCB>
+__device__ __forceinline__ float col_absmax(const f32x16 (&f)[4][NCB], int cb) {
+    float m = 0.f;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fabsf(f[rb][cb][r]));
+    return fmaxf(m, __shfl_xor(m, 32, 64));
+}
+// B fragments of K-step s of block kb from gradient accumulators: in * mul (no relu)
+template <int NCB>
+__device__ __forceinline__ void grad_frag(const f32x16 (&in)[4][NCB], int kb, int s, int cb, float mul, u32x4& hi, u32x4& lo) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = in[kb][cb][8 * s + j] * mul;
+    split8(v, hi, lo);
+}
+
+// d3 = W4^T dOut.  g8[cb] = this lane's 8 output gradients (k = 8 half + j; the heads have at most 14 outputs), already
+// multiplied by the column scale.  out carries 2^s x column scale.
+template <int NCB>
+__device__ __forceinline__ void bwd_out_x3(f32x16 (&out)[4][NCB], const float (&g8)[NCB][8], const float* arena, int head, int lane) {
+    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L4T + (size_t)head * 4 * 2 * 64 + lane;
+    u32x4 bh[NCB], bl[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) split8(g8[cb], bh[cb], bl[cb]);
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) {
+        const u32x4 ah = A[(rb * 2) * 64], al = A[(rb * 2 + 1) * 64];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            out[rb][cb] = mfma3(ah, al, bh[cb], bl[cb], z);
+        }
+    }
+}
+
+// d_prev = W^T d_cur for a 128x128 layer (which = 0: W3, 1: W2).  `in` carries 2^s x cs[cb]; the column scales are
+// renewed (cs updated) and `out` carries 2^s x the new cs.
+template <int NCB>
+__device__ __forceinline__ void bwd_hid_x3(f32x16 (&out)[4][NCB], const f32x16 (&in)[4][NCB], float (&cs)[NCB], const float* arena,
+                                           int head, int which, int lane) {
+    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L32T +
+                     ((size_t)head * 2 + which) * 4 * 2 * 4 * 2 * 64 + lane;
+    float mul[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const float f = col_scale_for(col_absmax<NCB>(in, cb) * QX_INV);
+        mul[cb] = QX_INV * f;
+        cs[cb] *= f;
+    }
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) out[rb][cb][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            u32x4 bh[NCB], bl[NCB];
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) grad_frag<NCB>(in, kb, s, cb, mul[cb], bh[cb], bl[cb]);
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb) {
+                const u32x4 ah = A[(((kb * 2 + s) * 4 + rb) * 2) * 64], al = A[(((kb * 2 + s) * 4 + rb) * 2 + 1) * 64];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(ah, al, bh[cb], bl[cb], out[rb][cb]);
+            }
+        }
+    }
+}
+
+// one 32-row block rb of dX_head = W1^T d1 (K = 128).  bh / bl: the 8 K-step fragments of d1 (see bwd_l1_frags_x3).
+template <int NCB>
+__device__ __forceinline__ void bwd_l1_block_x3(f32x16 (&dx)[NCB], const u32x4 (&bh)[8][NCB], const u32x4 (&bl)[8][NCB],
+                                                const float* arena, int head, int rb, int lane) {
+    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L1T + (size_t)head * 4 * 2 * QB_RB1 * 2 * 64 + lane;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const u32x4 ah = A[((ks * QB_RB1 + rb) * 2) * 64], al = A[((ks * QB_RB1 + rb) * 2 + 1) * 64];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) dx[cb] = mfma3(ah, al, bh[ks][cb], bl[ks][cb], dx[cb]);
+    }
+}
+template <int NCB>
+__device__ __forceinline__ void bwd_l1_frags_x3(u32x4 (&bh)[8][NCB], u32x4 (&bl)[8][NCB], const f32x16 (&in)[4][NCB], float (&cs)[NCB]) {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const float f = col_scale_for(col_absmax<NCB>(in, cb) * QX_INV);
+        cs[cb] *= f;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) grad_frag<NCB>(in, kb, s, cb, QX_INV * f, bh[kb * 2 + s][cb], bl[kb * 2 + s][cb]);
+    }
 }

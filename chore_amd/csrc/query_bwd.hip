@@ -8,7 +8,7 @@
 // ReLU sign bits, 12 registers) and then runs the transposed chain with the same register-resident
 // MFMA scheme (D fragment of one GEMM = B fragment of the next).  The four heads' contributions to
 // d(323-vector) are reduced through LDS in a fixed order, so the result is deterministic.
-#include "heads_f32.h"
+#include "heads_x3.h"
 #include <cstdlib>
 
 template <int PTS>
@@ -92,9 +92,11 @@ __device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, 
 // and the ReLU outputs (chore_query_fwd_train), so nothing is recomputed -- the ReLU masks are read back instead.
 // NW = 8 (NCB = 1): two waves per head, one 32-point column block each, of a 64-point tile -- two waves per SIMD hide
 // each other's weight / tap fetches (see query_fwd_f32_w8_kernel)
-template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4>
+// X3: the GEMM chain on the fp16 matrix cores with hi/lo split operands and per-point column scales (heads_x3.h)
+template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4, bool X3 = false>
 __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) {
     static_assert(!STAGED || TRAIN, "STAGED is a training mode");
+    static_assert(!X3 || !TRAIN || STAGED, "fp16 x 3 training reads the staged forward");
     static_assert(NW == 4 || (NW == 8 && NCB == 1), "eight waves = two column blocks of one 32-point block each");
     constexpr int PTS = 32 * NCB * (NW / 4), NT_ = NW * 64;
     static_assert(!TRAIN || PTS == 64, "the training staging is written for 64-point tiles");
@@ -138,6 +140,17 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         load_masks<NCB>(m1, a.tH + (0 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
         load_masks<NCB>(m2, a.tH + (1 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
         load_masks<NCB>(m3, a.tH + (2 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
+    } else if constexpr (X3) {      // the accumulators carry a positive scale: same sign bits
+        constexpr int PF = NW == 8 ? 1 : QX_PF;     // two waves per SIMD: 256 registers each, no room for a deeper ring
+        heads_layer1_x3<NCB, PF>(u, sm.X + pt0 * XS, arena, head, lane);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) m1[rb] = sign_mask<NCB>(u[rb]);
+        heads_layer_hid_x3<NCB, PF>(v, u, arena, head, 1, lane);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) m2[rb] = sign_mask<NCB>(v[rb]);
+        heads_layer_hid_x3<NCB, PF>(u, v, arena, head, 2, lane);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) m3[rb] = sign_mask<NCB>(u[rb]);
     } else {
     heads_layer1<NCB>(u, sm.X + pt0 * XS, arena, head, lane);
 #pragma unroll
@@ -153,6 +166,44 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, u, true, row0, n0, a.N, lane, pt0);
     }
 
+    // ---- d3 = W4^T * dOut ----
+    float cs[NCB], unscale[NCB];           // X3: the columns' scales, and 1 / (2^s cs) for what leaves the chain
+    if constexpr (X3) {
+        const float* g = a.g[head];
+        float g8[NCB][8];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+            const int pt = pt0 + cb * 32 + col;
+            const int n = n0 + pt;
+            const bool live = (g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
+            float m = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 8 * half + j;
+                g8[cb][j] = (live && k < odim) ? g[((size_t)b * odim + k) * a.N + n] : 0.f;
+                m = fmaxf(m, fabsf(g8[cb][j]));
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            cs[cb] = col_scale_for(m);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g8[cb][j] *= cs[cb];
+        }
+        bwd_out_x3<NCB>(v, g8, arena, head, lane);
+        apply_mask<NCB>(v, m3);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
+        if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0, unscale);
+        bwd_hid_x3<NCB>(u, v, cs, arena, head, 0, lane);  // d2 = W3^T d3
+        apply_mask<NCB>(u, m2);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
+        if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane, pt0, unscale);
+        bwd_hid_x3<NCB>(v, u, cs, arena, head, 1, lane);  // d1 = W2^T d2
+        apply_mask<NCB>(v, m1);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
+        if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0, unscale);
+    } else {
     // ---- d3 = W4^T * dOut  (K = 32 padded output rows, k = 2*s + half) ----
     {
         const float* g = a.g[head];
@@ -198,12 +249,27 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     apply_mask<NCB>(v, m1);
     if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (0 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0);
 
+    }
+
     // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
     __syncthreads();  // every wave is done reading X as the forward tile
     const f32x4* A1 = (const f32x4*)(arena + QB_OFF_L1T) + ((size_t)head * 16 * QB_RB1) * 64 + lane;
+    u32x4 d1h[X3 ? 8 : 1][NCB], d1l[X3 ? 8 : 1][NCB];
+    if constexpr (X3) {
+        bwd_l1_frags_x3<NCB>(d1h, d1l, v, cs);
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
+    }
 #pragma unroll 1
     for (int rb = 0; rb < QB_RB1; ++rb) {
         f32x16 dx[NCB];
+        if constexpr (X3) {
+            bwd_l1_block_x3<NCB>(dx, d1h, d1l, arena, head, rb, lane);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[cb][r] *= unscale[cb];
+        } else {
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -219,6 +285,7 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
                     for (int cb = 0; cb < NCB; ++cb) dx[cb] = MFMA_F32(aw[i], v[kb][cb][rg * 4 + i], dx[cb]);
                 }
             }
+        }
         }
         float* P = sm.P[head];
 #pragma unroll
@@ -304,18 +371,18 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     }
 }
 
-template <typename T, bool TRAIN, int NCB>
+template <typename T, bool TRAIN, int NCB, bool X3 = false>
 static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     constexpr int PTS = 32 * NCB;
     const size_t smem = sizeof(QueryBwdSmemT<PTS>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, NCB>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, NCB, false, 4, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + PTS - 1) / PTS, a.B);
-    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, NCB>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, NCB, false, 4, X3>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -323,33 +390,33 @@ static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64-point tiles would not fill the CUs
 
 // the eight-wave variants (64-point tile, two waves per head)
-template <typename T, bool TRAIN, bool STAGED>
+template <typename T, bool TRAIN, bool STAGED, bool X3 = false>
 static int launch_query_bwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryBwdSmemT<64>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + 63) / 64, a.B);
-    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, TRAIN, 1, STAGED, 8, X3>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
 static bool query_w4() { static const bool v = getenv("CHORE_QUERY_W4") != nullptr; return v; }   // A/B switch
 
-template <typename T, bool TRAIN>
+template <typename T, bool TRAIN, bool X3 = false>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if constexpr (!TRAIN) {
-        if (query_small_tiles(a.B, a.N)) return launch_query_bwd_n<T, false, 1>(h, a, s);
+        if (query_small_tiles(a.B, a.N)) return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
     }
     // the training variants are bound by their staging stores: measured slower with eight waves (39.4 vs 38.6 ms per step)
     if constexpr (!TRAIN) {
-        if (!query_w4()) return launch_query_bwd_w8<T, false, false>(h, a, s);
+        if (!query_w4()) return launch_query_bwd_w8<T, false, false, X3>(h, a, s);
     }
-    return launch_query_bwd_n<T, TRAIN, 2>(h, a, s);
+    return launch_query_bwd_n<T, TRAIN, 2, X3>(h, a, s);
 }
 
 template <typename T>
@@ -372,6 +439,9 @@ int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
 }
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_bwd_t<unsigned short, false>(h, a, s);
+}
+int launch_query_bwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_bwd_t<float, false, true>(h, a, s);
 }
 
 int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged) {

@@ -309,25 +309,26 @@ __global__ void heads_pack_f32_kernel(HeadsRaw raw, float* arena) {
 __global__ void heads_pack_x3_kernel(HeadsRaw raw, u32x4* dst) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n1 = QX_L1_VEC / 2, n23 = QX_L23_VEC / 2, n4 = QX_L4_VEC / 2;
-    if (idx >= n1 + n23 + n4) return;
+    const size_t n4t = QX_L4T_VEC / 2, n32t = QX_L32T_VEC / 2, n1t = QX_L1T_VEC / 2;
+    if (idx >= n1 + n23 + n4 + n4t + n32t + n1t) return;
     float v[8];
     size_t out;                                   // index of the hi vector; the lo vector follows 64 vectors later
+    size_t t = idx;
+    const int lane = t & 63, half = lane >> 5;
     if (idx < n1) {                               // [head][ks][rb][lane]
-        size_t t = idx;
-        const int lane = t & 63; t >>= 6;
+        t >>= 6;
         const int rb = t & 3; t >>= 2;
         const int ks = (int)(t % QX_KS1);
         const int hd = (int)(t / QX_KS1);
         const int row = rb * 32 + (lane & 31);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int k = ks * 16 + 8 * (lane >> 5) + j;
+            const int k = ks * 16 + 8 * half + j;
             v[j] = k < HEAD_IN ? raw.w[hd][0][(size_t)row * HEAD_IN + k] : 0.f;
         }
         out = (((size_t)hd * QX_KS1 + ks) * 4 + rb) * 2 * 64 + lane;
     } else if (idx < n1 + n23) {                  // [head][l][kb][s][rb][lane]
-        size_t t = idx - n1;
-        const int lane = t & 63; t >>= 6;
+        t = (idx - n1) >> 6;
         const int rb = t & 3; t >>= 2;
         const int s = t & 1; t >>= 1;
         const int kb = t & 3; t >>= 2;
@@ -335,19 +336,51 @@ __global__ void heads_pack_x3_kernel(HeadsRaw raw, u32x4* dst) {
         const int hd = (int)t;
         const int row = rb * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = raw.w[hd][1 + l][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, lane >> 5)];
+        for (int j = 0; j < 8; ++j) v[j] = raw.w[hd][1 + l][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, half)];
         out = QX_L1_VEC + ((((((size_t)hd * 2 + l) * 4 + kb) * 2 + s) * 4 + rb) * 2) * 64 + lane;
-    } else {                                      // [head][kb][s][lane]
-        size_t t = idx - n1 - n23;
-        const int lane = t & 63; t >>= 6;
+    } else if (idx < n1 + n23 + n4) {             // [head][kb][s][lane]
+        t = (idx - n1 - n23) >> 6;
         const int s = t & 1; t >>= 1;
         const int kb = t & 3; t >>= 2;
         const int hd = (int)t;
         const int row = lane & 31;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            v[j] = row < head_out_dim(hd) ? raw.w[hd][3][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, lane >> 5)] : 0.f;
+            v[j] = row < head_out_dim(hd) ? raw.w[hd][3][(size_t)row * HEAD_HID + kb * 32 + mfma32_row(8 * s + j, half)] : 0.f;
         out = QX_L1_VEC + QX_L23_VEC + ((((size_t)hd * 4 + kb) * 2 + s) * 2) * 64 + lane;
+    } else if (idx < n1 + n23 + n4 + n4t) {       // W4^T: [head][rb][lane], k = 8 half + j
+        t = (idx - n1 - n23 - n4) >> 6;
+        const int rb = t & 3; t >>= 2;
+        const int hd = (int)t;
+        const int in = rb * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * half + j;
+            v[j] = k < head_out_dim(hd) ? raw.w[hd][3][(size_t)k * HEAD_HID + in] : 0.f;
+        }
+        out = QX_OFF_L4T + (((size_t)hd * 4 + rb) * 2) * 64 + lane;
+    } else if (idx < n1 + n23 + n4 + n4t + n32t) {   // W3^T (j = 0), W2^T (j = 1): [head][j][kb][s][rb][lane]
+        t = (idx - n1 - n23 - n4 - n4t) >> 6;
+        const int rb = t & 3; t >>= 2;
+        const int s = t & 1; t >>= 1;
+        const int kb = t & 3; t >>= 2;
+        const int jl = t & 1; t >>= 1;
+        const int hd = (int)t;
+        const int in = rb * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = raw.w[hd][2 - jl][(size_t)(kb * 32 + mfma32_row(8 * s + j, half)) * HEAD_HID + in];
+        out = QX_OFF_L32T + ((((((size_t)hd * 2 + jl) * 4 + kb) * 2 + s) * 4 + rb) * 2) * 64 + lane;
+    } else {                                      // W1^T: [head][kb][s][rb(11)][lane]
+        t = (idx - n1 - n23 - n4 - n4t - n32t) >> 6;
+        const int rb = (int)(t % QB_RB1); t /= QB_RB1;
+        const int s = t & 1; t >>= 1;
+        const int kb = t & 3; t >>= 2;
+        const int hd = (int)t;
+        const int in = rb * 32 + (lane & 31);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[j] = in < HEAD_IN ? raw.w[hd][0][(size_t)(kb * 32 + mfma32_row(8 * s + j, half)) * HEAD_IN + in] : 0.f;
+        out = QX_OFF_L1T + (((((size_t)hd * 4 + kb) * 2 + s) * QB_RB1 + rb) * 2) * 64 + lane;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] *= QX_SCALE;
@@ -407,9 +440,14 @@ static int launch_query_fwd_w8(chore_handle* h, const QueryArgs& a, hipStream_t 
 
 template <typename T, bool X3 = false>
 static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switch: the four-wave kernel for large queries
+    static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switches for large queries
+    static const bool w8 = getenv("CHORE_QUERY_W8") != nullptr;
     if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1, X3>(h, a, s);
-    return w4 ? launch_query_fwd_n<T, 2, X3>(h, a, s) : launch_query_fwd_w8<T, X3>(h, a, s);
+    // fp16 x 3: a k-step of MFMAs is 2.7 x shorter than the fp32 one for the same weight bytes, and the eight-wave kernel
+    // (both waves of a head fetch the head's fragments) is bound by the L1's 64 B / clk: 0.227 ms against 0.203 ms for
+    // four waves with two column blocks each (4 x 20 000 points)
+    if (X3 ? !w8 : w4) return launch_query_fwd_n<T, 2, X3>(h, a, s);
+    return launch_query_fwd_w8<T, X3>(h, a, s);
 }
 
 template <typename T>

@@ -27,8 +27,8 @@ from .camera import KinectColorCamera
 from .hgfilter import HGFilter
 
 _DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
-# what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps; its query FORWARD runs the heads on the
-# fp16 matrix cores with split operands too (csrc/heads_x3.h), the backward kernels take the native fp32 MFMA
+# what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps; the inference query (forward and backward
+# to the points) runs the heads on the fp16 matrix cores with split operands too (csrc/heads_x3.h)
 _QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32}
 _QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
 
@@ -63,7 +63,7 @@ class _QueryFn(torch.autograd.Function):
                                             pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), None,
                                             stream), h, "chore_query_fwd")
         ctx.save_for_backward(points, crop_center, feat, tmpx, arena)
-        ctx.cam6, ctx.dtype = cam6, dtype
+        ctx.cam6, ctx.dtype = cam6, fwd_dtype
         return df, pca, parts, centers
 
     @staticmethod

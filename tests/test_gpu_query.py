@@ -99,6 +99,55 @@ def test_query_backward_to_points_matches_reference_autograd(net, synth_sd):
     assert np.isfinite(got).all()
 
 
+@pytest.mark.parametrize("gscale", [1.0, 1e-7, 3e5])
+def test_fp16x3_backward_to_points(net, synth_sd, gscale):
+    """fp16 x 3 mode: the backward chain on the fp16 matrix cores (split operands, per-point column scales) against the
+    reference's autograd gradients, with output gradients of ordinary, very small (a mean over many points) and very
+    large magnitude -- the same relative bound as the native-fp32 kernel in all three"""
+    g = golden("query_full.npz")
+    net.compute_dtype = "fp16x3"
+    try:
+        pts, (df, pca, parts, centers) = run_query(net, g, requires_grad=True)
+        loss = sum((o * torch.from_numpy(g["w_" + k]).cuda()).sum()
+                   for k, o in (("df", df), ("pca", pca), ("parts", parts), ("centers", centers)))
+        (loss * gscale).backward()
+    finally:
+        net.compute_dtype = "fp32"
+    got, ref = pts.grad.cpu().numpy().astype(np.float64) / gscale, g["dpoints"]
+    scale = np.abs(ref).max()
+    o = oq.query(g["points"], g["crop_center"], g["feat"], g["tmpx"], synth_sd)
+    stable = oq.relu_margin(o["features"], synth_sd) > 5e-6
+    err = np.abs(got - ref)[stable].max() / scale
+    assert err < 2e-5, err
+    assert np.isfinite(got).all()
+
+
+@pytest.mark.parametrize("B,N", [(1, 2048), (2, 333), (4, 20000)])
+def test_fp16x3_backward_against_fp32_kernel(net, B, N):
+    """both tile sizes, ragged counts, some heads without a gradient: fp16 x 3 against the fp32 chain on seeded maps"""
+    from chore_amd.utils import synth
+    rs = np.random.RandomState(23)
+    g = dict(feat=rs.standard_normal((B, 256, 128, 128)).astype(np.float32),
+             tmpx=rs.standard_normal((B, 64, 256, 256)).astype(np.float32),
+             points=synth.synth_points(B, N, seed=4), crop_center=np.tile(np.array([synth.CROP_CENTER], np.float32), (B, 1)))
+    wp = torch.from_numpy(rs.standard_normal((B, 14, N)).astype(np.float32)).cuda()
+
+    def grads(mode):
+        net.compute_dtype = mode
+        try:
+            pts, (df, pca, parts, centers) = run_query(net, g, requires_grad=True)
+            (torch.clamp(df[:, 0], max=2.0).sum() * 1e-3 + (parts * wp).sum()).backward()      # no pca / centers gradient
+        finally:
+            net.compute_dtype = "fp32"
+        return pts.grad
+    a, b = grads("fp16x3"), grads("fp32")
+    scale = float(b.abs().max())
+    # per-point error relative to the largest gradient; kink points (sign of a near-zero pre-activation) may differ
+    err = ((a - b).abs().amax(-1) / scale).flatten()
+    assert float(err.quantile(0.99)) < 2e-5 and float((err > 1e-3).float().mean()) < 2e-3, (float(err.max()), float(err.quantile(0.99)))
+    assert torch.isfinite(a).all()
+
+
 def test_generator_style_gradient(net):
     """d(sum clamp(df_h, max=2))/d(points): the backward recon/generator.py:62-77 runs"""
     g = golden("query_full.npz")
