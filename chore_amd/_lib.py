@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
 
 F32, BF16, F16X3 = 0, 1, 2
+HEADS_X3 = 0x100      # OR into a query dtype: heads on the fp16 matrix cores with split operands (include/chore_hip.h)
 
 
 class WeightDesc(ctypes.Structure):

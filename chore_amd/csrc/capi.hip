@@ -82,6 +82,13 @@ int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_desc
     return launch_heads_pack_f32(h, raw, (float*)arena, (hipStream_t)stream);
 }
 
+// split a query dtype into the map type and the heads mode (include/chore_hip.h: CHORE_HEADS_X3)
+static inline bool query_x3(int& dtype) {
+    const bool x3 = dtype == CHORE_F16X3 || (dtype & CHORE_HEADS_X3);
+    dtype = dtype == CHORE_F16X3 ? CHORE_F32 : (dtype & ~CHORE_HEADS_X3);
+    return x3;
+}
+
 static int fill_query_args(chore_handle* h, QueryArgs& a, const float* points, const float* crop_center, int B,
                            int N, const void* feat, int FH, int FW, const void* tmpx, int TH, int TW,
                            int dtype, const void* arena, const float* cam) {
@@ -106,9 +113,8 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
     if (!df || !pca || !parts || !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: null output");
     QueryArgs a;
     // CHORE_F16X3: fp32 feature maps (what the fp16 x 3 encoder writes) and the heads on the fp16 matrix cores
-    const bool x3 = dtype == CHORE_F16X3;
-    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, x3 ? CHORE_F32 : dtype,
-                             heads_arena, cam6_host);
+    const bool x3 = query_x3(dtype);
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena, cam6_host);
     if (rc) return rc;
     a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
     a.in_img = in_img;
@@ -139,9 +145,8 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
     CHORE_ENTER(h);
     if (!dpoints) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_points: null dpoints");
     QueryArgs a;
-    const bool x3 = dtype == CHORE_F16X3;       // fp32 maps, the chain on the fp16 matrix cores (see chore_query_fwd)
-    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, x3 ? CHORE_F32 : dtype,
-                             heads_arena, cam6_host);
+    const bool x3 = query_x3(dtype);            // the chain on the fp16 matrix cores (see chore_query_fwd)
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena, cam6_host);
     if (rc) return rc;
     a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
     a.dpoints = dpoints;
@@ -173,13 +178,14 @@ int chore_query_fwd_train(chore_handle* h, const float* points, const float* cro
     CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers || !staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: null output");
     QueryArgs a;
+    const bool x3 = query_x3(dtype);
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
                              cam6_host);
     if (rc) return rc;
     a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
     a.in_img = in_img;
     train_staging(a, staging);
-    return launch_query_fwd_train(h, dtype, a, (hipStream_t)stream);
+    return launch_query_fwd_train(h, dtype, a, (hipStream_t)stream, x3);
 }
 
 int chore_query_bwd_train(chore_handle* h, const float* points, const float* crop_center, int B, int N,
@@ -190,13 +196,15 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
     CHORE_ENTER(h);
     if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
     QueryArgs a;
+    const bool x3 = query_x3(dtype);
+    if (x3 && !have_forward) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: the fp16 x 3 heads need the staged forward");
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
                              cam6_host);
     if (rc) return rc;
     a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
     a.dpoints = dpoints;
     train_staging(a, staging);
-    return launch_query_bwd_train(h, dtype, a, (hipStream_t)stream, have_forward);
+    return launch_query_bwd_train(h, dtype, a, (hipStream_t)stream, have_forward, x3);
 }
 
 int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,

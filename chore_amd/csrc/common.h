@@ -163,7 +163,7 @@ struct QueryArgs {
 int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s);
 int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
-int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged = 0);
-int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged = 0, int x3 = 0);
+int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int x3 = 0);
 int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX, float* dfeat, float* dtmpx,
                             int accumulate, hipStream_t s);

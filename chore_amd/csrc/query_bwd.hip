@@ -420,6 +420,11 @@ static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
 }
 
 template <typename T>
+static int launch_query_bwd_staged_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return launch_query_bwd_w8<T, true, true, true>(h, a, s);     // no recompute: the eight-wave kernel fits its registers
+}
+
+template <typename T>
 static int launch_query_bwd_staged_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryBwdSmemT<64>);
@@ -444,7 +449,8 @@ int launch_query_bwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_bwd_t<float, false, true>(h, a, s);
 }
 
-int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged) {
+int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged, int x3) {
+    if (staged && x3) return dtype == CHORE_F32 ? launch_query_bwd_staged_x3<float>(h, a, s) : launch_query_bwd_staged_x3<unsigned short>(h, a, s);
     if (staged) return dtype == CHORE_F32 ? launch_query_bwd_staged_t<float>(h, a, s) : launch_query_bwd_staged_t<unsigned short>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_bwd_t<float, true>(h, a, s) : launch_query_bwd_t<unsigned short, true>(h, a, s);
 }

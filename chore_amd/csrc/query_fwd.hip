@@ -29,7 +29,6 @@ using QueryFwdSmem = QueryFwdSmemT<QT_PTS>;
 template <typename T, int NCB, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
-    static_assert(!(TRAIN && X3), "the training path stages fp32-MFMA activations");
     constexpr int PTS = 32 * NCB;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
@@ -62,10 +61,16 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
         }
     }
     f32x16 o[NCB];
-    if constexpr (X3) {
+    if constexpr (X3) {        // the accumulators carry the weights' 2^s: staged rows are rescaled on the way out
+        float inv[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) inv[cb] = QX_INV;
         heads_layer1_x3<NCB>(h1, sm.X, arena, head, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, 0, inv);
         heads_layer_hid_x3<NCB>(h2, h1, arena, head, 1, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, 0, inv);
         heads_layer_hid_x3<NCB>(h1, h2, arena, head, 2, lane);
+        if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, 0, inv);
         heads_layer_out_x3<NCB>(o, h1, arena, head, lane);
     } else {
         heads_layer1<NCB>(h1, sm.X, arena, head, lane);
@@ -103,7 +108,6 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
 // weight lines of the first in the L1, and the MFMA pipe stays busy while one of them waits.
 template <typename T, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
-    static_assert(!(TRAIN && X3), "the training path stages fp32-MFMA activations");
     constexpr int PTS = 64;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
@@ -136,9 +140,13 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     }
     f32x16 o[1];
     if constexpr (X3) {
+        const float inv[1] = {QX_INV};
         heads_layer1_x3<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
         heads_layer_hid_x3<1>(h2, h1, arena, head, 1, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32, inv);
         heads_layer_hid_x3<1>(h1, h2, arena, head, 2, lane);
+        if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
         heads_layer_out_x3<1>(o, h1, arena, head, lane);
     } else {
         heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
@@ -450,37 +458,39 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     return launch_query_fwd_w8<T, X3>(h, a, s);
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_query_fwd_train_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, true>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, true, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + 63) / 64, a.B);
-    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, true>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((query_fwd_f32_w8_kernel<T, true, X3>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 
-template <typename T>
+template <typename T, bool X3 = false>
 static int launch_query_fwd_train_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    if (!getenv("CHORE_QUERY_W4")) return launch_query_fwd_train_w8<T>(h, a, s);
+    if (!getenv("CHORE_QUERY_W4")) return launch_query_fwd_train_w8<T, X3>(h, a, s);
     bool& attr_set = CHORE_ONCE_FLAG(h);
     const size_t smem = sizeof(QueryFwdSmemT<64>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, 2, true>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_kernel<T, 2, true, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + 63) / 64, a.B);
-    hipLaunchKernelGGL((query_fwd_f32_kernel<T, 2, true>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((query_fwd_f32_kernel<T, 2, true, X3>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
-int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {
+// x3: the heads on the fp16 matrix cores with split operands (either map type)
+int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int x3) {
+    if (x3) return dtype == CHORE_F32 ? launch_query_fwd_train_t<float, true>(h, a, s) : launch_query_fwd_train_t<unsigned short, true>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_fwd_train_t<float>(h, a, s) : launch_query_fwd_train_t<unsigned short>(h, a, s);
 }
 

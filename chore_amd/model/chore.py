@@ -335,7 +335,13 @@ class CHORE(nn.Module):
             return
         for feat in self.im_feat_list:
             if train:
-                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
+                # the bf16 training mode runs the heads' GEMMs on the fp16 matrix cores with split operands (fp32-grade,
+                # csrc/heads_x3.h); the fp32 mode keeps the native fp32 MFMA everywhere
+                x3 = getattr(self, "heads_x3", None)          # None: by mode; True / False: forced (tests, A/B runs)
+                if x3 is None:
+                    x3 = self.compute_dtype != "fp32" and not os.environ.get("CHORE_HEADS_FP32")
+                tdt = dtype | (_lib.HEADS_X3 if x3 else 0)
+                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, tdt,
                                                               *head_params)
             else:
                 df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,

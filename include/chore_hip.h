@@ -41,6 +41,10 @@ enum {
 
 /* storage / MFMA-operand type of feature maps and packed weights */
 enum { CHORE_F32 = 0, CHORE_BF16 = 1, CHORE_F16X3 = 2 };
+/* query entry points (chore_query_fwd / _bwd_points / _fwd_train / _bwd_train, chore_heads_wgrad): OR into the map type
+ * to run the MLP heads on the fp16 matrix cores with hi/lo split operands (fp32-grade results, see csrc/heads_x3.h)
+ * instead of the native fp32 MFMA.  CHORE_F16X3 there means CHORE_F32 | CHORE_HEADS_X3. */
+enum { CHORE_HEADS_X3 = 0x100 };
 
 /* one tensor of a reference state_dict (Appendix D of SURVEY.md): name, device pointer to its
  * contiguous fp32 data in the reference layout, element count */

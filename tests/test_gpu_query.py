@@ -235,8 +235,11 @@ def test_rejects_bad_inputs(net):
         net.query(torch.from_numpy(g["points"]).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
 
 
-def test_training_backward_heads_and_feature_maps(opt):
-    """first half of the training backward: gradients of a random linear functional of the four outputs
+@pytest.mark.parametrize("heads_x3", [False, True])
+def test_training_backward_heads_and_feature_maps(opt, heads_x3):
+    """heads_x3: the GEMM chain of the heads on the fp16 matrix cores with split operands (what the bf16 training mode
+    runs) instead of the native fp32 MFMA -- same fixture, same bounds.
+    first half of the training backward: gradients of a random linear functional of the four outputs
     w.r.t. the 32 head parameters, the hourglass feature map and tmpx, against the reference's autograd
     (tests/golden/query_train_grads.npz: full tensors for the df head, the small tensors and the two maps; sums,
     abs-sums, L2 norms and a 16x24 crop for the large matrices of the other heads).  fp32 mode, 2e-5 relative."""
@@ -247,6 +250,7 @@ def test_training_backward_heads_and_feature_maps(opt):
     o = copy.copy(opt)
     o.compute_dtype = "fp32"
     net = CHORE(o).cuda().eval()
+    net.heads_x3 = heads_x3
     synth.load_synth_weights(net, seed=0)
     for p in net.image_filter.parameters():
         p.requires_grad_(False)
