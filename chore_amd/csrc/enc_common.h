@@ -147,6 +147,13 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
 int launch_pack_stem(chore_handle* h, int Cin, const float* w /*(64,Cin,7,7)*/, float* dst, hipStream_t s);
 // statistics of a tensor no convolution produced (pooling / upsampling / stem outputs): one pass, atomics
 int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, GroupStat* st, hipStream_t s);
+// train_bwd.hip: the layer backward pieces with channel-strided gradients (what a ConvBlock's concat hands its convs)
+int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
+                     const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
+                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s);
+int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                           const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
+                           float* dw, float* dbias, void* workspace, hipStream_t s);
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
                          const float* beta, const View& y, int B, int HW, hipStream_t s);

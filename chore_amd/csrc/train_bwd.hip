@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const GroupStat* __restrict__ st, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int C, int HW, GnBwdAcc acc,
                                                            T* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta) {
+                                                           float* __restrict__ dbeta, const T* __restrict__ extra, int ecs) {
     __shared__ float pc[1792];         // [C][7] mean, rstd, gamma, S1/n, S2/n, scale, shift
     const int b = blockIdx.y, tid = threadIdx.x;
     const int gs = C / GN_GROUPS;
@@ -565,6 +565,12 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             const float gy = fmaf(xv, q[5], q[6]) > 0.f ? da4[j] * q[2] : 0.f;
             r[j] = q[1] * ((gy - q[3]) - xh * q[4]);
         }
+        if (extra) {      // a second gradient of x (a skip connection / another consumer), channel-strided: summed here
+            const size_t pix = (size_t)b * HW + (i * 4) / C;
+            const f32x4 e4 = Vec4<T>::ld(extra + pix * ecs + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] += e4[j];
+        }
         Vec4<T>::st(dx + o, r);
     }
 }
@@ -595,20 +601,54 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
     return n * sizeof(float);
 }
 
-// dw (Cout,Cin,k,k) fp32 and dbias (Cout, or NULL) of y = conv(a) + bias, a = relu(groupnorm(x)) if stats else x
-int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
-                            const void* stats, const float* gamma, const float* beta, const void* dy, int Cout, float* dw,
-                            float* dbias, void* workspace, chore_stream_t stream) {
-    CHORE_ENTER(h);
+}  // extern "C"
+
+// extra (or null): (B,HW,*) with channel stride extra_cs, already offset to its first channel -- added to dx
+int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
+                     const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
+                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s) {
+    if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
+    if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);
+    if (!workspace_zeroed) CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, chore_gn_relu_bwd_workspace_bytes(B, C), s));
+    GnBwdAcc acc;
+    acc.grp = (GroupStat*)workspace;
+    acc.chan = acc.grp + (size_t)B * GN_GROUPS;
+    int S = HW / 64;
+    if (S < 1) S = 1;
+    if (S > GN_SPLITS_MAX) S = GN_SPLITS_MAX;
+    const size_t total4 = (size_t)HW * C / 4;
+    int blocks = (int)((total4 + 255) / 256);
+    if (blocks > 512) blocks = 512;
+    if (dtype == CHORE_F32) {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(S, B), dim3(256), 0, s, (const float*)x, (const float*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(blocks, B), dim3(256), 0, s, (const float*)x, (const float*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, acc, (float*)dx, dgamma, dbeta, (const float*)extra,
+                           extra_cs);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(S, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)da,
+                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(blocks, B), dim3(256), 0, s, (const bf16_t*)x,
+                           (const bf16_t*)da, (const GroupStat*)stats, gamma, beta, C, HW, acc, (bf16_t*)dx, dgamma, dbeta,
+                           (const bf16_t*)extra, extra_cs);
+    }
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// the weight gradient with a channel-strided dy (dy_stride = channels of the tensor dy is a slice of; dy already offset)
+int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                           const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
+                           float* dw, float* dbias, void* workspace, hipStream_t s) {
     if (!x || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: null argument");
     if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || Cin > 256)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: unsupported taps=%d Cin=%d Cout=%d", taps, Cin, Cout);
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
-    hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
     a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
-    a.xs = Cin; a.ys = Cout; a.npix = (long long)B * H * W;
+    a.xs = Cin; a.ys = dy_stride; a.npix = (long long)B * H * W;
     a.part = (float*)workspace;
     int ct = 32;
     if (wgrad_use64(dtype, taps, Cin, Cout)) {
@@ -659,6 +699,17 @@ int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x,
                        Cin, taps, dw, dbias, ct);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
+}
+
+extern "C" {
+
+// dw (Cout,Cin,k,k) fp32 and dbias (Cout, or NULL) of y = conv(a) + bias, a = relu(groupnorm(x)) if stats else x
+int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
+                            const void* stats, const float* gamma, const float* beta, const void* dy, int Cout, float* dw,
+                            float* dbias, void* workspace, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    return conv2d_bwd_weight_impl(h, dtype, taps, x, B, H, W, Cin, stats, gamma, beta, dy, Cout, Cout, dw, dbias, workspace,
+                                  (hipStream_t)stream);
 }
 
 // C (M x N, fp32, row-major) = A^T B for row-major A (P x M, row stride lda) and B (P x N, row stride ldb), fp32, exact
@@ -740,33 +791,8 @@ int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* sta
                       const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
                       int workspace_zeroed, chore_stream_t stream) {
     CHORE_ENTER(h);
-    if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
-        CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
-    if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);
-    hipStream_t s = (hipStream_t)stream;
-    if (!workspace_zeroed) CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, chore_gn_relu_bwd_workspace_bytes(B, C), s));
-    GnBwdAcc acc;
-    acc.grp = (GroupStat*)workspace;
-    acc.chan = acc.grp + (size_t)B * GN_GROUPS;
-    int S = HW / 64;
-    if (S < 1) S = 1;
-    if (S > GN_SPLITS_MAX) S = GN_SPLITS_MAX;
-    const size_t total4 = (size_t)HW * C / 4;
-    int blocks = (int)((total4 + 255) / 256);
-    if (blocks > 512) blocks = 512;
-    if (dtype == CHORE_F32) {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(S, B), dim3(256), 0, s, (const float*)x, (const float*)da,
-                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(blocks, B), dim3(256), 0, s, (const float*)x, (const float*)da,
-                           (const GroupStat*)stats, gamma, beta, C, HW, acc, (float*)dx, dgamma, dbeta);
-    } else {
-        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(S, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)da,
-                           (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(blocks, B), dim3(256), 0, s, (const bf16_t*)x,
-                           (const bf16_t*)da, (const GroupStat*)stats, gamma, beta, C, HW, acc, (bf16_t*)dx, dgamma, dbeta);
-    }
-    CHORE_LAUNCH_CHECK(h, s);
-    return CHORE_OK;
+    return gn_relu_bwd_impl(h, dtype, x, stats, gamma, beta, da, B, HW, C, dx, dgamma, dbeta, workspace, workspace_zeroed,
+                            nullptr, 0, (hipStream_t)stream);
 }
 
 }  // extern "C"

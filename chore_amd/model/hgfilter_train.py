@@ -11,6 +11,8 @@ composed from autograd nodes whose forward AND backward are HIP kernels (chore_a
 Only the glue that moves no FLOPs -- concat and residual adds -- is torch; tensors are NHWC throughout and no library
 convolution / GEMM is on the path (results are bit-reproducible run to run).
 """
+import os
+
 import torch
 
 from .. import ops
@@ -20,8 +22,15 @@ def _nchw(x):          # NHWC tensor -> (B,C,H,W) channels-last view
     return x.permute(0, 3, 1, 2)
 
 
-def conv_block(m, x):
-    """ConvBlock.forward (net_util.py:374-396)"""
+def conv_block(m, x, x_stats=None):
+    """ConvBlock.forward (net_util.py:374-396) -> (y, GroupNorm statistics of y): one fused operator (csrc/convblock.hip);
+    CHORE_TRAIN_LAYERWISE=1 composes it from per-layer nodes instead (the older path, kept for A/B runs)"""
+    if not os.environ.get("CHORE_TRAIN_LAYERWISE"):
+        return ops.conv_block(x, m, x_stats)
+    return _conv_block_layerwise(m, x), None
+
+
+def _conv_block_layerwise(m, x):
     sx = ops.gn_stats(x)                  # bn1 and bn4 normalise the same tensor: one statistics pass
     o1, s1 = ops.conv_gn(x, m.conv1.weight, None, m.bn1.weight, m.bn1.bias, x_stats=sx, want_stats=True)
     o2, s2 = ops.conv_gn(o1, m.conv2.weight, None, m.bn2.weight, m.bn2.bias, x_stats=s1, want_stats=True)
@@ -31,13 +40,13 @@ def conv_block(m, x):
     return out + res
 
 
-def hourglass(m, level, x):
-    """HourGlass._forward (HGFilters.py:26-50)"""
-    up1 = conv_block(getattr(m, f"b1_{level}"), x)
+def hourglass(m, level, x, xs=None):
+    """HourGlass._forward (HGFilters.py:26-50); xs: statistics of x when its producer made them"""
+    up1, _ = conv_block(getattr(m, f"b1_{level}"), x, xs)
     low1 = ops.avgpool2(x)
-    low1 = conv_block(getattr(m, f"b2_{level}"), low1)
-    low2 = hourglass(m, level - 1, low1) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1)
-    low3 = conv_block(getattr(m, f"b3_{level}"), low2)
+    low1, s1 = conv_block(getattr(m, f"b2_{level}"), low1)
+    low2, s2 = (hourglass(m, level - 1, low1, s1), None) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1, s1)
+    low3, _ = conv_block(getattr(m, f"b3_{level}"), low2, s2)
     return ops.upadd(up1, low3)
 
 
@@ -52,15 +61,16 @@ def _forward_train(enc, images, tdt):
     x = ops.stem(images, enc.conv1.weight, enc.conv1.bias, tdt)
     x = ops.gn_relu(x, enc.bn1.weight, enc.bn1.bias)
     tmpx = x
-    x = ops.avgpool2(conv_block(enc.conv2, x))
+    x = ops.avgpool2(conv_block(enc.conv2, x)[0])
     normx = x
-    x = conv_block(enc.conv3, x)
-    previous = conv_block(enc.conv4, x)
+    x, sx = conv_block(enc.conv3, x)
+    previous, sp = conv_block(enc.conv4, x, sx)
     outputs = []
     n = enc.num_modules
     for i in range(n):
-        hg = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous)
-        ll = conv_block(getattr(enc, f"top_m_{i}"), hg)
+        hg = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous, sp)
+        sp = None                  # `previous` is re-formed by torch adds below: its statistics are recomputed
+        ll, _ = conv_block(getattr(enc, f"top_m_{i}"), hg)
         cl, be = getattr(enc, f"conv_last{i}"), getattr(enc, f"bn_end{i}")
         ll, sl = ops.conv_gn(ll, cl.weight, cl.bias, want_stats=True)
         ll = ops.gn_relu(ll, be.weight, be.bias, x_stats=sl)

@@ -188,6 +188,84 @@ class _ConvGN(torch.autograd.Function):
         return dx, dw, dbias, dg, db, None, None
 
 
+class _ConvBlock(torch.autograd.Function):
+    """one ConvBlock (net_util.py:374-396) as ONE node: chore_convblock_fwd / chore_convblock_bwd (csrc/convblock.hip).
+    Returns (y, statistics of y) -- the statistics are what the next block's GroupNorms need."""
+
+    @staticmethod
+    def forward(ctx, x, x_stats, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, g4, b4):
+        import ctypes
+        dev, h, dt, stream = _env(x)
+        B, H, W, Cin = x.shape
+        Cout = w1.shape[0] * 2
+        ps = [None if p is None else p.detach().float().contiguous() for p in (w1, w2, w3, wd, g1, b1, g2, b2, g3, b3, g4, b4)]
+        L = _lib.lib
+        y = torch.empty(B, H, W, Cout, dtype=x.dtype, device=dev)
+        saved = _u8(L.chore_convblock_saved_bytes(dt, B, H, W, Cin, Cout), dev)
+        ws = _u8(L.chore_convblock_workspace_bytes(dt, B, H, W, Cin, Cout), dev)
+        gb = (ctypes.c_void_p * 8)(*[None if p is None else p.data_ptr() for p in ps[4:]])
+        _lib.check(L.chore_convblock_fwd(h, dt, x.data_ptr(), None if x_stats is None else x_stats.data_ptr(), B, H, W, Cin, Cout,
+                                         ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(),
+                                         None if ps[3] is None else ps[3].data_ptr(), gb, y.data_ptr(), saved.data_ptr(),
+                                         ws.data_ptr(), stream), h, "chore_convblock_fwd")
+        ctx.save_for_backward(x, saved, *[p for p in ps if p is not None])
+        ctx.x_stats = x_stats            # a plain (non-differentiable) byte tensor, kept alive for the backward
+        ctx.down = wd is not None
+        off, nb = L.chore_convblock_out_stats_offset(B), L.chore_gn_stats_bytes(B)
+        y_stats = saved[off:off + nb]
+        ctx.mark_non_differentiable(y_stats)
+        return y, y_stats
+
+    @staticmethod
+    def backward(ctx, dy, _unused):
+        import ctypes
+        x, saved = ctx.saved_tensors[:2]
+        ps = list(ctx.saved_tensors[2:])
+        if ctx.down:
+            w1, w2, w3, wd, g1, b1, g2, b2, g3, b3, g4, b4 = ps
+        else:
+            (w1, w2, w3, g1, b1, g2, b2, g3, b3), wd, g4, b4 = ps, None, None, None
+        dev, h, dt, stream = _env(x)
+        B, H, W, Cin = x.shape
+        Cout = w1.shape[0] * 2
+        C1, C2 = Cout // 2, Cout // 4
+        L = _lib.lib
+        dy = dy.contiguous().to(x.dtype)
+        dx = torch.empty_like(x)
+        grads = torch.empty(L.chore_convblock_grad_floats(Cin, Cout), device=dev)
+        ws = _u8(L.chore_convblock_workspace_bytes(dt, B, H, W, Cin, Cout), dev)
+        gb = (ctypes.c_void_p * 8)(*[None if p is None else p.data_ptr() for p in (g1, b1, g2, b2, g3, b3, g4, b4)])
+        xs = ctx.x_stats
+        _lib.check(L.chore_convblock_bwd(h, dt, x.data_ptr(), None if xs is None else xs.data_ptr(), dy.data_ptr(), B, H, W, Cin,
+                                         Cout, w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), None if wd is None else wd.data_ptr(),
+                                         gb, saved.data_ptr(), dx.data_ptr(), grads.data_ptr(), ws.data_ptr(), stream), h,
+                   "chore_convblock_bwd")
+        o = 0
+
+        def take(*shape):
+            nonlocal o
+            n = 1
+            for d in shape:
+                n *= d
+            t = grads[o:o + n].view(shape)
+            o += n
+            return t
+        dw1, dw2, dw3 = take(C1, Cin, 3, 3), take(C2, C1, 3, 3), take(C2, C2, 3, 3)
+        dwd = take(Cout, Cin, 1, 1) if ctx.down else None
+        dg1, db1, dg2, db2, dg3, db3 = take(Cin), take(Cin), take(C1), take(C1), take(C2), take(C2)
+        dg4, db4 = (take(Cin), take(Cin)) if ctx.down else (None, None)
+        return dx, None, dw1, dw2, dw3, dg1, db1, dg2, db2, dg3, db3, dwd, dg4, db4
+
+
+def conv_block(x, m, x_stats=None):
+    """ConvBlock module m (conv1..3, bn1..4, downsample) applied to x (B,H,W,Cin) -> (y, statistics of y)"""
+    ds = m.downsample
+    return _ConvBlock.apply(x, x_stats, m.conv1.weight, m.conv2.weight, m.conv3.weight, m.bn1.weight, m.bn1.bias,
+                            m.bn2.weight, m.bn2.bias, m.bn3.weight, m.bn3.bias,
+                            None if ds is None else ds[2].weight, None if ds is None else m.bn4.weight,
+                            None if ds is None else m.bn4.bias)
+
+
 class _UpAdd(torch.autograd.Function):
     """y = a + bicubic_up2(low), align_corners=True (HourGlass._forward, HGFilters.py:47-50)"""
 

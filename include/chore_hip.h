@@ -378,6 +378,28 @@ size_t chore_gn_relu_bwd_workspace_bytes(int B, int C);
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
                       const float* beta, const void* da, int B, int HW, int C, void* dx, float* dgamma,
                       float* dbeta, void* workspace, int workspace_zeroed, chore_stream_t stream);
+/* One ConvBlock (reference model/net_util.py:346-396: three GroupNorm -> ReLU -> conv3x3 stages, their concat, and the
+ * identity or GroupNorm -> ReLU -> conv1x1 residual) as a training operator, forward and backward in one call each: the
+ * convolutions write their slices of y with the residual added in the epilogue and produce the GroupNorm statistics of
+ * o1, o2 and y there; the backward reads dy in channel-strided slices and sums the skip gradients inside the GroupNorm
+ * backward.  dtype: CHORE_F32 | CHORE_BF16; Cout in {128, 256}, Cin a multiple of 32 (<= 256); conv weights in the
+ * reference layout (O,C,kh,kw) fp32, no biases; wd and gb[6], gb[7] only when Cin != Cout.
+ *   gb      host array of 8 device pointers: gamma, beta of bn1, bn2, bn3, bn4
+ *   x_stats chore_gn_stats_bytes(B) statistics of x (the previous block's: `saved` + chore_convblock_out_stats_offset(B)),
+ *           or NULL: computed by the forward (and kept in `saved` for the backward)
+ *   saved   chore_convblock_saved_bytes: o1, o2 and all statistics, forward -> backward
+ *   grads   chore_convblock_grad_floats: dW1 dW2 dW3 [dWd] then (dgamma, dbeta) of bn1, bn2, bn3 [, bn4] */
+size_t chore_convblock_saved_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
+size_t chore_convblock_out_stats_offset(int B);
+size_t chore_convblock_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout);
+size_t chore_convblock_grad_floats(int Cin, int Cout);
+int chore_convblock_fwd(chore_handle* h, int dtype, const void* x, const void* x_stats, int B, int H, int W, int Cin,
+                        int Cout, const float* w1, const float* w2, const float* w3, const float* wd,
+                        const float* const* gb, void* y, void* saved, void* workspace, chore_stream_t stream);
+int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x_stats, const void* dy, int B, int H,
+                        int W, int Cin, int Cout, const float* w1, const float* w2, const float* w3, const float* wd,
+                        const float* const* gb, const void* saved, void* dx, float* grads, void* workspace,
+                        chore_stream_t stream);
 /* y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C));  d_low = transpose of the upsampling applied to dy */
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
                     chore_stream_t stream);

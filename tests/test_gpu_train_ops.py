@@ -150,3 +150,110 @@ def test_avgpool2(dtype, shape):
     (yd * up.permute(0, 2, 3, 1).cuda().to(dtype)).sum().backward()
     check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
     check(xd.grad.permute(0, 3, 1, 2), x.grad, dtype, "dx")
+
+
+class _RefConvBlock(torch.nn.Module):
+    """the reference's ConvBlock (model/net_util.py:346-396, norm='group') restated with torch.nn layers"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        nn = torch.nn
+        self.conv1 = nn.Conv2d(cin, cout // 2, 3, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(cout // 2, cout // 4, 3, padding=1, bias=False)
+        self.conv3 = nn.Conv2d(cout // 4, cout // 4, 3, padding=1, bias=False)
+        self.bn1, self.bn2, self.bn3, self.bn4 = (nn.GroupNorm(32, c) for c in (cin, cout // 2, cout // 4, cin))
+        self.downsample = None if cin == cout else nn.Sequential(self.bn4, nn.ReLU(True), nn.Conv2d(cin, cout, 1, bias=False))
+
+    def forward(self, x):
+        o1 = self.conv1(F.relu(self.bn1(x)))
+        o2 = self.conv2(F.relu(self.bn2(o1)))
+        o3 = self.conv3(F.relu(self.bn3(o2)))
+        res = x if self.downsample is None else self.downsample(x)
+        return torch.cat((o1, o2, o3), 1) + res
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 24, 40)), (128, 128, (2, 16, 32)), (128, 256, (1, 32, 32)),
+                                            (256, 256, (3, 20, 44)), (256, 256, (4, 64, 64))])
+def test_conv_block_operator(dtype, cin, cout, shape):
+    """chore_convblock_fwd / _bwd (one call per direction: slices written in place, residual and skip gradients fused)
+    against torch CPU autograd of the reference block, and two chained blocks (the second normalises with the statistics
+    the first one's epilogues produced)"""
+    from chore_amd import ops
+    B, H, W = shape
+    torch.manual_seed(cin + cout + H)
+    blocks = [_RefConvBlock(cin, cout), _RefConvBlock(cout, cout)]
+    for m in blocks:
+        for n, p in m.named_parameters():
+            if "bn" in n:
+                p.data = (torch.rand_like(p) + 0.5) if n.endswith("weight") else torch.randn_like(p) * 0.2
+    x = torch.randn(B, cin, H, W) * 1.5 + 0.3
+    up = torch.randn(B, cout, H, W)
+    xr = x.to(dtype).float().clone().requires_grad_(True)
+    yr1 = blocks[0](xr)
+    yr = blocks[1](yr1)
+    (yr * up).sum().backward()
+    import copy
+    dev = [copy.deepcopy(m).cuda() for m in blocks]
+    for m in dev:
+        m.zero_grad()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
+    y1, s1 = ops.conv_block(xd, dev[0])
+    y2, _ = ops.conv_block(y1, dev[1], s1)
+    (y2.float() * up.permute(0, 2, 3, 1).cuda()).sum().backward()
+
+    def check(a, b, dtype, what):
+        # A pre-activation within rounding of zero takes a different ReLU branch here than on the CPU (about one per
+        # million activations in fp32), which moves that entry's gradient -- and the 5x5 pixels the next two 3x3
+        # data-gradient convolutions spread it over -- by its whole magnitude, and every parameter gradient that sums
+        # over those pixels by a little.  So the bounds are on a percentile and the relative L2 error, not on the maximum:
+        # fp32 99.8th percentile 3e-3 of the largest entry, L2 1e-2; bf16 (eight layers of bf16 activations deep: mask
+        # flips everywhere) 99th percentile 1.5e-1, L2 1e-1.  The sharp check of this operator is the next test: bit-equal
+        # to the composition of the per-layer operators, which test_conv_gn_layer holds to 2e-5 one layer at a time.
+        a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
+        scale, err = np.abs(b).max(), np.abs(a - b)
+        pct, q, l2 = (0.998, 3e-3, 1e-2) if dtype == torch.float32 else (0.99, 1.5e-1, 1e-1)
+        assert np.quantile(err, pct) <= q * scale, (what, np.quantile(err, pct), scale)
+        assert np.linalg.norm(err.ravel()) <= l2 * np.linalg.norm(b.ravel()), (what, "L2")
+    check(y1.permute(0, 3, 1, 2), yr1, dtype, "y1")
+    check(y2.permute(0, 3, 1, 2), yr, dtype, "y2")
+    check(xd.grad.permute(0, 3, 1, 2), xr.grad, dtype, "dx")
+    for i, (md, mr) in enumerate(zip(dev, blocks)):
+        ref = dict(mr.named_parameters())
+        for n, p in md.named_parameters():
+            if n.startswith("downsample.0") or ref[n].grad is None:      # bn4 twice / unused without a downsample branch
+                continue
+            assert p.grad is not None, (i, n)
+            check(p.grad, ref[n].grad, dtype, f"block{i}.{n}")
+    # the statistics handed on are those of a fresh statistics pass over y1 (128-bit fixed-point sums of per-workgroup
+    # fp32 partials in both: equal up to the grouping of those partials)
+    def decode(t):
+        w = t.cpu().numpy().view(np.uint64).astype(np.float64).reshape(-1, 2)
+        v = w[:, 0] + w[:, 1] * 2.0 ** 64
+        return np.where(w[:, 1] >= 2.0 ** 63, v - 2.0 ** 128, v)
+    a, b = decode(s1), decode(ops.gn_stats(y1.detach())[:s1.numel()])
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
+
+
+@pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 24, 40)), (256, 256, (4, 64, 64))])
+def test_conv_block_operator_equals_layerwise_composition(cin, cout, shape):
+    """fp32: the fused ConvBlock operator runs the same kernels on the same operands as the composition from per-layer
+    nodes + torch concat / adds (model/hgfilter_train._conv_block_layerwise) -- outputs and all gradients bit for bit"""
+    import copy
+    from chore_amd import ops
+    from chore_amd.model import hgfilter_train as ht
+    B, H, W = shape
+    torch.manual_seed(7)
+    m = _RefConvBlock(cin, cout)
+    x = torch.randn(B, H, W, cin) * 1.5 + 0.3
+    up = torch.randn(B, H, W, cout).cuda()
+    res = []
+    for mode in ("block", "layer"):
+        md = copy.deepcopy(m).cuda()
+        xd = x.clone().cuda().requires_grad_(True)
+        y = ops.conv_block(xd, md)[0] if mode == "block" else ht._conv_block_layerwise(md, xd)
+        (y * up).sum().backward()
+        res.append([y.detach(), xd.grad] + [p.grad for _, p in sorted(md.named_parameters()) if p.grad is not None])
+    assert len(res[0]) == len(res[1]) >= 11
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
