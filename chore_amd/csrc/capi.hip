@@ -49,6 +49,12 @@ void chore_encoder_cache_free(chore_handle* h);
 int chore_destroy(chore_handle* h) {
     CHORE_ENTER(h);
     chore_encoder_cache_free(h);
+    if (h->side) {
+        (void)hipStreamSynchronize(h->side);
+        (void)hipStreamDestroy(h->side);
+        for (hipEvent_t e : h->side_ev)
+            if (e) (void)hipEventDestroy(e);
+    }
     delete h;
     return CHORE_OK;
 }

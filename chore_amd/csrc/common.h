@@ -17,6 +17,10 @@ struct chore_handle {
     // one-off per-device setup that has been done for THIS handle's device (kernel attributes such as the dynamic LDS
     // limit are per device): keyed by the address of a marker that is unique per call site / template instantiation
     std::unordered_map<const void*, bool> once;
+    // training operators: a second stream (and fork / join events) for work that is independent inside one call, e.g. the
+    // weight gradients of a ConvBlock beside its data-gradient chain (convblock.hip); created on first use
+    hipStream_t side = nullptr;
+    hipEvent_t side_ev[8] = {};
 };
 
 // every entry point runs with the handle's device current (a caller whose current device is another GPU -- e.g. the

@@ -13,6 +13,7 @@
 // GroupNorm backward adds the skip gradients on its way out, so no glue kernel runs at all.
 // The arithmetic of every kernel is unchanged; in fp32 the results equal the per-layer composition bit for bit.
 #include "enc_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -58,6 +59,14 @@ PackOff pack_layout(const Dims& d, int dtype, size_t o, bool transposed) {
     p.wd = o; if (d.down) o += al(packed_conv_bytes(dtype, 1, d.Cin, d.Cout));
     p.end = o;
     return p;
+}
+
+// the handle's side stream and its events (lazily created on the handle's device)
+int side_stream(chore_handle* h) {
+    if (h->side) return CHORE_OK;
+    CHORE_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    for (hipEvent_t& e : h->side_ev) CHORE_HIP_CHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return CHORE_OK;
 }
 
 View mkview(const void* p, int cs, int co, int C) { View v; v.p = const_cast<void*>(p); v.cs = cs; v.co = co; v.C = C; return v; }
@@ -217,29 +226,54 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
         a.B = B; a.H = H; a.W = W; a.Cout = cin_fwd;
         return launch_conv(h, dtype, taps, a, s);
     };
-    // ---- conv3: its output gradient is the last slice of dy ----
+    // Two chains: the data-gradient chain  dgrad3 -> gn3 -> dgrad2 -> gn2 -> [downsample] -> dgrad1 -> gn1  on the
+    // caller's stream, and the four weight gradients on the handle's side stream, each released by the event after the
+    // kernel that produces its dy (dy itself for conv3 and the downsample conv).  The kernels of either chain fill a
+    // fraction of the chip (64 .. 256 workgroups), so the chains overlap almost completely.
+    static const bool serial = getenv("CHORE_CONVBLOCK_SERIAL") != nullptr;      // A/B switch: everything on one stream
+    hipStream_t s2 = s;
+    if (!serial) {
+        if ((rc = side_stream(h))) return rc;
+        s2 = h->side;
+    }
+    auto release = [&](int ev) -> int {      // side stream waits for what the main stream has issued so far
+        if (serial) return CHORE_OK;
+        CHORE_HIP_CHECK(h, hipEventRecord(h->side_ev[ev], s));
+        CHORE_HIP_CHECK(h, hipStreamWaitEvent(s2, h->side_ev[ev], 0));
+        return CHORE_OK;
+    };
     const int off2 = C1, off3 = C1 + C2;
+    if ((rc = release(0))) return rc;        // dy, the workspace clear
+    // ---- conv3: its output gradient is the last slice of dy ----
     if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o2, B, H, W, C2, sv.s2, gb[4], gb[5], dyb + (size_t)off3 * d.es, Cout, C2, dw3,
-                                     nullptr, wpart, s))) return rc;
+                                     nullptr, wpart, s2))) return rc;
+    if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpart, s2)))
+        return rc;
     if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o2, sv.s2, gb[4], gb[5], da, B, HW, C2, do2, dg3, db3, acc3, 1,
                                dyb + (size_t)off2 * d.es, Cout, s))) return rc;          // + the concat's gradient of o2
     // ---- conv2 ----
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart, s))) return rc;
+    if ((rc = release(1))) return rc;        // d(o2)
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart, s2))) return rc;
     if ((rc = dgrad(9, mkview(do2, C2, 0, C2), w2, pk.w2, C1, C2, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o1, sv.s1, gb[2], gb[3], da, B, HW, C1, do1, dg2, db2, acc2, 1, dyb, Cout, s))) return rc;
     // ---- conv1 (and the downsample branch): both normalise x ----
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart, s))) return rc;
+    if ((rc = release(2))) return rc;        // d(o1)
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart, s2))) return rc;
     const void* skip = dy;          // identity residual: dy itself flows to x
     int skip_cs = Cout;
     if (d.down) {
-        if ((rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpart, s))) return rc;
         if ((rc = dgrad(1, mkview(dy, Cout, 0, Cout), wd, pk.wd, Cin, Cout, da))) return rc;
         if ((rc = gn_relu_bwd_impl(h, dtype, x, sx, gb[6], gb[7], da, B, HW, Cin, dx4, dg4, db4, acc4, 1, nullptr, 0, s))) return rc;
         skip = dx4; skip_cs = Cin;
     }
     if ((rc = dgrad(9, mkview(do1, C1, 0, C1), w1, pk.w1, Cin, C1, da))) return rc;
-    return gn_relu_bwd_impl(h, dtype, x, sx, gb[0], gb[1], da, B, HW, Cin, dx, dg1, db1, acc1, 1, skip, skip_cs, s);
+    if ((rc = gn_relu_bwd_impl(h, dtype, x, sx, gb[0], gb[1], da, B, HW, Cin, dx, dg1, db1, acc1, 1, skip, skip_cs, s))) return rc;
+    if (!serial) {                    // join: the caller's stream continues after the weight gradients too
+        CHORE_HIP_CHECK(h, hipEventRecord(h->side_ev[3], s2));
+        CHORE_HIP_CHECK(h, hipStreamWaitEvent(s, h->side_ev[3], 0));
+    }
+    return CHORE_OK;
 }
 
 }  // extern "C"
