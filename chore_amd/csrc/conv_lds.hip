@@ -691,10 +691,9 @@ size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout) {
 // transposed = 1 packs the weights of the DATA-GRADIENT convolution of a layer whose forward weights are
 // w (O = Cin here, C = Cout here, taps): dX = conv(dY, w^T flipped), i.e. this conv's w'[n][c][tap] = w[c][n][taps-1-tap]
 template <typename T>
-__global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __restrict__ w, u32x4* __restrict__ dst,
-                                 size_t nvec, int transposed) {
+__device__ __forceinline__ void pack_conv_vec(size_t i, int taps, int Cin, int Cout, const float* __restrict__ w, u32x4* __restrict__ dst,
+                                              size_t nvec, int transposed) {
     constexpr int VE = CT<T>::VE, KGE = CT<T>::KGE;
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= nvec) return;
     const int NKG = Cin / KGE, NB = Cout / 32;
     const int lane = (int)(i & 63);
@@ -730,6 +729,48 @@ __global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __res
         for (int j = 0; j < 4; ++j) o[j] = __float_as_uint(vals[j]);
     }
     dst[i] = o;
+}
+
+template <typename T>
+__global__ void pack_conv_kernel(int taps, int Cin, int Cout, const float* __restrict__ w, u32x4* __restrict__ dst,
+                                 size_t nvec, int transposed) {
+    pack_conv_vec<T>((size_t)blockIdx.x * 256 + threadIdx.x, taps, Cin, Cout, w, dst, nvec, transposed);
+}
+
+// several convolutions' weights (and an optional region to clear) in ONE launch: a ConvBlock's training operator packs its
+// three or four weights and zeroes its accumulators with this instead of up to five launches
+template <typename T>
+__global__ void pack_conv_multi_kernel(PackJobs j) {
+    unsigned blk = blockIdx.x;
+#pragma unroll
+    for (int k = 0; k < PackJobs::MAXJ; ++k) {
+        if (k >= j.n) break;
+        if (blk < j.job[k].blocks) {
+            pack_conv_vec<T>((size_t)blk * 256 + threadIdx.x, j.job[k].taps, j.job[k].Cin, j.job[k].Cout, j.job[k].w,
+                             (u32x4*)j.job[k].dst, j.job[k].nvec, j.job[k].transposed);
+            return;
+        }
+        blk -= j.job[k].blocks;
+    }
+    const size_t i = (size_t)blk * 256 + threadIdx.x;      // the clear region, 16 bytes per thread
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    if (i < j.zero_vecs) ((u32x4*)j.zero)[i] = z;
+}
+
+int launch_pack_conv_multi(chore_handle* h, int dtype, PackJobs& j, hipStream_t s) {
+    unsigned blocks = 0;
+    for (int k = 0; k < j.n; ++k) {
+        j.job[k].nvec = packed_conv_bytes(dtype, j.job[k].taps, j.job[k].Cin, j.job[k].Cout) / 16 / (dtype == CHORE_F16X3 ? 2 : 1);
+        j.job[k].blocks = (unsigned)((j.job[k].nvec + 255) / 256);
+        blocks += j.job[k].blocks;
+    }
+    blocks += (unsigned)((j.zero_vecs + 255) / 256);
+    if (!blocks) return CHORE_OK;
+    if (dtype == CHORE_F16X3) hipLaunchKernelGGL(pack_conv_multi_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, j);
+    else if (dtype == CHORE_F32) hipLaunchKernelGGL(pack_conv_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, j);
+    else hipLaunchKernelGGL(pack_conv_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, j);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
 }
 
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w, void* dst,

@@ -122,22 +122,26 @@ int chore_convblock_fwd(chore_handle* h, int dtype, const void* x, const void* x
         CHORE_FAIL(h, CHORE_EINVAL, "chore_convblock_fwd: null argument");
     hipStream_t s = (hipStream_t)stream;
     const Saved sv = saved_layout(d, saved);
-    CHORE_HIP_CHECK(h, hipMemsetAsync(sv.sx, 0, 4 * d.nb, s));
-    const GroupStat* sx = (const GroupStat*)x_stats;
+    char* ws = (char*)workspace;
+    const PackOff pk = pack_layout(d, dtype, 0, false);
     int rc;
+    {   // one launch: the block's weights in fragment order, the statistics accumulators cleared
+        PackJobs pj;
+        pj.add(w1, ws + pk.w1, 9, Cin, d.C1, 0);
+        pj.add(w2, ws + pk.w2, 9, d.C1, d.C2, 0);
+        pj.add(w3, ws + pk.w3, 9, d.C2, d.C2, 0);
+        if (d.down) pj.add(wd, ws + pk.wd, 1, Cin, Cout, 0);
+        pj.zero = sv.sx; pj.zero_vecs = 4 * d.nb / 16;
+        if ((rc = launch_pack_conv_multi(h, dtype, pj, s))) return rc;
+    }
+    const GroupStat* sx = (const GroupStat*)x_stats;
     if (!sx) {
         if ((rc = launch_gn_stats(h, dtype, mkview(x, Cin, 0, Cin), B, H * W, (GroupStat*)sv.sx, s))) return rc;
         sx = (const GroupStat*)sv.sx;
     }
-    char* ws = (char*)workspace;
-    const PackOff pk = pack_layout(d, dtype, 0, false);
-    if ((rc = launch_pack_conv(h, dtype, 9, Cin, d.C1, w1, ws + pk.w1, s, 0))) return rc;
-    if ((rc = launch_pack_conv(h, dtype, 9, d.C1, d.C2, w2, ws + pk.w2, s, 0))) return rc;
-    if ((rc = launch_pack_conv(h, dtype, 9, d.C2, d.C2, w3, ws + pk.w3, s, 0))) return rc;
     const void* res = x;
     int res_cs = Cin;
     if (d.down) {      // residual = conv1x1(relu(gn4(x))), written to y and picked up from there
-        if ((rc = launch_pack_conv(h, dtype, 1, Cin, Cout, wd, ws + pk.wd, s, 0))) return rc;
         ConvArgs a{};
         a.in = mkview(x, Cin, 0, Cin); a.in_st = sx; a.gamma = gb[6]; a.beta = gb[7];
         a.wpk = ws + pk.wd;
@@ -196,7 +200,7 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     // workspace: GroupNorm-backward accumulators (zeroed) | transposed packed weights | wgrad partials | da | d(o2) | d(o1) | dx4
     char* acc1 = ws; char* acc4 = acc1 + gn_acc_bytes(B, Cin); char* acc2 = acc4 + gn_acc_bytes(B, Cin); char* acc3 = acc2 + gn_acc_bytes(B, C1);
     size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, C1) + gn_acc_bytes(B, C2));
-    CHORE_HIP_CHECK(h, hipMemsetAsync(ws, 0, o, s));
+    const size_t zero_bytes = o;
     const PackOff pk = pack_layout(d, dtype, o, true);
     o = pk.end;
     size_t part = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, C1);
@@ -215,10 +219,18 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     float *dg1 = gbp, *db1 = dg1 + Cin, *dg2 = db1 + Cin, *db2 = dg2 + C1, *dg3 = db2 + C1, *db3 = dg3 + C2, *dg4 = db3 + C2, *db4 = dg4 + Cin;
     const char* dyb = (const char*)dy;
     int rc;
+    {   // one launch: the transposed, flipped weights of the data-gradient convolutions; the accumulators cleared
+        PackJobs pj;
+        pj.add(w1, ws + pk.w1, 9, C1, Cin, 1);
+        pj.add(w2, ws + pk.w2, 9, C2, C1, 1);
+        pj.add(w3, ws + pk.w3, 9, C2, C2, 1);
+        if (d.down) pj.add(wd, ws + pk.wd, 1, Cout, Cin, 1);
+        pj.zero = ws; pj.zero_vecs = zero_bytes / 16;
+        if ((rc = launch_pack_conv_multi(h, dtype, pj, s))) return rc;
+    }
     auto dgrad = [&](int taps, const View& in, const float* w, size_t wpk_off, int cin_fwd, int cout_fwd, void* out) -> int {
         // data gradient of a layer Cin_fwd -> Cout_fwd: the forward kernel on the transposed, flipped weights
-        int r = launch_pack_conv(h, dtype, taps, cout_fwd, cin_fwd, w, ws + wpk_off, s, 1);
-        if (r) return r;
+        (void)w; (void)cout_fwd;
         ConvArgs a{};
         a.in = in;
         a.wpk = ws + wpk_off;

@@ -138,6 +138,18 @@ ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
+// up to MAXJ weight packs and one region to clear (16-byte multiples), one launch (conv_lds.hip)
+struct PackJobs {
+    static constexpr int MAXJ = 4;
+    struct Job { const float* w; void* dst; int taps, Cin, Cout, transposed; size_t nvec; unsigned blocks; } job[MAXJ];
+    int n = 0;
+    void* zero = nullptr; size_t zero_vecs = 0;
+    void add(const float* w, void* dst, int taps, int Cin, int Cout, int transposed) {
+        job[n].w = w; job[n].dst = dst; job[n].taps = taps; job[n].Cin = Cin; job[n].Cout = Cout; job[n].transposed = transposed;
+        ++n;
+    }
+};
+int launch_pack_conv_multi(chore_handle* h, int dtype, PackJobs& j, hipStream_t s);
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w /*(O,C,k,k)*/,
                      void* dst, hipStream_t s, int transposed = 0);
 
