@@ -189,6 +189,40 @@ def _mlp(input_sz, output_sz, hidden_sz):
                          nn.Conv1d(hidden_sz, output_sz, 1))
 
 
+class _StackLossFn(torch.autograd.Function):
+    """the six loss terms of one stack and their gradients in one pass (chore_train_loss, csrc/train_loss.hip).
+    Returns 7 floats: the terms in the reference's order (h, o, parts, pca, smpl, obj), each already divided by the number
+    of stacks, and their sum [6] -- the stack's share of the averaged error, the only differentiable entry."""
+
+    @staticmethod
+    def forward(ctx, df, pca, parts, centers, tgt):
+        dev = df.device
+        h = _lib.handle(dev.index or 0)
+        B, _, N = df.shape
+        preds = [t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous() for t in (df, pca, parts, centers)]
+        grads = [torch.empty_like(t) for t in preds]
+        losses = torch.empty(7, device=dev)
+        ws = torch.empty(_lib.lib.chore_train_loss_workspace_bytes(), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _lib.check(_lib.lib.chore_train_loss(h, *[t.data_ptr() for t in preds], tgt["df_h"].data_ptr(), tgt["df_o"].data_ptr(),
+                                             tgt["parts_gt"].data_ptr(), tgt["pca_gt"].data_ptr(), tgt["body_center"].data_ptr(),
+                                             tgt["obj_center"].data_ptr(), B, N, float(tgt["max_dist"]), tgt["weights"],
+                                             float(tgt["scale"]), *[g.data_ptr() for g in grads], losses.data_ptr(), 0,
+                                             ws.data_ptr(), stream), h, "chore_train_loss")
+        ctx.save_for_backward(*grads)
+        ctx.shapes = [t.shape for t in (df, pca, parts, centers)]
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, gs = list(ctx.saved_tensors), g[6]
+        try:
+            out = torch._foreach_mul(grads, gs)
+        except (RuntimeError, TypeError):
+            out = [t * gs for t in grads]
+        return tuple(o.view(sh) for o, sh in zip(out, ctx.shapes)) + (None,)
+
+
 class CHORE(nn.Module):
     def __init__(self, opt, projection_mode="perspective", error_term=nn.MSELoss(), rank=-1, num_parts=14,
                  hidden_dim=128):
@@ -368,6 +402,8 @@ class CHORE(nn.Module):
     def get_errors(self, df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs):
         """training loss of /root/reference/model/chore.py:192-237, averaged over the stacks"""
         w = self.loss_weights
+        if df_h.is_cuda and not os.environ.get("CHORE_TORCH_LOSS"):
+            return self._get_errors_fused(df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center)
         error, losses_all = 0.0, 0.0
         for df_pred, pca_pred, parts_pred, centers in self.intermediate_preds_list:
             loss_h = self.get_df_loss(df_h, df_pred[:, 0], max_dist) * w[0]
@@ -386,6 +422,22 @@ class CHORE(nn.Module):
         error = error / n
         losses_all = losses_all / n
         if self.losses_on_host:          # the reference returns a CPU tensor (model/chore.py:226): one host sync per call
+            losses_all = losses_all.cpu()
+        self.error_buffer = losses_all
+        return error, losses_all
+
+    def _get_errors_fused(self, df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center):
+        """get_errors with one loss kernel per stack (csrc/train_loss.hip) instead of ~60 tensor ops; CHORE_TORCH_LOSS=1
+        selects the tensor-op form above (same values: tests/test_gpu_encoder.py)"""
+        n = len(self.intermediate_preds_list)
+        f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()   # noqa: E731
+        tgt = dict(df_h=f32(df_h), df_o=f32(df_o), parts_gt=parts_gt.long().contiguous(), pca_gt=f32(pca_gt),
+                   body_center=f32(body_center), obj_center=f32(obj_center), max_dist=max_dist, scale=1.0 / n,
+                   weights=(ctypes.c_float * 6)(*[float(v) for v in self.loss_weights]))
+        outs = [_StackLossFn.apply(df, pca, parts, centers, tgt) for df, pca, parts, centers in self.intermediate_preds_list]
+        tot = outs[0] if n == 1 else torch.stack(outs).sum(0)
+        error, losses_all = tot[6], tot[:6].detach()
+        if self.losses_on_host:
             losses_all = losses_all.cpu()
         self.error_buffer = losses_all
         return error, losses_all

@@ -400,6 +400,17 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
                         int W, int Cin, int Cout, const float* w1, const float* w2, const float* w3, const float* wd,
                         const float* const* gb, const void* saved, void* dx, float* grads, void* workspace,
                         chore_stream_t stream);
+/* The training loss of one stack (reference model/chore.py:192-237, CHORE.get_errors) and its gradients with respect to
+ * the four predictions, one pass: clamped-L1 of the two distance fields, cross entropy of the part logits, masked MSE of
+ * the PCA axes and the two centre predictions.  losses: 7 device floats -- the six terms in the reference's order (h, o,
+ * parts, pca, smpl, obj) and their sum, each times `scale`; accumulate != 0 adds to them.  weights: host array, the
+ * reference's self.loss_weights.  g_*: gradients of the added sum.  Exact (order-independent) reductions. */
+size_t chore_train_loss_workspace_bytes(void);
+int chore_train_loss(chore_handle* h, const float* df, const float* pca, const float* parts, const float* centers,
+                     const float* df_h, const float* df_o, const int64_t* parts_gt, const float* pca_gt,
+                     const float* body_center, const float* obj_center, int B, int N, float max_dist,
+                     const float* weights, float scale, float* g_df, float* g_pca, float* g_parts, float* g_centers,
+                     float* losses, int accumulate, void* workspace, chore_stream_t stream);
 /* y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C));  d_low = transpose of the upsampling applied to dy */
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
                     chore_stream_t stream);

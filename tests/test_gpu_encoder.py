@@ -260,3 +260,40 @@ def test_full_training_backward_bf16_mode_within_stated_bound(opt):
     assert n_grad == 475
     print("bf16 mode: relative L2 error of the small gradient tensors: median %.3f max %.3f" % (np.median(rel), max(rel)))
     assert np.median(rel) < 0.08
+
+
+def test_fused_loss_kernel_equals_tensor_op_loss(opt):
+    """chore_train_loss (one kernel per stack: six terms + four gradient tensors, exact reductions) against the same loss
+    written with torch ops (CHORE_TORCH_LOSS=1, the form checked against the reference by the tests above): the six terms,
+    the error and its gradients with respect to all four predictions of both stacks"""
+    import os
+    from chore_amd.model import CHORE
+    torch.manual_seed(3)
+    net = CHORE(opt).cuda()
+    B, N = 3, 1111
+    tg = dict(df_h=torch.rand(B, N).cuda() * 0.2, df_o=torch.rand(B, N).cuda() * 0.2, parts_gt=torch.randint(0, 14, (B, N)).cuda(),
+              pca_gt=torch.randn(B, 3, 3, N).cuda(), body_center=torch.randn(B, 3).cuda() * 0.3, obj_center=torch.randn(B, 3, N).cuda() * 0.3)
+    res = {}
+    for mode in ("fused", "torch"):
+        torch.manual_seed(4)
+        preds = []
+        for _ in range(2):
+            df = (torch.rand(B, 2, N) * 0.7).cuda()
+            df[:, :, ::17] = 5.0                                   # OUT_DIST entries: clamped, no gradient
+            preds.append([t.requires_grad_(True) for t in (df, torch.randn(B, 3, 3, N).cuda(), torch.randn(B, 14, N).cuda() * 2,
+                                                           torch.randn(B, 6, N).cuda() * 0.3)])
+        net.intermediate_preds_list = [tuple(p) for p in preds]
+        if mode == "torch":
+            os.environ["CHORE_TORCH_LOSS"] = "1"
+        try:
+            err, losses = net.get_errors(max_dist=0.5, **tg)
+        finally:
+            os.environ.pop("CHORE_TORCH_LOSS", None)
+        (err * 1.7).backward()
+        res[mode] = (err.detach(), losses.detach().cpu() if losses.is_cuda else losses, [t.grad for p in preds for t in p])
+    a, b = res["fused"], res["torch"]
+    assert abs(float(a[0]) - float(b[0])) <= 2e-6 * abs(float(b[0]))
+    assert torch.allclose(a[1].float(), b[1].float(), rtol=2e-6, atol=0)
+    for ga, gb in zip(a[2], b[2]):
+        assert ga.shape == gb.shape
+        assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
