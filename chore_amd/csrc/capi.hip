@@ -163,7 +163,7 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
 
 size_t chore_query_train_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return (size_t)B * N * (2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float);
+    return (size_t)B * N * ((2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float) + 3 * HEAD_NUM * 2 * sizeof(unsigned long long));
 }
 
 static void train_staging(QueryArgs& a, void* staging) {
@@ -173,6 +173,7 @@ static void train_staging(QueryArgs& a, void* staging) {
     a.tH = a.tX + P * QF_KPAD;
     a.tdZ = a.tH + P * 3 * HEAD_NUM * HEAD_HID;
     a.tdX = a.tdZ + P * 3 * HEAD_NUM * HEAD_HID;
+    a.tM = (unsigned long long*)(a.tdX + P * QF_KPAD);
 }
 
 // the query forward of a training step: as chore_query_fwd, and the 323-vectors and ReLU outputs of the hidden layers go

@@ -161,6 +161,7 @@ struct QueryArgs {
     float* tH = nullptr;    // [3][HEAD_NUM][B*N][128]  relu outputs of hidden layers 1..3
     float* tdZ = nullptr;   // [3][HEAD_NUM][B*N][128]  gradients w.r.t. the pre-activations of layers 1..3
     float* tdX = nullptr;   // [B*N][QF_KPAD]           gradient w.r.t. the 323-vector (summed over the heads)
+    unsigned long long* tM = nullptr;   // [3][HEAD_NUM][B*N][2]  ReLU sign bits of the hidden layers (heads_f32.h, store_masks)
 };
 
 // launchers implemented in the .hip files

@@ -188,3 +188,41 @@ __device__ __forceinline__ void store_tile(float* base /*[B*N][128], this head*/
             }
     }
 }
+
+// training staging, ReLU sign bits: the backward needs only the signs of the hidden activations, and reading them back
+// from the staged fp32 rows costs 512 B per (point, layer, head); the forward also leaves them as 128 bits.
+// Layout [B*N][2] u64 per (layer, head) plane: entry (point, half) holds, for rb = 0..3, bit 16 rb + r = [row
+// rb*32 + mfma32_row(r, half) of the point is positive] -- the bits a lane of a D fragment owns, in register order.
+template <int NCB>
+__device__ __forceinline__ void store_masks(unsigned long long* base, const f32x16 (&f)[4][NCB], size_t row0, int n0, int N, int lane,
+                                            int pt0 = 0) {
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int pt = pt0 + cb * 32 + col;
+        unsigned long long v = 0ull;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+            unsigned m = 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m |= (f[rb][cb][r] > 0.f ? 1u : 0u) << r;
+            v |= (unsigned long long)m << (16 * rb);
+        }
+        if (n0 + pt < N) base[(row0 + pt) * 2 + half] = v;
+    }
+}
+// -> the backward's mask registers: bit 16 cb + r of m[rb]
+template <int NCB>
+__device__ __forceinline__ void load_mask_bits(unsigned (&m)[4], const unsigned long long* base, size_t row0, int n0, int N, int lane,
+                                               int pt0) {
+    const int half = lane >> 5, col = lane & 31;
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) m[rb] = 0u;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const int pt = pt0 + cb * 32 + col;
+        const unsigned long long v = n0 + pt < N ? base[(row0 + pt) * 2 + half] : 0ull;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) m[rb] |= (unsigned)((v >> (16 * rb)) & 0xffffull) << (16 * cb);
+    }
+}

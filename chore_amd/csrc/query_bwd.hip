@@ -137,9 +137,10 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
     if constexpr (STAGED) {
-        load_masks<NCB>(m1, a.tH + (0 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
-        load_masks<NCB>(m2, a.tH + (1 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
-        load_masks<NCB>(m3, a.tH + (2 * HEAD_NUM + head) * plane, row0, n0, a.N, lane, pt0);
+        const size_t mplane = (size_t)a.B * a.N * 2;      // the forward's sign bits (heads_f32.h, store_masks): 16 B per point
+        load_mask_bits<NCB>(m1, a.tM + (0 * HEAD_NUM + head) * mplane, row0, n0, a.N, lane, pt0);
+        load_mask_bits<NCB>(m2, a.tM + (1 * HEAD_NUM + head) * mplane, row0, n0, a.N, lane, pt0);
+        load_mask_bits<NCB>(m3, a.tM + (2 * HEAD_NUM + head) * mplane, row0, n0, a.N, lane, pt0);
     } else if constexpr (X3) {      // the accumulators carry a positive scale: same sign bits
         constexpr int PF = NW == 8 ? 1 : QX_PF;     // two waves per SIMD: 256 registers each, no room for a deeper ring
         heads_layer1_x3<NCB, PF>(u, sm.X + pt0 * XS, arena, head, lane);

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     const float* arena = (const float*)a.arena;
     const int head = wid;
     f32x16 h1[4][NCB], h2[4][NCB];
-    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID;
+    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID, mplane = (size_t)a.B * a.N * 2;
     if constexpr (TRAIN) {
         for (int i = tid; i < PTS * (QF_KPAD / 4); i += 256) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
@@ -67,18 +67,24 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
         for (int cb = 0; cb < NCB; ++cb) inv[cb] = QX_INV;
         heads_layer1_x3<NCB>(h1, sm.X, arena, head, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, 0, inv);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, 0);
         heads_layer_hid_x3<NCB>(h2, h1, arena, head, 1, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, 0, inv);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane, 0);
         heads_layer_hid_x3<NCB>(h1, h2, arena, head, 2, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, 0, inv);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, 0);
         heads_layer_out_x3<NCB>(o, h1, arena, head, lane);
     } else {
         heads_layer1<NCB>(h1, sm.X, arena, head, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane);
         heads_layer_hid<NCB>(h2, h1, arena, head, 1, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane);
         heads_layer_hid<NCB>(h1, h2, arena, head, 2, lane);
         if constexpr (TRAIN) store_tile<NCB>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane);
+        if constexpr (TRAIN) store_masks<NCB>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane);
         heads_layer_out<NCB>(o, h1, arena, head, lane);
     }
 
@@ -131,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     const float* arena = (const float*)a.arena;
     const int head = wid & 3, cb0 = wid >> 2;
     f32x16 h1[4][1], h2[4][1];
-    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID;
+    const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID, mplane = (size_t)a.B * a.N * 2;
     if constexpr (TRAIN) {
         for (int i = tid; i < PTS * (QF_KPAD / 4); i += 512) {
             const int pt = i / (QF_KPAD / 4), q = i % (QF_KPAD / 4);
@@ -143,18 +149,24 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
         const float inv[1] = {QX_INV};
         heads_layer1_x3<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid_x3<1>(h2, h1, arena, head, 1, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid_x3<1>(h1, h2, arena, head, 2, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_out_x3<1>(o, h1, arena, head, lane);
     } else {
         heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
         if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_masks<1>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_out<1>(o, h1, arena, head, lane);
     }
 
