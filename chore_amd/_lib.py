@@ -112,7 +112,7 @@ SIGNATURES = {
     "chore_heads_wgrad_floats": (c_size_t, []),
     "chore_heads_wgrad_workspace_bytes": (c_size_t, []),
     "chore_heads_wgrad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p]),
+                                  c_int, c_void_p]),
     "chore_gemm_tn_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_gemm_tn_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                   c_void_p]),

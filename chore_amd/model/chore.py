@@ -156,7 +156,8 @@ class _QueryTrainFn(torch.autograd.Function):
         garena = torch.empty(_lib.lib.chore_heads_wgrad_floats(), device=dev)
         ws = torch.empty(_lib.lib.chore_heads_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib.chore_heads_wgrad(h, staging.data_ptr(), B, N, g_c[0].data_ptr(), g_c[2].data_ptr(),
-                                              g_c[1].data_ptr(), g_c[3].data_ptr(), garena.data_ptr(), ws.data_ptr(), stream),
+                                              g_c[1].data_ptr(), g_c[3].data_ptr(), garena.data_ptr(), ws.data_ptr(),
+                                              1 if (ctx.dtype & _lib.HEADS_X3) else 0, stream),
                    h, "chore_heads_wgrad")
         o = 0
         for k in range(4):                                            # module order = kernel head order

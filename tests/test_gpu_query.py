@@ -235,10 +235,11 @@ def test_rejects_bad_inputs(net):
         net.query(torch.from_numpy(g["points"]).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
 
 
-@pytest.mark.parametrize("heads_x3", [False, True])
-def test_training_backward_heads_and_feature_maps(opt, heads_x3):
-    """heads_x3: the GEMM chain of the heads on the fp16 matrix cores with split operands (what the bf16 training mode
-    runs) instead of the native fp32 MFMA -- same fixture, same bounds.
+@pytest.mark.parametrize("heads_x3,gscale", [(False, 1.0), (True, 1.0), (True, 1e-7), (True, 3e5)])
+def test_training_backward_heads_and_feature_maps(opt, heads_x3, gscale):
+    """heads_x3: the GEMM chain of the heads AND their weight gradients on the fp16 matrix cores with split operands
+    (what the bf16 training mode runs) instead of the native fp32 MFMA -- same fixture, same bounds, also with the loss
+    scaled down to where an unscaled fp16 operand would be all subnormal, and up (per-point / per-chunk scales).
     first half of the training backward: gradients of a random linear functional of the four outputs
     w.r.t. the 32 head parameters, the hourglass feature map and tmpx, against the reference's autograd
     (tests/golden/query_train_grads.npz: full tensors for the df head, the small tensors and the two maps; sums,
@@ -266,10 +267,10 @@ def test_training_backward_heads_and_feature_maps(opt, heads_x3):
     st = torch.from_numpy(gg["stable"]).cuda()
     loss = sum((o_ * torch.from_numpy(g["w_" + k]).cuda() * st.view(st.shape[0], *([1] * (o_.dim() - 2)), -1)).sum()
                for k, o_ in zip(("df", "pca", "parts", "centers"), preds))
-    loss.backward()
+    (loss * gscale).backward()
 
     def close(a, b, what, tol=2e-5):
-        a = a.detach().float().cpu().numpy().reshape(b.shape)
+        a = a.detach().double().cpu().numpy().reshape(b.shape) / gscale
         assert np.abs(a - b).max() <= tol * max(1e-6, np.abs(b).max()), (what, np.abs(a - b).max(), np.abs(b).max())
 
     stable = gg["stable"] > 0
@@ -289,7 +290,7 @@ def test_training_backward_heads_and_feature_maps(opt, heads_x3):
             if "g_" + name in gg.files:
                 close(gr, gg["g_" + name], name, tol=5e-5)
             else:
-                a = gr.detach().cpu().numpy().astype(np.float64)
+                a = gr.detach().cpu().numpy().astype(np.float64) / gscale
                 ref = gg["s_" + name]
                 got = np.array([a.sum(), np.abs(a).sum(), np.sqrt((a ** 2).sum())])
                 assert np.abs(got - ref).max() < 5e-5 * ref[1], (name, got, ref)
