@@ -95,13 +95,15 @@ int chore_stem_fwd(chore_handle* h, int dtype, const float* images, int B, int C
 }
 
 // y (B,H/2,W/2,C) = 2x2 average pooling of x (B,H,W,C), C in {64,128,256}; dx = its transpose applied to dy
-int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C, chore_stream_t stream) {
+// out_stats (or NULL): ZEROED chore_gn_stats_bytes(B) accumulators that receive the GroupNorm statistics of y
+int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C, void* out_stats,
+                       chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!x || !y || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: bad argument");
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_avgpool2_fwd: dtype");
     View vx; vx.p = const_cast<void*>(x); vx.cs = C; vx.co = 0; vx.C = C;
     View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
-    return launch_avgpool2(h, dtype, vx, vy, B, H, W, nullptr, (hipStream_t)stream);
+    return launch_avgpool2(h, dtype, vx, vy, B, H, W, (GroupStat*)out_stats, (hipStream_t)stream);
 }
 
 int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C, chore_stream_t stream) {
@@ -113,13 +115,13 @@ int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int
 
 // y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C)), align_corners=True  (HourGlass._forward, HGFilters.py:47-50); y may be a
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
-                    chore_stream_t stream) {
+                    void* out_stats, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!a || !low || !y) CHORE_FAIL(h, CHORE_EINVAL, "chore_upadd_fwd: null argument");
     View va; va.p = const_cast<void*>(a); va.cs = C; va.co = 0; va.C = C;
     View vl; vl.p = const_cast<void*>(low); vl.cs = C; vl.co = 0; vl.C = C;
     View vy; vy.p = y; vy.cs = C; vy.co = 0; vy.C = C;
-    return launch_upadd(h, dtype, va, vl, vy, B, H, W, nullptr, (hipStream_t)stream);
+    return launch_upadd(h, dtype, va, vl, vy, B, H, W, (GroupStat*)out_stats, (hipStream_t)stream);
 }
 
 // d_low (B,H,W,C) = transpose of the bicubic x2 upsampling applied to dy (B,2H,2W,C)

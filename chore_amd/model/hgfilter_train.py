@@ -43,11 +43,11 @@ def _conv_block_layerwise(m, x):
 def hourglass(m, level, x, xs=None):
     """HourGlass._forward (HGFilters.py:26-50); xs: statistics of x when its producer made them"""
     up1, _ = conv_block(getattr(m, f"b1_{level}"), x, xs)
-    low1 = ops.avgpool2(x)
-    low1, s1 = conv_block(getattr(m, f"b2_{level}"), low1)
-    low2, s2 = (hourglass(m, level - 1, low1, s1), None) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1, s1)
+    low1, sl = ops.avgpool2(x, True)              # the pooling / upsampling kernels produce their output's statistics too
+    low1, s1 = conv_block(getattr(m, f"b2_{level}"), low1, sl)
+    low2, s2 = hourglass(m, level - 1, low1, s1) if level > 1 else conv_block(getattr(m, f"b2_plus_{level}"), low1, s1)
     low3, _ = conv_block(getattr(m, f"b3_{level}"), low2, s2)
-    return ops.upadd(up1, low3)
+    return ops.upadd(up1, low3, True)
 
 
 def forward_train(enc, images, tdt):
@@ -61,16 +61,16 @@ def _forward_train(enc, images, tdt):
     x = ops.stem(images, enc.conv1.weight, enc.conv1.bias, tdt)
     x = ops.gn_relu(x, enc.bn1.weight, enc.bn1.bias)
     tmpx = x
-    x = ops.avgpool2(conv_block(enc.conv2, x)[0])
+    x, sn = ops.avgpool2(conv_block(enc.conv2, x)[0], True)
     normx = x
-    x, sx = conv_block(enc.conv3, x)
+    x, sx = conv_block(enc.conv3, x, sn)
     previous, sp = conv_block(enc.conv4, x, sx)
     outputs = []
     n = enc.num_modules
     for i in range(n):
-        hg = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous, sp)
+        hg, sh = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous, sp)
         sp = None                  # `previous` is re-formed by torch adds below: its statistics are recomputed
-        ll, _ = conv_block(getattr(enc, f"top_m_{i}"), hg)
+        ll, _ = conv_block(getattr(enc, f"top_m_{i}"), hg, sh)
         cl, be = getattr(enc, f"conv_last{i}"), getattr(enc, f"bn_end{i}")
         ll, sl = ops.conv_gn(ll, cl.weight, cl.bias, want_stats=True)
         ll = ops.gn_relu(ll, be.weight, be.bias, x_stats=sl)

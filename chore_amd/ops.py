@@ -75,6 +75,14 @@ def _zeros(nbytes, dev):
     return _u8(nbytes, dev), 0
 
 
+def _zeroed_stats(B, dev):
+    """zeroed GroupNorm statistics accumulators (from the pass's arena when one is active)"""
+    nb = _lib.lib.chore_gn_stats_bytes(B)
+    if _arena is not None and _arena.dev == dev:
+        return _arena.take(nb)
+    return torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
+
+
 def gn_stats(x):
     dev, h, dt, stream = _env(x)
     B, H, W, C = x.shape
@@ -270,47 +278,56 @@ class _UpAdd(torch.autograd.Function):
     """y = a + bicubic_up2(low), align_corners=True (HourGlass._forward, HGFilters.py:47-50)"""
 
     @staticmethod
-    def forward(ctx, a, low):
+    def forward(ctx, a, low, want_stats=False):
         dev, h, dt, stream = _env(low)
         B, H, W, C = low.shape
         if a.shape != (B, 2 * H, 2 * W, C) or a.dtype != low.dtype or not a.is_contiguous():
             raise ValueError("upadd: a must be (B,2H,2W,C), contiguous, same dtype as low")
         y = torch.empty_like(a)
-        _lib.check(_lib.lib.chore_upadd_fwd(h, dt, a.data_ptr(), low.data_ptr(), y.data_ptr(), B, H, W, C, stream), h,
-                   "chore_upadd_fwd")
+        st = _zeroed_stats(B, dev) if want_stats else None
+        _lib.check(_lib.lib.chore_upadd_fwd(h, dt, a.data_ptr(), low.data_ptr(), y.data_ptr(), B, H, W, C,
+                                            None if st is None else st.data_ptr(), stream), h, "chore_upadd_fwd")
         ctx.shape = (B, H, W, C)
+        if want_stats:
+            ctx.mark_non_differentiable(st)
+            return y, st
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         B, H, W, C = ctx.shape
         dy = dy.contiguous()
         dev, h, dt, stream = _env(dy)
         dlow = torch.empty(B, H, W, C, dtype=dy.dtype, device=dev)
         _lib.check(_lib.lib.chore_up2_bwd(h, dt, dy.data_ptr(), dlow.data_ptr(), B, H, W, C, stream), h, "chore_up2_bwd")
-        return dy, dlow
+        return dy, dlow, None
 
 
 class _AvgPool2(torch.autograd.Function):
     """2x2 average pooling (HGFilters.py:33,153)"""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, want_stats=False):
         dev, h, dt, stream = _env(x)
         B, H, W, C = x.shape
         y = torch.empty(B, H // 2, W // 2, C, dtype=x.dtype, device=dev)
-        _lib.check(_lib.lib.chore_avgpool2_fwd(h, dt, x.data_ptr(), y.data_ptr(), B, H, W, C, stream), h, "chore_avgpool2_fwd")
+        st = _zeroed_stats(B, dev) if want_stats else None
+        _lib.check(_lib.lib.chore_avgpool2_fwd(h, dt, x.data_ptr(), y.data_ptr(), B, H, W, C, None if st is None else st.data_ptr(),
+                                               stream), h, "chore_avgpool2_fwd")
         ctx.shape = tuple(x.shape)
+        if want_stats:
+            ctx.mark_non_differentiable(st)
+            return y, st
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, *unused):
         dy = dy.contiguous()
         dev, h, dt, stream = _env(dy)
         B, H, W, C = ctx.shape
         dx = torch.empty(B, H, W, C, dtype=dy.dtype, device=dev)
         _lib.check(_lib.lib.chore_avgpool2_bwd(h, dt, dy.data_ptr(), dx.data_ptr(), B, H, W, C, stream), h, "chore_avgpool2_bwd")
-        return dx
+        return dx, None
 
 
 class _Stem(torch.autograd.Function):
@@ -345,16 +362,17 @@ class _Stem(torch.autograd.Function):
         return None, dw, db, None
 
 
-def avgpool2(x):
-    return _AvgPool2.apply(x)
+def avgpool2(x, want_stats=False):
+    """want_stats: -> (y, GroupNorm statistics of y), accumulated by the pooling kernel itself"""
+    return _AvgPool2.apply(x, want_stats)
 
 
 def stem(images, w, bias, tdt):
     return _Stem.apply(images, w, bias, tdt)
 
 
-def upadd(a, low):
-    return _UpAdd.apply(a, low)
+def upadd(a, low, want_stats=False):
+    return _UpAdd.apply(a, low, want_stats)
 
 
 def conv_gn(x, w, bias=None, gamma=None, beta=None, x_stats=None, want_stats=False):

@@ -413,13 +413,15 @@ int chore_train_loss(chore_handle* h, const float* df, const float* pca, const f
                      const float* weights, float scale, float* g_df, float* g_pca, float* g_parts, float* g_centers,
                      float* losses, int accumulate, void* workspace, chore_stream_t stream);
 /* y (B,2H,2W,C) = a + bicubic_up2(low (B,H,W,C));  d_low = transpose of the upsampling applied to dy */
+/* out_stats (both operators; or NULL): ZEROED chore_gn_stats_bytes(B) accumulators that receive the GroupNorm statistics
+ * of y from the same pass (what a ConvBlock consuming y takes as x_stats) */
 int chore_upadd_fwd(chore_handle* h, int dtype, const void* a, const void* low, void* y, int B, int H, int W, int C,
-                    chore_stream_t stream);
+                    void* out_stats, chore_stream_t stream);
 int chore_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C,
                   chore_stream_t stream);
 /* y (B,H/2,W/2,C) = 2x2 average pooling of x (B,H,W,C) (nn.AvgPool2d / F.avg_pool2d(2, stride 2), HGFilters.py:33,153),
  * C in {64,128,256}; dx (B,H,W,C) = its transpose applied to dy */
-int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C,
+int chore_avgpool2_fwd(chore_handle* h, int dtype, const void* x, void* y, int B, int H, int W, int C, void* out_stats,
                        chore_stream_t stream);
 int chore_avgpool2_bwd(chore_handle* h, int dtype, const void* dy, void* dx, int B, int H, int W, int C,
                        chore_stream_t stream);
