@@ -1,13 +1,19 @@
 #!/bin/bash
-# training-step profile on the GPU box:  scripts/profile_train.sh r01
-tag=${1:-r01}
+# training-step and fit-loop evidence on the GPU box:  scripts/profile_train.sh r02
+#   <tag>_bench_train.json / _bench_train_fp32.json / _bench_fit.json   bench.py lines of the other two modes
+#   <tag>_train_kernel_stats.txt   per-kernel-class time of a traced training step (rocprofv3 --kernel-trace) + device timeline
+tag=${1:-r02}
 repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
-python bench.py --mode train --steps 20 --warmup 5 > $out/${tag}_bench_train.json 2> $out/${tag}_bench_train.err
-python bench.py --mode train --steps 20 --warmup 5 --dtype fp32 > $out/${tag}_bench_train_fp32.json 2>> $out/${tag}_bench_train.err
+timeout 900 python bench.py --mode train --steps 20 --warmup 5 > $out/${tag}_bench_train.json 2> $out/${tag}_bench_train.err
+timeout 900 python bench.py --mode train --steps 10 --warmup 3 --dtype fp32 --no-cpu-baseline > $out/${tag}_bench_train_fp32.json 2>> $out/${tag}_bench_train.err
+timeout 900 python bench.py --mode fit > $out/${tag}_bench_fit.json 2> $out/${tag}_bench_fit.err
 cd /tmp; rm -rf /tmp/proft_$tag
-rocprofv3 --kernel-trace -d /tmp/proft_$tag -o $tag --output-format csv -- \
-    python $repo/bench.py --mode train --steps 16 --warmup 4 > /dev/null 2> $out/${tag}_train_rocprof.err
-f=$(find /tmp/proft_$tag -name "*kernel_trace.csv" | head -1)
-[ -n "$f" ] && python $repo/scripts/train_prof_summary.py $f > $out/${tag}_train_kernel_stats.txt
+timeout 600 rocprofv3 --kernel-trace -d /tmp/proft_$tag -o train -- \
+    python $repo/bench.py --mode train --steps 5 --warmup 2 --no-cpu-baseline > /dev/null 2> $out/${tag}_train_rocprof.err
+f=$(find /tmp/proft_$tag -name "*results.db" | head -1)
+if [ -n "$f" ]; then
+    python $repo/scripts/train_prof_summary.py $f 7 60 > $out/${tag}_train_kernel_stats.txt
+    python $repo/scripts/train_timeline.py $f 5 >> $out/${tag}_train_kernel_stats.txt
+fi
 cd $repo
