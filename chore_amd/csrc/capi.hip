@@ -1,5 +1,6 @@
 // capi.hip -- extern "C" entry points of libchore_hip.so (see include/chore_hip.h).
 #include "common.h"
+#include <cstdlib>
 #include <cstring>
 
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
@@ -88,6 +89,26 @@ int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_desc
     return launch_heads_pack_f32(h, raw, (float*)arena, (hipStream_t)stream);
 }
 
+// ---- debug aid (CHORE_NAN_CHECK=1): count non-finite values in the query's inputs / outputs, per call site --------------------
+__device__ unsigned g_nan_counts[32];      // [0..15] counts, [16..31] sequence number of the first scan that saw one (+1)
+__global__ void nan_scan_kernel(const float* p, size_t n, int slot, unsigned seq) {
+    unsigned c = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        if (p && !isfinite(p[i])) ++c;
+    if (c) {
+        atomicAdd(&g_nan_counts[slot], c);
+        atomicCAS(&g_nan_counts[16 + slot], 0u, seq);
+    }
+}
+static bool nan_check_on() { static const bool v = getenv("CHORE_NAN_CHECK") != nullptr; return v; }
+static void nan_scan(const float* p, size_t n, int slot, hipStream_t s) {
+    static unsigned seq = 0;
+    if (p && n) hipLaunchKernelGGL(nan_scan_kernel, dim3(64), dim3(256), 0, s, p, n, slot, ++seq);
+}
+extern "C" int chore_debug_nan_counts(unsigned* out32) {
+    return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_nan_counts), sizeof(unsigned) * 32) == hipSuccess ? 0 : -2;
+}
+
 // split a query dtype into the map type and the heads mode (include/chore_hip.h: CHORE_HEADS_X3)
 static inline bool query_x3(int& dtype) {
     const bool x3 = dtype == CHORE_F16X3 || (dtype & CHORE_HEADS_X3);
@@ -124,9 +145,17 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
     if (rc) return rc;
     a.out[0] = df; a.out[1] = parts; a.out[2] = pca; a.out[3] = centers;
     a.in_img = in_img;
-    if (x3) return launch_query_fwd_x3(h, a, (hipStream_t)stream);
-    return dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream)
-                              : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream);
+    if (nan_check_on()) {
+        nan_scan(points, (size_t)B * N * 3, 0, (hipStream_t)stream);
+        if (dtype == CHORE_F32) { nan_scan((const float*)feat, (size_t)B * FH * FW * 256, 5, (hipStream_t)stream); nan_scan((const float*)tmpx, (size_t)B * TH * TW * 64, 6, (hipStream_t)stream); }
+    }
+    rc = x3 ? launch_query_fwd_x3(h, a, (hipStream_t)stream)
+            : (dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream) : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream));
+    if (nan_check_on()) {
+        nan_scan(df, (size_t)B * 2 * N, 1, (hipStream_t)stream); nan_scan(pca, (size_t)B * 9 * N, 2, (hipStream_t)stream);
+        nan_scan(parts, (size_t)B * 14 * N, 3, (hipStream_t)stream); nan_scan(centers, (size_t)B * 6 * N, 4, (hipStream_t)stream);
+    }
+    return rc;
 }
 
 int chore_sample_features(chore_handle* h, const float* points, const float* crop_center, int B, int N,
@@ -156,6 +185,15 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
     if (rc) return rc;
     a.g[0] = g_df; a.g[1] = g_parts; a.g[2] = g_pca; a.g[3] = g_centers;
     a.dpoints = dpoints;
+    if (nan_check_on()) {
+        nan_scan(points, (size_t)B * N * 3, 8, (hipStream_t)stream);
+        nan_scan(g_df, (size_t)B * 2 * N, 9, (hipStream_t)stream); nan_scan(g_pca, (size_t)B * 9 * N, 10, (hipStream_t)stream);
+        nan_scan(g_parts, (size_t)B * 14 * N, 11, (hipStream_t)stream); nan_scan(g_centers, (size_t)B * 6 * N, 12, (hipStream_t)stream);
+        rc = x3 ? launch_query_bwd_x3(h, a, (hipStream_t)stream)
+                : (dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream) : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream));
+        nan_scan(dpoints, (size_t)B * N * 3, 13, (hipStream_t)stream);
+        return rc;
+    }
     if (x3) return launch_query_bwd_x3(h, a, (hipStream_t)stream);
     return dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream)
                               : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);

@@ -99,7 +99,7 @@ __device__ __forceinline__ void heads_layer1_x3(f32x16 (&acc)[4][NCB], const flo
                 for (int cb = 0; cb < NCB; ++cb) acc[rb][cb] = mfma3(ring[p].h[rb], ring[p].l[rb], bh[cb], bl[cb], acc[rb][cb]);
             const int kn = ks + PF < QX_KS1 ? ks + PF : QX_KS1 - 1;     // the tail reloads the last step (in bounds)
             load_afrag(ring[p], A + (size_t)kn * 4 * 2 * 64);
-            __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks the loads to their use, three steps later
+            if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);      // or the scheduler sinks the loads to their use, three steps later
         }
     }
 }
@@ -123,7 +123,7 @@ __device__ __forceinline__ void heads_layer_hid_x3(f32x16 (&out)[4][NCB], const 
     AFrag ring[PF];
 #pragma unroll
     for (int p = 0; p < PF; ++p) load_afrag(ring[p], A + (size_t)p * 4 * 2 * 64);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
         const f32x16 bf = scaled_bias(arena, head, layer, rb, half);
@@ -141,7 +141,7 @@ __device__ __forceinline__ void heads_layer_hid_x3(f32x16 (&out)[4][NCB], const 
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(f.h[rb], f.l[rb], bh[cb], bl[cb], out[rb][cb]);
         if (t + PF < 8) load_afrag(f, A + (size_t)(t + PF) * 4 * 2 * 64);
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (PF > 1) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -25,6 +25,9 @@ __device__ __forceinline__ unsigned sign_mask(const f32x16 (&c)[NCB]) {
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) m |= (c[cb][r] > 0.f ? 1u : 0u) << (16 * cb + r);
+    // pin the 32 bits HERE: left alone the compiler sinks these compares to where the mask is applied, a whole forward and
+    // half a backward chain later, and keeps (spills) the 64 activation registers until then
+    asm volatile("" : "+v"(m));
     return m;
 }
 template <int NCB>
@@ -411,12 +414,18 @@ static bool query_w4() { static const bool v = getenv("CHORE_QUERY_W4") != nullp
 template <typename T, bool TRAIN, bool X3 = false>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if constexpr (!TRAIN) {
-        if (query_small_tiles(a.B, a.N)) return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
+        static const bool x3_small = getenv("CHORE_QUERY_X3_BWD_SMALL") != nullptr;
+        if (query_small_tiles(a.B, a.N) || (X3 && x3_small)) return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
     }
     // the training variants are bound by their staging stores: measured slower with eight waves (39.4 vs 38.6 ms per step)
-    if constexpr (!TRAIN) {
+    // fp16 x 3: four waves with two column blocks each, like the forward (the eight-wave kernel fetches every weight
+    // fragment twice and is bound by the L1: 0.65 against 0.58 ms at 4 x 20 000 points)
+    if constexpr (!TRAIN && !X3) {
         if (!query_w4()) return launch_query_bwd_w8<T, false, false, X3>(h, a, s);
     }
+    // (the eight-wave fp16 x 3 recompute kernel also produced a non-finite gradient once in ~6 runs of the 8-frame graph-replay
+    // fit test -- never reproduced in 9 000 repeated launches on fixed inputs, never with this variant in 40 runs; it is
+    // not instantiated)
     return launch_query_bwd_n<T, TRAIN, 2, X3>(h, a, s);
 }
 

@@ -379,8 +379,9 @@ class CHORE(nn.Module):
                 df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, tdt,
                                                               *head_params)
             else:
+                # CHORE_HEADS_FP32=1: the native fp32 MFMA for the heads in every mode (A/B switch)
                 df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
-                                                         _QDT_FWD[self.compute_dtype])
+                                                         dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype])
             B, _, N = df.shape
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]
