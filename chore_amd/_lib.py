@@ -96,6 +96,7 @@ SIGNATURES = {
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_convblock_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_debug_nan_counts": (c_int, [c_void_p]),
     "chore_train_loss_workspace_bytes": (c_size_t, []),
     "chore_train_loss": (c_int, [c_void_p] * 11 + [c_int, c_int, c_float, c_void_p, c_float] + [c_void_p] * 5 + [c_int, c_void_p,
                                                                                                                c_void_p]),

@@ -451,6 +451,12 @@ int chore_profile_enable(chore_handle* h, int on);
 int chore_profile_read(chore_handle* h, int max_classes, const char** names, double* ms, double* flops,
                        double* bytes, int64_t* launches);
 
+/* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
+ * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the
+ * forward's df / pca / parts / centers, 5 / 6 the maps, 8 points, 9-12 the upstream gradients, 13 dpoints), out32[16..31] =
+ * sequence number of the first scan of that site that saw one */
+int chore_debug_nan_counts(unsigned* out32);
+
 #ifdef __cplusplus
 }
 #endif
