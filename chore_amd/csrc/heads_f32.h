@@ -226,3 +226,40 @@ __device__ __forceinline__ void load_mask_bits(unsigned (&m)[4], const unsigned 
         for (int rb = 0; rb < 4; ++rb) m[rb] |= (unsigned)((v >> (16 * rb)) & 0xffffull) << (16 * cb);
     }
 }
+
+// store_tile through a wave-private LDS tile: the D-fragment layout gives every store instruction 32 points x 32 bytes
+// (two lanes per point), i.e. 32-byte segments 512 bytes apart; transposed through [32 points][ST_LD] floats a store
+// instruction covers 8 points x 128 contiguous bytes.  scr: 32 * ST_LD floats owned by the calling wave.
+constexpr int ST_LD = 36;
+template <int NCB>
+__device__ __forceinline__ void store_tile_lds(float* base, const f32x16 (&f)[4][NCB], bool relu_it, size_t row0, int n0, int N,
+                                               int lane, int pt0, const float* mul, float* scr) {
+    const int half = lane >> 5, col = lane & 31, pl = lane >> 3, c4 = lane & 7;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+        const float m = mul ? mul[cb] : 1.f;
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = {f[rb][cb][4 * j], f[rb][cb][4 * j + 1], f[rb][cb][4 * j + 2], f[rb][cb][4 * j + 3]};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (mul) v[e] *= m;
+                    if (relu_it) v[e] = v[e] > 0.f ? v[e] : 0.f;
+                }
+                *(f32x4*)(scr + col * ST_LD + 8 * j + 4 * half) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p = pl + 8 * i, pt = pt0 + cb * 32 + p;
+                const f32x4 v = *(const f32x4*)(scr + p * ST_LD + 4 * c4);
+                if (n0 + pt < N) *(f32x4*)(base + (row0 + pt) * HEAD_HID + rb * 32 + 4 * c4) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+    }
+}

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float* scr = reinterpret_cast<float*>(smem_raw + sizeof(QueryFwdSmemT<PTS>)) + wid * (32 * ST_LD);   // TRAIN only (store_tile_lds)
     int b, tile_;
     query_block(b, tile_);
     const int n0 = tile_ * PTS;
@@ -148,24 +149,24 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     if constexpr (X3) {
         const float inv[1] = {QX_INV};
         heads_layer1_x3<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid_x3<1>(h2, h1, arena, head, 1, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32, inv, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid_x3<1>(h1, h2, arena, head, 2, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, inv, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_out_x3<1>(o, h1, arena, head, lane);
     } else {
         heads_layer1<1>(h1, sm.X + cb0 * 32 * XS, arena, head, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (0 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, nullptr, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (0 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid<1>(h2, h1, arena, head, 1, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (1 * HEAD_NUM + head) * plane, h2, true, row0, n0, a.N, lane, cb0 * 32, nullptr, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (1 * HEAD_NUM + head) * mplane, h2, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_hid<1>(h1, h2, arena, head, 2, lane);
-        if constexpr (TRAIN) store_tile<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32);
+        if constexpr (TRAIN) store_tile_lds<1>(a.tH + (2 * HEAD_NUM + head) * plane, h1, true, row0, n0, a.N, lane, cb0 * 32, nullptr, scr);
         if constexpr (TRAIN) store_masks<1>(a.tM + (2 * HEAD_NUM + head) * mplane, h1, row0, n0, a.N, lane, cb0 * 32);
         heads_layer_out<1>(o, h1, arena, head, lane);
     }
@@ -473,7 +474,7 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
 template <typename T, bool X3 = false>
 static int launch_query_fwd_train_w8(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
-    const size_t smem = sizeof(QueryFwdSmemT<64>);
+    const size_t smem = sizeof(QueryFwdSmemT<64>) + 8 * 32 * ST_LD * sizeof(float);     // + the waves' store-transpose tiles
     if (!attr_set) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_f32_w8_kernel<T, true, X3>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
