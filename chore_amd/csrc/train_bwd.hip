@@ -489,20 +489,39 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int tpr = C / 4, P = 256 / tpr, cv = tid % tpr, pl = tid / tpr;
     const int p0 = (int)((long long)HW * s / S), p1 = (int)((long long)HW * (s + 1) / S);
     float dgam[4] = {0, 0, 0, 0}, dbet[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    for (int p = p0 + pl; p < p1; p += P) {
-        const size_t o = ((size_t)b * HW + p) * C + cv * 4;
-        const f32x4 xv4 = Vec4<T>::ld(x + o), da4 = Vec4<T>::ld(da + o);
+    constexpr int GNB_U = 8;
+    // GNB_U pixels per round, their loads issued together and unconditionally (rows past the share are re-reads of its last
+    // row with a zero weight): one load pair per round left the pass latency-bound at 1.4 TB/s
+    float cm[4], cr[4], csc[4], csh[4], cg[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c = cv * 4 + j;
-            const float xv = xv4[j];
-            const float xh = (xv - mr[4 * c]) * mr[4 * c + 1];
-            const float g = fmaf(xv, mr[4 * c + 2], mr[4 * c + 3]) > 0.f ? da4[j] : 0.f;
-            dbet[j] += g;
-            dgam[j] += g * xh;
-            const float gy = g * gamma[c];
-            s1[j] += gy;
-            s2[j] += gy * xh;
+    for (int j = 0; j < 4; ++j) {
+        const int c = cv * 4 + j;
+        cm[j] = mr[4 * c]; cr[j] = mr[4 * c + 1]; csc[j] = mr[4 * c + 2]; csh[j] = mr[4 * c + 3]; cg[j] = gamma[c];
+    }
+    for (int p = p0 + pl; p < p1; p += GNB_U * P) {
+        f32x4 xq[GNB_U], dq[GNB_U];
+        float live[GNB_U];
+#pragma unroll
+        for (int u = 0; u < GNB_U; ++u) {
+            const int pp = p + u * P;
+            live[u] = pp < p1 ? 1.f : 0.f;
+            const size_t o = ((size_t)b * HW + (pp < p1 ? pp : p1 - 1)) * C + cv * 4;
+            xq[u] = Vec4<T>::ld(x + o);
+            dq[u] = Vec4<T>::ld(da + o);
+        }
+#pragma unroll
+        for (int u = 0; u < GNB_U; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xv = xq[u][j];
+                const float xh = (xv - cm[j]) * cr[j];
+                const float g = fmaf(xv, csc[j], csh[j]) > 0.f ? dq[u][j] * live[u] : 0.f;
+                dbet[j] += g;
+                dgam[j] += g * xh;
+                const float gy = g * cg[j];
+                s1[j] += gy;
+                s2[j] += gy * xh;
+            }
         }
     }
 #pragma unroll
