@@ -555,24 +555,22 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 for (int w = 0; w < WAVES_M; ++w) t[k] += red[(k * WAVES_M + w) * NT + tid];
             const int cg = n_tile * NT + tid;
             if (DBG(a) & 16) return;
-            // channels -> GroupNorm groups of the tensor the slice belongs to (gs consecutive lanes), one lane adds
+            // channels -> GroupNorm groups of the tensor the slice belongs to (gs consecutive lanes).  An add is an atomic
+            // round trip (its carry needs the old value), so the (up to) four sums of a group go out from DIFFERENT lanes
+            // of the group, concurrently, instead of one lane waiting for them in turn.
             if (a.st_raw) {
                 const int gs = a.st_raw_C / GN_GROUPS;
                 const float s1 = group_lane_sum(t[0], gs), s2 = group_lane_sum(t[1], gs);
-                if (tid % gs == 0) {
-                    GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
-                    stat_add(&o->sum, s1);
-                    stat_add(&o->sq, s2);
-                }
+                GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
+                if (tid % gs == 0) stat_add(&o->sum, s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, s2);
             }
             if (a.st_out) {
                 const int gs = a.st_out_C / GN_GROUPS;
                 const float s1 = group_lane_sum(t[2], gs), s2 = group_lane_sum(t[3], gs);
-                if (tid % gs == 0) {
-                    GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
-                    stat_add(&o->sum, s1);
-                    stat_add(&o->sq, s2);
-                }
+                GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
+                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, s1);
+                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, s2);
             }
         }
     }
