@@ -302,20 +302,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
             if (a.st_raw) {
                 const int gs = a.st_raw_C / GN_GROUPS;
                 const float s1 = group_lane_sum(tsum[0], gs), s2 = group_lane_sum(tsum[1], gs);
-                if (tid % gs == 0) {
-                    GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + ch) / gs;
-                    stat_add(&o->sum, s1);
-                    stat_add(&o->sq, s2);
-                }
+                // the group's sums go out from different lanes of the group, concurrently (conv_lds.hip, same place)
+                GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + ch) / gs;
+                if (tid % gs == 0) stat_add(&o->sum, s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, s2);
             }
             if (a.st_out) {
                 const int gs = a.st_out_C / GN_GROUPS;
                 const float s1 = group_lane_sum(tsum[2], gs), s2 = group_lane_sum(tsum[3], gs);
-                if (tid % gs == 0) {
-                    GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + ch) / gs;
-                    stat_add(&o->sum, s1);
-                    stat_add(&o->sq, s2);
-                }
+                GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + ch) / gs;
+                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, s1);
+                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, s2);
             }
         }
     }

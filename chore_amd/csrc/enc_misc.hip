@@ -150,11 +150,9 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         const int gs = C / GN_GROUPS;
         a = group_lane_sum(a, gs);
         q = group_lane_sum(q, gs);
-        if (tid % gs == 0) {
-            GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;
-            stat_add(&o->sum, a);
-            stat_add(&o->sq, q);
-        }
+        GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
+        if (tid % gs == 0) stat_add(&o->sum, a);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, q);
     }
 }
 
@@ -382,11 +380,9 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
         const int gs = C / GN_GROUPS;
         a = group_lane_sum(a, gs);
         q = group_lane_sum(q, gs);
-        if (tid % gs == 0) {
-            GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;
-            stat_add(&o->sum, a);
-            stat_add(&o->sq, q);
-        }
+        GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
+        if (tid % gs == 0) stat_add(&o->sum, a);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, q);
     }
 }
 

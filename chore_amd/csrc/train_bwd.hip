@@ -540,11 +540,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         stat_add(&acc.chan[tid].sum, t[0]);
         stat_add(&acc.chan[tid].sq, t[1]);
         const float g1 = group_lane_sum(t[2], gs), g2 = group_lane_sum(t[3], gs);
-        if (tid % gs == 0) {
-            GroupStat* o = acc.grp + (size_t)b * GN_GROUPS + tid / gs;
-            stat_add(&o->sum, g1);
-            stat_add(&o->sq, g2);
-        }
+        GroupStat* o = acc.grp + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
+        if (tid % gs == 0) stat_add(&o->sum, g1);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, g2);
     }
 }
 
