@@ -1,0 +1,95 @@
+// fit_step.hip -- the optimiser update and the early-stop bookkeeping of one inner fitting step, two launches.
+//
+// An inner step of recon_fit_behave.py:143-160, 270-287 ends with Adam on a handful of tiny tensors (pose 72, betas 10,
+// translation 3 per frame; object rotation / translation / scale) and the stop rule  |prev - loss| / prev < prev * tol.
+// Written with tensor ops that is ~35 launches per step (multi-tensor Adam with device-side bias corrections, clones of
+// the parameters so that a latched stop can undo the update, the rule itself) in a step of ~190; here it is one launch
+// for the update of all tensors and one single-thread launch for the rule and the step counter.
+// Adam as torch.optim.Adam(capturable=True) evaluates it (torch/optim/adam.py, _multi_tensor_adam):
+//     m += (g - m) (1 - b1);  v = b2 v + (1 - b2) g g;  step_size = -lr / (1 - b1^t);
+//     p += m / ( sqrt(v) / (sqrt(1 - b2^t) step_size) + eps / step_size )
+// `stop` (latched by an earlier step): the moments and the counter still advance, the parameters stay (the reference
+// has returned by then; everything after the latch is a no-op for the result).
+#include "common.h"
+
+namespace {
+
+constexpr int FS_MAXT = 8;
+struct AdamTensors {
+    float* p[FS_MAXT]; const float* g[FS_MAXT]; float* m[FS_MAXT]; float* v[FS_MAXT];
+    int n[FS_MAXT];
+    int nt;
+};
+
+__global__ void fit_adam_kernel(AdamTensors t, const float* step, float lr, float b1, float b2, float eps, const unsigned char* stop) {
+    const int k = blockIdx.y;
+    const bool frozen = *stop != 0;
+    const float s = *step + 1.0f;
+    const float bc1 = 1.0f - powf(b1, s), bc2 = 1.0f - powf(b2, s);
+    const float step_size = -(lr / bc1);
+    const float bc2s = sqrtf(bc2);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n[k]; i += gridDim.x * blockDim.x) {
+        const float g = t.g[k][i];
+        float m = t.m[k][i], v = t.v[k][i];
+        m = m + (g - m) * (1.0f - b1);
+        v = v * b2 + (1.0f - b2) * g * g;
+        t.m[k][i] = m; t.v[k][i] = v;
+        if (!frozen) {
+            const float denom = sqrtf(v) / (bc2s * step_size) + eps / step_size;
+            t.p[k][i] += m / denom;
+        }
+    }
+}
+
+__global__ void fit_stop_rule_kernel(const float* loss, float* prev, unsigned char* stop, const unsigned char* armed, float tol,
+                                     float* loss_out, float* step) {
+    if (threadIdx.x || blockIdx.x) return;
+    const bool frozen = *stop != 0;
+    const float lv = *loss, pv = *prev;
+    const bool hit = fabsf(pv - lv) / pv < pv * tol;
+    if (hit && *armed) *stop = 1;
+    if (!frozen) *prev = lv;
+    *loss_out = lv;
+    if (step) *step += 1.0f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// One Adam step on nt <= 8 fp32 device tensors (p, g, m, v: host arrays of device pointers, n: their lengths).  step: device
+// float, the number of steps taken so far (NOT incremented here: chore_fit_stop_rule does, after this launch); stop: device
+// byte, nonzero = leave the parameters alone.
+int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
+                        int nt, const float* step, float lr, float beta1, float beta2, float eps, const uint8_t* stop,
+                        chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!p || !g || !m || !v || !n || !step || !stop || nt <= 0 || nt > FS_MAXT)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step: bad argument (at most %d tensors)", FS_MAXT);
+    AdamTensors t;
+    int nmax = 0;
+    for (int k = 0; k < nt; ++k) {
+        if (!p[k] || !g[k] || !m[k] || !v[k] || n[k] <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step: null tensor %d", k);
+        t.p[k] = p[k]; t.g[k] = g[k]; t.m[k] = m[k]; t.v[k] = v[k]; t.n[k] = n[k];
+        nmax = n[k] > nmax ? n[k] : nmax;
+    }
+    t.nt = nt;
+    int bx = (nmax + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(fit_adam_kernel, dim3(bx, nt), dim3(256), 0, (hipStream_t)stream, t, step, lr, beta1, beta2, eps, stop);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+
+// the stop rule of one inner step: hit = |prev - loss| / prev < prev * tol;  stop |= hit & armed;  prev = loss unless stop was
+// already set;  loss_out = loss;  step (or NULL) += 1.  All device scalars.
+int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
+                        float* loss_out, float* step, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!loss || !prev || !stop || !armed || !loss_out) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_stop_rule: null argument");
+    hipLaunchKernelGGL(fit_stop_rule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, prev, stop, armed, tol, loss_out, step);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+
+}  // extern "C"

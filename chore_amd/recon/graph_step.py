@@ -13,8 +13,60 @@ outer iteration; the caller zeroes them through `begin_outer`; the early-stop ru
 everything after the step that meets it is a no-op, which equals the reference's immediate return).  Adam runs with capturable=True in the graph
 stepper (same formulas evaluated on the device).
 """
+import ctypes
+import os
+
 import torch
 from torch import optim
+
+from .. import _lib
+
+
+class FusedAdam:
+    """torch.optim.Adam(params, lr, betas, capturable=True) for a handful of small fp32 device tensors as ONE launch
+    (chore_fit_adam_step, csrc/fit_step.hip), gated by the stepper's latched stop flag.  Same formulas, same state (step
+    count, exp_avg, exp_avg_sq); the reference builds exactly this optimiser (recon_fit_behave.py:108, 236, 246)."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
+        self.params = list(params)
+        if not 0 < len(self.params) <= 8 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.params):
+            raise ValueError("FusedAdam: 1..8 contiguous fp32 device tensors")
+        self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
+        dev = self.params[0].device
+        self.step_t = torch.zeros((), device=dev)
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        self._args = None
+
+    def state_tensors(self):
+        return [self.step_t] + self.m + self.v
+
+    def step(self, stop):
+        """stop: device bool scalar; the step counter is advanced by the stop-rule launch that follows (EagerStep._one)"""
+        live = [(p, p.grad, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        key = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _ in live)
+        if self._args is None or self._args[0] != key:
+            n = len(live)
+            arr = lambda xs: (ctypes.c_void_p * n)(*xs)   # noqa: E731
+            self._args = (key, arr([p.data_ptr() for p, _, _, _ in live]), arr([g.data_ptr() for _, g, _, _ in live]),
+                          arr([m.data_ptr() for _, _, m, _ in live]), arr([v.data_ptr() for _, _, _, v in live]),
+                          (ctypes.c_int * n)(*[p.numel() for p, _, _, _ in live]), n)
+        _, pp, gg, mm, vv, nn, n = self._args
+        if n == 0:
+            return
+        dev = self.params[0].device
+        for _, g, _, _ in live:
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                raise ValueError("FusedAdam: gradients must be contiguous fp32")
+        h = _lib.handle(dev.index or 0)
+        _lib.check(_lib.lib.chore_fit_adam_step(h, pp, gg, mm, vv, nn, n, self.step_t.data_ptr(), self.lr, self.betas[0],
+                                                self.betas[1], self.eps, stop.data_ptr(),
+                                                torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step")
+
+
+def _fused_ok(params):
+    return (not os.environ.get("CHORE_FIT_TORCH_ADAM")) and 0 < len(params) <= 8 and all(
+        p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
 
 
 class _OnePlusDecay:
@@ -39,9 +91,20 @@ class EagerStep:
         carry: parameters this phase does not step but whose .grad keeps accumulating (every leaf the loss reaches does in
         the reference, and a later phase's new Adam starts from those sums, recon_fit_behave.py:243-259)"""
         self.params = list(params)
-        self.opt = opt if opt is not None else optim.Adam(self.params, lr=lr, betas=betas, capturable=capturable)
+        self.opt = opt if opt is not None else self._make_opt(lr, betas, capturable)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
         self._init_flags(self.params[0].device)
+
+    def _make_opt(self, lr, betas, capturable):
+        """the reference's Adam: as one HIP launch where the tensors allow (CHORE_FIT_TORCH_ADAM=1: torch's)"""
+        if _fused_ok(self.params):
+            return FusedAdam(self.params, lr, betas)
+        return optim.Adam(self.params, lr=lr, betas=betas, capturable=capturable)
+
+    def _opt_state_tensors(self):
+        if isinstance(self.opt, FusedAdam):
+            return self.opt.state_tensors()
+        return [v for st in self.opt.state.values() for v in st.values() if torch.is_tensor(v)]
 
     def _init_flags(self, dev):
         self.denom = torch.ones((), device=dev)           # 1 + decay
@@ -69,6 +132,21 @@ class EagerStep:
         # update (recon_fit_behave.py:158-160, 278-285).  Here the host looks at the flag once per outer iteration, so
         # the remaining inner steps still run -- as no-ops: once `stop` is latched every later step leaves the
         # parameters and the previous loss as they were.
+        if isinstance(self.opt, FusedAdam):
+            # two launches: Adam on all tensors (the latched flag freezes the parameters), then the stop rule + step counter
+            loss = self.loss_fn(_OnePlusDecay(self.denom))
+            loss.backward()
+            self.opt.step(self.stop)
+            lv = loss.detach()
+            if lv.dtype != torch.float32:
+                lv = lv.float()
+            dev = lv.device
+            h = _lib.handle(dev.index or 0)
+            _lib.check(_lib.lib.chore_fit_stop_rule(h, lv.data_ptr(), self.prev.data_ptr(), self.stop.data_ptr(),
+                                                    self.armed.data_ptr(), float(self.tol), self.loss.data_ptr(),
+                                                    self.opt.step_t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+                       h, "chore_fit_stop_rule")
+            return
         frozen = self.stop.clone()
         saved = [p.detach().clone() for p in self.params]
         loss = self.loss_fn(_OnePlusDecay(self.denom))
@@ -105,12 +183,12 @@ class GraphedStep(EagerStep):
         for p in self.params + carry:
             if p.grad is None:       # a recorded backward must ADD into a tensor that exists (a missing .grad would be
                 p.grad = torch.zeros_like(p)   # replaced by a graph-private tensor and overwritten on every replay)
-        self.opt = opt if opt is not None else optim.Adam(self.params, lr=lr, betas=betas, capturable=True)
+        self.opt = opt if opt is not None else self._make_opt(lr, betas, True)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
         self._init_flags(dev)
         mutable = [p.data for p in self.params] + [p.grad for p in self.params + carry] + [self.prev, self.stop, self.loss]
         mutable += list(state)
-        mutable += [v for st in self.opt.state.values() for v in st.values() if torch.is_tensor(v)]   # continued Adam
+        mutable += self._opt_state_tensors()   # a continued Adam (torch's creates its state lazily; see _restore)
         snap = [t.clone() for t in mutable]
         known = {id(t) for t in mutable}
         self.release = release
@@ -133,10 +211,9 @@ class GraphedStep(EagerStep):
         with torch.no_grad():
             for t, s in zip(mutable, snap):
                 t.copy_(s)
-            for st in self.opt.state.values():   # state created lazily by the warm-up = a fresh optimiser: zero
-                for v in st.values():
-                    if torch.is_tensor(v) and id(v) not in known:
-                        v.zero_()
+            for v in self._opt_state_tensors():   # state created lazily by the warm-up = a fresh optimiser: zero
+                if id(v) not in known:
+                    v.zero_()
         if self.release is not None:
             self.release()   # results memoised during the warm-up are stale now (.data writes bump no version)
 

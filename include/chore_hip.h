@@ -451,6 +451,17 @@ int chore_profile_enable(chore_handle* h, int on);
 int chore_profile_read(chore_handle* h, int max_classes, const char** names, double* ms, double* flops,
                        double* bytes, int64_t* launches);
 
+/* The tail of one inner fitting step (reference recon/recon_fit_behave.py:143-160, 270-287): Adam -- the formulas of
+ * torch.optim.Adam(capturable=True) -- on nt <= 8 small fp32 tensors in one launch, and the early-stop rule
+ * |prev - loss| / prev < prev * tol with its latch in another.  p / g / m / v: host arrays of device pointers, n: lengths;
+ * step, prev, loss, loss_out: device floats; stop, armed: device bytes.  A set `stop` freezes the parameters (the moments and
+ * the counter still advance).  chore_fit_stop_rule increments `step` (if not NULL): call it after chore_fit_adam_step. */
+int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g, float* const* m, float* const* v,
+                        const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
+                        const uint8_t* stop, chore_stream_t stream);
+int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
+                        float* loss_out, float* step, chore_stream_t stream);
+
 /* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
  * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the
  * forward's df / pca / parts / centers, 5 / 6 the maps, 8 points, 9-12 the upstream gradients, 13 dpoints), out32[16..31] =
