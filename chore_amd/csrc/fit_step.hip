@@ -53,6 +53,21 @@ __global__ void fit_stop_rule_kernel(const float* loss, float* prev, unsigned ch
     if (step) *step += 1.0f;
 }
 
+constexpr int FS_MAXL = 16;
+struct LossTerms { const float* l[FS_MAXL]; float c[FS_MAXL]; int n; };
+
+__global__ void fit_weighted_sum_kernel(LossTerms t, const float* denom, float* out) {
+    if (threadIdx.x || blockIdx.x) return;
+    const float d = *denom;
+    float s = 0.f;
+    for (int k = 0; k < t.n; ++k) s += t.c[k] * *t.l[k] / d;      // the reference's c * L / (1 + it), summed in dict order
+    *out = s;
+}
+__global__ void fit_weighted_sum_bwd_kernel(LossTerms t, const float* denom, const float* g, float* grads) {
+    const int k = threadIdx.x;
+    if (k < t.n) grads[k] = *g * t.c[k] / *denom;
+}
+
 }  // namespace
 
 extern "C" {
@@ -88,6 +103,32 @@ int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t
     CHORE_ENTER(h);
     if (!loss || !prev || !stop || !armed || !loss_out) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_stop_rule: null argument");
     hipLaunchKernelGGL(fit_stop_rule_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, loss, prev, stop, armed, tol, loss_out, step);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+
+// out = sum_k coeff[k] * loss[k] / denom over n <= 16 device scalars (losses: host array of device pointers; coeffs: host
+// floats; denom, out: device floats) -- the weighting of the fit's loss dictionary, recon_fit_behave.py:339-358 -- and its
+// backward: grads[k] = g * coeff[k] / denom.
+int chore_fit_weighted_sum(chore_handle* h, const float* const* losses, const float* coeffs, int n, const float* denom, float* out,
+                           chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!losses || !coeffs || !denom || !out || n <= 0 || n > FS_MAXL) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_weighted_sum: bad argument");
+    LossTerms t;
+    for (int k = 0; k < n; ++k) { t.l[k] = losses[k]; t.c[k] = coeffs[k]; if (!losses[k]) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_weighted_sum: null term"); }
+    t.n = n;
+    hipLaunchKernelGGL(fit_weighted_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, denom, out);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+int chore_fit_weighted_sum_bwd(chore_handle* h, const float* coeffs, int n, const float* denom, const float* g, float* grads,
+                               chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!coeffs || !denom || !g || !grads || n <= 0 || n > FS_MAXL) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_weighted_sum_bwd: bad argument");
+    LossTerms t;
+    for (int k = 0; k < n; ++k) { t.l[k] = nullptr; t.c[k] = coeffs[k]; }
+    t.n = n;
+    hipLaunchKernelGGL(fit_weighted_sum_bwd_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, t, denom, g, grads);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
     return CHORE_OK;
 }

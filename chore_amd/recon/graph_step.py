@@ -64,6 +64,42 @@ class FusedAdam:
                                                 torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step")
 
 
+class _WeightedSum(torch.autograd.Function):
+    """sum_k c_k L_k / denom over device scalars (chore_fit_weighted_sum, csrc/fit_step.hip)"""
+
+    @staticmethod
+    def forward(ctx, denom, coeffs, *losses):
+        dev = denom.device
+        h = _lib.handle(dev.index or 0)
+        n = len(losses)
+        out = torch.empty((), device=dev)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in losses])
+        cs = (ctypes.c_float * n)(*coeffs)
+        _lib.check(_lib.lib.chore_fit_weighted_sum(h, ptrs, cs, n, denom.data_ptr(), out.data_ptr(),
+                                                   torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_weighted_sum")
+        ctx.save_for_backward(denom)
+        ctx.cs, ctx.n = cs, n
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (denom,) = ctx.saved_tensors
+        dev = denom.device
+        h = _lib.handle(dev.index or 0)
+        g = g.contiguous().float()
+        grads = torch.empty(ctx.n, device=dev)
+        _lib.check(_lib.lib.chore_fit_weighted_sum_bwd(h, ctx.cs, ctx.n, denom.data_ptr(), g.data_ptr(), grads.data_ptr(),
+                                                       torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_fit_weighted_sum_bwd")
+        return (None, None) + tuple(grads[k] for k in range(ctx.n))
+
+
+def weighted_sum(losses, coeffs, denom):
+    if os.environ.get("CHORE_FIT_TORCH_SUM"):
+        return torch.stack([c * v / denom for c, v in zip(coeffs, losses)]).sum()
+    return _WeightedSum.apply(denom, tuple(coeffs), *losses)
+
+
 def _fused_ok(params):
     return (not os.environ.get("CHORE_FIT_TORCH_ADAM")) and 0 < len(params) <= 8 and all(
         p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)

@@ -420,6 +420,14 @@ class ReconFitterBase:
     # ---- loss terms --------------------------------------------------------------------------------
     @staticmethod
     def sum_dict(loss_dict, weight_dict, it):
+        """[recon_fit_behave.py:339-358] sum_k w_k(L_k, it) with w_k = c_k * L / (1 + it).  Inside the steppers `it` stands for
+        a device scalar (graph_step._OnePlusDecay) and the terms are device scalars: one launch computes the sum and one its
+        backward (csrc/fit_step.hip) instead of two tensor ops per term, a stack and a reduction, each way."""
+        from .graph_step import _OnePlusDecay, weighted_sum
+        vals = list(loss_dict.values())
+        if isinstance(it, _OnePlusDecay) and vals and all(torch.is_tensor(v) and v.is_cuda and v.dim() == 0 and
+                                                          v.dtype == torch.float32 for v in vals) and len(vals) <= 16:
+            return weighted_sum(vals, [float(weight_dict[k](1.0, 0)) for k in loss_dict], it.denom)
         return torch.stack([weight_dict[k](v, it) for k, v in loss_dict.items()]).sum()
 
     def compute_obj_loss(self, data_dict, loss_dict, model, obj_s, object):

@@ -461,6 +461,12 @@ int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g,
                         const uint8_t* stop, chore_stream_t stream);
 int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
                         float* loss_out, float* step, chore_stream_t stream);
+/* the weighting of the fit's loss dictionary (recon_fit_behave.py:339-358): out = sum_k coeff[k] * loss[k] / denom over
+ * n <= 16 device scalars (losses: host array of device pointers; coeffs: host floats), and grads[k] = g * coeff[k] / denom */
+int chore_fit_weighted_sum(chore_handle* h, const float* const* losses, const float* coeffs, int n, const float* denom,
+                           float* out, chore_stream_t stream);
+int chore_fit_weighted_sum_bwd(chore_handle* h, const float* coeffs, int n, const float* denom, const float* g, float* grads,
+                               chore_stream_t stream);
 
 /* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
  * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the
