@@ -41,6 +41,7 @@ struct HeadsWgradArgs {
     float* part4;          // [4][S4][14*128]
     float* part_b4;        // [4][S4][16]
     float* out;            // parameter gradients, module order per head: W1 b1 W2 b2 W3 b3 W4 b4
+    int accumulate;        // != 0: added to what `out` holds (the stacks of a step share one gradient arena)
 };
 
 __host__ __device__ inline size_t head_grad_floats(int k) {
@@ -368,8 +369,9 @@ __global__ void heads_wgrad_finish_kernel(HeadsWgradArgs a) {
         float sum = 0.f;
         for (int k = 0; k < HW_S; ++k) sum += a.part[((size_t)t * HW_S + k) * 16384 + e];
         float* o = a.out + head_grad_offset(head);
-        if (sub < 3) o[(size_t)m * HEAD_IN + sub * 128 + n] = sum;
-        else o[(size_t)HEAD_HID * HEAD_IN + HEAD_HID + (size_t)(sub - 3) * (HEAD_HID * HEAD_HID + HEAD_HID) + m * HEAD_HID + n] = sum;
+        float* dst = sub < 3 ? o + (size_t)m * HEAD_IN + sub * 128 + n
+                             : o + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + (size_t)(sub - 3) * (HEAD_HID * HEAD_HID + HEAD_HID) + m * HEAD_HID + n;
+        *dst = a.accumulate ? *dst + sum : sum;
     } else if (i < N2) {
         const int j = (int)(i - N1), t = j >> 7, m = j & 127, head = t / 5, sub = t % 5;
         if (sub == 1 || sub == 2) return;
@@ -377,20 +379,22 @@ __global__ void heads_wgrad_finish_kernel(HeadsWgradArgs a) {
         for (int k = 0; k < HW_S; ++k) sum += a.part_b[((size_t)t * HW_S + k) * 128 + m];
         float* o = a.out + head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN;
         if (sub >= 3) o += HEAD_HID + (size_t)(sub - 3) * (HEAD_HID * HEAD_HID + HEAD_HID) + (size_t)HEAD_HID * HEAD_HID;
-        o[m] = sum;
+        o[m] = a.accumulate ? o[m] + sum : sum;
     } else if (i < N3) {
         const int j = (int)(i - N2), head = j / (HW_OMAX * 128), e = j % (HW_OMAX * 128), od = head_out_dim(head);
         if (e >= od * 128) return;
         float sum = 0.f;
         for (int k = 0; k < HW_S4; ++k) sum += a.part4[((size_t)head * HW_S4 + k) * (HW_OMAX * 128) + e];
-        a.out[head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) + e] = sum;
+        float* dst = a.out + head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) + e;
+        *dst = a.accumulate ? *dst + sum : sum;
     } else if (i < N4) {
         const int j = (int)(i - N3), head = j >> 4, o = j & 15, od = head_out_dim(head);
         if (o >= od) return;
         float sum = 0.f;
         for (int k = 0; k < HW_S4; ++k) sum += a.part_b4[((size_t)head * HW_S4 + k) * 16 + o];
-        a.out[head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) +
-              (size_t)od * HEAD_HID + o] = sum;
+        float* dst = a.out + head_grad_offset(head) + (size_t)HEAD_HID * HEAD_IN + HEAD_HID + 2 * ((size_t)HEAD_HID * HEAD_HID + HEAD_HID) +
+                     (size_t)od * HEAD_HID + o;
+        *dst = a.accumulate ? *dst + sum : sum;
     }
 }
 
@@ -409,6 +413,9 @@ size_t chore_heads_wgrad_workspace_bytes(void) { return (HW_PART + HW_PART_B + H
 int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
                       const float* g_parts, const float* g_centers, float* grads, void* workspace, int heads_x3,
                       chore_stream_t stream) {
+    // heads_x3 bit 0: fp16 x 3 arithmetic; bit 1: ADD to `grads` instead of overwriting it
+    const int accumulate = (heads_x3 >> 1) & 1;
+    heads_x3 &= 1;
     CHORE_ENTER(h);
     if (!staging || !g_df || !g_pca || !g_parts || !g_centers || !grads || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_heads_wgrad: null argument");
@@ -425,7 +432,7 @@ int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const 
     a.part_b = a.part + HW_PART;
     a.part4 = a.part_b + HW_PART_B;
     a.part_b4 = a.part4 + HW_PART4;
-    a.out = grads;
+    a.out = grads; a.accumulate = accumulate;
     const size_t smem = (size_t)2 * HW_KT * 256 * sizeof(float);
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {

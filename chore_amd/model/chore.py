@@ -101,7 +101,7 @@ class _QueryTrainFn(torch.autograd.Function):
     ODIM = (2, 14, 9, 6)
 
     @staticmethod
-    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype, *params):
+    def forward(ctx, points, crop_center, feat, tmpx, arena, cam6, dtype, share, *params):
         B, N, _ = points.shape
         dev = points.device
         h = _lib.handle(dev.index or 0)
@@ -120,7 +120,7 @@ class _QueryTrainFn(torch.autograd.Function):
                                                   pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), in_img.data_ptr(),
                                                   staging.data_ptr(), stream), h, "chore_query_fwd_train")
         ctx.save_for_backward(points, crop_center, feat, tmpx, arena, in_img, staging)
-        ctx.cam6, ctx.dtype = cam6, dtype
+        ctx.cam6, ctx.dtype, ctx.share = cam6, dtype, share
         return df, pca, parts, centers
 
     @staticmethod
@@ -153,14 +153,29 @@ class _QueryTrainFn(torch.autograd.Function):
 
         # all 32 parameter gradients from the staged rows in three launches (heads_wgrad.hip)
         g_c = [t.float().contiguous() for t in g_out]
-        garena = torch.empty(_lib.lib.chore_heads_wgrad_floats(), device=dev)
+        # The stacks of one forward share ONE gradient arena: the first backward writes it, the others add to it inside
+        # the kernel, and only the last one hands the 32 views to autograd (the rest return None = zero) -- instead of
+        # 32 AccumulateGrad additions per further stack.
+        share = ctx.share
+        first = last = True
+        if share is not None:
+            first = share["arena"] is None
+            if first:
+                share["arena"] = torch.empty(_lib.lib.chore_heads_wgrad_floats(), device=dev)
+            share["done"] += 1
+            last = share["done"] == share["n"]
+            garena = share["arena"]
+            if last:
+                share["arena"], share["done"] = None, 0
+        else:
+            garena = torch.empty(_lib.lib.chore_heads_wgrad_floats(), device=dev)
         ws = torch.empty(_lib.lib.chore_heads_wgrad_workspace_bytes(), dtype=torch.uint8, device=dev)
         _lib.check(_lib.lib.chore_heads_wgrad(h, staging.data_ptr(), B, N, g_c[0].data_ptr(), g_c[2].data_ptr(),
                                               g_c[1].data_ptr(), g_c[3].data_ptr(), garena.data_ptr(), ws.data_ptr(),
-                                              1 if (ctx.dtype & _lib.HEADS_X3) else 0, stream),
+                                              (1 if (ctx.dtype & _lib.HEADS_X3) else 0) | (0 if first else 2), stream),
                    h, "chore_heads_wgrad")
         o = 0
-        for k in range(4):                                            # module order = kernel head order
+        for k in range(4 if last else 0):                             # module order = kernel head order
             od = g_out[k].shape[1]
             for j, shape in enumerate(((HD, 323, 1), (HD,), (HD, HD, 1), (HD,), (HD, HD, 1), (HD,), (od, HD, 1), (od,))):
                 n = 1
@@ -179,7 +194,7 @@ class _QueryTrainFn(torch.autograd.Function):
                        "chore_scatter_features")
             dfeat = None if dfe is None else dfe.permute(0, 3, 1, 2).to(feat.dtype)
             dtmpx = None if dtm is None else dtm.permute(0, 3, 1, 2).to(tmpx.dtype)
-        return (dpoints, None, dfeat, dtmpx, None, None, None) + tuple(grads)
+        return (dpoints, None, dfeat, dtmpx, None, None, None, None) + tuple(grads)
 
 
 def _mlp(input_sz, output_sz, hidden_sz):
@@ -368,6 +383,13 @@ class CHORE(nn.Module):
             self.intermediate_preds_list = [(z(B, 2, 0), z(B, 3, 3, 0), z(B, 14, 0), z(B, 6, 0)) for _ in self.im_feat_list]
             self.preds = self.intermediate_preds_list[-1]
             return
+        # (training) one gradient arena for the head parameters over all stacks, see _QueryTrainFn.backward.  Only inside
+        # CHORE.forward, whose loss reaches every stack (get_errors sums over all of them): a backward that does not visit
+        # all the nodes must not share.  CHORE_HEADS_NO_SHARE=1 switches it off.
+        share = None
+        if train and len(self.im_feat_list) > 1 and getattr(self, "_share_head_grads", False) and \
+                not os.environ.get("CHORE_HEADS_NO_SHARE"):
+            share = {"n": len(self.im_feat_list), "done": 0, "arena": None}
         for feat in self.im_feat_list:
             if train:
                 # the bf16 training mode runs the heads' GEMMs on the fp16 matrix cores with split operands (fp32-grade,
@@ -376,7 +398,7 @@ class CHORE(nn.Module):
                 if x3 is None:
                     x3 = self.compute_dtype != "fp32" and not os.environ.get("CHORE_HEADS_FP32")
                 tdt = dtype | (_lib.HEADS_X3 if x3 else 0)
-                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, tdt,
+                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, tdt, share,
                                                               *head_params)
             else:
                 # CHORE_HEADS_FP32=1: the native fp32 MFMA for the heads in every mode (A/B switch)
@@ -398,7 +420,11 @@ class CHORE(nn.Module):
     def forward(self, images, points, df_h, df_o, parts_gt, pca_gt, body_center=None, max_dist=5.0,
                 obj_center=None, crop_center=None, **kwargs):
         self.filter(images)
-        self.query(points=points, crop_center=crop_center, **kwargs)
+        self._share_head_grads = True          # the loss below reaches every stack (see query)
+        try:
+            self.query(points=points, crop_center=crop_center, **kwargs)
+        finally:
+            self._share_head_grads = False
         return self.get_errors(df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs)
 
     def get_errors(self, df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs):

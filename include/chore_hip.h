@@ -152,7 +152,8 @@ size_t chore_heads_wgrad_floats(void);
 size_t chore_heads_wgrad_workspace_bytes(void);
 int chore_heads_wgrad(chore_handle* h, const void* staging, int B, int N, const float* g_df, const float* g_pca,
                       const float* g_parts, const float* g_centers, float* grads, void* workspace,
-                      int heads_x3 /* != 0: fp16 matrix cores, split operands, per-chunk scales (see CHORE_HEADS_X3) */,
+                      int heads_x3 /* bit 0: fp16 matrix cores, split operands, per-chunk scales (see CHORE_HEADS_X3); bit 1: add to
+                                      `grads` instead of overwriting (the stacks of a step into one arena) */,
                       chore_stream_t stream);
 int chore_scatter_features(chore_handle* h, const float* points, const float* crop_center, int B, int N, int FH, int FW,
                            int TH, int TW, const float* camera, const void* staging, float* dfeat, float* dtmpx,
