@@ -328,17 +328,19 @@ __global__ __launch_bounds__(256) void heads_out_wgrad_kernel(HeadsWgradArgs a) 
         }
         __syncthreads();
         const int p0 = chunk * 64 + half * 32;
-#pragma unroll 2
-        for (int q = 0; q < 32; q += 4) {
-            float hv[4];
+        // the thread's 32 activation values of the chunk first (unconditional, clamped loads: the rows past the end meet a
+        // zero gradient), then the FMAs -- four loads per round left this pass latency-bound at 0.4 TB/s
+        float hv[32];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hv[e] = p0 + q + e < P ? H3[(size_t)(p0 + q + e) * HEAD_HID + c] : 0.f;
+        for (int e = 0; e < 32; ++e) hv[e] = H3[(size_t)(p0 + e < P ? p0 + e : P - 1) * HEAD_HID + c];
+#pragma unroll
+        for (int q = 0; q < 32; q += 4) {
 #pragma unroll
             for (int o = 0; o < HW_OMAX; ++o)
                 if (o < od) {
                     const f32x4 g4 = *(const f32x4*)&gl[o][half * 32 + q];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[o] = fmaf(g4[e], hv[e], acc[o]);
+                    for (int e = 0; e < 4; ++e) acc[o] = fmaf(g4[e], hv[q + e], acc[o]);
                 }
         }
         if (tid < od)
