@@ -473,8 +473,9 @@ __device__ __forceinline__ float up2_weight(int o, int l, int n) {
 template <typename T>
 __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dlow, int C, int H, int W,
                                                       size_t total4) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
+    const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i0 < total4;
+    const size_t i = live ? i0 : total4 - 1;      // every lane takes part in the weight broadcast below
     const int tpr = C / 4;
     const int cv = (int)(i % tpr);
     size_t p = i / tpr;
@@ -484,10 +485,24 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
     constexpr int NC = 12;
     const int oy0 = max(0, 2 * ly - 5), ox0 = max(0, 2 * lx - 5);
     float wy[NC], wx[NC];
+    if (tpr >= 2 * NC) {
+        // the tpr threads of a pixel need the same 24 weights (each a cubic in a floor-ed coordinate): one lane each,
+        // then broadcasts, instead of 24 evaluations per thread
+        const int lane = threadIdx.x & 63, base = lane - (lane % tpr), j = lane % tpr;
+        float mine = 0.f;
+        if (j < NC) mine = (oy0 + j < 2 * H) ? up2_weight(oy0 + j, ly, H) : 0.f;
+        else if (j < 2 * NC) mine = (ox0 + j - NC < 2 * W) ? up2_weight(ox0 + j - NC, lx, W) : 0.f;
 #pragma unroll
-    for (int k = 0; k < NC; ++k) {
-        wy[k] = (oy0 + k < 2 * H) ? up2_weight(oy0 + k, ly, H) : 0.f;
-        wx[k] = (ox0 + k < 2 * W) ? up2_weight(ox0 + k, lx, W) : 0.f;
+        for (int k = 0; k < NC; ++k) {
+            wy[k] = __shfl(mine, base + k, 64);
+            wx[k] = __shfl(mine, base + NC + k, 64);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            wy[k] = (oy0 + k < 2 * H) ? up2_weight(oy0 + k, ly, H) : 0.f;
+            wx[k] = (ox0 + k < 2 * W) ? up2_weight(ox0 + k, lx, W) : 0.f;
+        }
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -495,17 +510,19 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
         if (wy[ky] == 0.f) continue;
         f32x4 row = {0.f, 0.f, 0.f, 0.f};
         const T* src = dy + (((size_t)b * 2 * H + oy0 + ky) * 2 * W) * C + cv * 4;
+        // the row's 12 candidate columns with unconditional (clamped) loads, all in flight together: the zero weights at the
+        // ends cost a multiply, a branch per tap cost a round trip each
+        f32x4 v[NC];
 #pragma unroll
-        for (int kx = 0; kx < NC; ++kx) {
-            if (wx[kx] == 0.f) continue;
-            const f32x4 v = Vec4<T>::ld(src + (size_t)(ox0 + kx) * C);
+        for (int kx = 0; kx < NC; ++kx) v[kx] = Vec4<T>::ld(src + (size_t)min(ox0 + kx, 2 * W - 1) * C);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) row[e] = fmaf(v[e], wx[kx], row[e]);
-        }
+        for (int kx = 0; kx < NC; ++kx)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) row[e] = fmaf(v[kx][e], wx[kx], row[e]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[e] = fmaf(row[e], wy[ky], acc[e]);
     }
-    Vec4<T>::st(dlow + i * 4, acc);
+    if (live) Vec4<T>::st(dlow + i * 4, acc);
 }
 
 int launch_up2_bwd(chore_handle* h, int dtype, const void* dy, void* dlow, int B, int H, int W, int C, hipStream_t s) {
