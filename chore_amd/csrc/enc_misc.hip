@@ -11,10 +11,14 @@
 
 // ------------------------------------------------------------------------------------------------
 // stem: conv 7x7 stride 2 pad 3, Cin(5) -> 64, + bias      (model/HGFilters.py:102,149)
-// block = 8x8 output pixels x 4 groups of 16 channels; input patch and weights staged in LDS.
+// block = 16x16 output pixels x 4 groups of 16 channels (one wave each); the input patch staged in LDS.  A thread
+// owns 4 horizontally adjacent pixels x 16 channels: per kernel row it reads the 13 input values the four pixels share once,
+// and every weight vector it fetches feeds 4 pixels -- 0.09 LDS instructions per FMA (one pixel per thread: 0.31, and the
+// 63 KB of weights were staged once per 64 pixels).  The accumulation order (c, ky, kx) is that of the one-pixel kernel:
+// results are bit-identical.
 // ------------------------------------------------------------------------------------------------
-constexpr int STEM_T = 8;
-constexpr int STEM_P = 2 * STEM_T + 5;  // 21
+constexpr int STEM_T = 16;
+constexpr int STEM_P = 2 * STEM_T + 5;  // 37
 constexpr int STEM_MAXC = 8;
 
 template <typename T>
@@ -22,12 +26,10 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
                                                    const float* __restrict__ wk, const float* __restrict__ bias,
                                                    T* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* wl = sm;                       // [Cin*49][64]
-    float* patch = sm + Cin * 49 * 64;    // [Cin][21][21]
+    float* patch = sm;                    // [Cin][37][37]
     const int OH = H / 2, OW = W / 2;
     const int b = blockIdx.z, ty0 = blockIdx.y * STEM_T, tx0 = blockIdx.x * STEM_T;
     const int tid = threadIdx.x;
-    for (int i = tid; i < Cin * 49 * 64 / 4; i += 256) ((f32x4*)wl)[i] = ((const f32x4*)wk)[i];
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
     for (int i = tid; i < Cin * STEM_P * STEM_P; i += 256) {
         const int c = i / (STEM_P * STEM_P), r = i % (STEM_P * STEM_P);
@@ -37,35 +39,52 @@ __global__ __launch_bounds__(256) void stem_kernel(const float* __restrict__ img
         patch[i] = v;
     }
     __syncthreads();
-    const int pix = tid & 63, cg = tid >> 6;  // wave = channel group -> weight reads broadcast
-    const int py = pix >> 3, px = pix & 7;
-    float acc[16];
+    // wave = channel group: its 16 weights of a tap are the same for all lanes -> scalar loads straight from the packed
+    // array (the scalar cache / L2), no LDS copy: the patch alone (27 KB) lets five workgroups share a CU, so one's staging
+    // overlaps the others' arithmetic (with the 63 KB weight copy one workgroup per CU staged, then computed: 188 us)
+    const int lane = tid & 63, cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int py = lane >> 2, px = (lane & 3) * 4;   // this thread's row and first column of the tile
+    typedef float f32x2 __attribute__((ext_vector_type(2)));      // pairs of channels: v_pk_fma_f32 (two FMAs per lane and cycle)
+    f32x2 acc[4][8];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = bias[cg * 16 + j];
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[p][j] = f32x2{bias[cg * 16 + 2 * j], bias[cg * 16 + 2 * j + 1]};
     for (int c = 0; c < Cin; ++c) {
         for (int ky = 0; ky < 7; ++ky) {
+            const float* prow = patch + (c * STEM_P + 2 * py + ky) * STEM_P + 2 * px;
+            float in[13];
+#pragma unroll
+            for (int q = 0; q < 13; ++q) in[q] = prow[q];
 #pragma unroll
             for (int kx = 0; kx < 7; ++kx) {
-                const float v = patch[(c * STEM_P + 2 * py + ky) * STEM_P + 2 * px + kx];
-                const f32x4* w4 = (const f32x4*)(wl + ((c * 7 + ky) * 7 + kx) * 64 + cg * 16);
+                const f32x4* w4 = (const f32x4*)(wk + ((c * 7 + ky) * 7 + kx) * 64 + cg * 16);
+                f32x4 w[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 w = w4[q];
-                    acc[q * 4 + 0] = fmaf(v, w[0], acc[q * 4 + 0]);
-                    acc[q * 4 + 1] = fmaf(v, w[1], acc[q * 4 + 1]);
-                    acc[q * 4 + 2] = fmaf(v, w[2], acc[q * 4 + 2]);
-                    acc[q * 4 + 3] = fmaf(v, w[3], acc[q * 4 + 3]);
+                for (int q = 0; q < 4; ++q) w[q] = w4[q];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x2 v2 = {in[2 * p + kx], in[2 * p + kx]};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[p][2 * q] = __builtin_elementwise_fma(v2, f32x2{w[q][0], w[q][1]}, acc[p][2 * q]);
+                        acc[p][2 * q + 1] = __builtin_elementwise_fma(v2, f32x2{w[q][2], w[q][3]}, acc[p][2 * q + 1]);
+                    }
                 }
             }
         }
     }
-    const int oy = ty0 + py, ox = tx0 + px;
-    if (oy < OH && ox < OW) {
-        T* o = out + (((size_t)b * OH + oy) * OW + ox) * 64 + cg * 16;
+    const int oy = ty0 + py;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = {acc[q * 4], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
-            Vec4<T>::st(o + q * 4, v);
+    for (int p = 0; p < 4; ++p) {
+        const int ox = tx0 + px + p;
+        if (oy < OH && ox < OW) {
+            T* o = out + (((size_t)b * OH + oy) * OW + ox) * 64 + cg * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 v = {acc[p][2 * q][0], acc[p][2 * q][1], acc[p][2 * q + 1][0], acc[p][2 * q + 1][1]};
+                Vec4<T>::st(o + q * 4, v);
+            }
         }
     }
 }
@@ -89,7 +108,7 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
     if (Cin > STEM_MAXC) CHORE_FAIL(h, CHORE_EINVAL, "stem: Cin > %d", STEM_MAXC);
     const int OH = H / 2, OW = W / 2;
     dim3 grid((OW + STEM_T - 1) / STEM_T, (OH + STEM_T - 1) / STEM_T, B);
-    const size_t smem = ((size_t)Cin * 49 * 64 + (size_t)Cin * STEM_P * STEM_P) * sizeof(float);
+    const size_t smem = (size_t)Cin * STEM_P * STEM_P * sizeof(float);
     bool* attr[2] = {&CHORE_ONCE_FLAG(h), &CHORE_ONCE_FLAG(h)};
     if (dtype == CHORE_F32) {
         if (!*attr[0]) {
