@@ -321,19 +321,19 @@ def mode_query(args, ctx):
             traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
         # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
         # 32-point tiles when 64-point tiles would not fill the CUs)
-        x3 = args.dtype == "fp16x3"
-        qt = "float" if x3 else tname
+        x3 = args.dtype in ("fp16x3", "bf16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)
+        qt = "float" if args.dtype == "fp16x3" else tname
         if B * ((N + 63) // 64) <= 256:
             qname = "query_fwd_f32_kernel<%s, 1, false, %s>" % (qt, "true" if x3 else "false")
         elif x3:        # fp16 x 3 heads: four waves, two column blocks each (the eight-wave kernel is bound by the L1 there)
-            qname = "query_fwd_f32_kernel<float, 2, false, true>"
+            qname = "query_fwd_f32_kernel<%s, 2, false, true>" % qt
         else:
             qname = "query_fwd_f32_w8_kernel<%s, false, false>" % qt
         kernels[qname] = {"ms_per_step": qry_ms, "launches_per_step": 1,
                           "tflops": HEADS_FLOP_PER_POINT * B * N / qry_ms / 1e9, "gbps": None}
         dom = max((k for k in kernels if kernels[k]["tflops"]), key=lambda k: kernels[k]["ms_per_step"])
         dv = kernels[dom]
-        dom_dtype = "fp32" if (dom == qname and not x3) else args.dtype     # the heads run the fp32 MFMA unless the mode is fp16x3
+        dom_dtype = ("fp16x3" if x3 else "fp32") if dom == qname else args.dtype     # the heads: fp16 x 3, or the fp32 MFMA in fp32 mode
         roof = {"kernel": dom, "bound": "mfma", "achieved": dv["tflops"], "peak": PEAK_TFLOPS[dom_dtype],
                 "unit": "TFLOP/s", "frac": dv["tflops"] / PEAK_TFLOPS[dom_dtype], "traffic": traffic.get(dom),
                 "traffic_source": "profiles/pmc_traffic_%s.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes/launch)"
@@ -349,10 +349,10 @@ def mode_query(args, ctx):
                          "precision": {"fp16x3": "fp32 tensors; the encoder's convolutions as three fp16 MFMAs per product on hi/lo "
                                                  "split operands, fp32 accumulation (fp32-grade: meets the 1e-4 field tolerance); "
                                                  "BASELINE names bf16 for this config -- that mode is in other_modes with its error",
-                                       "bf16": "bf16 feature maps and MFMA operands, fp32 accumulation (a 1e-2 mode)",
+                                       "bf16": "bf16 feature maps and MFMA operands in the encoder, fp32 accumulation (a 1e-2 mode); heads fp32-grade",
                                        "fp32": "fp32 tensors, native fp32 MFMA"}[args.dtype],
                          "images_per_gpu": B, "points_per_image": N, "image": "512x512x5",
-                         "heads_dtype": "fp32 results on the fp16 matrix cores, hi/lo split operands" if args.dtype == "fp16x3"
+                         "heads_dtype": "fp32 results on the fp16 matrix cores, hi/lo split operands" if args.dtype != "fp32"
                                         else "fp32 (native fp32 MFMA)", "sharding": "images across ranks, no collective",
                          "field_err": field_err,
                          "field_err_note": "max / mean absolute and relative-L2 difference to the values THE REFERENCE "

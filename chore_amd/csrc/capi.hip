@@ -4,8 +4,8 @@
 #include <cstring>
 
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
-int launch_query_fwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s);
-int launch_query_bwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_fwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s);
+int launch_query_bwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s);
 size_t heads_arena_bytes();
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_sample_features(chore_handle* h, int dtype, const QueryArgs& a, float* features, float* nxy, hipStream_t s);
@@ -149,7 +149,7 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
         nan_scan(points, (size_t)B * N * 3, 0, (hipStream_t)stream);
         if (dtype == CHORE_F32) { nan_scan((const float*)feat, (size_t)B * FH * FW * 256, 5, (hipStream_t)stream); nan_scan((const float*)tmpx, (size_t)B * TH * TW * 64, 6, (hipStream_t)stream); }
     }
-    rc = x3 ? launch_query_fwd_x3(h, a, (hipStream_t)stream)
+    rc = x3 ? launch_query_fwd_x3(h, dtype, a, (hipStream_t)stream)
             : (dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream) : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream));
     if (nan_check_on()) {
         nan_scan(df, (size_t)B * 2 * N, 1, (hipStream_t)stream); nan_scan(pca, (size_t)B * 9 * N, 2, (hipStream_t)stream);
@@ -189,12 +189,12 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
         nan_scan(points, (size_t)B * N * 3, 8, (hipStream_t)stream);
         nan_scan(g_df, (size_t)B * 2 * N, 9, (hipStream_t)stream); nan_scan(g_pca, (size_t)B * 9 * N, 10, (hipStream_t)stream);
         nan_scan(g_parts, (size_t)B * 14 * N, 11, (hipStream_t)stream); nan_scan(g_centers, (size_t)B * 6 * N, 12, (hipStream_t)stream);
-        rc = x3 ? launch_query_bwd_x3(h, a, (hipStream_t)stream)
+        rc = x3 ? launch_query_bwd_x3(h, dtype, a, (hipStream_t)stream)
                 : (dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream) : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream));
         nan_scan(dpoints, (size_t)B * N * 3, 13, (hipStream_t)stream);
         return rc;
     }
-    if (x3) return launch_query_bwd_x3(h, a, (hipStream_t)stream);
+    if (x3) return launch_query_bwd_x3(h, dtype, a, (hipStream_t)stream);
     return dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream)
                               : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);
 }

@@ -455,8 +455,8 @@ int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
 int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_bwd_t<unsigned short, false>(h, a, s);
 }
-int launch_query_bwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return launch_query_bwd_t<float, false, true>(h, a, s);
+int launch_query_bwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    return dtype == CHORE_F32 ? launch_query_bwd_t<float, false, true>(h, a, s) : launch_query_bwd_t<unsigned short, false, true>(h, a, s);
 }
 
 int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged, int x3) {

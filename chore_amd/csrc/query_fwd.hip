@@ -513,6 +513,6 @@ int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s) {
 int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     return launch_query_fwd_t<unsigned short>(h, a, s);
 }
-int launch_query_fwd_x3(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return launch_query_fwd_t<float, true>(h, a, s);
+int launch_query_fwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    return dtype == CHORE_F32 ? launch_query_fwd_t<float, true>(h, a, s) : launch_query_fwd_t<unsigned short, true>(h, a, s);
 }

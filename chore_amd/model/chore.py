@@ -28,9 +28,10 @@ from .hgfilter import HGFilter
 
 _DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
 # what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps; the inference query (forward and backward
-# to the points) runs the heads on the fp16 matrix cores with split operands too (csrc/heads_x3.h)
+# to the points) of the fp16x3 AND the bf16 mode runs the heads on the fp16 matrix cores with split operands
+# (csrc/heads_x3.h: fp32-grade results); the fp32 mode keeps the native fp32 MFMA
 _QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32}
-_QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
+_QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16 | _lib.HEADS_X3, "fp16x3": _lib.F16X3}
 
 
 def _nhwc_ptr(t, C):
