@@ -11,8 +11,8 @@ __device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, 
     using L = MapLoad<T>;
 #pragma unroll 1
     for (int i = 0; i < PTS / NW; i += 4) {
-        f32x4 fv[4][4];
-        float tv[4][4];
+        typename L::Raw4 fv[4][4];
+        typename L::Raw1 tv[4][4];
         float fw[4][4], tw[4][4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -23,21 +23,20 @@ __device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, 
                 const int to = tab.toff[k][pt];
                 fw[u][k] = tab.fw[k][pt];
                 tw[u][k] = tab.tw[k][pt];
-                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                fv[u][k] = (fo >= 0) ? L::load4(feat_b + fo + lane * 4) : z4;
-                tv[u][k] = (to >= 0) ? L::load1(tmpx_b + to + lane) : 0.f;
+                fv[u][k] = (fo >= 0) ? L::raw4(feat_b + fo + lane * 4) : L::zero4();
+                tv[u][k] = (to >= 0) ? L::raw1(tmpx_b + to + lane) : L::zero1();
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int pt = wid * (PTS / NW) + i + u;
             f32x4 r;
+            const f32x4 c0 = L::cvt4(fv[u][0]), c1 = L::cvt4(fv[u][1]), c2 = L::cvt4(fv[u][2]), c3 = L::cvt4(fv[u][3]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                r[c] = interp4(fv[u][0][c], fv[u][1][c], fv[u][2][c], fv[u][3][c], fw[u]);
+            for (int c = 0; c < 4; ++c) r[c] = interp4(c0[c], c1[c], c2[c], c3[c], fw[u]);
             float* row = X + pt * XS;
             *(f32x4*)(row + lane * 4) = r;
-            row[FEAT_C + 3 + lane] = interp4(tv[u][0], tv[u][1], tv[u][2], tv[u][3], tw[u]);
+            row[FEAT_C + 3 + lane] = interp4(L::cvt1(tv[u][0]), L::cvt1(tv[u][1]), L::cvt1(tv[u][2]), L::cvt1(tv[u][3]), tw[u]);
             if (lane < 3) row[FEAT_C + lane] = tab.xyz[lane][pt];
             if (lane >= 3 && lane < 3 + (QF_KPAD - HEAD_IN)) row[HEAD_IN + lane - 3] = 0.f;
         }

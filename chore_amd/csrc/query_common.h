@@ -62,9 +62,20 @@ __device__ __forceinline__ Taps make_taps(float nx, float ny, int H, int W, int 
 
 // ---- typed loads of NHWC feature rows ----
 template <typename T> struct MapLoad;
+// raw4 / raw1 + cvt4 / cvt1: the loads of a gather are issued under (wave-uniform) validity branches; converting inside
+// the branch makes every load wait for its data there, one round trip after the other -- keep the raw bits and convert
+// when the values are combined
 template <> struct MapLoad<float> {
+    typedef f32x4 Raw4;
+    typedef float Raw1;
     static __device__ __forceinline__ f32x4 load4(const float* p) { return *(const f32x4*)p; }
     static __device__ __forceinline__ float load1(const float* p) { return *p; }
+    static __device__ __forceinline__ Raw4 raw4(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ Raw1 raw1(const float* p) { return *p; }
+    static __device__ __forceinline__ Raw4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+    static __device__ __forceinline__ Raw1 zero1() { return 0.f; }
+    static __device__ __forceinline__ f32x4 cvt4(Raw4 v) { return v; }
+    static __device__ __forceinline__ float cvt1(Raw1 v) { return v; }
 };
 template <> struct MapLoad<unsigned short> {  // bf16 storage
     static __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
@@ -74,6 +85,14 @@ template <> struct MapLoad<unsigned short> {  // bf16 storage
         return r;
     }
     static __device__ __forceinline__ float load1(const unsigned short* p) { return bf2f(*p); }
+    typedef u16x4 Raw4;
+    typedef unsigned short Raw1;
+    static __device__ __forceinline__ Raw4 raw4(const unsigned short* p) { return *(const u16x4*)p; }
+    static __device__ __forceinline__ Raw1 raw1(const unsigned short* p) { return *p; }
+    static __device__ __forceinline__ Raw4 zero4() { return u16x4{0, 0, 0, 0}; }
+    static __device__ __forceinline__ Raw1 zero1() { return 0; }
+    static __device__ __forceinline__ f32x4 cvt4(Raw4 v) { return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
+    static __device__ __forceinline__ float cvt1(Raw1 v) { return bf2f(v); }
 };
 
 __device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
