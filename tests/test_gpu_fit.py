@@ -294,3 +294,47 @@ def test_coco_variant_matches_reference():
     assert sorted(wd) == [str(k) for k in g["weight_names"]]
     for k, v in zip(g["weight_names"], g["weights_at_2_3"]):
         assert abs(float(wd[str(k)](2.0, 3)) - float(v)) <= 1e-12 * abs(float(v))
+
+
+def test_fused_adam_step_equals_torch_adam():
+    """chore_fit_adam_step + chore_fit_stop_rule (csrc/fit_step.hip: all tensors of a step in one launch, the stop rule and
+    the step counter in another) against torch.optim.Adam(capturable=True) and the tensor-op stop rule of EagerStep, 30
+    steps on random gradients with the rule firing in between: parameters, moments, flags"""
+    import os
+    from chore_amd.recon import graph_step as gs
+    torch.manual_seed(11)
+    shapes = [(2, 72), (2, 10), (2, 3), (2, 3, 3), (2,)]
+    res = {}
+    for mode in ("fused", "torch"):
+        torch.manual_seed(12)
+        params = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+        targets = [torch.randn(s, device="cuda") for s in shapes]
+        if mode == "torch":
+            os.environ["CHORE_FIT_TORCH_ADAM"] = "1"
+        try:
+            prev = torch.tensor(300.0, device="cuda")
+            calls = {"n": 0}
+
+            def loss_fn(decay):
+                calls["n"] += 1
+                k = calls["n"]
+                # a loss whose value stalls for a while (the rule fires), gradients that keep changing
+                base = sum(((p - t) ** 2).sum() for p, t in zip(params, targets))
+                return base * (0.0 if 12 <= k <= 14 else 1.0) + 5.0 + 0 * (1 + decay)
+            st = gs.EagerStep(params, 0.02, loss_fn, 0.001, prev, capturable=True)
+            assert isinstance(st.opt, gs.FusedAdam) == (mode == "fused")
+            trace = []
+            for it in range(6):
+                st.begin_outer(it, armed=it >= 2, zero=True)
+                for _ in range(5):
+                    st.step()
+                    trace.append((float(st.loss), bool(st.stop), float(st.prev)))
+        finally:
+            os.environ.pop("CHORE_FIT_TORCH_ADAM", None)
+        res[mode] = ([p.detach().clone() for p in params], trace)
+    (pa, ta), (pb, tb) = res["fused"], res["torch"]
+    assert [t[1] for t in ta] == [t[1] for t in tb] and any(t[1] for t in ta)          # the latch fires at the same step
+    for (la, _, pva), (lb, _, pvb) in zip(ta, tb):
+        assert abs(la - lb) <= 2e-6 * abs(lb) and abs(pva - pvb) <= 2e-6 * abs(pvb)
+    for a, b in zip(pa, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
