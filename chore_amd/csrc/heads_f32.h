@@ -36,7 +36,8 @@ __device__ __forceinline__ void gather_tile(float* X, const PtTableT<PTS>& tab, 
             for (int c = 0; c < 4; ++c) r[c] = interp4(c0[c], c1[c], c2[c], c3[c], fw[u]);
             float* row = X + pt * XS;
             *(f32x4*)(row + lane * 4) = r;
-            row[FEAT_C + 3 + lane] = interp4(L::cvt1(tv[u][0]), L::cvt1(tv[u][1]), L::cvt1(tv[u][2]), L::cvt1(tv[u][3]), tw[u]);
+            row[FEAT_C + 3 + lane] = interp4(L::cvt1(tv[u][0], lane & 1), L::cvt1(tv[u][1], lane & 1), L::cvt1(tv[u][2], lane & 1),
+                                             L::cvt1(tv[u][3], lane & 1), tw[u]);
             if (lane < 3) row[FEAT_C + lane] = tab.xyz[lane][pt];
             if (lane >= 3 && lane < 3 + (QF_KPAD - HEAD_IN)) row[HEAD_IN + lane - 3] = 0.f;
         }

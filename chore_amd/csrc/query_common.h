@@ -75,7 +75,7 @@ template <> struct MapLoad<float> {
     static __device__ __forceinline__ Raw4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
     static __device__ __forceinline__ Raw1 zero1() { return 0.f; }
     static __device__ __forceinline__ f32x4 cvt4(Raw4 v) { return v; }
-    static __device__ __forceinline__ float cvt1(Raw1 v) { return v; }
+    static __device__ __forceinline__ float cvt1(Raw1 v, int = 0) { return v; }
 };
 template <> struct MapLoad<unsigned short> {  // bf16 storage
     static __device__ __forceinline__ f32x4 load4(const unsigned short* p) {
@@ -85,14 +85,21 @@ template <> struct MapLoad<unsigned short> {  // bf16 storage
         return r;
     }
     static __device__ __forceinline__ float load1(const unsigned short* p) { return bf2f(*p); }
-    typedef u16x4 Raw4;
-    typedef unsigned short Raw1;
-    static __device__ __forceinline__ Raw4 raw4(const unsigned short* p) { return *(const u16x4*)p; }
-    static __device__ __forceinline__ Raw1 raw1(const unsigned short* p) { return *p; }
-    static __device__ __forceinline__ Raw4 zero4() { return u16x4{0, 0, 0, 0}; }
-    static __device__ __forceinline__ Raw1 zero1() { return 0; }
-    static __device__ __forceinline__ f32x4 cvt4(Raw4 v) { return f32x4{bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3])}; }
-    static __device__ __forceinline__ float cvt1(Raw1 v) { return bf2f(v); }
+    // 32-bit containers: with 16-bit vector types the select against the zero value repacks the halves right after each
+    // load, i.e. waits for it (33 x s_waitcnt vmcnt(0) in the gather: every tap a serial round trip, 3 x the fp32 gather)
+    typedef unsigned Raw4 __attribute__((ext_vector_type(2)));
+    typedef unsigned Raw1;
+    static __device__ __forceinline__ Raw4 raw4(const unsigned short* p) { return *(const Raw4*)p; }
+    // one channel per lane: lanes 2i and 2i+1 read the same aligned dword (rows of 64 channels start 4-byte aligned) and
+    // pick their half when the taps are combined (cvt1's `odd` = the channel's parity) -- a plain dword load
+    static __device__ __forceinline__ Raw1 raw1(const unsigned short* p) { return *(const unsigned*)((uintptr_t)p & ~(uintptr_t)3); }
+    static __device__ __forceinline__ Raw4 zero4() { return Raw4{0u, 0u}; }
+    static __device__ __forceinline__ Raw1 zero1() { return 0u; }
+    static __device__ __forceinline__ f32x4 cvt4(Raw4 v) {
+        return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                     __uint_as_float(v[1] & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ float cvt1(Raw1 v, int odd) { return __uint_as_float(odd ? (v & 0xffff0000u) : (v << 16)); }
 };
 
 __device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
