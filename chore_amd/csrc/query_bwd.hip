@@ -326,13 +326,15 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
         {
             const f32x4 g = *(const f32x4*)(drow + lane * 4);
-            f32x4 tv[4];
+            typename L::Raw4 tr[4];      // raw bits under the validity branches, converted below (query_common.h, MapLoad)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int fo = sm.tab.foff[k][pt];
-                f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                tv[k] = (fo >= 0) ? L::load4(feat_b + fo + lane * 4) : z4;
+                tr[k] = (fo >= 0) ? L::raw4(feat_b + fo + lane * 4) : L::zero4();
             }
+            f32x4 tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv[k] = L::cvt4(tr[k]);
             const float w = sm.tab.ffrac[0][pt], n = sm.tab.ffrac[1][pt];
             const float e = 1.f - w, s = 1.f - n;
 #pragma unroll
@@ -343,12 +345,15 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         }
         {
             const float g = drow[FEAT_C + 3 + lane];
-            float tv[4];
+            typename L::Raw1 tr[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int to = sm.tab.toff[k][pt];
-                tv[k] = (to >= 0) ? L::load1(tmpx_b + to + lane) : 0.f;
+                tr[k] = (to >= 0) ? L::raw1(tmpx_b + to + lane) : L::zero1();
             }
+            float tv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tv[k] = L::cvt1(tr[k], lane & 1);
             const float w = sm.tab.tfrac[0][pt], n = sm.tab.tfrac[1][pt];
             const float e = 1.f - w, s = 1.f - n;
             gix_t = g * ((tv[1] - tv[0]) * s + (tv[3] - tv[2]) * n);
