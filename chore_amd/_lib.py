@@ -73,6 +73,8 @@ SIGNATURES = {
                                    c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_smpl_lbs_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_float, c_int, c_void_p,
                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_landmarks_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chore_landmarks_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "chore_so3_aux_bytes": (c_size_t, [c_int]),
     "chore_so3_project_fwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_so3_project_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

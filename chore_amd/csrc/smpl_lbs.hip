@@ -2,20 +2,21 @@
 //
 // Replaces SMPL_Layer.forward (lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:72-175) and
 // its autograd: ~500 tiny ATen launches per call in the reference (52 batch_rodrigues, 51 chained
-// 4x4 matmuls, 52 bmm, a (V*3 x 459) blend-shape matmul) become 2 kernels forward, 5 backward.
+// 4x4 matmuls, 52 bmm, a (V*3 x 459) blend-shape matmul) become 2 kernels forward, 4 backward.
 //   * pose kernel (one workgroup per frame): 52 Rodrigues rotations through the reference's quaternion
 //     path (angle = ||theta + 1e-8||, rodrigues_layer.py:41-52), joint locations J = JT + JS*beta
 //     (J_regressor folded into JT/JS at pack time), the kinematic chain and the skinning transforms.
-//   * vertex kernel: thread = vertex; the pose blend shapes are stored p-major ([459][V*3]) so the
-//     38 MB matrix streams once, fully coalesced, for a group of up to 4 frames whose pose maps and
-//     transforms sit in LDS -- the op is HBM-bound on that matrix.
-//   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), three
-//     fixed-order reduction kernels (dA = W^T dT, d pose_map = P^T d v_posed, d beta = S^T d v_posed)
+//   * vertex kernel: thread = one coordinate of a vertex; the pose blend shapes are stored p-major
+//     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 27 rows at a time, for a
+//     group of up to 4 frames whose pose maps and transforms sit in LDS.
+//   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), two
+//     fixed-order reduction kernels (dA = W^T dT; d pose_map = P^T d v_posed with d beta = S^T d v_posed)
 //     and the pose kernel backward (reverse kinematic chain, Rodrigues Jacobian by forward-mode
 //     dual numbers).  All reductions are tree reductions in a fixed order: deterministic.
 // Gradients are produced for pose, betas and trans (what the fitting optimises,
 // recon/recon_fit_behave.py:224-291); offsets / v_posed / naked upstream gradients are not consumed.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -27,7 +28,7 @@ struct Dims {
     int V, J, NB, NP;          // vertices, joints, betas, pose-blend directions = 9 (J-1)
 };
 struct Arena {                 // float offsets into the packed model
-    size_t T, S, PT, WT, JT, JS, parents, total;
+    size_t T, S, PT, WT, JT, JS, parents, ST, total;
 };
 __host__ __device__ inline Arena arena_layout(const Dims& d) {
     Arena a;
@@ -40,11 +41,12 @@ __host__ __device__ inline Arena arena_layout(const Dims& d) {
     a.JT = take((size_t)d.J * 3);
     a.JS = take((size_t)d.J * 3 * d.NB);
     a.parents = take(d.J);
+    a.ST = take((size_t)d.NB * d.V * 3);      // shapedirs transposed: [n][v*3+k]
     a.total = o;
     return a;
 }
 struct Work {                  // float offsets into the per-call workspace
-    size_t R, Jl, G, A, pm, gvp, dT, dA, dpm, dbv, total;
+    size_t R, Jl, G, A, pm, gvp, dT, dA, dpm, dbv, tpart, total;
 };
 __host__ __device__ inline Work work_layout(const Dims& d, int B) {
     Work w;
@@ -60,6 +62,7 @@ __host__ __device__ inline Work work_layout(const Dims& d, int B) {
     w.dA = take((size_t)B * d.J * 12);
     w.dpm = take((size_t)B * d.NP);
     w.dbv = take((size_t)B * d.NB);
+    w.tpart = take((size_t)B * ((d.V + 255) / 256) * 3 * 2);     // doubles: per-workgroup partial sums of d trans
     w.total = o;
     return w;
 }
@@ -127,6 +130,13 @@ __global__ void pack_posedirs_kernel(Dims d, const float* __restrict__ posedirs 
     if (i >= V3 * d.NP) return;
     const size_t p = i / V3, vk = i % V3;
     PT[i] = posedirs[vk * d.NP + p];
+}
+__global__ void pack_shapedirs_t_kernel(Dims d, const float* __restrict__ S /*(V*3,NB)*/, float* __restrict__ ST) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // index into ST [n][v*3+k]
+    const size_t V3 = (size_t)d.V * 3;
+    if (i >= V3 * d.NB) return;
+    const size_t n = i / V3, vk = i % V3;
+    ST[i] = S[vk * d.NB + n];
 }
 __global__ void pack_weights_kernel(Dims d, const float* __restrict__ weights /*(V,J)*/, float* __restrict__ WT) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // [j][v]
@@ -235,72 +245,91 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// vertex kernel forward: thread = vertex, FB frames per workgroup
+// vertex kernel forward: thread = one coordinate of one vertex (VF_V vertices per workgroup), FB frames per workgroup.
+// A thread owns the whole sum of its coordinate, in the order p = 0, 1, ... (the result does not depend on the launch shape);
+// the loads of VF_U pose directions are issued together, ahead of their multiply-adds: the 38 MB matrix streams with
+// V*3 x VF_U loads in flight (one vertex per thread and one load at a time left 27 workgroups waiting on a chain of 459
+// round trips: 64 us per call).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void lbs_vertex_fwd_kernel(Dims d, const float* __restrict__ model,
-                                                             const float* __restrict__ betas, const float* __restrict__ trans,
-                                                             const float* __restrict__ offsets, float scale,
-                                                             const float* __restrict__ work, int B, float* __restrict__ verts,
-                                                             float* __restrict__ v_posed, float* __restrict__ naked) {
+constexpr int VF_V = 64, VF_T = VF_V * 3, VF_U = 27;
+constexpr int SKIN_U = 13;     // 52 = 4 x 13 joints (SMPL-H); SMPL's 24: 13 + 11
+constexpr int DPM_U = 9;       // steps of a 256-thread reduction loop whose loads are issued together
+__global__ __launch_bounds__(VF_T) void lbs_vertex_fwd_kernel(Dims d, const float* __restrict__ model,
+                                                              const float* __restrict__ betas, const float* __restrict__ trans,
+                                                              const float* __restrict__ offsets, float scale,
+                                                              const float* __restrict__ work, int B, float* __restrict__ verts,
+                                                              float* __restrict__ v_posed, float* __restrict__ naked) {
     extern __shared__ float sm[];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     float* pm = sm;                       // [FB][NP]
     float* A = sm + FB * d.NP;            // [FB][J][12]
     float* bt = A + FB * d.J * 12;        // [FB][NB]
+    float* vpl = bt + FB * d.NB;          // [FB][VF_T]
     const int b0 = blockIdx.y * FB, nf = min(FB, B - b0);
-    const int tid = threadIdx.x, v = blockIdx.x * 256 + tid;
-    for (int i = tid; i < nf * d.NP; i += 256) pm[i] = work[wk.pm + (size_t)b0 * d.NP + i];
-    for (int i = tid; i < nf * d.J * 12; i += 256) A[i] = work[wk.A + (size_t)b0 * d.J * 12 + i];
-    for (int i = tid; i < nf * d.NB; i += 256) bt[i] = betas[(size_t)b0 * d.NB + i];
-    __syncthreads();
-    if (v >= d.V) return;
+    const int tid = threadIdx.x;
     const size_t V3 = (size_t)d.V * 3;
-    float acc[FB][3];
+    const size_t i_raw = (size_t)blockIdx.x * VF_T + tid;
+    const bool live = i_raw < V3;
+    const size_t i = live ? i_raw : V3 - 1;          // idle threads of the last workgroup repeat the last coordinate
+    const int v = (int)(i / 3), k = (int)(i - (size_t)v * 3);
+    for (int q = tid; q < nf * d.NP; q += VF_T) pm[q] = work[wk.pm + (size_t)b0 * d.NP + q];
+    for (int q = tid; q < nf * d.J * 12; q += VF_T) A[q] = work[wk.A + (size_t)b0 * d.J * 12 + q];
+    for (int q = tid; q < nf * d.NB; q += VF_T) bt[q] = betas[(size_t)b0 * d.NB + q];
+    __syncthreads();
+    float acc[FB];
 #pragma unroll
-    for (int f = 0; f < FB; ++f)
+    for (int f = 0; f < FB; ++f) {
+        float a = model[ar.T + i];
+        if (f < nf)
+            for (int n = 0; n < d.NB; ++n) a += model[ar.S + i * d.NB + n] * bt[f * d.NB + n];
+        acc[f] = a;
+    }
+    const float* PT = model + ar.PT + i;
+    int p = 0;
+    for (; p + VF_U <= d.NP; p += VF_U) {
+        float x[VF_U];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            float a = model[ar.T + (size_t)v * 3 + k];
-            if (f < nf)
-                for (int n = 0; n < d.NB; ++n) a += model[ar.S + ((size_t)v * 3 + k) * d.NB + n] * bt[f * d.NB + n];
-            acc[f][k] = a;
-        }
-    const float* PT = model + ar.PT + (size_t)v * 3;
-    for (int p = 0; p < d.NP; ++p) {
-        const float p0 = PT[(size_t)p * V3], p1 = PT[(size_t)p * V3 + 1], p2 = PT[(size_t)p * V3 + 2];
+        for (int u = 0; u < VF_U; ++u) x[u] = PT[(size_t)(p + u) * V3];
 #pragma unroll
-        for (int f = 0; f < FB; ++f) {
-            const float m = pm[f * d.NP + p];   // frames beyond nf read stale LDS: never stored
-            acc[f][0] = fmaf(p0, m, acc[f][0]);
-            acc[f][1] = fmaf(p1, m, acc[f][1]);
-            acc[f][2] = fmaf(p2, m, acc[f][2]);
+        for (int u = 0; u < VF_U; ++u)
+#pragma unroll
+            for (int f = 0; f < FB; ++f) acc[f] = fmaf(x[u], pm[f * d.NP + p + u], acc[f]);   // frames beyond nf read stale LDS: never stored
+    }
+    for (; p < d.NP; ++p) {
+        const float x = PT[(size_t)p * V3];
+#pragma unroll
+        for (int f = 0; f < FB; ++f) acc[f] = fmaf(x, pm[f * d.NP + p], acc[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < FB; ++f) {
+        if (f < nf) {
+            const size_t o = (size_t)(b0 + f) * V3 + i;
+            const float vp = acc[f] + (offsets ? offsets[o] : 0.f);
+            if (live) { naked[o] = acc[f]; v_posed[o] = vp; }
+            vpl[f * VF_T + tid] = vp;
         }
     }
+    __syncthreads();
+    // skinning: this thread's row k of T = sum_j w_j A_j, applied to the vertex' three posed coordinates
+    const float* vrow = vpl + (tid - k);
     for (int f = 0; f < nf; ++f) {
-        const int b = b0 + f;
-        const size_t o = ((size_t)b * d.V + v) * 3;
-        float vp[3];
+        float T[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < d.J; j0 += SKIN_U) {      // the weights of SKIN_U joints requested together, used in joint order
+            float w[SKIN_U];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            naked[o + k] = acc[f][k];
-            vp[k] = acc[f][k] + (offsets ? offsets[o + k] : 0.f);
-            v_posed[o + k] = vp[k];
+            for (int u = 0; u < SKIN_U; ++u) w[u] = model[ar.WT + (size_t)min(j0 + u, d.J - 1) * d.V + v];
+#pragma unroll
+            for (int u = 0; u < SKIN_U; ++u)
+                if (j0 + u < d.J && w[u] != 0.f) {
+                    const float* Aj = A + ((size_t)f * d.J + j0 + u) * 12 + k * 4;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) T[e] = fmaf(w[u], Aj[e], T[e]);
+                }
         }
-        float T[12];
-#pragma unroll
-        for (int e = 0; e < 12; ++e) T[e] = 0.f;
-        for (int j = 0; j < d.J; ++j) {
-            const float w = model[ar.WT + (size_t)j * d.V + v];
-            if (w != 0.f) {
-                const float* Aj = A + ((size_t)f * d.J + j) * 12;
-#pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Aj[e], T[e]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-            verts[o + r] = (T[r * 4] * vp[0] + T[r * 4 + 1] * vp[1] + T[r * 4 + 2] * vp[2] + T[r * 4 + 3]) * scale + trans[b * 3 + r];
+        const float* vp = vrow + f * VF_T;
+        if (live)
+            verts[(size_t)(b0 + f) * V3 + i] = (T[0] * vp[0] + T[1] * vp[1] + T[2] * vp[2] + T[3]) * scale + trans[(b0 + f) * 3 + k];
     }
 }
 
@@ -318,32 +347,55 @@ __global__ __launch_bounds__(256) void lbs_vertex_bwd_kernel(Dims d, const float
     const int b = blockIdx.y, tid = threadIdx.x, v = blockIdx.x * 256 + tid;
     for (int i = tid; i < d.J * 12; i += 256) A[i] = work[wk.A + (size_t)b * d.J * 12 + i];
     __syncthreads();
-    if (v >= d.V) return;
-    float T[9];
+    const bool live = v < d.V;
+    double gs[3] = {0.0, 0.0, 0.0};     // this thread's share of d trans = sum_v g_verts (trans is added after the scale)
+    if (live) {
+        float T[9];
 #pragma unroll
-    for (int e = 0; e < 9; ++e) T[e] = 0.f;
-    for (int j = 0; j < d.J; ++j) {
-        const float w = model[ar.WT + (size_t)j * d.V + v];
-        if (w != 0.f) {
+        for (int e = 0; e < 9; ++e) T[e] = 0.f;
+        for (int j0 = 0; j0 < d.J; j0 += SKIN_U) {
+            float w[SKIN_U];
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int u = 0; u < SKIN_U; ++u) w[u] = model[ar.WT + (size_t)min(j0 + u, d.J - 1) * d.V + v];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, A[j * 12 + r * 4 + c], T[r * 3 + c]);
+            for (int u = 0; u < SKIN_U; ++u)
+                if (j0 + u < d.J && w[u] != 0.f) {
+                    const int j = j0 + u;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w[u], A[j * 12 + r * 4 + c], T[r * 3 + c]);
+                }
+        }
+        const size_t o = ((size_t)b * d.V + v) * 3;
+        const float r0 = g_verts ? g_verts[o] : 0.f, r1 = g_verts ? g_verts[o + 1] : 0.f, r2 = g_verts ? g_verts[o + 2] : 0.f;
+        gs[0] = (double)r0; gs[1] = (double)r1; gs[2] = (double)r2;
+        const float g0 = r0 * scale, g1 = r1 * scale, g2 = r2 * scale;
+        const float vp0 = v_posed[o], vp1 = v_posed[o + 1], vp2 = v_posed[o + 2];
+        float* gvp = work + wk.gvp + o;
+        gvp[0] = T[0] * g0 + T[3] * g1 + T[6] * g2;
+        gvp[1] = T[1] * g0 + T[4] * g1 + T[7] * g2;
+        gvp[2] = T[2] * g0 + T[5] * g1 + T[8] * g2;
+        float* dT = work + wk.dT + ((size_t)b * d.V + v) * 12;
+        const float g[3] = {g0, g1, g2};
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            dT[r * 4] = g[r] * vp0; dT[r * 4 + 1] = g[r] * vp1; dT[r * 4 + 2] = g[r] * vp2; dT[r * 4 + 3] = g[r];
         }
     }
-    const size_t o = ((size_t)b * d.V + v) * 3;
-    const float g0 = g_verts ? g_verts[o] * scale : 0.f, g1 = g_verts ? g_verts[o + 1] * scale : 0.f,
-                g2 = g_verts ? g_verts[o + 2] * scale : 0.f;
-    const float vp0 = v_posed[o], vp1 = v_posed[o + 1], vp2 = v_posed[o + 2];
-    float* gvp = work + wk.gvp + o;
-    gvp[0] = T[0] * g0 + T[3] * g1 + T[6] * g2;
-    gvp[1] = T[1] * g0 + T[4] * g1 + T[7] * g2;
-    gvp[2] = T[2] * g0 + T[5] * g1 + T[8] * g2;
-    float* dT = work + wk.dT + ((size_t)b * d.V + v) * 12;
-    const float g[3] = {g0, g1, g2};
+    // fixed-order fp64 tree over the workgroup; the pose kernel adds the per-workgroup partial sums in workgroup order
+    __syncthreads();      // A (sm) is reused
+    double* sh = (double*)sm;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        dT[r * 4] = g[r] * vp0; dT[r * 4 + 1] = g[r] * vp1; dT[r * 4 + 2] = g[r] * vp2; dT[r * 4 + 3] = g[r];
+    for (int k = 0; k < 3; ++k) {
+        sh[tid] = gs[k];
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (tid < o) sh[tid] += sh[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) ((double*)(work + wk.tpart))[((size_t)b * gridDim.x + blockIdx.x) * 3 + k] = sh[0];
+        __syncthreads();
     }
 }
 
@@ -372,13 +424,17 @@ __global__ __launch_bounds__(256) void lbs_dA_kernel(Dims d, const float* __rest
     float a[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) a[e] = 0.f;
-    for (int v = tid; v < d.V; v += 256) {
-        const float w = model[ar.WT + (size_t)j * d.V + v];
-        if (w != 0.f) {
-            const float* dT = work + wk.dT + ((size_t)b * d.V + v) * 12;
+    for (int v0 = tid; v0 < d.V; v0 += 256 * DPM_U) {
+        float w[DPM_U];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) a[e] = fmaf(w, dT[e], a[e]);
-        }
+        for (int u = 0; u < DPM_U; ++u) w[u] = model[ar.WT + (size_t)j * d.V + min(v0 + 256 * u, d.V - 1)];
+#pragma unroll
+        for (int u = 0; u < DPM_U; ++u)
+            if (v0 + 256 * u < d.V && w[u] != 0.f) {
+                const float* dT = work + wk.dT + ((size_t)b * d.V + v0 + 256 * u) * 12;
+#pragma unroll
+                for (int e = 0; e < 12; ++e) a[e] = fmaf(w[u], dT[e], a[e]);
+            }
     }
     float r[12];
     block_reduce<12>(a, sh, tid, r);
@@ -389,41 +445,45 @@ __global__ __launch_bounds__(256) void lbs_dA_kernel(Dims d, const float* __rest
     }
 }
 
-// dpm[b][p] = sum_i PT[p][i] gvp[b][i]             grid (NP, ceil(B/FB))
+// dpm[b][p] = sum_i PT[p][i] gvp[b][i]  (p < NP)  and  dbv[b][n] = sum_i S[i][n] gvp[b][i]  (row NP + n, from the transposed
+// copy ST)             grid (NP + NB, ceil(B/FB)).  A thread's sum runs over i = tid, tid + 256, ... in that order; the loads of
+// DPM_U steps are issued together (one at a time: 81 dependent round trips, 33 + 25 us for the two former kernels)
 __global__ __launch_bounds__(256) void lbs_dpm_kernel(Dims d, const float* __restrict__ model, float* __restrict__ work, int B) {
     __shared__ double sh[256];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     const int p = blockIdx.x, b0 = blockIdx.y * FB, nf = min(FB, B - b0), tid = threadIdx.x;
     const size_t V3 = (size_t)d.V * 3;
-    const float* row = model + ar.PT + (size_t)p * V3;
+    const float* row = p < d.NP ? model + ar.PT + (size_t)p * V3 : model + ar.ST + (size_t)(p - d.NP) * V3;
+    const float* gv[FB];
+#pragma unroll
+    for (int f = 0; f < FB; ++f) gv[f] = work + wk.gvp + (size_t)(b0 + min(f, nf - 1)) * V3;   // frames beyond nf: a valid row, unused
     float a[FB];
 #pragma unroll
     for (int f = 0; f < FB; ++f) a[f] = 0.f;
-    for (size_t i = tid; i < V3; i += 256) {
-        const float x = row[i];
+    for (size_t i0 = tid; i0 < V3; i0 += 256 * DPM_U) {
+        float x[DPM_U], g[DPM_U][FB];
 #pragma unroll
-        for (int f = 0; f < FB; ++f)
-            if (f < nf) a[f] = fmaf(x, work[wk.gvp + (size_t)(b0 + f) * V3 + i], a[f]);
+        for (int u = 0; u < DPM_U; ++u) {
+            const size_t i = min(i0 + (size_t)256 * u, V3 - 1);
+            x[u] = row[i];
+#pragma unroll
+            for (int f = 0; f < FB; ++f) g[u][f] = gv[f][i];
+        }
+#pragma unroll
+        for (int u = 0; u < DPM_U; ++u)
+            if (i0 + (size_t)256 * u < V3) {
+#pragma unroll
+                for (int f = 0; f < FB; ++f) a[f] = fmaf(x[u], g[u][f], a[f]);
+            }
     }
     float r[FB];
     block_reduce<FB>(a, sh, tid, r);
     if (tid == 0)
-        for (int f = 0; f < nf; ++f) work[wk.dpm + (size_t)(b0 + f) * d.NP + p] = r[f];
-}
-
-// dbv[b][n] = sum_i S[i][n] gvp[b][i]              grid (NB, B)
-__global__ __launch_bounds__(256) void lbs_dbeta_kernel(Dims d, const float* __restrict__ model, float* __restrict__ work, int B) {
-    __shared__ double sh[256];
-    const Arena ar = arena_layout(d);
-    const Work wk = work_layout(d, B);
-    const int n = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const size_t V3 = (size_t)d.V * 3;
-    float a[1] = {0.f};
-    for (size_t i = tid; i < V3; i += 256) a[0] = fmaf(model[ar.S + i * d.NB + n], work[wk.gvp + (size_t)b * V3 + i], a[0]);
-    float r[1];
-    block_reduce<1>(a, sh, tid, r);
-    if (tid == 0) work[wk.dbv + (size_t)b * d.NB + n] = r[0];
+        for (int f = 0; f < nf; ++f) {
+            if (p < d.NP) work[wk.dpm + (size_t)(b0 + f) * d.NP + p] = r[f];
+            else work[wk.dbv + (size_t)(b0 + f) * d.NB + (p - d.NP)] = r[f];
+        }
 }
 
 // pose kernel backward: reverse chain, Rodrigues Jacobian, betas through J, trans
@@ -433,7 +493,6 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
                                                           float* __restrict__ dpose, float* __restrict__ dbetas,
                                                           float* __restrict__ dtrans) {
     __shared__ float R[MAXJ][9], Jl[MAXJ][3], G[MAXJ][12], dG[MAXJ][12], dR[MAXJ][9], dJ[MAXJ][3];
-    __shared__ double tsum[64][3];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     const int b = blockIdx.x, j = threadIdx.x;
@@ -461,19 +520,6 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
             dJ[j][c] = -(G[j][c] * dA[3] + G[j][4 + c] * dA[7] + G[j][8 + c] * dA[11]);
 #pragma unroll
         for (int e = 0; e < 9; ++e) dR[j][e] = 0.f;
-    }
-    // d trans = sum_v g_verts + sum_j g_joints (trans is added after the scale)
-    {
-        double a[3] = {0.0, 0.0, 0.0};
-        if (g_verts)
-            for (int v = j; v < d.V; v += 64)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) a[k] += (double)g_verts[((size_t)b * d.V + v) * 3 + k];
-        if (g_joints && j < d.J)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) a[k] += (double)g_joints[((size_t)b * d.J + j) * 3 + k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) tsum[j][k] = a[k];
     }
     __syncthreads();
     if (j == 0) {
@@ -529,10 +575,82 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
             for (int k = 0; k < 3; ++k) a += model[ar.JS + ((size_t)i * 3 + k) * d.NB + j] * dJ[i][k];
         dbetas[(size_t)b * d.NB + j] = a;
     }
-    if (j < 3) {
+    if (j < 3) {   // d trans = sum_v g_verts (per-workgroup partial sums of the vertex kernel) + sum_j g_joints
         double a = 0.0;
-        for (int i = 0; i < 64; ++i) a += tsum[i][j];
+        const int nblk = (d.V + 255) / 256;
+        const double* part = (const double*)(work + wk.tpart) + (size_t)b * nblk * 3;
+        for (int i = 0; i < nblk; ++i) a += part[i * 3 + j];
+        if (g_joints)
+            for (int i = 0; i < d.J; ++i) a += (double)g_joints[((size_t)b * d.J + i) * 3 + j];
         dtrans[b * 3 + j] = (float)a;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// landmark regression: lm[b][r] = sum_v reg[r][v] verts[b][v]   (R = 25 + 70 + 42 rows for the body / face / hand
+// regressors, V = 6890).  As one (R x V) x (V x 3) product per frame this is a shape the GEMM library serves badly
+// (60 us per call, measured: three columns); here one workgroup per (row, frame), loads issued together, fp64 tree.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void landmarks_fwd_kernel(const float* __restrict__ reg, const float* __restrict__ verts,
+                                                            int R, int V, float* __restrict__ out) {
+    __shared__ double sh[256];
+    const int r = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* row = reg + (size_t)r * V;
+    const float* vb = verts + (size_t)b * V * 3;
+    float a[3] = {0.f, 0.f, 0.f};
+    for (int v0 = tid; v0 < V; v0 += 256 * DPM_U) {
+        float w[DPM_U], x[DPM_U][3];
+#pragma unroll
+        for (int u = 0; u < DPM_U; ++u) {
+            const int v = min(v0 + 256 * u, V - 1);
+            w[u] = row[v];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) x[u][k] = vb[(size_t)v * 3 + k];
+        }
+#pragma unroll
+        for (int u = 0; u < DPM_U; ++u)
+            if (v0 + 256 * u < V) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[k] = fmaf(w[u], x[u][k], a[k]);
+            }
+    }
+    float o[3];
+    block_reduce<3>(a, sh, tid, o);
+    if (tid < 3) out[((size_t)b * R + r) * 3 + tid] = o[tid];
+}
+
+// d verts[b][v] = sum_r reg[r][v] g[b][r]: 64 vertices per workgroup, the rows dealt to four groups of threads in
+// contiguous quarters, the four partial sums added in group order
+__global__ __launch_bounds__(256) void landmarks_bwd_kernel(const float* __restrict__ reg, const float* __restrict__ g, int R, int V,
+                                                            float* __restrict__ dverts) {
+    extern __shared__ float lsm[];
+    float* gl = lsm;                                  // [R][3]
+    float* part = lsm + (size_t)R * 3;                // [4][64][3]
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, grp = tid >> 6;
+    const int v = blockIdx.x * 64 + lane, vc = min(v, V - 1);
+    for (int q = tid; q < R * 3; q += 256) gl[q] = g[(size_t)b * R * 3 + q];
+    __syncthreads();
+    const int per = (R + 3) / 4, r0 = grp * per, r1 = min(R, r0 + per);
+    float a[3] = {0.f, 0.f, 0.f};
+    constexpr int U = 12;
+    for (int rr = r0; rr < r1; rr += U) {
+        float w[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) w[u] = reg[(size_t)min(rr + u, R - 1) * V + vc];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (rr + u < r1) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) a[k] = fmaf(w[u], gl[(rr + u) * 3 + k], a[k]);
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) part[(grp * 64 + lane) * 3 + k] = a[k];
+    __syncthreads();
+    if (grp == 0 && v < V) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            dverts[((size_t)b * V + v) * 3 + k] = ((part[lane * 3 + k] + part[(64 + lane) * 3 + k]) + part[(128 + lane) * 3 + k]) + part[(192 + lane) * 3 + k];
     }
 }
 
@@ -574,6 +692,7 @@ int chore_smpl_pack(chore_handle* h, int V, int J, int num_betas, const float* v
     hipLaunchKernelGGL(pack_copy_kernel, blocks((size_t)V * 3), dim3(256), 0, s, v_template, m + ar.T, (size_t)V * 3);
     hipLaunchKernelGGL(pack_copy_kernel, blocks((size_t)V * 3 * num_betas), dim3(256), 0, s, shapedirs, m + ar.S,
                        (size_t)V * 3 * num_betas);
+    hipLaunchKernelGGL(pack_shapedirs_t_kernel, blocks((size_t)V * 3 * num_betas), dim3(256), 0, s, d, shapedirs, m + ar.ST);
     hipLaunchKernelGGL(pack_posedirs_kernel, blocks((size_t)V * 3 * d.NP), dim3(256), 0, s, d, posedirs, m + ar.PT);
     hipLaunchKernelGGL(pack_weights_kernel, blocks((size_t)V * J), dim3(256), 0, s, d, weights, m + ar.WT);
     hipLaunchKernelGGL(pack_jreg_kernel, dim3(J, 3 + 3 * num_betas), dim3(256), 0, s, d, J_regressor, v_template, shapedirs,
@@ -596,8 +715,8 @@ int chore_smpl_lbs_fwd(chore_handle* h, const void* arena, int V, int J, int num
     float* w = (float*)workspace;
     hipLaunchKernelGGL(lbs_pose_fwd_kernel, dim3(B), dim3(64), 0, s, d, m, pose, betas, trans, scale, w, B, joints);
     CHORE_LAUNCH_CHECK(h, s);
-    const size_t smem = ((size_t)FB * d.NP + (size_t)FB * J * 12 + (size_t)FB * num_betas) * sizeof(float);
-    hipLaunchKernelGGL(lbs_vertex_fwd_kernel, dim3((V + 255) / 256, (B + FB - 1) / FB), dim3(256), smem, s, d, m, betas, trans,
+    const size_t smem = ((size_t)FB * d.NP + (size_t)FB * J * 12 + (size_t)FB * num_betas + (size_t)FB * VF_T) * sizeof(float);
+    hipLaunchKernelGGL(lbs_vertex_fwd_kernel, dim3((V + VF_V - 1) / VF_V, (B + FB - 1) / FB), dim3(VF_T), smem, s, d, m, betas, trans,
                        offsets, scale, (const float*)w, B, verts, v_posed, naked);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
@@ -614,17 +733,36 @@ int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num
     hipStream_t s = (hipStream_t)stream;
     const float* m = (const float*)arena;
     float* w = (float*)workspace;
-    hipLaunchKernelGGL(lbs_vertex_bwd_kernel, dim3((V + 255) / 256, B), dim3(256), (size_t)J * 12 * sizeof(float), s, d, m, scale, w,
+    hipLaunchKernelGGL(lbs_vertex_bwd_kernel, dim3((V + 255) / 256, B), dim3(256), std::max((size_t)J * 12 * sizeof(float), 256 * sizeof(double)), s, d, m, scale, w,
                        B, v_posed, g_verts);
     CHORE_LAUNCH_CHECK(h, s);
     hipLaunchKernelGGL(lbs_dA_kernel, dim3(J, B), dim3(256), 0, s, d, m, w, B);
     CHORE_LAUNCH_CHECK(h, s);
-    hipLaunchKernelGGL(lbs_dpm_kernel, dim3(d.NP, (B + FB - 1) / FB), dim3(256), 0, s, d, m, w, B);
-    CHORE_LAUNCH_CHECK(h, s);
-    hipLaunchKernelGGL(lbs_dbeta_kernel, dim3(num_betas, B), dim3(256), 0, s, d, m, w, B);
+    hipLaunchKernelGGL(lbs_dpm_kernel, dim3(d.NP + num_betas, (B + FB - 1) / FB), dim3(256), 0, s, d, m, w, B);
     CHORE_LAUNCH_CHECK(h, s);
     hipLaunchKernelGGL(lbs_pose_bwd_kernel, dim3(B), dim3(64), 0, s, d, m, pose, scale, (const float*)w, B, g_verts, g_joints,
                        dpose, dbetas, dtrans);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+int chore_landmarks_fwd(chore_handle* h, const float* reg, const float* verts, int R, int V, int B, float* out, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!reg || !verts || !out || R < 1 || V < 1 || B < 1 || B > 65535)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_landmarks_fwd: bad argument (R=%d V=%d B=%d)", R, V, B);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(landmarks_fwd_kernel, dim3(R, B), dim3(256), 0, s, reg, verts, R, V, out);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+int chore_landmarks_bwd(chore_handle* h, const float* reg, const float* g, int R, int V, int B, float* dverts, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!reg || !g || !dverts || R < 1 || R > 2048 || V < 1 || B < 1 || B > 65535)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_landmarks_bwd: bad argument (R=%d V=%d B=%d)", R, V, B);
+    hipStream_t s = (hipStream_t)stream;
+    const size_t smem = ((size_t)R * 3 + 4 * 64 * 3) * sizeof(float);
+    hipLaunchKernelGGL(landmarks_bwd_kernel, dim3((V + 63) / 64, B), dim3(256), smem, s, reg, g, R, V, dverts);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -5,11 +5,13 @@ Same roles and attribute names as /root/reference/lib_smpl/wrapper_pytorch.py:
 `SMPLPyTorchWrapperBatchSplitParams` (:93-218) splits them into `global_pose / body_pose / hand_pose /
 top_betas / other_betas / trans` so the fit can optimise subsets, `get_landmarks()` returns the body-25 /
 face / hand keypoints.  Differences: the body model arrives as arrays (see lib_smpl/smpl_layer.py), the
-landmark regressors are dense (K,V) device tensors applied with one matmul (the reference loops
+landmark regressors are dense (K,V) device tensors applied by one kernel (chore_landmarks_fwd; the reference loops
 torch.sparse.mm over the batch, lib_smpl/torch_functions.py:52-76), and `get_landmarks` reuses the
 vertices of the preceding `forward()` when the parameters have not changed instead of running LBS a
 second time (reference quirk, wrapper_pytorch.py:186).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -49,6 +51,45 @@ def synthetic_regressors(V=6890, seed=0):
     return out
 
 
+_TORCH_LANDMARKS = bool(os.environ.get("CHORE_LANDMARKS_TORCH"))    # A/B switch: the product as a library GEMM
+
+
+class _LandmarkFn(torch.autograd.Function):
+    """lm (B,R,3) = reg (R,V) @ verts (B,V,3) through chore_landmarks_fwd / _bwd (csrc/smpl_lbs.hip)"""
+
+    @staticmethod
+    def forward(ctx, reg, verts):
+        from .. import _lib
+        verts = verts.contiguous()
+        B, V, _ = verts.shape
+        R = reg.shape[0]
+        out = torch.empty(B, R, 3, device=verts.device, dtype=torch.float32)
+        h = _lib.handle(verts.device.index or 0)
+        _lib.check(_lib.lib.chore_landmarks_fwd(h, reg.data_ptr(), verts.data_ptr(), R, V, B, out.data_ptr(),
+                                                torch.cuda.current_stream(verts.device).cuda_stream), h, "chore_landmarks_fwd")
+        ctx.save_for_backward(reg)
+        ctx.dims = (R, V, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        from .. import _lib
+        reg, = ctx.saved_tensors
+        R, V, B = ctx.dims
+        g = g.contiguous()
+        dv = torch.empty(B, V, 3, device=g.device, dtype=torch.float32)
+        h = _lib.handle(g.device.index or 0)
+        _lib.check(_lib.lib.chore_landmarks_bwd(h, reg.data_ptr(), g.data_ptr(), R, V, B, dv.data_ptr(),
+                                                torch.cuda.current_stream(g.device).cuda_stream), h, "chore_landmarks_bwd")
+        return None, dv
+
+
+def landmarks(reg, verts):
+    if not (verts.is_cuda and reg.is_cuda and verts.dtype == torch.float32 and reg.dtype == torch.float32 and reg.is_contiguous()):
+        raise RuntimeError("landmarks: fp32 device tensors expected (there is no CPU path)")
+    return _LandmarkFn.apply(reg, verts)
+
+
 class _Landmarks:
     """landmark regressors + a one-entry memo of the LBS result.
 
@@ -64,7 +105,10 @@ class _Landmarks:
         self.register_buffer("body25_reg", t(b25))
         self.register_buffer("face_reg", t(face))
         self.register_buffer("hand_reg", t(hand))
+        # the three regressors stacked (25 + 70 + 42 rows): one product, split afterwards
+        self.register_buffer("all_reg", torch.cat([self.body25_reg, self.face_reg, self.hand_reg], 0).contiguous(), persistent=False)
         self._memo = None
+        self._lm_memo = None
 
     def _memo_key(self):
         ps = list(self.parameters())
@@ -81,6 +125,7 @@ class _Landmarks:
     def forget(self):
         """drop the memo (it holds an autograd graph)"""
         self._memo = None
+        self._lm_memo = None
 
     @property
     def faces(self):
@@ -97,10 +142,14 @@ class _Landmarks:
 
     def get_landmarks(self):
         verts = self.forward()[0]
-        # one product for the three regressors (25 + 70 + 42 rows), split afterwards
         n1, n2 = self.body25_reg.shape[0], self.face_reg.shape[0]
-        allreg = torch.cat([self.body25_reg, self.face_reg, self.hand_reg], 0)
-        lm = torch.matmul(allreg, verts)
+        # like the vertices, the landmarks of unchanged parameters are the same tensors (a 'kpts' step asks twice:
+        # recon_fit_behave.py:300-306), keyed on the vertices they were computed from
+        if self._lm_memo is not None and self._lm_memo[0] is verts:
+            lm = self._lm_memo[1]
+        else:
+            lm = torch.matmul(self.all_reg, verts) if _TORCH_LANDMARKS else landmarks(self.all_reg, verts)
+            self._lm_memo = (verts, lm)
         return lm[:, :n1], lm[:, n1:n1 + n2], lm[:, n1 + n2:]
 
 

@@ -209,6 +209,14 @@ int chore_smpl_lbs_fwd(chore_handle* h, const void* arena, int V, int J, int num
 int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num_betas, const float* pose,
                        float scale, int B, const float* v_posed, const float* g_verts, const float* g_joints,
                        float* dpose, float* dbetas, float* dtrans, void* workspace, chore_stream_t stream);
+/* landmark regression on the skinned vertices (replaces the per-regressor torch.sparse.mm loop of
+ * lib_smpl/torch_functions.py:52-76 behind SMPLPyTorchWrapperBatch.get_landmarks, lib_smpl/wrapper_pytorch.py:186-205):
+ * reg (R,V) dense fp32 (rows of the body-25 / face / hand regressors stacked), verts (B,V,3) -> out (B,R,3); backward:
+ * g (B,R,3) -> dverts (B,V,3), written (not accumulated); R <= 2048 */
+int chore_landmarks_fwd(chore_handle* h, const float* reg, const float* verts, int R, int V, int B, float* out,
+                        chore_stream_t stream);
+int chore_landmarks_bwd(chore_handle* h, const float* reg, const float* g, int R, int V, int B, float* dverts,
+                        chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Projection onto SO(3)  (replaces ReconFitterBase.project_so3, recon/recon_fit_base.py:168-188:

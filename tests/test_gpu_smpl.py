@@ -56,3 +56,24 @@ def test_lbs_batch_sizes_and_determinism(layer):
     v1, j1, _, _ = layer(args[0], th_betas=args[1], th_trans=args[2])
     v2, j2, _, _ = layer(args[0][4:5], th_betas=args[1][4:5], th_trans=args[2][4:5])
     assert torch.equal(v1[4:5], v2) and torch.equal(j1[4:5], j2)   # frames are independent, bit for bit
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_landmark_regression_forward_and_backward(B):
+    """chore_landmarks_fwd / _bwd = reg @ verts and its transpose (fp64 product as the reference; fp32 sums: 2e-6 of
+    the result's scale), dense and sparse rows, a vertex count that is no multiple of the tile sizes"""
+    from chore_amd.lib_smpl.wrapper_pytorch import landmarks, synthetic_regressors
+    V = 6890
+    rs = np.random.RandomState(5)
+    reg = np.concatenate(synthetic_regressors(V) + [rs.standard_normal((3, V)).astype(np.float32)], 0)   # 137 sparse + 3 dense rows
+    verts = rs.standard_normal((B, V, 3)).astype(np.float32)
+    w = rs.standard_normal((B, reg.shape[0], 3)).astype(np.float32)
+    vt = torch.from_numpy(verts).cuda().requires_grad_(True)
+    lm = landmarks(torch.from_numpy(reg).cuda(), vt)
+    (lm * torch.from_numpy(w).cuda()).sum().backward()
+    ref = np.einsum("rv,bvk->brk", reg.astype(np.float64), verts.astype(np.float64))
+    dref = np.einsum("rv,brk->bvk", reg.astype(np.float64), w.astype(np.float64))
+    assert np.abs(lm.detach().cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max()
+    assert np.abs(vt.grad.cpu().numpy() - dref).max() < 2e-6 * np.abs(dref).max()
+    lm2 = landmarks(torch.from_numpy(reg).cuda(), vt.detach())
+    assert torch.equal(lm2, lm.detach())                    # fixed summation order
