@@ -7,7 +7,7 @@
 //     path (angle = ||theta + 1e-8||, rodrigues_layer.py:41-52), joint locations J = JT + JS*beta
 //     (J_regressor folded into JT/JS at pack time), the kinematic chain and the skinning transforms.
 //   * vertex kernel: thread = one coordinate of a vertex; the pose blend shapes are stored p-major
-//     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 27 rows at a time, for a
+//     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 51 rows at a time, for a
 //     group of up to 4 frames whose pose maps and transforms sit in LDS.
 //   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), two
 //     fixed-order reduction kernels (dA = W^T dT; d pose_map = P^T d v_posed with d beta = S^T d v_posed)
@@ -184,6 +184,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
                                                           float scale, float* __restrict__ work, int B,
                                                           float* __restrict__ joints) {
     __shared__ float R[MAXJ][9], Jl[MAXJ][3], G[MAXJ][12];
+    __shared__ int dep[64];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     const int b = blockIdx.x, j = threadIdx.x;
@@ -199,12 +200,23 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
         }
     }
     __syncthreads();
-    if (j == 0) {   // kinematic chain (smpl_layer.py:114-131): G_i = G_parent * [R_i | J_i - J_parent]
+    // kinematic chain (smpl_layer.py:114-131): G_i = G_parent * [R_i | J_i - J_parent].  One lane per joint, one round per
+    // tree depth (a joint's transform needs its parent's only): 10 rounds for SMPL-H instead of 51 steps on one lane
+    int depth = 0;
+    if (j < d.J)
+        for (int q = j; q > 0; q = parents[q]) ++depth;
+    dep[j] = j < d.J ? depth : 0;
+    if (j == 0) {
 #pragma unroll
         for (int e = 0; e < 9; ++e) G[0][(e / 3) * 4 + e % 3] = R[0][e];
         G[0][3] = Jl[0][0]; G[0][7] = Jl[0][1]; G[0][11] = Jl[0][2];
-        for (int i = 1; i < d.J; ++i) {
-            const int p = parents[i];
+    }
+    __syncthreads();
+    int maxdep = 0;
+    for (int q = 0; q < d.J; ++q) maxdep = max(maxdep, dep[q]);
+    for (int level = 1; level <= maxdep; ++level) {
+        if (j < d.J && depth == level) {
+            const int i = j, p = parents[i];
             float gr[9], rr[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) gr[e] = G[p][(e / 3) * 4 + e % 3];
@@ -216,6 +228,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
                 G[i][r * 4 + 3] = gr[r * 3] * t0 + gr[r * 3 + 1] * t1 + gr[r * 3 + 2] * t2 + G[p][r * 4 + 3];
             }
         }
+        __syncthreads();
     }
     __syncthreads();
     if (j < d.J) {
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
 // V*3 x VF_U loads in flight (one vertex per thread and one load at a time left 27 workgroups waiting on a chain of 459
 // round trips: 64 us per call).
 // ------------------------------------------------------------------------------------------------
-constexpr int VF_V = 64, VF_T = VF_V * 3, VF_U = 27;
+constexpr int VF_V = 64, VF_T = VF_V * 3, VF_U = 51;
 constexpr int SKIN_U = 13;     // 52 = 4 x 13 joints (SMPL-H); SMPL's 24: 13 + 11
 constexpr int DPM_U = 9;       // steps of a 256-thread reduction loop whose loads are issued together
 __global__ __launch_bounds__(VF_T) void lbs_vertex_fwd_kernel(Dims d, const float* __restrict__ model,
@@ -522,27 +535,29 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
         for (int e = 0; e < 9; ++e) dR[j][e] = 0.f;
     }
     __syncthreads();
-    if (j == 0) {
-        for (int i = d.J - 1; i >= 1; --i) {   // children before parents (parents[i] < i in SMPL trees)
-            const int p = parents[i];
-            const float t[3] = {Jl[i][0] - Jl[p][0], Jl[i][1] - Jl[p][1], Jl[i][2] - Jl[p][2]};
-            float dt[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) dt[c] = G[p][c] * dG[i][3] + G[p][4 + c] * dG[i][7] + G[p][8 + c] * dG[i][11];
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    // dG_p.R += dG_i.R R_i^T + dG_i.t (x) t ;  dR_i += G_p.R^T dG_i.R
-                    dG[p][r * 4 + c] += dG[i][r * 4] * R[i][c * 3] + dG[i][r * 4 + 1] * R[i][c * 3 + 1] +
-                                        dG[i][r * 4 + 2] * R[i][c * 3 + 2] + dG[i][r * 4 + 3] * t[c];
-                    dR[i][r * 3 + c] += G[p][r] * dG[i][c] + G[p][4 + r] * dG[i][4 + c] + G[p][8 + r] * dG[i][8 + c];
-                }
-                dG[p][r * 4 + 3] += dG[i][r * 4 + 3];
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { dJ[i][c] += dt[c]; dJ[p][c] -= dt[c]; }
+    // reverse chain, children before parents (parents[i] < i in SMPL trees), one step per joint; inside a step the 9 + 3 + 3
+    // independent results go to 15 lanes (every result is the expression the one-lane loop evaluated)
+    for (int i = d.J - 1; i >= 1; --i) {
+        const int p = parents[i];
+        if (j < 9) {
+            const int r = j / 3, c = j % 3;
+            const float tc = Jl[i][c] - Jl[p][c];
+            // dG_p.R += dG_i.R R_i^T + dG_i.t (x) t ;  dR_i += G_p.R^T dG_i.R
+            dG[p][r * 4 + c] += dG[i][r * 4] * R[i][c * 3] + dG[i][r * 4 + 1] * R[i][c * 3 + 1] +
+                                dG[i][r * 4 + 2] * R[i][c * 3 + 2] + dG[i][r * 4 + 3] * tc;
+            dR[i][r * 3 + c] += G[p][r] * dG[i][c] + G[p][4 + r] * dG[i][4 + c] + G[p][8 + r] * dG[i][8 + c];
+        } else if (j < 12) {
+            const int r = j - 9;
+            dG[p][r * 4 + 3] += dG[i][r * 4 + 3];
+        } else if (j < 15) {
+            const int c = j - 12;
+            const float dt = G[p][c] * dG[i][3] + G[p][4 + c] * dG[i][7] + G[p][8 + c] * dG[i][11];
+            dJ[i][c] += dt;
+            dJ[p][c] -= dt;
         }
+        __syncthreads();
+    }
+    if (j == 0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
 #pragma unroll

@@ -40,6 +40,7 @@ class _LBSFn(torch.autograd.Function):
         ctx.save_for_backward(pose, v_posed, ws, arena)
         ctx.layer, ctx.scale = layer, float(scale)
         ctx.mark_non_differentiable(v_posed, naked)
+        ctx.set_materialize_grads(False)      # an unused output arrives as None (a NULL pointer for the kernels), not as a zero tensor
         return verts, joints, v_posed, naked
 
     @staticmethod

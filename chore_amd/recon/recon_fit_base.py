@@ -430,9 +430,13 @@ class ReconFitterBase:
             return weighted_sum(vals, [float(weight_dict[k](1.0, 0)) for k in loss_dict], it.denom)
         return torch.stack([weight_dict[k](v, it) for k, v in loss_dict.items()]).sum()
 
-    def compute_obj_loss(self, data_dict, loss_dict, model, obj_s, object):
-        model.query(object, **data_dict["query_dict"])
-        preds = model.get_preds()
+    def compute_obj_loss(self, data_dict, loss_dict, model, obj_s, object, preds=None):
+        """`preds`: the field at `object` when the caller has queried these very points already in this step (the
+        reference queries them twice per step, recon_fit_behave.py:171,183 -> recon_fit_base.py:505-506, with the same
+        result): one query forward and one backward instead of two"""
+        if preds is None:
+            model.query(object, **data_dict["query_dict"])
+            preds = model.get_preds()
         loss_dict["object"] = torch.clamp(preds[0][:, 1:2, :], max=0.8).mean()
         loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
         return preds

@@ -7,7 +7,10 @@ quirks are kept on purpose because they change the fitted poses (SURVEY Appendix
   * zero_grad() once per OUTER iteration, then `steps_per_iter` x {backward; step} -> gradients accumulate
     over the inner steps;
   * a new Adam at every phase switch; in `optimize_smpl_object` the SMPL parameters are never stepped;
-  * `forward_step` queries the object points twice per step (once directly, once in compute_obj_loss).
+Work the reference repeats with the same result every time is done once (same values, fewer launches): `forward_step`
+queries the object points twice per step (:171 and in compute_obj_loss) -- one query here, its gradient is the sum of both
+uses; in `optimize_smpl_object` the body is fixed, so LBS and the 6 890-point query of the joint phase run once per call
+instead of once per step; the 'sil' phase, whose terms do not read the field, does not query it.
 The 'sil' phase runs if the caller provides data_dict['silhouette'] (SilLossROI); the 'collide' term of the joint
 phase (recon_fit_behave.py:213-216) runs if the fitter was given the object template mesh (scan_verts / scan_faces).
 Per-step host synchronisation of the reference (tqdm strings, .item()) is gone: the early-stop rule is evaluated on the
@@ -190,26 +193,34 @@ class ReconFitterBehave(ReconFitterBase):
 
     # ---- object + joint -----------------------------------------------------------------------------
     def forward_step(self, model, smpl, data_dict, obj_R, obj_t, obj_s, phase, noise=None):
-        smpl.forget()
-        smpl_verts = smpl()[0]
+        const = data_dict.get("smpl_const")     # optimize_smpl_object: the body does not move, see there
+        if const is None:
+            smpl.forget()
+            smpl_verts = smpl()[0]
+        else:
+            smpl_verts = const["verts"]
         loss_dict = {}
         R = self.decopose_axis(obj_R, noise=noise)
-        object = self.transform_obj_verts(data_dict["objects"], R, obj_t, obj_s)
-        model.query(object, **data_dict["query_dict"])
-        df_pred, _, part_o, centers_o = model.get_preds()
-        obj_center_pred = data_dict["smpl_center"] + torch.mean(centers_o[:, 3:, :], -1)
-        if phase == "sil":
+        if phase == "sil":      # none of its terms reads the field (the reference queries the object points all the same, :171)
             obj_losses = data_dict["silhouette"](R, obj_t, obj_s)[0]
             loss_dict["mask"] = obj_losses["mask"]
             loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
             loss_dict["trans"] = torch.mean((obj_t - data_dict["trans_init"]) ** 2)
             return loss_dict
-        self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object)
+        object = self.transform_obj_verts(data_dict["objects"], R, obj_t, obj_s)
+        model.query(object, **data_dict["query_dict"])
+        preds = model.get_preds()
+        df_pred, _, part_o, centers_o = preds
+        obj_center_pred = data_dict["smpl_center"] + torch.mean(centers_o[:, 3:, :], -1)
+        self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object, preds=preds)
         loss_dict["ocent"] = F.mse_loss(torch.mean(object, 1), obj_center_pred, reduction="none").sum(-1).mean()
         if phase == "joint":
             df_obj_h = df_pred[:, 0, :]
-            model.query(smpl_verts, **data_dict["query_dict"])
-            df_hum_o = model.get_preds()[0][:, 1, :]
+            if const is None:
+                model.query(smpl_verts, **data_dict["query_dict"])
+                df_hum_o = model.get_preds()[0][:, 1, :]
+            else:
+                df_hum_o = const["df_hum_o"]
             self.compute_contact_loss(df_hum_o, df_obj_h, object, smpl_verts, loss_dict, part_o=part_o)
             if self.scan_faces is not None:
                 loss_dict["collide"] = self.compute_collision_loss(smpl_verts, smpl.faces, R, obj_t, obj_s)
@@ -240,6 +251,15 @@ class ReconFitterBehave(ReconFitterBase):
         # computed (LBS backward, the 6 890-point query backward of the joint phase) and never read -- switched off
         for p in split.parameters():
             p.requires_grad_(False)
+        # ... and with them the body is a constant of all three phases: its vertices and the object distance queried at
+        # them (the reference re-evaluates LBS and the 6 890-point query in every step, :167-168,196-197, with the same
+        # result every time).  Evaluated once, the same values enter every step.
+        with torch.no_grad():
+            split.forget()
+            body = split()[0].detach()
+            model.query(body, **data_dict["query_dict"])
+            data_dict["smpl_const"] = {"verts": body, "df_hum_o": model.get_preds()[0][:, 1, :].detach().clone()}
+        split.forget()
         prev = torch.tensor(300.0, device=self.device)
         n_outer = joint_iter + obj_iter + max_iter + sil_iter
         # The SO(3) perturbation (recon_fit_base.py:384) comes from the CPU generator in the order the reference
@@ -286,6 +306,7 @@ class ReconFitterBehave(ReconFitterBase):
             if armed and st.stopped():
                 break
         rel()
+        data_dict.pop("smpl_const", None)
         return smpl, data_dict["obj_R"], data_dict["obj_t"]
 
 
