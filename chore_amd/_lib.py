@@ -103,6 +103,13 @@ SIGNATURES = {
                                     c_float, c_float, c_void_p, c_void_p]),
     "chore_fit_weighted_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_fit_weighted_sum_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_smpl_terms_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_smpl_terms_bwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_point_terms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "chore_fit_point_terms_fwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p]),
+    "chore_fit_point_terms_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_fit_stop_rule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "chore_train_loss_workspace_bytes": (c_size_t, []),
     "chore_train_loss": (c_int, [c_void_p] * 11 + [c_int, c_int, c_float, c_void_p, c_float] + [c_void_p] * 5 + [c_int, c_void_p,

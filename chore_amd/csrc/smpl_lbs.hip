@@ -7,7 +7,7 @@
 //     path (angle = ||theta + 1e-8||, rodrigues_layer.py:41-52), joint locations J = JT + JS*beta
 //     (J_regressor folded into JT/JS at pack time), the kinematic chain and the skinning transforms.
 //   * vertex kernel: thread = one coordinate of a vertex; the pose blend shapes are stored p-major
-//     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 51 rows at a time, for a
+//     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 27 rows at a time, for a
 //     group of up to 4 frames whose pose maps and transforms sit in LDS.
 //   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), two
 //     fixed-order reduction kernels (dA = W^T dT; d pose_map = P^T d v_posed with d beta = S^T d v_posed)
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
 // V*3 x VF_U loads in flight (one vertex per thread and one load at a time left 27 workgroups waiting on a chain of 459
 // round trips: 64 us per call).
 // ------------------------------------------------------------------------------------------------
-constexpr int VF_V = 64, VF_T = VF_V * 3, VF_U = 51;
+constexpr int VF_V = 64, VF_T = VF_V * 3, VF_U = 27;    // 51 rows at a time: 53 us against 29
 constexpr int SKIN_U = 13;     // 52 = 4 x 13 joints (SMPL-H); SMPL's 24: 13 + 11
 constexpr int DPM_U = 9;       // steps of a 256-thread reduction loop whose loads are issued together
 __global__ __launch_bounds__(VF_T) void lbs_vertex_fwd_kernel(Dims d, const float* __restrict__ model,

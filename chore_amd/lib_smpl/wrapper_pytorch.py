@@ -140,9 +140,9 @@ class _Landmarks:
     def faces(self, f):
         self.__dict__["_faces"] = f
 
-    def get_landmarks(self):
+    def landmarks_all(self):
+        """(B, 25 + 70 + 42, 3): the rows of the three regressors in one tensor (body-25 first)"""
         verts = self.forward()[0]
-        n1, n2 = self.body25_reg.shape[0], self.face_reg.shape[0]
         # like the vertices, the landmarks of unchanged parameters are the same tensors (a 'kpts' step asks twice:
         # recon_fit_behave.py:300-306), keyed on the vertices they were computed from
         if self._lm_memo is not None and self._lm_memo[0] is verts:
@@ -150,6 +150,11 @@ class _Landmarks:
         else:
             lm = torch.matmul(self.all_reg, verts) if _TORCH_LANDMARKS else landmarks(self.all_reg, verts)
             self._lm_memo = (verts, lm)
+        return lm
+
+    def get_landmarks(self):
+        lm = self.landmarks_all()
+        n1, n2 = self.body25_reg.shape[0], self.face_reg.shape[0]
         return lm[:, :n1], lm[:, n1:n1 + n2], lm[:, n1 + n2:]
 
 

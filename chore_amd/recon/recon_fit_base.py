@@ -18,6 +18,7 @@ from .. import _lib
 from ..lib_smpl.const import SMPL_PARTS_NUM, SMPL_POSE_PRAMS_NUM  # noqa: F401
 from ..lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatchSplitParams
 from ..model.camera import KinectColorCamera
+from . import fit_terms
 
 
 # 14 body-part colours of the visualisations (recon/opt_utils.py:13-28)
@@ -437,7 +438,10 @@ class ReconFitterBase:
         if preds is None:
             model.query(object, **data_dict["query_dict"])
             preds = model.get_preds()
-        loss_dict["object"] = torch.clamp(preds[0][:, 1:2, :], max=0.8).mean()
+        if fit_terms.point_terms_supported(preds[0]):
+            loss_dict["object"] = fit_terms.point_terms(preds[0], 1, 0.8)[0]
+        else:
+            loss_dict["object"] = torch.clamp(preds[0][:, 1:2, :], max=0.8).mean()
         loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
         return preds
 
@@ -450,7 +454,10 @@ class ReconFitterBase:
     def compute_df_h_loss(self, data_dict, loss_dict, model, smpl_verts):
         model.query(smpl_verts, **data_dict["query_dict"])
         df_pred, _, parts_pred, centers_pred = model.get_preds()
-        loss_dict["df_h"] = torch.clamp(df_pred[:, 0:1, :], max=0.1).mean()
+        if fit_terms.point_terms_supported(df_pred):
+            loss_dict["df_h"] = fit_terms.point_terms(df_pred, 0, 0.1)[0]
+        else:
+            loss_dict["df_h"] = torch.clamp(df_pred[:, 0:1, :], max=0.1).mean()
         return df_pred, parts_pred, centers_pred
 
     def compute_smpl_center_pred(self, data_dict, model, smpl):

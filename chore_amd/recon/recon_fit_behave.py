@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
+from . import fit_terms
 from .graph_step import EagerStep, GraphedStep
 from .recon_fit_base import ReconFitterBase
 
@@ -141,6 +142,21 @@ class ReconFitterBehave(ReconFitterBase):
         model = data_dict["net"]
         smpl.forget()   # the LBS memo lives for one step (its autograd graph is consumed by this step's backward)
         smpl_verts = smpl()[0]
+        pose = smpl.pose
+        if fit_terms.smpl_terms_supported(pose, self.body_prior, self.hand_prior):
+            # the same seven terms from two operators (fit_terms.py): 6 launches each way instead of ~45 / ~85
+            model.query(smpl_verts, **data_dict["query_dict"])
+            df_pred, _, parts_pred, _ = model.get_preds()
+            if fit_terms.point_terms_supported(df_pred, parts_pred):
+                qd = data_dict["query_dict"]
+                df_h, part = fit_terms.point_terms(df_pred, 0, 0.1, parts_pred, data_dict["part_labels"])
+                p_pose, p_hand, pinit, smplz, j2d = fit_terms.smpl_terms(
+                    pose, smpl.landmarks_all(), data_dict["pose_init"], data_dict["body_kpts"] if phase == "kpts" else None,
+                    qd["crop_center"], self.body_prior, self.hand_prior, self.camera, self.net_in_size, self.z_0)
+                loss_dict.update(df_h=df_h, pose=p_pose, hand=p_hand, part=part, smplz=smplz, pinit=pinit)
+                if phase == "kpts":
+                    loss_dict["j2d"] = j2d
+                return loss_dict
         _, parts_pred, _ = self.compute_df_h_loss(data_dict, loss_dict, model, smpl_verts)
         self.compute_prior_loss(loss_dict, smpl, nobeta=True)
         loss_dict["part"] = F.cross_entropy(parts_pred, data_dict["part_labels"], reduction="none").sum(-1).mean()

@@ -477,6 +477,35 @@ int chore_fit_weighted_sum(chore_handle* h, const float* const* losses, const fl
 int chore_fit_weighted_sum_bwd(chore_handle* h, const float* coeffs, int n, const float* denom, const float* g, float* grads,
                                chore_stream_t stream);
 
+/* The small loss terms of forward_smpl (recon_fit_behave.py:293-337) in one launch each way.  pose (B,156) SMPL-H
+ * axis-angle, pose_init (B,69) = the initial pose[3:72], J (B,R,3) landmarks whose first 25 rows are the body-25 keypoints
+ * (row 8 = MidHip), kpts (B,25,3) = (x, y, confidence) in pixels of the network input or NULL (no keypoint term),
+ * crop_center (B,2); body prior mean (63) / precision (63,63) applied to pose[3:66] (th_smpl_prior.py:32-39), hand prior
+ * mean (90) and the two (45,45) precisions applied to pose[66:156] (th_hand_prior.py:63-72, incl. its sum over frames and
+ * hands / 45); cam8 = HOST floats {fx, fy, cx, cy in pixels, crop/2, crop, network input size, z_0}.
+ * out5 / up5: HOST arrays of 5 device scalars in the order pose prior, hand prior, pose-init, depth (smplz), keypoints (j2d);
+ * a NULL entry of up5 is a zero gradient.  dpose (B,156) and dJ (B,R,3) are written completely. */
+int chore_fit_smpl_terms_fwd(chore_handle* h, const float* pose, const float* pose_init, const float* J, const float* kpts,
+                             const float* crop_center, const float* body_mean, const float* body_prec, const float* hand_mean,
+                             const float* lhand_prec, const float* rhand_prec, int B, int P, int R, const float* cam8,
+                             float* const* out5, chore_stream_t stream);
+int chore_fit_smpl_terms_bwd(chore_handle* h, const float* pose, const float* pose_init, const float* J, const float* kpts,
+                             const float* crop_center, const float* body_mean, const float* body_prec, const float* hand_mean,
+                             const float* lhand_prec, const float* rhand_prec, int B, int P, int R, const float* cam8,
+                             const float* const* up5, float* dpose, float* dJ, chore_stream_t stream);
+/* Per-point terms: out_clamped_mean = mean over (B,N) of min(df[:, channel, :], clamp_max)  (df_h with channel 0 / 0.1,
+ * recon_fit_base.py:520-526; the object term with channel 1 / 0.8, :505-511) and, if logits (B,C,N) is not NULL,
+ * out_cross_entropy = mean over B of sum over N of the cross entropy against labels (B,N) int64 (recon_fit_behave.py:318-320),
+ * C <= 16.  workspace: chore_fit_point_terms_workspace_bytes(B, N).  Backward: up_* device scalars (NULL = 0) -> ddf (B,2,N)
+ * (the other channel zero) and dlogits (B,C,N). */
+size_t chore_fit_point_terms_workspace_bytes(int B, int N);
+int chore_fit_point_terms_fwd(chore_handle* h, const float* df, int channel, float clamp_max, const float* logits,
+                              const int64_t* labels, int B, int N, int C, float* out_clamped_mean, float* out_cross_entropy,
+                              void* workspace, chore_stream_t stream);
+int chore_fit_point_terms_bwd(chore_handle* h, const float* df, int channel, float clamp_max, const float* logits,
+                              const int64_t* labels, int B, int N, int C, const float* up_clamped_mean,
+                              const float* up_cross_entropy, float* ddf, float* dlogits, chore_stream_t stream);
+
 /* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
  * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the
  * forward's df / pca / parts / centers, 5 / 6 the maps, 8 points, 9-12 the upstream gradients, 13 dpoints), out32[16..31] =
