@@ -110,6 +110,12 @@ SIGNATURES = {
                                           c_void_p, c_void_p, c_void_p]),
     "chore_fit_point_terms_bwd": (c_int, [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_obj_transform_fwd": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p, c_void_p]),
+    "chore_fit_obj_transform_bwd": (c_int, [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_obj_terms_workspace_bytes": (c_size_t, [c_int]),
+    "chore_fit_obj_terms_fwd": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_fit_obj_terms_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
+                                        c_void_p, c_void_p]),
     "chore_fit_stop_rule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "chore_train_loss_workspace_bytes": (c_size_t, []),
     "chore_train_loss": (c_int, [c_void_p] * 11 + [c_int, c_int, c_float, c_void_p, c_float] + [c_void_p] * 5 + [c_int, c_void_p,

@@ -10,8 +10,9 @@
 //   * chore_fit_point_terms: the mean of a clamped distance channel (df_h: recon_fit_base.py:520-526, object:
 //     :505-511) and the part cross-entropy summed over the points (recon_fit_behave.py:318-320) -- per-workgroup partial
 //     sums in fp64, added in workgroup order by a one-workgroup finish launch.
+//   * chore_fit_obj_transform / chore_fit_obj_terms: the placement of the object points and the scale / object-centre
+//     terms of forward_step (recon_fit_behave.py:165-186).
 // The backward entry points recompute from the inputs and take the upstream gradient of every term as a device scalar.
-// (object-centre / scale / translation terms of forward_step stay tensor expressions.)
 #include "common.h"
 
 namespace {
@@ -214,6 +215,112 @@ __global__ __launch_bounds__(256) void point_terms_finish_kernel(PointTermArgs a
     }
 }
 
+// ---- object placement: out = (v R + t) s   (transform_obj_verts, recon_fit_base.py:367-371: rotate, translate, THEN scale) ----
+__global__ __launch_bounds__(256) void obj_transform_fwd_kernel(const float* __restrict__ v0, const float* __restrict__ R,
+                                                                const float* __restrict__ t, const float* __restrict__ sc, int N,
+                                                                float* __restrict__ out) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float* r = R + (size_t)b * 9;
+    const float* v = v0 + ((size_t)b * N + n) * 3;
+    const float x = v[0], y = v[1], z = v[2], s = sc[b];
+    float* o = out + ((size_t)b * N + n) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (((x * r[c] + y * r[3 + c]) + z * r[6 + c]) + t[b * 3 + c]) * s;
+}
+
+// d R[k][c] = s sum_n v[n][k] g[n][c];  d t[c] = s sum_n g[n][c];  d s = sum_n g[n] . (v[n] R + t)      one workgroup per frame
+__global__ __launch_bounds__(256) void obj_transform_bwd_kernel(const float* __restrict__ v0, const float* __restrict__ R,
+                                                                const float* __restrict__ t, const float* __restrict__ sc,
+                                                                const float* __restrict__ g, int N, float* __restrict__ dR,
+                                                                float* __restrict__ dt, float* __restrict__ ds) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* r = R + (size_t)b * 9;
+    float a[13];
+#pragma unroll
+    for (int e = 0; e < 13; ++e) a[e] = 0.f;
+    for (int n = tid; n < N; n += 256) {
+        const float* v = v0 + ((size_t)b * N + n) * 3;
+        const float* gg = g + ((size_t)b * N + n) * 3;
+        const float x[3] = {v[0], v[1], v[2]}, gv[3] = {gg[0], gg[1], gg[2]};
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[k * 3 + c] += x[k] * gv[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[9 + c] += gv[c];
+            a[12] += gv[c] * (((x[0] * r[c] + x[1] * r[3 + c]) + x[2] * r[6 + c]) + t[b * 3 + c]);
+        }
+    }
+    const float s = sc[b];
+#pragma unroll
+    for (int e = 0; e < 13; ++e) {
+        const double v = block_sum((double)a[e], sh, tid);
+        if (tid == 0) {
+            if (e < 9) dR[(size_t)b * 9 + e] = (float)(v * (double)s);
+            else if (e < 12) dt[b * 3 + e - 9] = (float)(v * (double)s);
+            else ds[b] = (float)v;
+        }
+    }
+}
+
+// ---- object terms of forward_step (recon_fit_behave.py:174-186): scale = mean_b (s - s0)^2 and
+//      ocent = mean_b sum_k (mean_n object[b][n][k] - (smpl_center[b][k] + mean_n centers[b][3 + k][n]))^2 ----
+__global__ __launch_bounds__(256) void obj_terms_sums_kernel(const float* __restrict__ object, const float* __restrict__ centers, int N,
+                                                             double* __restrict__ sums /*[B][6]*/) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float a[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int n = tid; n < N; n += 256) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            a[k] += object[((size_t)b * N + n) * 3 + k];
+            a[3 + k] += centers[((size_t)b * 6 + 3 + k) * N + n];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 6; ++e) {
+        const double v = block_sum((double)a[e], sh, tid);
+        if (tid == 0) sums[(size_t)b * 6 + e] = v;
+    }
+}
+__global__ void obj_terms_finish_kernel(const double* __restrict__ sums, const float* __restrict__ smpl_center,
+                                        const float* __restrict__ obj_s, float s0, int B, int N, float* __restrict__ diff /*[B][3]*/,
+                                        float* out_scale, float* out_ocent) {
+    if (threadIdx.x || blockIdx.x) return;
+    double sc = 0.0, oc = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float ds = obj_s[b] - s0;
+        sc += (double)(ds * ds);
+        for (int k = 0; k < 3; ++k) {
+            const float mo = (float)(sums[(size_t)b * 6 + k] / N), mc = (float)(sums[(size_t)b * 6 + 3 + k] / N);
+            const float d = mo - (smpl_center[b * 3 + k] + mc);
+            diff[b * 3 + k] = d;
+            oc += (double)(d * d);
+        }
+    }
+    *out_scale = (float)(sc / B);
+    *out_ocent = (float)(oc / B);
+}
+__global__ __launch_bounds__(256) void obj_terms_bwd_kernel(const float* __restrict__ diff, const float* __restrict__ obj_s, float s0,
+                                                            const float* up_scale, const float* up_ocent, int B, int N,
+                                                            float* __restrict__ dobject, float* __restrict__ dcenters,
+                                                            float* __restrict__ dscale) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    const float uo = up_ocent ? *up_ocent : 0.f;
+    if (blockIdx.x == 0 && threadIdx.x == 0) dscale[b] = (up_scale ? *up_scale : 0.f) * 2.0f * (obj_s[b] - s0) / (float)B;
+    if (n >= N) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float gk = uo * 2.0f * diff[b * 3 + k] / (float)B / (float)N;
+        dobject[((size_t)b * N + n) * 3 + k] = gk;
+        dcenters[((size_t)b * 6 + k) * N + n] = 0.f;
+        dcenters[((size_t)b * 6 + 3 + k) * N + n] = -gk;
+    }
+}
+
 int check_smpl(chore_handle* h, const SmplTermArgs& a, const char* who) {
     if (!a.pose || !a.pose_init || !a.J || !a.cc || !a.bmean || !a.bprec || !a.hmean || !a.lprec || !a.rprec)
         CHORE_FAIL(h, CHORE_EINVAL, "%s: null argument", who);
@@ -305,6 +412,58 @@ int chore_fit_point_terms_bwd(chore_handle* h, const float* df, int channel, flo
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(point_terms_kernel<true>, dim3((N + 255) / 256, B), dim3(256), 0, s, a);
     CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+int chore_fit_obj_transform_fwd(chore_handle* h, const float* verts, const float* R, const float* t, const float* s, int B, int N,
+                                float* out, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!verts || !R || !t || !s || !out || B < 1 || B > 65535 || N < 1)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_obj_transform_fwd: bad argument (B=%d N=%d)", B, N);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(obj_transform_fwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, verts, R, t, s, N, out);
+    CHORE_LAUNCH_CHECK(h, st);
+    return CHORE_OK;
+}
+
+int chore_fit_obj_transform_bwd(chore_handle* h, const float* verts, const float* R, const float* t, const float* s, const float* g,
+                                int B, int N, float* dR, float* dt, float* ds, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!verts || !R || !t || !s || !g || !dR || !dt || !ds || B < 1 || N < 1)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_obj_transform_bwd: bad argument (B=%d N=%d)", B, N);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(obj_transform_bwd_kernel, dim3(B), dim3(256), 0, st, verts, R, t, s, g, N, dR, dt, ds);
+    CHORE_LAUNCH_CHECK(h, st);
+    return CHORE_OK;
+}
+
+size_t chore_fit_obj_terms_workspace_bytes(int B) { return (size_t)B * 6 * sizeof(double); }
+
+int chore_fit_obj_terms_fwd(chore_handle* h, const float* object, const float* centers, const float* smpl_center, const float* obj_s,
+                            float scale0, int B, int N, float* diff, float* out_scale, float* out_ocent, void* workspace,
+                            chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!object || !centers || !smpl_center || !obj_s || !diff || !out_scale || !out_ocent || !workspace || B < 1 || N < 1)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_obj_terms_fwd: bad argument (B=%d N=%d)", B, N);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(obj_terms_sums_kernel, dim3(B), dim3(256), 0, st, object, centers, N, (double*)workspace);
+    CHORE_LAUNCH_CHECK(h, st);
+    hipLaunchKernelGGL(obj_terms_finish_kernel, dim3(1), dim3(64), 0, st, (const double*)workspace, smpl_center, obj_s, scale0, B, N,
+                       diff, out_scale, out_ocent);
+    CHORE_LAUNCH_CHECK(h, st);
+    return CHORE_OK;
+}
+
+int chore_fit_obj_terms_bwd(chore_handle* h, const float* diff, const float* obj_s, float scale0, const float* up_scale,
+                            const float* up_ocent, int B, int N, float* dobject, float* dcenters, float* dscale,
+                            chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!diff || !obj_s || !dobject || !dcenters || !dscale || B < 1 || B > 65535 || N < 1)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_obj_terms_bwd: bad argument (B=%d N=%d)", B, N);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(obj_terms_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, diff, obj_s, scale0, up_scale, up_ocent, B, N,
+                       dobject, dcenters, dscale);
+    CHORE_LAUNCH_CHECK(h, st);
     return CHORE_OK;
 }
 

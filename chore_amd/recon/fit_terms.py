@@ -132,3 +132,93 @@ def point_terms(df, channel, cmax, logits=None, labels=None):
     if logits is None:
         return _PointTermsFn.apply(df, None, None, channel, cmax), None
     return _PointTermsFn.apply(df, logits, labels.long().contiguous(), channel, cmax)
+
+
+class _ObjTransformFn(torch.autograd.Function):
+    """(verts R + t) s with gradients for R, t, s (the template points are constants of the fit)"""
+
+    @staticmethod
+    def forward(ctx, verts, R, t, s):
+        dev = verts.device
+        h = _lib.handle(dev.index or 0)
+        R, t, s = R.contiguous(), t.contiguous(), s.contiguous()
+        B, N, _ = verts.shape
+        out = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.chore_fit_obj_transform_fwd(h, verts.data_ptr(), R.data_ptr(), t.data_ptr(), s.data_ptr(), B, N,
+                                                        out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_fit_obj_transform_fwd")
+        ctx.save_for_backward(verts, R, t, s)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        verts, R, t, s = ctx.saved_tensors
+        dev = verts.device
+        h = _lib.handle(dev.index or 0)
+        B, N, _ = verts.shape
+        g = g.float().contiguous()
+        dR, dt, ds = torch.empty_like(R), torch.empty_like(t), torch.empty_like(s)
+        _lib.check(_lib.lib.chore_fit_obj_transform_bwd(h, verts.data_ptr(), R.data_ptr(), t.data_ptr(), s.data_ptr(), g.data_ptr(),
+                                                        B, N, dR.data_ptr(), dt.data_ptr(), ds.data_ptr(),
+                                                        torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_obj_transform_bwd")
+        return None, dR, dt, ds
+
+
+def obj_transform_supported(verts, R, t, s):
+    ok = lambda x: x.is_cuda and x.dtype == torch.float32      # noqa: E731
+    return (not TORCH_TERMS and all(ok(x) for x in (verts, R, t, s)) and not verts.requires_grad and verts.is_contiguous() and
+            verts.dim() == 3 and tuple(R.shape) == (verts.shape[0], 3, 3) and tuple(t.shape) == (verts.shape[0], 3) and
+            tuple(s.shape) == (verts.shape[0],))
+
+
+def obj_transform(verts, R, t, s):
+    return _ObjTransformFn.apply(verts, R, t, s)
+
+
+class _ObjTermsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, object, centers, obj_s, smpl_center, scale0):
+        dev = object.device
+        h = _lib.handle(dev.index or 0)
+        object, centers, obj_s = object.contiguous(), centers.contiguous(), obj_s.contiguous()
+        B, N, _ = object.shape
+        diff = torch.empty(B, 3, device=dev, dtype=torch.float32)
+        o_scale = torch.empty((), device=dev, dtype=torch.float32)
+        o_cent = torch.empty((), device=dev, dtype=torch.float32)
+        ws = torch.empty(_lib.lib.chore_fit_obj_terms_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.chore_fit_obj_terms_fwd(h, object.data_ptr(), centers.data_ptr(), smpl_center.data_ptr(), obj_s.data_ptr(),
+                                                    float(scale0), B, N, diff.data_ptr(), o_scale.data_ptr(), o_cent.data_ptr(),
+                                                    ws.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_fit_obj_terms_fwd")
+        ctx.save_for_backward(diff, obj_s)
+        ctx.dims, ctx.scale0 = (B, N), float(scale0)
+        ctx.set_materialize_grads(False)
+        return o_scale, o_cent
+
+    @staticmethod
+    def backward(ctx, u_scale, u_cent):
+        diff, obj_s = ctx.saved_tensors
+        dev = diff.device
+        h = _lib.handle(dev.index or 0)
+        B, N = ctx.dims
+        u_scale = None if u_scale is None else u_scale.float().contiguous()
+        u_cent = None if u_cent is None else u_cent.float().contiguous()
+        dobj = torch.empty(B, N, 3, device=dev, dtype=torch.float32)
+        dcen = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
+        dsc = torch.empty(B, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.chore_fit_obj_terms_bwd(h, diff.data_ptr(), obj_s.data_ptr(), ctx.scale0, _ptr(u_scale), _ptr(u_cent), B, N,
+                                                    dobj.data_ptr(), dcen.data_ptr(), dsc.data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_obj_terms_bwd")
+        return dobj, dcen, dsc, None, None
+
+
+def obj_terms_supported(object, centers, obj_s, smpl_center):
+    ok = lambda x: x.is_cuda and x.dtype == torch.float32      # noqa: E731
+    return (not TORCH_TERMS and all(ok(x) for x in (object, centers, obj_s, smpl_center)) and object.dim() == 3 and
+            centers.dim() == 3 and centers.shape[1] == 6 and centers.shape[2] == object.shape[1] and not smpl_center.requires_grad)
+
+
+def obj_terms(object, centers, obj_s, smpl_center, scale0):
+    """-> (scale, ocent): mean((obj_s - scale0)^2) and
+    mse(mean(object, 1), smpl_center + mean(centers[:, 3:], -1)).sum(-1).mean()"""
+    return _ObjTermsFn.apply(object, centers, obj_s, smpl_center.detach().float().contiguous(), scale0)

@@ -394,6 +394,8 @@ class ReconFitterBase:
 
     def transform_obj_verts(self, verts, obj_R, obj_t, obj_s):
         """rotate, translate, THEN scale (reference order, recon_fit_base.py:367-371)"""
+        if fit_terms.obj_transform_supported(verts, obj_R, obj_t, obj_s):
+            return fit_terms.obj_transform(verts, obj_R, obj_t, obj_s)     # one launch each way (csrc/fit_terms.hip)
         verts = torch.bmm(verts, obj_R) + obj_t.unsqueeze(1)
         return verts * obj_s.unsqueeze(1).unsqueeze(1)
 
@@ -431,7 +433,7 @@ class ReconFitterBase:
             return weighted_sum(vals, [float(weight_dict[k](1.0, 0)) for k in loss_dict], it.denom)
         return torch.stack([weight_dict[k](v, it) for k, v in loss_dict.items()]).sum()
 
-    def compute_obj_loss(self, data_dict, loss_dict, model, obj_s, object, preds=None):
+    def compute_obj_loss(self, data_dict, loss_dict, model, obj_s, object, preds=None, scale_term=True):
         """`preds`: the field at `object` when the caller has queried these very points already in this step (the
         reference queries them twice per step, recon_fit_behave.py:171,183 -> recon_fit_base.py:505-506, with the same
         result): one query forward and one backward instead of two"""
@@ -442,7 +444,8 @@ class ReconFitterBase:
             loss_dict["object"] = fit_terms.point_terms(preds[0], 1, 0.8)[0]
         else:
             loss_dict["object"] = torch.clamp(preds[0][:, 1:2, :], max=0.8).mean()
-        loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
+        if scale_term:
+            loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
         return preds
 
     def compute_prior_loss(self, loss_dict, smpl, nobeta=False):

@@ -227,9 +227,14 @@ class ReconFitterBehave(ReconFitterBase):
         model.query(object, **data_dict["query_dict"])
         preds = model.get_preds()
         df_pred, _, part_o, centers_o = preds
-        obj_center_pred = data_dict["smpl_center"] + torch.mean(centers_o[:, 3:, :], -1)
-        self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object, preds=preds)
-        loss_dict["ocent"] = F.mse_loss(torch.mean(object, 1), obj_center_pred, reduction="none").sum(-1).mean()
+        if fit_terms.obj_terms_supported(object, centers_o, obj_s, data_dict["smpl_center"]):
+            self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object, preds=preds, scale_term=False)
+            loss_dict["scale"], loss_dict["ocent"] = fit_terms.obj_terms(object, centers_o, obj_s, data_dict["smpl_center"],
+                                                                         self.obj_scale)
+        else:
+            obj_center_pred = data_dict["smpl_center"] + torch.mean(centers_o[:, 3:, :], -1)
+            self.compute_obj_loss(data_dict, loss_dict, model, obj_s, object, preds=preds)
+            loss_dict["ocent"] = F.mse_loss(torch.mean(object, 1), obj_center_pred, reduction="none").sum(-1).mean()
         if phase == "joint":
             df_obj_h = df_pred[:, 0, :]
             if const is None:

@@ -505,6 +505,22 @@ int chore_fit_point_terms_fwd(chore_handle* h, const float* df, int channel, flo
 int chore_fit_point_terms_bwd(chore_handle* h, const float* df, int channel, float clamp_max, const float* logits,
                               const int64_t* labels, int B, int N, int C, const float* up_clamped_mean,
                               const float* up_cross_entropy, float* ddf, float* dlogits, chore_stream_t stream);
+/* Object side of forward_step (recon_fit_behave.py:165-186).  chore_fit_obj_transform: out (B,N,3) = (verts (B,N,3) R (B,3,3)
+ * + t (B,3)) * s (B)  (transform_obj_verts, recon_fit_base.py:367-371); backward: g (B,N,3) -> dR, dt, ds (no gradient for
+ * the template points).  chore_fit_obj_terms: out_scale = mean_b (s - scale0)^2 and out_ocent = mean_b sum_k (mean_n
+ * object[b,n,k] - (smpl_center[b,k] + mean_n centers[b,3+k,n]))^2 with centers (B,6,N); `diff` (B,3) carries the bracket to
+ * the backward, which writes dobject (B,N,3), dcenters (B,6,N) and dscale (B) completely (up_*: device scalars, NULL = 0). */
+int chore_fit_obj_transform_fwd(chore_handle* h, const float* verts, const float* R, const float* t, const float* s, int B, int N,
+                                float* out, chore_stream_t stream);
+int chore_fit_obj_transform_bwd(chore_handle* h, const float* verts, const float* R, const float* t, const float* s, const float* g,
+                                int B, int N, float* dR, float* dt, float* ds, chore_stream_t stream);
+size_t chore_fit_obj_terms_workspace_bytes(int B);
+int chore_fit_obj_terms_fwd(chore_handle* h, const float* object, const float* centers, const float* smpl_center, const float* obj_s,
+                            float scale0, int B, int N, float* diff, float* out_scale, float* out_ocent, void* workspace,
+                            chore_stream_t stream);
+int chore_fit_obj_terms_bwd(chore_handle* h, const float* diff, const float* obj_s, float scale0, const float* up_scale,
+                            const float* up_ocent, int B, int N, float* dobject, float* dcenters, float* dscale,
+                            chore_stream_t stream);
 
 /* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
  * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the

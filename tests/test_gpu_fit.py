@@ -180,6 +180,40 @@ def test_forward_step_phases(fit_setup):
     assert torch.isfinite(R.grad).all() and torch.isfinite(t.grad).all() and R.grad.abs().max() > 0
 
 
+@pytest.mark.parametrize("phase", ["object only", "joint"])
+def test_fused_object_terms_equal_tensor_expressions(fit_setup, phase, monkeypatch):
+    """chore_fit_obj_transform / chore_fit_obj_terms / chore_fit_point_terms inside forward_step against the tensor
+    expressions (bmm + broadcast adds, clamp / mse / mean): terms to 2e-6 relative, the gradients of obj_R, obj_t, obj_s
+    w.r.t. every term to 2e-5 of that gradient's largest entry"""
+    from chore_amd.recon import fit_terms
+    fitter, net, smpl, data = fit_setup
+    split = fitter.split_smpl(smpl)
+    data = dict(data)
+    data["smpl_center"] = fitter.compute_smpl_center_pred(data, net, smpl)
+    rs = np.random.RandomState(3)
+    R = (torch.eye(3).repeat(2, 1, 1) + torch.from_numpy(rs.standard_normal((2, 3, 3)).astype(np.float32)) * 0.05).cuda().requires_grad_(True)
+    t = torch.tensor([[0.2, 0.3, 2.3], [0.1, 0.25, 2.4]]).cuda().requires_grad_(True)
+    s = torch.tensor([1.05, 0.93]).cuda().requires_grad_(True)
+    noise = torch.from_numpy(rs.uniform(0, 1, (2, 3, 3)).astype(np.float32)).cuda()
+
+    def run(torch_terms):
+        monkeypatch.setattr(fit_terms, "TORCH_TERMS", torch_terms)
+        ld = fitter.forward_step(net, split, data, R, t, s, phase, noise=noise)
+        grads = {k: torch.autograd.grad(v, [R, t, s], retain_graph=True, allow_unused=True) for k, v in ld.items()}
+        return {k: float(v.detach()) for k, v in ld.items()}, grads
+
+    ref_v, ref_g = run(True)
+    got_v, got_g = run(False)
+    assert list(ref_v) == list(got_v)
+    for k in ref_v:
+        assert abs(got_v[k] - ref_v[k]) <= 2e-6 * max(abs(ref_v[k]), 1e-3), (k, got_v[k], ref_v[k])
+        for a, b, n in zip(got_g[k], ref_g[k], "Rts"):
+            if b is None or float(b.abs().max()) == 0.0:
+                assert a is None or float(a.abs().max()) == 0.0, (k, n)
+                continue
+            assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (k, n, float((a - b).abs().max()), float(b.abs().max()))
+
+
 def test_optimize_loops_run(fit_setup):
     fitter, net, smpl, data = fit_setup
     d = dict(data)
