@@ -154,16 +154,19 @@ __device__ __forceinline__ void heads_layer_out_x3(f32x16 (&out)[NCB], const f32
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) out[cb] = bf;
     const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_L1_VEC + QX_L23_VEC + (size_t)head * 4 * 2 * 2 * 64 + lane;
+    u32x4 ah[8], al[8];       // the 8 k-steps' fragments requested together (inline, every k-step waited for its own pair)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { ah[t] = A[(t * 2) * 64]; al[t] = A[(t * 2 + 1) * 64]; }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const u32x4 ah = A[((kb * 2 + s) * 2) * 64], al = A[((kb * 2 + s) * 2 + 1) * 64];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {
                 u32x4 bh, bl;
                 act_frag<NCB>(in, kb, s, cb, bh, bl);
-                out[cb] = mfma3(ah, al, bh, bl, out[cb]);
+                out[cb] = mfma3(ah[kb * 2 + s], al[kb * 2 + s], bh, bl, out[cb]);
             }
         }
     }
@@ -213,26 +216,34 @@ __device__ __forceinline__ void bwd_out_x3(f32x16 (&out)[4][NCB], const float (&
     u32x4 bh[NCB], bl[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) split8(g8[cb], bh[cb], bl[cb]);
+    AFrag f;
+    load_afrag(f, A);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int rb = 0; rb < 4; ++rb) {
-        const u32x4 ah = A[(rb * 2) * 64], al = A[(rb * 2 + 1) * 64];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             f32x16 z;
 #pragma unroll
             for (int r = 0; r < 16; ++r) z[r] = 0.f;
-            out[rb][cb] = mfma3(ah, al, bh[cb], bl[cb], z);
+            out[rb][cb] = mfma3(f.h[rb], f.l[rb], bh[cb], bl[cb], z);
         }
     }
 }
 
 // d_prev = W^T d_cur for a 128x128 layer (which = 0: W3, 1: W2).  `in` carries 2^s x cs[cb]; the column scales are
 // renewed (cs updated) and `out` carries 2^s x the new cs.
-template <int NCB>
+// The weight fragments run PF k-steps ahead in a register ring like the forward's (inline loads were sunk to their use by
+// the scheduler: every row block of every k-step an L2 round trip of its own).
+template <int NCB, int PF = QX_PF>
 __device__ __forceinline__ void bwd_hid_x3(f32x16 (&out)[4][NCB], const f32x16 (&in)[4][NCB], float (&cs)[NCB], const float* arena,
                                            int head, int which, int lane) {
     const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L32T +
                      ((size_t)head * 2 + which) * 4 * 2 * 4 * 2 * 64 + lane;
+    AFrag ring[PF];
+#pragma unroll
+    for (int p = 0; p < PF; ++p) load_afrag(ring[p], A + (size_t)p * 4 * 2 * 64);
+    __builtin_amdgcn_sched_barrier(0);
     float mul[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
@@ -247,36 +258,47 @@ __device__ __forceinline__ void bwd_hid_x3(f32x16 (&out)[4][NCB], const f32x16 (
 #pragma unroll
             for (int r = 0; r < 16; ++r) out[rb][cb][r] = 0.f;
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int t = 0; t < 8; ++t) {          // k-step t = (kb, s)
+        u32x4 bh[NCB], bl[NCB];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            u32x4 bh[NCB], bl[NCB];
+        for (int cb = 0; cb < NCB; ++cb) grad_frag<NCB>(in, t >> 1, t & 1, cb, mul[cb], bh[cb], bl[cb]);
+        AFrag& f = ring[t % PF];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) grad_frag<NCB>(in, kb, s, cb, mul[cb], bh[cb], bl[cb]);
+        for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
-            for (int rb = 0; rb < 4; ++rb) {
-                const u32x4 ah = A[(((kb * 2 + s) * 4 + rb) * 2) * 64], al = A[(((kb * 2 + s) * 4 + rb) * 2 + 1) * 64];
+            for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(f.h[rb], f.l[rb], bh[cb], bl[cb], out[rb][cb]);
+        if (t + PF < 8) load_afrag(f, A + (size_t)(t + PF) * 4 * 2 * 64);
+        // the products of this k-step are pinned here, in accumulation registers: otherwise they are sunk below the last
+        // sched_barrier (nothing uses them before), all 64 fragment loads of the layer end up ahead of the first MFMA and
+        // are parked, load by load and wait by wait, in AGPRs
 #pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) out[rb][cb] = mfma3(ah, al, bh[cb], bl[cb], out[rb][cb]);
-            }
-        }
+        for (int rb = 0; rb < 4; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) asm volatile("" : "+a"(out[rb][cb]));
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // one 32-row block rb of dX_head = W1^T d1 (K = 128).  bh / bl: the 8 K-step fragments of d1 (see bwd_l1_frags_x3).
+// The caller requests block rb + 1's sixteen fragments (load_l1t_x3) before it multiplies block rb: the round trip runs
+// under the MFMAs and the cross-head reduction of the block in hand.
+struct L1TFrag { u32x4 h[8], l[8]; };
+__device__ __forceinline__ void load_l1t_x3(L1TFrag& f, const float* arena, int head, int rb, int lane) {
+    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L1T + (size_t)head * 4 * 2 * QB_RB1 * 2 * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) { f.h[ks] = A[((ks * QB_RB1 + rb) * 2) * 64]; f.l[ks] = A[((ks * QB_RB1 + rb) * 2 + 1) * 64]; }
+}
 template <int NCB>
 __device__ __forceinline__ void bwd_l1_block_x3(f32x16 (&dx)[NCB], const u32x4 (&bh)[8][NCB], const u32x4 (&bl)[8][NCB],
-                                                const float* arena, int head, int rb, int lane) {
-    const u32x4* A = (const u32x4*)((const char*)arena + QX_OFF_BYTES) + QX_OFF_L1T + (size_t)head * 4 * 2 * QB_RB1 * 2 * 64 + lane;
+                                                const L1TFrag& f) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-        const u32x4 ah = A[((ks * QB_RB1 + rb) * 2) * 64], al = A[((ks * QB_RB1 + rb) * 2 + 1) * 64];
 #pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) dx[cb] = mfma3(ah, al, bh[ks][cb], bl[ks][cb], dx[cb]);
+        for (int cb = 0; cb < NCB; ++cb) dx[cb] = mfma3(f.h[ks], f.l[ks], bh[ks][cb], bl[ks][cb], dx[cb]);
     }
 }
 template <int NCB>

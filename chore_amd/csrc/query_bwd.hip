@@ -192,17 +192,18 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
 #pragma unroll
             for (int j = 0; j < 8; ++j) g8[cb][j] *= cs[cb];
         }
+        constexpr int BPF = NW == 8 ? 1 : QX_PF;     // as in the forward recompute: the depth of the ring by the registers per wave
         bwd_out_x3<NCB>(v, g8, arena, head, lane);
         apply_mask<NCB>(v, m3);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
         if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (2 * HEAD_NUM + head) * plane, v, false, row0, n0, a.N, lane, pt0, unscale);
-        bwd_hid_x3<NCB>(u, v, cs, arena, head, 0, lane);  // d2 = W3^T d3
+        bwd_hid_x3<NCB, BPF>(u, v, cs, arena, head, 0, lane);  // d2 = W3^T d3
         apply_mask<NCB>(u, m2);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
         if constexpr (TRAIN) store_tile<NCB>(a.tdZ + (1 * HEAD_NUM + head) * plane, u, false, row0, n0, a.N, lane, pt0, unscale);
-        bwd_hid_x3<NCB>(v, u, cs, arena, head, 1, lane);  // d1 = W2^T d2
+        bwd_hid_x3<NCB, BPF>(v, u, cs, arena, head, 1, lane);  // d1 = W2^T d2
         apply_mask<NCB>(v, m1);
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
@@ -264,11 +265,23 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
     }
+    L1TFrag wcur[1];
+    if constexpr (X3) {
+        load_l1t_x3(wcur[0], arena, head, 0, lane);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll 1
     for (int rb = 0; rb < QB_RB1; ++rb) {
         f32x16 dx[NCB];
         if constexpr (X3) {
-            bwd_l1_block_x3<NCB>(dx, d1h, d1l, arena, head, rb, lane);
+            L1TFrag wnext;
+            if constexpr (NW != 8) {      // (two waves per SIMD: no registers for the second set, the other wave covers the wait)
+                load_l1t_x3(wnext, arena, head, rb + 1 < QB_RB1 ? rb + 1 : rb, lane);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            bwd_l1_block_x3<NCB>(dx, d1h, d1l, wcur[0]);
+            if constexpr (NW != 8) wcur[0] = wnext;
+            else if (rb + 1 < QB_RB1) load_l1t_x3(wcur[0], arena, head, rb + 1, lane);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
