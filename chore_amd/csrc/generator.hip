@@ -89,6 +89,27 @@ __global__ void gen_resample_kernel(const float* __restrict__ samples, int N, co
     for (int d = 0; d < 3; ++d) o[d] = src[d] + s * nz[d];
 }
 
+// one projection step of Alg. 1 (generator.py:50-79): the upstream gradient of sum(clamp(df_k, max = thr)) and
+// p <- p - normalize(grad_p) * clamp(df_k, max = thr)   (F.normalize: v / max(||v||, 1e-12))
+__global__ void gen_clamp_mask_kernel(const float* __restrict__ df, int k, float thr, int N, float* __restrict__ g) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    g[((size_t)b * 2 + k) * N + n] = df[((size_t)b * 2 + k) * N + n] <= thr ? 1.f : 0.f;     // clamp passes the gradient where x <= max
+    g[((size_t)b * 2 + (1 - k)) * N + n] = 0.f;
+}
+__global__ void gen_surface_step_kernel(const float* __restrict__ p, const float* __restrict__ grad, const float* __restrict__ df, int k,
+                                        float thr, int N, float* __restrict__ out) {
+    const int b = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const size_t o = ((size_t)b * N + n) * 3;
+    const float gx = grad[o], gy = grad[o + 1], gz = grad[o + 2];
+    const float d = fminf(df[((size_t)b * 2 + k) * N + n], thr);
+    const float den = fmaxf(sqrtf((gx * gx + gy * gy) + gz * gz), 1e-12f);
+    out[o] = p[o] - gx / den * d;
+    out[o + 1] = p[o + 1] - gy / den * d;
+    out[o + 2] = p[o + 2] - gz / den * d;
+}
+
 }  // namespace
 
 extern "C" {
@@ -128,6 +149,25 @@ int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, cons
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_resample: bad argument");
     hipLaunchKernelGGL(gen_resample_kernel, dim3((M + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, samples, N, order, counts, init,
                        Ninit, u, noise, M, sigma, out);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+
+int chore_gen_clamp_mask(chore_handle* h, const float* df, int k, float thr, int B, int N, float* g, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!df || !g || B <= 0 || B > 65535 || N <= 0 || (k != 0 && k != 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_clamp_mask: bad argument");
+    hipLaunchKernelGGL(gen_clamp_mask_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, df, k, thr, N, g);
+    CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
+    return CHORE_OK;
+}
+
+int chore_gen_surface_step(chore_handle* h, const float* points, const float* grad, const float* df, int k, float thr, int B, int N,
+                           float* out, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!points || !grad || !df || !out || B <= 0 || B > 65535 || N <= 0 || (k != 0 && k != 1))
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_surface_step: bad argument");
+    hipLaunchKernelGGL(gen_surface_step_kernel, dim3((N + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, points, grad, df, k, thr, N,
+                       out);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
     return CHORE_OK;
 }

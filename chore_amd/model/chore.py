@@ -410,6 +410,33 @@ class CHORE(nn.Module):
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]
 
+    def query_grad_points(self, points, crop_center, g_df=None, g_pca=None, g_parts=None, g_centers=None):
+        """d(sum_k <g_k, output_k>) / d points of the LAST stack's field at `points`, straight from chore_query_bwd_points: no
+        autograd graph, for loops that need nothing but this gradient (Generator.approx_surface).  g_* like the outputs of
+        query(): (B,2,N), (B,9,N) or (B,3,3,N), (B,14,N), (B,6,N); None = zero."""
+        if not self.im_feat_list:
+            raise RuntimeError("call filter(images) before query_grad_points()")
+        pts = points.detach()
+        if not (pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous() and pts.dim() == 3 and pts.shape[2] == 3):
+            raise ValueError("points must be a contiguous fp32 (B,N,3) device tensor")
+        B, N, _ = pts.shape
+        cc = crop_center.to(device=pts.device, dtype=torch.float32).contiguous()
+        dev = pts.device
+        h = _lib.handle(dev.index or 0)
+        feat = self.im_feat_list[-1]
+        fp, FH, FW = _nhwc_ptr(feat, 256)
+        tp, TH, TW = _nhwc_ptr(self.tmpx, 64)
+        gs = [None if g is None else g.detach().reshape(B, -1, N).float().contiguous() for g in (g_df, g_pca, g_parts, g_centers)]
+        ptr = [None if g is None else g.data_ptr() for g in gs]
+        dtype = _QDT[self.compute_dtype]
+        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        dpoints = torch.empty_like(pts)
+        _lib.check(_lib.lib.chore_query_bwd_points(h, pts.data_ptr(), cc.data_ptr(), B, N, fp, FH, FW, tp, TH, TW, fwd_dtype,
+                                                   self._heads_arena(dev).data_ptr(), self._cam6, ptr[0], ptr[1], ptr[2], ptr[3],
+                                                   dpoints.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_query_bwd_points")
+        return dpoints
+
     def get_preds(self):
         return self.preds
 

@@ -76,6 +76,32 @@ class Generator:
     def approx_surface(self, model, samples, num_steps, query_input, df_type):
         k = 0 if df_type == "human" else 1
         preds = None
+        if (hasattr(model, "query_grad_points") and samples.is_cuda and samples.dtype == torch.float32 and
+                not os.environ.get("CHORE_GEN_AUTOGRAD")):
+            # the same step without an autograd graph: query forward, the clamp's gradient mask, backward to the points,
+            # projection -- 4 launches (the tensor-expression loop below: ~20 per step, and the host is what it waits for)
+            from .. import _lib
+            dev = samples.device
+            h = _lib.handle(dev.index or 0)
+            s = samples.detach().contiguous()
+            B, N, _ = s.shape
+            cc = query_input["crop_center"]
+            thr = float(self.threshold)
+            for _ in range(num_steps):
+                stream = torch.cuda.current_stream(dev).cuda_stream
+                with torch.no_grad():
+                    model.query(s, **query_input)
+                preds = model.get_preds()
+                df = preds[0].contiguous()
+                g = torch.empty_like(df)
+                _lib.check(_lib.lib.chore_gen_clamp_mask(h, df.data_ptr(), k, thr, B, N, g.data_ptr(), stream), h, "chore_gen_clamp_mask")
+                grad = model.query_grad_points(s, cc, g_df=g)
+                new = torch.empty_like(s)
+                _lib.check(_lib.lib.chore_gen_surface_step(h, s.data_ptr(), grad.data_ptr(), df.data_ptr(), k, thr, B, N,
+                                                           new.data_ptr(), stream), h, "chore_gen_surface_step")
+                s = new
+            s.requires_grad = True
+            return s, preds
         for _ in range(num_steps):
             model.query(samples, **query_input)
             preds = model.get_preds()

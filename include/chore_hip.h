@@ -304,6 +304,13 @@ int chore_gen_advance(chore_handle* h, const int* counts, int B, int* offsets, i
 int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, const int* order, const int* counts,
                        const float* init, int Ninit, const float* u, const float* noise, int M, float sigma, float* out,
                        chore_stream_t stream);
+/* one projection step of Alg. 1 (Generator.approx_surface, recon/generator.py:50-79) around chore_query_fwd /
+ * chore_query_bwd_points: chore_gen_clamp_mask writes the upstream gradient of sum(clamp(df[:, k], max = thr)) -- g (B,2,N):
+ * 1 where df[b,k,n] <= thr, else 0, the other channel 0 --, chore_gen_surface_step moves the points:
+ * out = points - normalize(grad) * min(df[:, k], thr), normalize as F.normalize (v / max(||v||, 1e-12)) */
+int chore_gen_clamp_mask(chore_handle* h, const float* df, int k, float thr, int B, int N, float* g, chore_stream_t stream);
+int chore_gen_surface_step(chore_handle* h, const float* points, const float* grad, const float* df, int k, float thr, int B,
+                           int N, float* out, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image preparation of the test loader on the device  (replaces, from the decoded uint8 images on,

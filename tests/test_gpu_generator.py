@@ -123,3 +123,24 @@ def test_device_loop_equals_host_loop(gen):
     assert torch.equal(dev["parts"], host["parts"])
     assert (dev["pca_axis"] - host["pca_axis"]).abs().max() < 1e-6
     assert (dev["centers"] - host["centers"]).abs().max() < 1e-6
+
+
+@pytest.mark.parametrize("name", ["human", "object"])
+def test_approx_surface_direct_path_equals_autograd_path(gen, name, monkeypatch):
+    """the four-launch step (chore_gen_clamp_mask / chore_query_bwd_points / chore_gen_surface_step) against the tensor
+    expressions + autograd of generator.py:50-79 on the same kernels: one step, identical field values, points to 1e-6
+    relative of the step length (division and norm are the only operations whose rounding may differ)"""
+    g = golden("query_full.npz")
+    gen.model.im_feat_list = [nhwc(g["feat"])]
+    gen.model.tmpx = nhwc(g["tmpx"])
+    q = {"crop_center": torch.from_numpy(g["crop_center"]).cuda()}
+    pts = torch.from_numpy(g["points"]).cuda()
+    monkeypatch.setenv("CHORE_GEN_AUTOGRAD", "1")
+    ref, ref_preds = gen.approx_surface(gen.model, pts.clone().requires_grad_(True), 1, q, name)
+    monkeypatch.delenv("CHORE_GEN_AUTOGRAD")
+    got, got_preds = gen.approx_surface(gen.model, pts.clone().requires_grad_(True), 1, q, name)
+    assert got.requires_grad
+    for a, b in zip(got_preds, ref_preds):
+        assert torch.equal(a, b)
+    step = (ref.detach() - pts).norm(dim=-1).max()
+    assert float((got.detach() - ref.detach()).abs().max()) <= 1e-6 * float(step)
