@@ -331,64 +331,84 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         if (!a.dpoints) return;   // uniform
     }
     // ---- taps again: d(value)/d(ix,iy), then the projection Jacobian ----
+    // TU points at a time: their 8 x TU tap rows are requested together (one point per round was one cache round trip per
+    // point with nothing else in flight: 32 of them per wave in a 128-point tile)
     using L = MapLoad<T>;
+    constexpr int TU = 4;
+    static_assert((PTS / NW) % TU == 0, "points per wave");
 #pragma unroll 1
-    for (int i = 0; i < PTS / NW; ++i) {
-        const int pt = wid * (PTS / NW) + i;
-        const float* drow = sm.X + pt * XS;
-        float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
-        {
-            const f32x4 g = *(const f32x4*)(drow + lane * 4);
-            typename L::Raw4 tr[4];      // raw bits under the validity branches, converted below (query_common.h, MapLoad)
+    for (int i0 = 0; i0 < PTS / NW; i0 += TU) {
+        typename L::Raw4 trf[TU][4];      // raw bits under the validity branches, converted below (query_common.h, MapLoad)
+        typename L::Raw1 trt[TU][4];
+        bool fin[TU][4], tin[TU][4];
+#pragma unroll
+        for (int u = 0; u < TU; ++u) {
+            const int pt = wid * (PTS / NW) + i0 + u;
+            // unconditional loads (a tap outside the map reads the map's first row and is zeroed when used): under a
+            // validity branch every 16-byte load was followed by its own s_waitcnt (the vector phi is a copy)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int fo = sm.tab.foff[k][pt];
-                tr[k] = (fo >= 0) ? L::raw4(feat_b + fo + lane * 4) : L::zero4();
+                fin[u][k] = fo >= 0;
+                trf[u][k] = L::raw4(feat_b + (fo >= 0 ? fo : 0) + lane * 4);
             }
-            f32x4 tv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tv[k] = L::cvt4(tr[k]);
-            const float w = sm.tab.ffrac[0][pt], n = sm.tab.ffrac[1][pt];
-            const float e = 1.f - w, s = 1.f - n;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                gix_f += g[c] * ((tv[1][c] - tv[0][c]) * s + (tv[3][c] - tv[2][c]) * n);
-                giy_f += g[c] * ((tv[2][c] - tv[0][c]) * e + (tv[3][c] - tv[1][c]) * w);
-            }
-        }
-        {
-            const float g = drow[FEAT_C + 3 + lane];
-            typename L::Raw1 tr[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int to = sm.tab.toff[k][pt];
-                tr[k] = (to >= 0) ? L::raw1(tmpx_b + to + lane) : L::zero1();
+                tin[u][k] = to >= 0;
+                trt[u][k] = L::raw1(tmpx_b + (to >= 0 ? to : 0) + lane);
             }
-            float tv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) tv[k] = L::cvt1(tr[k], lane & 1);
-            const float w = sm.tab.tfrac[0][pt], n = sm.tab.tfrac[1][pt];
-            const float e = 1.f - w, s = 1.f - n;
-            gix_t = g * ((tv[1] - tv[0]) * s + (tv[3] - tv[2]) * n);
-            giy_t = g * ((tv[2] - tv[0]) * e + (tv[3] - tv[1]) * w);
         }
-        float gnx = gix_f * ((float)(a.FW - 1) * 0.5f) + gix_t * ((float)(a.TW - 1) * 0.5f);
-        float gny = giy_f * ((float)(a.FH - 1) * 0.5f) + giy_t * ((float)(a.TH - 1) * 0.5f);
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            gnx += __shfl_xor(gnx, o, 64);
-            gny += __shfl_xor(gny, o, 64);
-        }
-        if (lane == 0 && sm.tab.valid[pt]) {
-            const float x = sm.tab.xyz[0][pt], y = sm.tab.xyz[1][pt], z = sm.tab.zraw[pt];
-            const float k = 2.0f / cam.crop;
-            const float gpx = gnx * k, gpy = gny * k;  // d/d(px), d/d(py)
-            const float iz = 1.0f / z;
-            const float dx = drow[FEAT_C + 0] + gpx * cam.fx * iz;
-            const float dy = drow[FEAT_C + 1] + gpy * cam.fy * iz;
-            const float dz = drow[FEAT_C + 2] - (gpx * cam.fx * x + gpy * cam.fy * y) * iz * iz;
-            float* o = a.dpoints + ((size_t)b * a.N + n0 + pt) * 3;
-            o[0] = dx; o[1] = dy; o[2] = dz;
+        for (int u = 0; u < TU; ++u) {
+            const int pt = wid * (PTS / NW) + i0 + u;
+            const float* drow = sm.X + pt * XS;
+            float gix_f = 0.f, giy_f = 0.f, gix_t = 0.f, giy_t = 0.f;
+            {
+                const f32x4 g = *(const f32x4*)(drow + lane * 4);
+                f32x4 tv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t4 = L::cvt4(trf[u][k]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) tv[k][c] = fin[u][k] ? t4[c] : 0.f;
+                }
+                const float w = sm.tab.ffrac[0][pt], n = sm.tab.ffrac[1][pt];
+                const float e = 1.f - w, s = 1.f - n;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    gix_f += g[c] * ((tv[1][c] - tv[0][c]) * s + (tv[3][c] - tv[2][c]) * n);
+                    giy_f += g[c] * ((tv[2][c] - tv[0][c]) * e + (tv[3][c] - tv[1][c]) * w);
+                }
+            }
+            {
+                const float g = drow[FEAT_C + 3 + lane];
+                float tv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) tv[k] = tin[u][k] ? L::cvt1(trt[u][k], lane & 1) : 0.f;
+                const float w = sm.tab.tfrac[0][pt], n = sm.tab.tfrac[1][pt];
+                const float e = 1.f - w, s = 1.f - n;
+                gix_t = g * ((tv[1] - tv[0]) * s + (tv[3] - tv[2]) * n);
+                giy_t = g * ((tv[2] - tv[0]) * e + (tv[3] - tv[1]) * w);
+            }
+            float gnx = gix_f * ((float)(a.FW - 1) * 0.5f) + gix_t * ((float)(a.TW - 1) * 0.5f);
+            float gny = giy_f * ((float)(a.FH - 1) * 0.5f) + giy_t * ((float)(a.TH - 1) * 0.5f);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                gnx += __shfl_xor(gnx, o, 64);
+                gny += __shfl_xor(gny, o, 64);
+            }
+            if (lane == 0 && sm.tab.valid[pt]) {
+                const float x = sm.tab.xyz[0][pt], y = sm.tab.xyz[1][pt], z = sm.tab.zraw[pt];
+                const float k = 2.0f / cam.crop;
+                const float gpx = gnx * k, gpy = gny * k;  // d/d(px), d/d(py)
+                const float iz = 1.0f / z;
+                const float dx = drow[FEAT_C + 0] + gpx * cam.fx * iz;
+                const float dy = drow[FEAT_C + 1] + gpy * cam.fy * iz;
+                const float dz = drow[FEAT_C + 2] - (gpx * cam.fx * x + gpy * cam.fy * y) * iz * iz;
+                float* o = a.dpoints + ((size_t)b * a.N + n0 + pt) * 3;
+                o[0] = dx; o[1] = dy; o[2] = dz;
+            }
         }
     }
 }
