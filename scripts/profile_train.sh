@@ -2,6 +2,8 @@
 # training-step and fit-loop evidence on the GPU box:  scripts/profile_train.sh r02
 #   <tag>_bench_train.json / _bench_train_fp32.json / _bench_fit.json   bench.py lines of the other two modes
 #   <tag>_train_kernel_stats.txt   per-kernel-class time of a traced training step (rocprofv3 --kernel-trace) + device timeline
+#   <tag>_fit_kernel_stats.txt     the same for one traced fit_recon chain (300 iterations) + the launch sequence of one iteration of
+#                                  each phase (optimize_smpl 'kpts', 'object only', 'joint')
 tag=${1:-r02}
 repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
@@ -15,5 +17,13 @@ f=$(find /tmp/proft_$tag -name "*results.db" | head -1)
 if [ -n "$f" ]; then
     python $repo/scripts/train_prof_summary.py $f 7 60 > $out/${tag}_train_kernel_stats.txt
     python $repo/scripts/train_timeline.py $f 5 >> $out/${tag}_train_kernel_stats.txt
+fi
+cd /tmp; rm -rf /tmp/proff_$tag
+timeout 600 rocprofv3 --kernel-trace -d /tmp/proff_$tag -o fit -- \
+    python $repo/bench.py --mode fit --steps 1 --warmup 0 --no-cpu-baseline > /dev/null 2> $out/${tag}_fit_rocprof.err
+f=$(find /tmp/proff_$tag -name "*results.db" | head -1)
+if [ -n "$f" ]; then
+    python $repo/scripts/train_prof_summary.py $f 1 50 > $out/${tag}_fit_kernel_stats.txt
+    python $repo/scripts/fit_iter_trace.py $f 60 130 250 | cut -c1-160 >> $out/${tag}_fit_kernel_stats.txt
 fi
 cd $repo
