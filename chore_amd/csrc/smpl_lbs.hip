@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
                                                           float scale, float* __restrict__ work, int B,
                                                           float* __restrict__ joints) {
     __shared__ float R[MAXJ][9], Jl[MAXJ][3], G[MAXJ][12];
-    __shared__ int dep[64];
+    __shared__ int dep[64], par[64];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     const int b = blockIdx.x, j = threadIdx.x;
@@ -195,16 +195,26 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             float a = model[ar.JT + j * 3 + k];
-            for (int n = 0; n < d.NB; ++n) a += model[ar.JS + ((size_t)j * 3 + k) * d.NB + n] * betas[(size_t)b * d.NB + n];
+            float c[MAXNB], bt[MAXNB];       // requested together, added in index order
+#pragma unroll
+            for (int n = 0; n < MAXNB; ++n) {
+                c[n] = model[ar.JS + ((size_t)j * 3 + k) * d.NB + min(n, d.NB - 1)];
+                bt[n] = betas[(size_t)b * d.NB + min(n, d.NB - 1)];
+            }
+#pragma unroll
+            for (int n = 0; n < MAXNB; ++n)
+                if (n < d.NB) a += c[n] * bt[n];
             Jl[j][k] = a;
         }
     }
     __syncthreads();
     // kinematic chain (smpl_layer.py:114-131): G_i = G_parent * [R_i | J_i - J_parent].  One lane per joint, one round per
     // tree depth (a joint's transform needs its parent's only): 10 rounds for SMPL-H instead of 51 steps on one lane
+    par[j] = j < d.J ? parents[j] : 0;      // the tree in LDS: the walks below are chains of dependent reads
+    __syncthreads();
     int depth = 0;
     if (j < d.J)
-        for (int q = j; q > 0; q = parents[q]) ++depth;
+        for (int q = j; q > 0; q = par[q]) ++depth;
     dep[j] = j < d.J ? depth : 0;
     if (j == 0) {
 #pragma unroll
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(64) void lbs_pose_fwd_kernel(Dims d, const float* _
     for (int q = 0; q < d.J; ++q) maxdep = max(maxdep, dep[q]);
     for (int level = 1; level <= maxdep; ++level) {
         if (j < d.J && depth == level) {
-            const int i = j, p = parents[i];
+            const int i = j, p = par[i];
             float gr[9], rr[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) gr[e] = G[p][(e / 3) * 4 + e % 3];
@@ -506,10 +516,12 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
                                                           float* __restrict__ dpose, float* __restrict__ dbetas,
                                                           float* __restrict__ dtrans) {
     __shared__ float R[MAXJ][9], Jl[MAXJ][3], G[MAXJ][12], dG[MAXJ][12], dR[MAXJ][9], dJ[MAXJ][3];
+    __shared__ int par[64];
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
     const int b = blockIdx.x, j = threadIdx.x;
     const int* parents = (const int*)(model + ar.parents);
+    par[j] = j < d.J ? parents[j] : 0;      // read by every step of the chain below
     if (j < d.J) {
         const float* dA = work + wk.dA + ((size_t)b * d.J + j) * 12;
 #pragma unroll
@@ -538,7 +550,7 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
     // reverse chain, children before parents (parents[i] < i in SMPL trees), one step per joint; inside a step the 9 + 3 + 3
     // independent results go to 15 lanes (every result is the expression the one-lane loop evaluated)
     for (int i = d.J - 1; i >= 1; --i) {
-        const int p = parents[i];
+        const int p = par[i];
         if (j < 9) {
             const int r = j / 3, c = j % 3;
             const float tc = Jl[i][c] - Jl[p][c];
@@ -585,18 +597,39 @@ __global__ __launch_bounds__(64) void lbs_pose_bwd_kernel(Dims d, const float* _
     }
     if (j < d.NB) {   // d beta = S^T d v_posed (vertex part) + JS^T dJ (joint part)
         float a = work[wk.dbv + (size_t)b * d.NB + j];
-        for (int i = 0; i < d.J; ++i)
+        const int n3 = d.J * 3;
+        const float* dJf = &dJ[0][0];
+        for (int i0 = 0; i0 < n3; i0 += 12) {       // twelve coefficients requested together, added in index order
+            float c[12];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) a += model[ar.JS + ((size_t)i * 3 + k) * d.NB + j] * dJ[i][k];
+            for (int u = 0; u < 12; ++u) c[u] = model[ar.JS + (size_t)min(i0 + u, n3 - 1) * d.NB + j];
+#pragma unroll
+            for (int u = 0; u < 12; ++u)
+                if (i0 + u < n3) a += c[u] * dJf[i0 + u];
+        }
         dbetas[(size_t)b * d.NB + j] = a;
     }
     if (j < 3) {   // d trans = sum_v g_verts (per-workgroup partial sums of the vertex kernel) + sum_j g_joints
         double a = 0.0;
         const int nblk = (d.V + 255) / 256;
         const double* part = (const double*)(work + wk.tpart) + (size_t)b * nblk * 3;
-        for (int i = 0; i < nblk; ++i) a += part[i * 3 + j];
+        for (int i0 = 0; i0 < nblk; i0 += 9) {          // nine partial sums requested together, added in order
+            double c[9];
+#pragma unroll
+            for (int u = 0; u < 9; ++u) c[u] = part[min(i0 + u, nblk - 1) * 3 + j];
+#pragma unroll
+            for (int u = 0; u < 9; ++u)
+                if (i0 + u < nblk) a += c[u];
+        }
         if (g_joints)
-            for (int i = 0; i < d.J; ++i) a += (double)g_joints[((size_t)b * d.J + i) * 3 + j];
+            for (int i0 = 0; i0 < d.J; i0 += 13) {
+                float c[13];
+#pragma unroll
+                for (int u = 0; u < 13; ++u) c[u] = g_joints[((size_t)b * d.J + min(i0 + u, d.J - 1)) * 3 + j];
+#pragma unroll
+                for (int u = 0; u < 13; ++u)
+                    if (i0 + u < d.J) a += (double)c[u];
+            }
         dtrans[b * 3 + j] = (float)a;
     }
 }
