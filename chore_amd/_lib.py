@@ -160,6 +160,8 @@ SIGNATURES = {
     "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),
     "chore_collision_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "chore_sil_project_fwd": (c_int, [c_void_p] * 9 + [c_int, c_void_p, c_float, c_float, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "chore_sil_project_bwd": (c_int, [c_void_p] * 8 + [c_int, c_void_p, c_float, c_float, c_int, c_int, c_int] + [c_void_p] * 7),
     "chore_silhouette_workspace_bytes": (c_size_t, [c_int, c_int]),
     "chore_silhouette_fwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p,
                                      c_void_p, c_void_p]),

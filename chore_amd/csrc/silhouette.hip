@@ -258,6 +258,132 @@ __global__ __launch_bounds__(384) void sil_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---- placement + camera projection of the template, straight into the rasteriser's triangle list -----------------------
+// SilLossROI.apply_transformation (recon/obj_pose_roi.py:159-162: s (v Ro + to)) -> neural_renderer projection
+// (external/neural_renderer/neural_renderer/projection.py:6-43: v Rc^T + tc, perspective divide by z + eps, the radial /
+// tangential distortion polynomial, K, the [-1,1] mapping with the vertical flip) -> vertices_to_faces with both windings.
+struct SilCam {
+    float k1, k2, p1, p2, k3, orig, eps;
+};
+struct SilProj {      // one vertex through the chain, with what the backward needs
+    float w[3];       // s (v0 Ro + to)
+    float pre[3];     // v0 Ro + to
+    float c[3];       // camera space
+    float out[3];     // u, v, z
+};
+__device__ __forceinline__ void sil_project_vertex(const float* v0, const float* Ro, const float* to, float s, const float* Rc,
+                                                   const float* tc, const float* K, const SilCam& cam, SilProj& p) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        p.pre[c] = ((v0[0] * Ro[c] + v0[1] * Ro[3 + c]) + v0[2] * Ro[6 + c]) + to[c];
+        p.w[c] = s * p.pre[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.c[c] = ((p.w[0] * Rc[c * 3] + p.w[1] * Rc[c * 3 + 1]) + p.w[2] * Rc[c * 3 + 2]) + tc[c];
+    const float zi = p.c[2] + cam.eps;
+    const float x_ = p.c[0] / zi, y_ = p.c[1] / zi;
+    const float r2 = x_ * x_ + y_ * y_;
+    const float rad = 1.f + cam.k1 * r2 + cam.k2 * (r2 * r2) + cam.k3 * (r2 * r2 * r2);
+    const float xd = x_ * rad + 2.f * cam.p1 * x_ * y_ + cam.p2 * (r2 + 2.f * (x_ * x_));
+    const float yd = y_ * rad + cam.p1 * (r2 + 2.f * (y_ * y_)) + 2.f * cam.p2 * x_ * y_;
+    const float u = (K[0] * xd + K[1] * yd) + K[2];
+    const float vv = cam.orig - ((K[3] * xd + K[4] * yd) + K[5]);
+    p.out[0] = 2.f * (u - cam.orig / 2.0f) / cam.orig;
+    p.out[1] = 2.f * (vv - cam.orig / 2.0f) / cam.orig;
+    p.out[2] = p.c[2];
+}
+
+// thread = (frame, face of the doubled list): faces2[f] for f < F, the reversed corner order for f >= F (fill_back)
+__global__ __launch_bounds__(256) void sil_project_fwd_kernel(const float* __restrict__ verts, const int* __restrict__ faces,
+                                                              const float* __restrict__ Ro, const float* __restrict__ to,
+                                                              const float* __restrict__ sc, const float* __restrict__ K,
+                                                              const float* __restrict__ Rc, const float* __restrict__ tc, int cam_bcast,
+                                                              SilCam cam, int V, int F, float* __restrict__ tri) {
+    const int b = blockIdx.y, f2 = blockIdx.x * 256 + threadIdx.x;
+    if (f2 >= 2 * F) return;
+    const int f = f2 < F ? f2 : f2 - F;
+    const float* rc = Rc + (cam_bcast ? 0 : (size_t)b * 9);
+    const float* t3 = tc + (cam_bcast ? 0 : (size_t)b * 3);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int corner = f2 < F ? c : 2 - c;
+        const int vi = faces[((size_t)b * F + f) * 3 + corner];
+        SilProj p;
+        sil_project_vertex(verts + ((size_t)b * V + vi) * 3, Ro + (size_t)b * 9, to + (size_t)b * 3, sc[b], rc, t3, K + (size_t)b * 9, cam, p);
+        float* o = tri + (((size_t)b * 2 * F + f2) * 3 + c) * 3;
+        o[0] = p.out[0]; o[1] = p.out[1]; o[2] = p.out[2];
+    }
+}
+
+// one workgroup per frame: every vertex collects the gradients of its triangle corners in the order of the adjacency list
+// (adj_off (V+1), adj (entries = (f2 * 3 + c) of the doubled list)), pulls them back through the projection, and the
+// 13 sums over the vertices (d Ro, d to, d s) are fixed-order fp64 trees
+__global__ __launch_bounds__(256) void sil_project_bwd_kernel(const float* __restrict__ verts, const float* __restrict__ Ro,
+                                                              const float* __restrict__ to, const float* __restrict__ sc,
+                                                              const float* __restrict__ K, const float* __restrict__ Rc,
+                                                              const float* __restrict__ tc, int cam_bcast, SilCam cam, int V, int F,
+                                                              const int* __restrict__ adj_off, const int* __restrict__ adj,
+                                                              const float* __restrict__ g_tri, float* __restrict__ dRo,
+                                                              float* __restrict__ dto, float* __restrict__ dsc) {
+    __shared__ double sh[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* rc = Rc + (cam_bcast ? 0 : (size_t)b * 9);
+    const float* t3 = tc + (cam_bcast ? 0 : (size_t)b * 3);
+    const float* Kb = K + (size_t)b * 9;
+    const float s = sc[b];
+    float a[13];
+#pragma unroll
+    for (int e = 0; e < 13; ++e) a[e] = 0.f;
+    for (int v = tid; v < V; v += 256) {
+        float g[3] = {0.f, 0.f, 0.f};
+        for (int q = adj_off[v]; q < adj_off[v + 1]; ++q) {
+            const float* gt = g_tri + ((size_t)b * 2 * F * 3 + adj[q]) * 3;
+            g[0] += gt[0]; g[1] += gt[1]; g[2] += gt[2];
+        }
+        const float* v0 = verts + ((size_t)b * V + v) * 3;
+        SilProj p;
+        sil_project_vertex(v0, Ro + (size_t)b * 9, to + (size_t)b * 3, s, rc, t3, Kb, cam, p);
+        const float zi = p.c[2] + cam.eps;
+        const float x_ = p.c[0] / zi, y_ = p.c[1] / zi, r2 = x_ * x_ + y_ * y_;
+        const float rad = 1.f + cam.k1 * r2 + cam.k2 * (r2 * r2) + cam.k3 * (r2 * r2 * r2);
+        const float D = cam.k1 + 2.f * cam.k2 * r2 + 3.f * cam.k3 * (r2 * r2);
+        const float gu = g[0] * (2.f / cam.orig), gv = -g[1] * (2.f / cam.orig);
+        const float gxd = gu * Kb[0] + gv * Kb[3], gyd = gu * Kb[1] + gv * Kb[4];
+        const float gx_ = gxd * (rad + 2.f * D * x_ * x_ + 2.f * cam.p1 * y_ + 6.f * cam.p2 * x_) +
+                          gyd * (2.f * D * x_ * y_ + 2.f * cam.p1 * x_ + 2.f * cam.p2 * y_);
+        const float gy_ = gxd * (2.f * D * x_ * y_ + 2.f * cam.p1 * x_ + 2.f * cam.p2 * y_) +
+                          gyd * (rad + 2.f * D * y_ * y_ + 6.f * cam.p1 * y_ + 2.f * cam.p2 * x_);
+        const float gc[3] = {gx_ / zi, gy_ / zi, g[2] - (gx_ * x_ + gy_ * y_) / zi};
+        float gw[3];      // gradient of the placed vertex w = s (v0 Ro + to):  c = Rc w + tc
+#pragma unroll
+        for (int k = 0; k < 3; ++k) gw[k] = (gc[0] * rc[k] + gc[1] * rc[3 + k]) + gc[2] * rc[6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[k * 3 + c] += v0[k] * gw[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            a[9 + c] += gw[c];
+            a[12] += gw[c] * p.pre[c];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 13; ++e) {
+        sh[tid] = (double)a[e];
+        __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (tid < o) sh[tid] += sh[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            if (e < 9) dRo[(size_t)b * 9 + e] = (float)(sh[0] * (double)s);
+            else if (e < 12) dto[b * 3 + e - 9] = (float)(sh[0] * (double)s);
+            else dsc[b] = (float)sh[0];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" size_t chore_silhouette_workspace_bytes(int B, int F) { return (size_t)B * F * sizeof(TriSetup); }
@@ -291,6 +417,42 @@ extern "C" int chore_silhouette_bwd(chore_handle* h, const float* faces, const i
     const int n = B * F;
     hipLaunchKernelGGL(sil_bwd_kernel, dim3(n), dim3(384), 0, s, faces, face_index, alpha, grad_alpha, B, F, size, eps,
                        grad_faces);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// dist5: HOST floats {k1, k2, p1, p2, k3} or NULL (no distortion); cam_R / cam_t: (B,3,3) / (B,3), or one matrix / vector for
+// all frames when cam_broadcast != 0
+extern "C" int chore_sil_project_fwd(chore_handle* h, const float* verts, const int* faces, const float* obj_R, const float* obj_t,
+                                     const float* obj_s, const float* K, const float* cam_R, const float* cam_t, int cam_broadcast,
+                                     const float* dist5, float orig_size, float eps, int B, int V, int F, float* tri,
+                                     chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!verts || !faces || !obj_R || !obj_t || !obj_s || !K || !cam_R || !cam_t || !tri)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_sil_project_fwd: null argument");
+    if (B <= 0 || B > 65535 || V <= 0 || F <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_sil_project_fwd: bad sizes B=%d V=%d F=%d", B, V, F);
+    SilCam cam{0.f, 0.f, 0.f, 0.f, 0.f, orig_size, eps};
+    if (dist5) { cam.k1 = dist5[0]; cam.k2 = dist5[1]; cam.p1 = dist5[2]; cam.p2 = dist5[3]; cam.k3 = dist5[4]; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sil_project_fwd_kernel, dim3((2 * F + 255) / 256, B), dim3(256), 0, s, verts, faces, obj_R, obj_t, obj_s, K, cam_R,
+                       cam_t, cam_broadcast, cam, V, F, tri);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+extern "C" int chore_sil_project_bwd(chore_handle* h, const float* verts, const float* obj_R, const float* obj_t, const float* obj_s,
+                                     const float* K, const float* cam_R, const float* cam_t, int cam_broadcast, const float* dist5,
+                                     float orig_size, float eps, int B, int V, int F, const int* adj_off, const int* adj,
+                                     const float* g_tri, float* d_obj_R, float* d_obj_t, float* d_obj_s, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!verts || !obj_R || !obj_t || !obj_s || !K || !cam_R || !cam_t || !adj_off || !adj || !g_tri || !d_obj_R || !d_obj_t || !d_obj_s)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_sil_project_bwd: null argument");
+    if (B <= 0 || V <= 0 || F <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_sil_project_bwd: bad sizes B=%d V=%d F=%d", B, V, F);
+    SilCam cam{0.f, 0.f, 0.f, 0.f, 0.f, orig_size, eps};
+    if (dist5) { cam.k1 = dist5[0]; cam.k2 = dist5[1]; cam.p1 = dist5[2]; cam.p2 = dist5[3]; cam.k3 = dist5[4]; }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sil_project_bwd_kernel, dim3(B), dim3(256), 0, s, verts, obj_R, obj_t, obj_s, K, cam_R, cam_t, cam_broadcast, cam, V,
+                       F, adj_off, adj, g_tri, d_obj_R, d_obj_t, d_obj_s);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

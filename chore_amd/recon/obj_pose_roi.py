@@ -3,8 +3,9 @@
 Counterpart of /root/reference/recon/obj_pose_roi.py (SilLossROI) and of the pieces of the vendored
 neural_renderer it drives (external/neural_renderer/neural_renderer/: projection.py:6-43, vertices_to_faces.py,
 renderer.py:119-152 render_silhouettes, rasterize.py rasterize_silhouettes).  The rasterisation -- forward and the
-edge-walk backward -- runs in libchore_hip.so (chore_silhouette_fwd / _bwd); the camera projection is a handful of
-torch ops on (B,V,3) tensors, differentiable by autograd.
+edge-walk backward -- runs in libchore_hip.so (chore_silhouette_fwd / _bwd); object placement, camera projection and the
+triangle list are one launch each way (chore_sil_project_fwd / _bwd; `projection` / `vertices_to_faces` below are the tensor
+expressions of the reference, kept for its other callers and as what the tests compare with, `CHORE_SIL_TORCH_PROJECT=1`).
 
 `SilLossROI.forward(R, obj_t, obj_s)` returns what the reference returns: `(loss_dict, image, edges, image_ref,
 edt_ref_edge)` with `loss_dict["mask"] = mean_b sum_pixels (keep_mask * silhouette - image_ref)^2`.
@@ -16,6 +17,8 @@ detectron2's BitMasks.crop_and_resize and builds the ROI intrinsics from the Kin
 That preprocessing is setup code outside the fitting loop and its parity with detectron2 is NOT pinned; callers
 that already own the cropped masks can pass them with `SilLossROI.from_crops`.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -58,6 +61,54 @@ class _RasterizeFn(torch.autograd.Function):
         _lib.check(_lib.lib.chore_silhouette_bwd(h, t.data_ptr(), fim.data_ptr(), alpha.data_ptr(), g.data_ptr(), B, Fn,
                                                  ctx.size, EPS, gt.data_ptr(), stream), h, "chore_silhouette_bwd")
         return gt, None
+
+
+class _PlacedTrianglesFn(torch.autograd.Function):
+    """object pose -> the rasteriser's (B,2F,3,3) triangle list in one launch each way (chore_sil_project_fwd / _bwd):
+    apply_transformation, projection, vertices_to_faces with both windings.  Gradients for R, obj_t, obj_s."""
+
+    @staticmethod
+    def forward(ctx, R, obj_t, obj_s, verts, faces32, K, cam_R, cam_t, adj_off, adj):
+        dev = verts.device
+        h = _lib.handle(dev.index or 0)
+        R, obj_t, obj_s = R.float().contiguous(), obj_t.float().contiguous(), obj_s.float().contiguous()
+        B, V, _ = verts.shape
+        Fn = faces32.shape[1]
+        tri = torch.empty(B, 2 * Fn, 3, 3, device=dev, dtype=torch.float32)
+        bc = 1 if cam_R.shape[0] == 1 else 0
+        _lib.check(_lib.lib.chore_sil_project_fwd(h, verts.data_ptr(), faces32.data_ptr(), R.data_ptr(), obj_t.data_ptr(),
+                                                  obj_s.data_ptr(), K.data_ptr(), cam_R.data_ptr(), cam_t.data_ptr(), bc, None, 1.0,
+                                                  1e-9, B, V, Fn, tri.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_sil_project_fwd")
+        ctx.save_for_backward(R, obj_t, obj_s, verts, K, cam_R, cam_t, adj_off, adj)
+        ctx.dims = (B, V, Fn, bc)
+        return tri
+
+    @staticmethod
+    def backward(ctx, g):
+        R, obj_t, obj_s, verts, K, cam_R, cam_t, adj_off, adj = ctx.saved_tensors
+        dev = verts.device
+        h = _lib.handle(dev.index or 0)
+        B, V, Fn, bc = ctx.dims
+        g = g.float().contiguous()
+        dR, dt, ds = torch.empty_like(R), torch.empty_like(obj_t), torch.empty_like(obj_s)
+        _lib.check(_lib.lib.chore_sil_project_bwd(h, verts.data_ptr(), R.data_ptr(), obj_t.data_ptr(), obj_s.data_ptr(), K.data_ptr(),
+                                                  cam_R.data_ptr(), cam_t.data_ptr(), bc, None, 1.0, 1e-9, B, V, Fn, adj_off.data_ptr(),
+                                                  adj.data_ptr(), g.data_ptr(), dR.data_ptr(), dt.data_ptr(), ds.data_ptr(),
+                                                  torch.cuda.current_stream(dev).cuda_stream), h, "chore_sil_project_bwd")
+        return (dR, dt, ds) + (None,) * 7
+
+
+def corner_adjacency(faces, num_verts):
+    """for every vertex the entries (f2 * 3 + corner) of the doubled face list (faces, then faces with reversed corners) that
+    reference it, ascending: (offsets (V+1) int32, entries int32)"""
+    f = np.asarray(faces, np.int64)
+    both = np.concatenate([f, f[:, ::-1]], 0).reshape(-1)           # entry e = f2 * 3 + corner -> vertex
+    order = np.argsort(both, kind="stable")
+    counts = np.bincount(both, minlength=num_verts)
+    off = np.zeros(num_verts + 1, np.int64)
+    off[1:] = np.cumsum(counts)
+    return off.astype(np.int32), order.astype(np.int32)
 
 
 def projection(vertices, K, R, t, dist_coeffs=None, orig_size=1.0, eps=1e-9):
@@ -181,6 +232,11 @@ class SilLossROI(nn.Module):
         self.register_buffer("K", Ks)
         self.register_buffer("R", torch.eye(3, device=dev).unsqueeze(0))
         self.register_buffer("t", torch.zeros(1, 3, device=dev))
+        # for the one-launch placement + projection (_PlacedTrianglesFn): int32 faces and the corner lists of the vertices
+        off, ent = corner_adjacency(faces.numpy(), verts.shape[0])
+        self.register_buffer("faces32", self.faces.to(torch.int32).contiguous(), persistent=False)
+        self.register_buffer("adj_off", torch.from_numpy(off).to(dev), persistent=False)
+        self.register_buffer("adj", torch.from_numpy(ent).to(dev), persistent=False)
 
     def prepare_dist_trans(self, image_refs, power=0.25):
         """distance transform of the reference edges (obj_pose_roi.py:92-103); debugging output of forward()"""
@@ -224,9 +280,18 @@ class SilLossROI(nn.Module):
         verts = torch.bmm(self.vertices, R) + obj_t.unsqueeze(1)
         return obj_s.view(-1, 1, 1) * verts
 
-    def forward(self, R, obj_t, obj_s):
+    def render(self, R, obj_t, obj_s):
+        """silhouettes (B,S,S) of the template under the pose: apply_transformation -> render_silhouettes"""
+        if (not os.environ.get("CHORE_SIL_TORCH_PROJECT") and R.is_cuda and self.vertices.is_cuda and
+                tuple(obj_s.shape) == (self.vertices.shape[0],)):
+            tri = _PlacedTrianglesFn.apply(R, obj_t, obj_s, self.vertices, self.faces32, self.K, self.R, self.t, self.adj_off, self.adj)
+            alpha, _ = _RasterizeFn.apply(tri, self.rend_size)
+            return alpha.flip(1)
         verts = self.apply_transformation(R, obj_t, obj_s)
-        image = self.keep_mask * render_silhouettes(verts, self.faces, self.K, self.R, self.t, self.rend_size)
+        return render_silhouettes(verts, self.faces, self.K, self.R, self.t, self.rend_size)
+
+    def forward(self, R, obj_t, obj_s):
+        image = self.keep_mask * self.render(R, obj_t, obj_s)
         loss_dict = {"mask": torch.sum((image - self.image_ref) ** 2, dim=(1, 2)).mean()}
         return loss_dict, image, self.compute_edges(image), self.image_ref, self.edt_ref_edge
 

@@ -266,6 +266,22 @@ int chore_silhouette_fwd(chore_handle* h, const float* faces, int B, int F, int 
 int chore_silhouette_bwd(chore_handle* h, const float* faces, const int* face_index, const float* alpha,
                          const float* grad_alpha, int B, int F, int size, float eps, float* grad_faces,
                          chore_stream_t stream);
+/* The rasteriser's triangle list from the object pose in one launch: SilLossROI.apply_transformation (recon/obj_pose_roi.py:
+ * 159-162, w = s (v Ro + to)), neural_renderer's projection (external/neural_renderer/neural_renderer/projection.py:6-43:
+ * c = Rc w + tc, divide by z + eps, distortion polynomial, K, [-1,1] with the vertical flip) and vertices_to_faces with both
+ * windings (renderer.py:119-152, fill_back).  verts (B,V,3) template, faces (B,F,3) int32, obj_R (B,3,3) applied as v Ro,
+ * obj_t (B,3), obj_s (B), K (B,3,3), cam_R / cam_t (B,3,3) / (B,3) or one for all frames (cam_broadcast != 0), dist5 HOST
+ * {k1,k2,p1,p2,k3} or NULL -> tri (B,2F,3,3): face f and, at F + f, its reversed winding.
+ * Backward: g_tri (B,2F,3,3) -> d_obj_R, d_obj_t, d_obj_s; adj_off (V+1) / adj: for every vertex the entries (f2 * 3 + corner)
+ * of the doubled list that reference it, ascending (the order its corner gradients are added in; one topology for all frames). */
+int chore_sil_project_fwd(chore_handle* h, const float* verts, const int* faces, const float* obj_R, const float* obj_t,
+                          const float* obj_s, const float* K, const float* cam_R, const float* cam_t, int cam_broadcast,
+                          const float* dist5, float orig_size, float eps, int B, int V, int F, float* tri,
+                          chore_stream_t stream);
+int chore_sil_project_bwd(chore_handle* h, const float* verts, const float* obj_R, const float* obj_t, const float* obj_s,
+                          const float* K, const float* cam_R, const float* cam_t, int cam_broadcast, const float* dist5,
+                          float orig_size, float eps, int B, int V, int F, const int* adj_off, const int* adj,
+                          const float* g_tri, float* d_obj_R, float* d_obj_t, float* d_obj_s, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Evaluation metrics, fp64  (replace recon/eval/chamfer_distance.py:10-52 = sklearn kd-tree nearest neighbours, and

@@ -141,3 +141,42 @@ def test_sil_phase_runs_in_the_fit_loop(opt):
     sil = SilLossROI.from_crops(obj_crop, np.zeros_like(obj_crop), K, v, f)
     out = tf.run_fit_with(copy.copy(opt), use_graphs=False, silhouette=sil, obj_iter=1, sil_iter=2, joint_iter=1)
     assert all(np.isfinite(x).all() for x in out)
+
+
+def test_placed_triangles_operator_equals_tensor_expressions():
+    """chore_sil_project_fwd / _bwd (placement, projection, both windings in one launch) against apply_transformation ->
+    projection -> vertices_to_faces as tensor expressions with autograd: triangles to 2e-6 of their scale, the pose
+    gradients for a random upstream gradient to 2e-5 of their largest entry"""
+    from chore_amd.recon.obj_pose_roi import SilLossROI, _PlacedTrianglesFn, projection, vertices_to_faces
+    B, S = 3, 32
+    v, f = cube()
+    yy, xx = np.mgrid[0:S, 0:S]
+    crop = np.stack([((xx - 16) ** 2 + (yy - 16) ** 2) < 64] * B)
+    rs = np.random.RandomState(4)
+    K = np.array([[[1.6, 0.02, 0.5], [0.01, 1.5, 0.48], [0, 0, 1]]] * B, np.float32) + rs.uniform(-0.02, 0.02, (B, 3, 3)).astype(np.float32)
+    sil = SilLossROI.from_crops(crop, np.zeros_like(crop), K, v, f)
+    # a camera that is not the identity (the fit's is), to cover that part of the chain too
+    cam_R = torch.linalg.qr(torch.eye(3) + 0.1 * torch.from_numpy(rs.standard_normal((3, 3)).astype(np.float32)))[0][None].cuda()
+    cam_t = torch.tensor([[0.03, -0.02, 0.1]]).cuda()
+    sil.R, sil.t = cam_R.contiguous(), cam_t
+
+    def pose():
+        R = (torch.eye(3).repeat(B, 1, 1) + 0.2 * torch.from_numpy(rs.standard_normal((B, 3, 3)).astype(np.float32))).cuda()
+        t = torch.from_numpy(np.array([[0.05, -0.03, 2.0], [-0.1, 0.08, 2.4], [0.0, 0.0, 3.0]], np.float32)).cuda()
+        s = torch.tensor([1.0, 1.2, 0.8]).cuda()
+        return [x.requires_grad_(True) for x in (R, t, s)]
+
+    rs_state = rs.get_state()
+    R, t, s = pose()
+    rs.set_state(rs_state)
+    R2, t2, s2 = pose()
+    tri = _PlacedTrianglesFn.apply(R, t, s, sil.vertices, sil.faces32, sil.K, sil.R, sil.t, sil.adj_off, sil.adj)
+    faces2 = torch.cat((sil.faces, sil.faces.flip(-1)), dim=1)
+    ref = vertices_to_faces(projection(sil.apply_transformation(R2, t2, s2), sil.K, sil.R, sil.t), faces2)
+    assert tri.shape == ref.shape
+    assert float((tri - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
+    g = torch.from_numpy(rs.standard_normal(tuple(ref.shape)).astype(np.float32)).cuda()
+    (tri * g).sum().backward()
+    (ref * g).sum().backward()
+    for a, b, n in ((R.grad, R2.grad, "R"), (t.grad, t2.grad, "t"), (s.grad, s2.grad, "s")):
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (n, float((a - b).abs().max()), float(b.abs().max()))
