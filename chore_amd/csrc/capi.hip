@@ -137,7 +137,7 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
                     const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
                     float* centers, uint8_t* in_img, chore_stream_t stream) {
     CHORE_ENTER(h);
-    if (!df || !pca || !parts || !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: null output");
+    if (!df && !pca && !parts && !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: no output asked for");
     QueryArgs a;
     // CHORE_F16X3: fp32 feature maps (what the fp16 x 3 encoder writes) and the heads on the fp16 matrix cores
     const bool x3 = query_x3(dtype);
@@ -152,8 +152,10 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
     rc = x3 ? launch_query_fwd_x3(h, dtype, a, (hipStream_t)stream)
             : (dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream) : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream));
     if (nan_check_on()) {
-        nan_scan(df, (size_t)B * 2 * N, 1, (hipStream_t)stream); nan_scan(pca, (size_t)B * 9 * N, 2, (hipStream_t)stream);
-        nan_scan(parts, (size_t)B * 14 * N, 3, (hipStream_t)stream); nan_scan(centers, (size_t)B * 6 * N, 4, (hipStream_t)stream);
+        if (df) nan_scan(df, (size_t)B * 2 * N, 1, (hipStream_t)stream);
+        if (pca) nan_scan(pca, (size_t)B * 9 * N, 2, (hipStream_t)stream);
+        if (parts) nan_scan(parts, (size_t)B * 14 * N, 3, (hipStream_t)stream);
+        if (centers) nan_scan(centers, (size_t)B * 6 * N, 4, (hipStream_t)stream);
     }
     return rc;
 }

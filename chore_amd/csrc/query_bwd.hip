@@ -136,9 +136,15 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         }
     }
 
+    // A head without an upstream gradient contributes exact zeros: its wave skips the GEMM chain and the weight traffic that
+    // goes with it (1.3 MB of fragments per tile and head) and only keeps the barriers.  The generator's projection steps
+    // and most fit phases hand over one or two of the four gradients.
+    const bool active = TRAIN || a.g[head] != nullptr;
     // ---- forward recompute, keep ReLU sign bits only (STAGED: read them back) ----
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
+    float cs[NCB], unscale[NCB];           // X3: the columns' scales, and 1 / (2^s cs) for what leaves the chain
+    if (active) {
     if constexpr (STAGED) {
         const size_t mplane = (size_t)a.B * a.N * 2;      // the forward's sign bits (heads_f32.h, store_masks): 16 B per point
         load_mask_bits<NCB>(m1, a.tM + (0 * HEAD_NUM + head) * mplane, row0, n0, a.N, lane, pt0);
@@ -171,7 +177,6 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     }
 
     // ---- d3 = W4^T * dOut ----
-    float cs[NCB], unscale[NCB];           // X3: the columns' scales, and 1 / (2^s cs) for what leaves the chain
     if constexpr (X3) {
         const float* g = a.g[head];
         float g8[NCB][8];
@@ -256,24 +261,30 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
 
     }
 
+    }   // active
     // ---- dX = sum_heads W1^T d1, one 32-row block at a time, fixed-order reduction through LDS ----
     __syncthreads();  // every wave is done reading X as the forward tile
     const f32x4* A1 = (const f32x4*)(arena + QB_OFF_L1T) + ((size_t)head * 16 * QB_RB1) * 64 + lane;
     u32x4 d1h[X3 ? 8 : 1][NCB], d1l[X3 ? 8 : 1][NCB];
-    if constexpr (X3) {
-        bwd_l1_frags_x3<NCB>(d1h, d1l, v, cs);
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
-    }
     L1TFrag wcur[1];
     if constexpr (X3) {
-        load_l1t_x3(wcur[0], arena, head, 0, lane);
-        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+            bwd_l1_frags_x3<NCB>(d1h, d1l, v, cs);
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) unscale[cb] = QX_INV / cs[cb];
+            load_l1t_x3(wcur[0], arena, head, 0, lane);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 #pragma unroll 1
     for (int rb = 0; rb < QB_RB1; ++rb) {
         f32x16 dx[NCB];
-        if constexpr (X3) {
+        if (!active) {           // this head's slice of the reduction buffer: zeros, written once
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dx[cb][r] = 0.f;
+        } else if constexpr (X3) {
             L1TFrag wnext;
             if constexpr (NW != 8) {      // (two waves per SIMD: no registers for the second set, the other wave covers the wait)
                 load_l1t_x3(wnext, arena, head, rb + 1 < QB_RB1 ? rb + 1 : rb, lane);
@@ -304,12 +315,14 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
             }
         }
         }
-        float* P = sm.P[head];
+        if (active || rb == 0) {
+            float* P = sm.P[head];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma32_row(r, half);
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, half);
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) P[row * PTS + pt0 + cb * 32 + col] = dx[cb][r];
+                for (int cb = 0; cb < NCB; ++cb) P[row * PTS + pt0 + cb * 32 + col] = dx[cb][r];
+            }
         }
         __syncthreads();
 #pragma unroll

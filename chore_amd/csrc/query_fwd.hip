@@ -52,6 +52,9 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
 
     const float* arena = (const float*)a.arena;
     const int head = wid;
+    if constexpr (!TRAIN) {
+        if (a.out[head] == nullptr) return;     // output not asked for (chore_query_fwd with a NULL pointer): no barrier follows
+    }
     f32x16 h1[4][NCB], h2[4][NCB];
     const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID, mplane = (size_t)a.B * a.N * 2;
     if constexpr (TRAIN) {
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
 
     const float* arena = (const float*)a.arena;
     const int head = wid & 3, cb0 = wid >> 2;
+    if constexpr (!TRAIN) {
+        if (a.out[head] == nullptr) return;     // as in the four-wave kernel
+    }
     f32x16 h1[4][1], h2[4][1];
     const size_t row0 = (size_t)b * a.N + n0, plane = (size_t)a.B * a.N * HEAD_HID, mplane = (size_t)a.B * a.N * 2;
     if constexpr (TRAIN) {
@@ -464,6 +470,8 @@ static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switches for large queries
     static const bool w8 = getenv("CHORE_QUERY_W8") != nullptr;
     if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1, X3>(h, a, s);
+    // (a single output asked for, CHORE.query_df: 32-point tiles do not pay -- a workgroup is placed with the registers of all
+    // four waves, so the CU holds one whatever the three leaving waves free: 363 against 335 us at 8 x 20 000 points)
     // fp16 x 3: a k-step of MFMAs is 2.7 x shorter than the fp32 one for the same weight bytes, and the eight-wave kernel
     // (both waves of a head fetch the head's fragments) is bound by the L1's 64 B / clk: 0.227 ms against 0.203 ms for
     // four waves with two column blocks each (4 x 20 000 points)

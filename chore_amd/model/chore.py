@@ -410,6 +410,29 @@ class CHORE(nn.Module):
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]
 
+    def query_df(self, points, crop_center):
+        """the two distance fields (B,2,N) of the LAST stack at `points` and nothing else: chore_query_fwd with the other three
+        outputs NULL -- their heads' waves leave after the gather, a quarter of the weight traffic and MFMA work.  No autograd
+        graph (see query_grad_points); does not touch get_preds()."""
+        if not self.im_feat_list:
+            raise RuntimeError("call filter(images) before query_df()")
+        pts = points.detach()
+        if not (pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous() and pts.dim() == 3 and pts.shape[2] == 3):
+            raise ValueError("points must be a contiguous fp32 (B,N,3) device tensor")
+        B, N, _ = pts.shape
+        dev = pts.device
+        cc = crop_center.to(device=dev, dtype=torch.float32).contiguous()
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(self.im_feat_list[-1], 256)
+        tp, TH, TW = _nhwc_ptr(self.tmpx, 64)
+        dtype = _QDT[self.compute_dtype]
+        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        df = torch.empty(B, 2, N, device=dev, dtype=torch.float32)
+        _lib.check(_lib.lib.chore_query_fwd(h, pts.data_ptr(), cc.data_ptr(), B, N, fp, FH, FW, tp, TH, TW, fwd_dtype,
+                                            self._heads_arena(dev).data_ptr(), self._cam6, df.data_ptr(), None, None, None, None,
+                                            torch.cuda.current_stream(dev).cuda_stream), h, "chore_query_fwd")
+        return df
+
     def query_grad_points(self, points, crop_center, g_df=None, g_pca=None, g_parts=None, g_centers=None):
         """d(sum_k <g_k, output_k>) / d points of the LAST stack's field at `points`, straight from chore_query_bwd_points: no
         autograd graph, for loops that need nothing but this gradient (Generator.approx_surface).  g_* like the outputs of

@@ -87,12 +87,16 @@ class Generator:
             B, N, _ = s.shape
             cc = query_input["crop_center"]
             thr = float(self.threshold)
-            for _ in range(num_steps):
+            df_only = hasattr(model, "query_df") and not os.environ.get("CHORE_GEN_ALL_HEADS")
+            for it in range(num_steps):
                 stream = torch.cuda.current_stream(dev).cuda_stream
-                with torch.no_grad():
-                    model.query(s, **query_input)
-                preds = model.get_preds()
-                df = preds[0].contiguous()
+                if df_only and it < num_steps - 1:
+                    df = model.query_df(s, cc)        # only the last step's other predictions are read (generator.py:78-79)
+                else:
+                    with torch.no_grad():
+                        model.query(s, **query_input)
+                    preds = model.get_preds()
+                    df = preds[0].contiguous()
                 g = torch.empty_like(df)
                 _lib.check(_lib.lib.chore_gen_clamp_mask(h, df.data_ptr(), k, thr, B, N, g.data_ptr(), stream), h, "chore_gen_clamp_mask")
                 grad = model.query_grad_points(s, cc, g_df=g)

@@ -90,7 +90,9 @@ int chore_heads_pack(chore_handle* h, const chore_weight_desc* descs, int n_desc
  *   points      (B,N,3) fp32 camera-space      crop_center (B,2) fp32
  *   feat        (B,FH,FW,256) NHWC `dtype`     tmpx (B,TH,TW,64) NHWC `dtype`
  *   df (B,2,N)  pca (B,9,N)  parts (B,14,N)  centers (B,6,N)  fp32;  in_img (B,N) uint8 (may be NULL)
- * df is written with OUT_DIST (5.0) where the projected point falls outside [-1,1]^2. */
+ * df is written with OUT_DIST (5.0) where the projected point falls outside [-1,1]^2.
+ * Any of df / pca / parts / centers may be NULL (not all four): that head is not evaluated (its wave leaves after the
+ * gather).  chore_query_bwd_points skips the chain of every head whose upstream gradient is NULL. */
 int chore_query_fwd(chore_handle* h, const float* points, const float* crop_center, int B, int N,
                     const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                     const void* heads_arena, const float* cam6_host, float* df, float* pca,

@@ -325,3 +325,32 @@ def test_empty_query(net):
     net.query(torch.zeros(B, 0, 3).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
     df, pca, parts, centers = net.get_preds()
     assert df.shape == (B, 2, 0) and pca.shape == (B, 3, 3, 0) and parts.shape == (B, 14, 0) and centers.shape == (B, 6, 0)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_skipped_heads_change_nothing(opt, mode):
+    """chore_query_fwd with NULL outputs (CHORE.query_df) and chore_query_bwd_points with NULL upstream gradients: the heads
+    that are not asked for are not evaluated, what is asked for is bit-identical to the full evaluation (forward) / to the
+    evaluation with explicit zero gradients (backward), for the 32- and the 64-point tiles"""
+    import copy
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    o = copy.copy(opt)
+    o.compute_dtype = mode
+    net = CHORE(o).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    for B, N in ((1, 3000), (2, 20000)):
+        with torch.no_grad():
+            net.filter(torch.from_numpy(synth.synth_images(B, 128, 128, 0)).cuda())
+        cc = torch.tensor([synth.CROP_CENTER] * B).cuda()
+        pts = torch.from_numpy(synth.synth_points(B, N, seed=2)).cuda()
+        with torch.no_grad():
+            net.query(pts, crop_center=cc)
+        df, pca, parts, centers = net.get_preds()
+        assert torch.equal(net.query_df(pts, cc), df)
+        g = torch.from_numpy(np.random.RandomState(0).standard_normal((B, 2, N)).astype(np.float32)).cuda()
+        only = net.query_grad_points(pts, cc, g_df=g)
+        zeros = net.query_grad_points(pts, cc, g_df=g, g_pca=torch.zeros_like(pca), g_parts=torch.zeros_like(parts),
+                                      g_centers=torch.zeros_like(centers))
+        assert torch.isfinite(only).all() and float(only.abs().max()) > 0
+        assert torch.equal(only, zeros)
