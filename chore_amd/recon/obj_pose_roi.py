@@ -290,9 +290,13 @@ class SilLossROI(nn.Module):
         verts = self.apply_transformation(R, obj_t, obj_s)
         return render_silhouettes(verts, self.faces, self.K, self.R, self.t, self.rend_size)
 
-    def forward(self, R, obj_t, obj_s):
+    def mask_loss(self, R, obj_t, obj_s):
+        """forward()[0] without the outputs the fitting loop does not read (the edge image costs a max-pool per step)"""
         image = self.keep_mask * self.render(R, obj_t, obj_s)
-        loss_dict = {"mask": torch.sum((image - self.image_ref) ** 2, dim=(1, 2)).mean()}
+        return {"mask": torch.sum((image - self.image_ref) ** 2, dim=(1, 2)).mean()}, image
+
+    def forward(self, R, obj_t, obj_s):
+        loss_dict, image = self.mask_loss(R, obj_t, obj_s)
         return loss_dict, image, self.compute_edges(image), self.image_ref, self.edt_ref_edge
 
     def compute_offscreen_loss(self, verts):

@@ -218,7 +218,8 @@ class ReconFitterBehave(ReconFitterBase):
         loss_dict = {}
         R = self.decopose_axis(obj_R, noise=noise)
         if phase == "sil":      # none of its terms reads the field (the reference queries the object points all the same, :171)
-            obj_losses = data_dict["silhouette"](R, obj_t, obj_s)[0]
+            sil = data_dict["silhouette"]
+            obj_losses = sil.mask_loss(R, obj_t, obj_s)[0] if hasattr(sil, "mask_loss") else sil(R, obj_t, obj_s)[0]
             loss_dict["mask"] = obj_losses["mask"]
             loss_dict["scale"] = torch.mean((obj_s - self.obj_scale) ** 2)
             loss_dict["trans"] = torch.mean((obj_t - data_dict["trans_init"]) ** 2)
