@@ -146,6 +146,8 @@ SIGNATURES = {
     "chore_eval_apply_similarity": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_gen_clamp_mask": (c_int, [c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
     "chore_gen_surface_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
+    "chore_gen_surface_step_fused": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int,
+                                             c_int, c_void_p, POINTER(c_float), c_int, c_float, c_void_p, c_void_p]),
     "chore_gen_compact": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_gen_append": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_longlong, c_void_p, c_void_p, c_void_p, c_void_p,
                                  c_longlong, c_longlong, c_longlong, c_int, c_int, c_int, c_int, c_void_p]),

@@ -201,6 +201,22 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
                               : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream);
 }
 
+int chore_gen_surface_step_fused(chore_handle* h, const float* points, const float* crop_center, int B, int N, const void* feat,
+                                 int FH, int FW, const void* tmpx, int TH, int TW, int dtype, const void* heads_arena,
+                                 const float* cam6_host, int k, float thr, float* out_points, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!out_points || (k != 0 && k != 1)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_surface_step_fused: bad argument");
+    if (!query_x3(dtype))
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_gen_surface_step_fused: needs the fp16 x 3 heads (CHORE_F16X3, or CHORE_HEADS_X3 with the maps' type)");
+    QueryArgs a;
+    int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena, cam6_host);
+    if (rc) return rc;
+    a.dpoints = out_points;
+    a.surf_k = k;
+    a.surf_thr = thr;
+    return launch_query_surface_step(h, dtype, a, (hipStream_t)stream);
+}
+
 size_t chore_query_train_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
     return (size_t)B * N * ((2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float) + 3 * HEAD_NUM * 2 * sizeof(unsigned long long));

@@ -162,12 +162,16 @@ struct QueryArgs {
     float* tdZ = nullptr;   // [3][HEAD_NUM][B*N][128]  gradients w.r.t. the pre-activations of layers 1..3
     float* tdX = nullptr;   // [B*N][QF_KPAD]           gradient w.r.t. the 323-vector (summed over the heads)
     unsigned long long* tM = nullptr;   // [3][HEAD_NUM][B*N][2]  ReLU sign bits of the hidden layers (heads_f32.h, store_masks)
+    // surface step only (chore_gen_surface_step_fused): distance channel and clamp of generator.py:50-79; dpoints = the moved points
+    int surf_k = 0;
+    float surf_thr = 0.f;
 };
 
 // launchers implemented in the .hip files
 int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s);
 int launch_query_fwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
 int launch_query_bwd_f32(chore_handle* h, const QueryArgs& a, hipStream_t s);
+int launch_query_surface_step(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s);
 int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int staged = 0, int x3 = 0);
 int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int x3 = 0);
 int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX, float* dfeat, float* dtmpx,

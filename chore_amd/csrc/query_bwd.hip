@@ -16,6 +16,7 @@ struct QueryBwdSmemT {
     float X[PTS * XS];             // forward: feature tile; backward: d(feature) tile
     float P[HEAD_NUM][32 * PTS];   // per-head partial of one 32-row block, [row][pt]
     PtTableT<PTS> tab;
+    float dfk[PTS];                // SURF: the clamped distance of every point
 };
 
 template <int NCB>
@@ -96,9 +97,15 @@ __device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, 
 // NW = 8 (NCB = 1): two waves per head, one 32-point column block each, of a 64-point tile -- two waves per SIMD hide
 // each other's weight / tap fetches (see query_fwd_f32_w8_kernel)
 // X3: the GEMM chain on the fp16 matrix cores with hi/lo split operands and per-point column scales (heads_x3.h)
-template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4, bool X3 = false>
+// SURF: one projection step of the surface generator (generator.py:50-79) in this launch: only the distance head runs, its
+// output decides its own upstream gradient (1 where df_k <= thr, the gradient of sum(clamp(df_k, max = thr))), and the
+// last lane writes the moved point  p - normalize(grad) * min(df_k, thr)  instead of the gradient.  Bit for bit what
+// chore_query_fwd -> chore_gen_clamp_mask -> chore_query_bwd_points -> chore_gen_surface_step produce, without the second
+// gather and the forward pass the backward recomputes anyway.
+template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4, bool X3 = false, bool SURF = false>
 __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) {
     static_assert(!STAGED || TRAIN, "STAGED is a training mode");
+    static_assert(!SURF || (X3 && !TRAIN && NW == 4), "the surface step exists for the fp16 x 3 recompute kernels");
     static_assert(!X3 || !TRAIN || STAGED, "fp16 x 3 training reads the staged forward");
     static_assert(NW == 4 || (NW == 8 && NCB == 1), "eight waves = two column blocks of one 32-point block each");
     constexpr int PTS = 32 * NCB * (NW / 4), NT_ = NW * 64;
@@ -139,7 +146,7 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     // A head without an upstream gradient contributes exact zeros: its wave skips the GEMM chain and the weight traffic that
     // goes with it (1.3 MB of fragments per tile and head) and only keeps the barriers.  The generator's projection steps
     // and most fit phases hand over one or two of the four gradients.
-    const bool active = TRAIN || a.g[head] != nullptr;
+    const bool active = TRAIN || (SURF ? head == 0 : a.g[head] != nullptr);
     // ---- forward recompute, keep ReLU sign bits only (STAGED: read them back) ----
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
@@ -180,16 +187,25 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     if constexpr (X3) {
         const float* g = a.g[head];
         float g8[NCB][8];
+        f32x16 osurf[SURF ? NCB : 1];
+        if constexpr (SURF) heads_layer_out_x3<NCB>(osurf, u, arena, head, lane);      // u: the third hidden layer, still whole
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) {
             const int pt = pt0 + cb * 32 + col;
             const int n = n0 + pt;
-            const bool live = (g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
+            const bool live = (SURF || g != nullptr) && (n < a.N) && !(head == 0 && sm.tab.in_img[pt] == 0);
             float m = 0.f;
+            float gsel = 0.f;
+            if constexpr (SURF) {       // rows 0 / 1 of the output (the two distances) sit in registers 0 / 1 of the lower half
+                const float dfv = a.surf_k ? osurf[cb][1] : osurf[cb][0];
+                if (half == 0) sm.dfk[pt] = fminf(sm.tab.in_img[pt] ? dfv : 5.0f, a.surf_thr);     // (outside the image: OUT_DIST)
+                gsel = (live && half == 0 && dfv <= a.surf_thr) ? 1.f : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = 8 * half + j;
-                g8[cb][j] = (live && k < odim) ? g[((size_t)b * odim + k) * a.N + n] : 0.f;
+                if constexpr (SURF) g8[cb][j] = (j == a.surf_k) ? gsel : 0.f;
+                else g8[cb][j] = (live && k < odim) ? g[((size_t)b * odim + k) * a.N + n] : 0.f;
                 m = fmaxf(m, fabsf(g8[cb][j]));
             }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
@@ -420,7 +436,13 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
                 const float dy = drow[FEAT_C + 1] + gpy * cam.fy * iz;
                 const float dz = drow[FEAT_C + 2] - (gpx * cam.fx * x + gpy * cam.fy * y) * iz * iz;
                 float* o = a.dpoints + ((size_t)b * a.N + n0 + pt) * 3;
-                o[0] = dx; o[1] = dy; o[2] = dz;
+                if constexpr (SURF) {       // F.normalize(grad) * clamp(df): the arithmetic of gen_surface_step_kernel
+                    const float d = sm.dfk[pt];
+                    const float den = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-12f);
+                    o[0] = x - dx / den * d; o[1] = y - dy / den * d; o[2] = z - dz / den * d;
+                } else {
+                    o[0] = dx; o[1] = dy; o[2] = dz;
+                }
             }
         }
     }
@@ -443,6 +465,29 @@ static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 }
 
 bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64-point tiles would not fill the CUs
+
+template <typename T, int NCB>
+static int launch_query_surf_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    bool& attr_set = CHORE_ONCE_FLAG(h);
+    constexpr int PTS = 32 * NCB;
+    const size_t smem = sizeof(QueryBwdSmemT<PTS>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, false, NCB, false, 4, true, true>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + PTS - 1) / PTS, a.B);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, false, NCB, false, 4, true, true>), grid, dim3(256), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+template <typename T>
+static int launch_query_surf_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    return query_small_tiles(a.B, a.N) ? launch_query_surf_n<T, 1>(h, a, s) : launch_query_surf_n<T, 2>(h, a, s);     // as the backward
+}
+int launch_query_surface_step(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    return dtype == CHORE_F32 ? launch_query_surf_t<float>(h, a, s) : launch_query_surf_t<unsigned short>(h, a, s);
+}
 
 // the eight-wave variants (64-point tile, two waves per head)
 template <typename T, bool TRAIN, bool STAGED, bool X3 = false>

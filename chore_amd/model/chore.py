@@ -433,6 +433,33 @@ class CHORE(nn.Module):
                                             torch.cuda.current_stream(dev).cuda_stream), h, "chore_query_fwd")
         return df
 
+    def surface_step(self, points, crop_center, k, threshold):
+        """one projection step of Generator.approx_surface (recon/generator.py:50-79) on the LAST stack's field:
+        points - normalize(d sum(clamp(df_k, max=threshold)) / d points) * clamp(df_k, max=threshold), one launch
+        (chore_gen_surface_step_fused).  None if the mode has no fused step (the fp32-MFMA heads): the caller composes it
+        from query_df / query_grad_points."""
+        dtype = _QDT[self.compute_dtype]
+        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        if not (fwd_dtype == _lib.F16X3 or (fwd_dtype & _lib.HEADS_X3)) or os.environ.get("CHORE_GEN_FOUR_LAUNCHES"):
+            return None
+        if not self.im_feat_list:
+            raise RuntimeError("call filter(images) before surface_step()")
+        pts = points.detach()
+        if not (pts.is_cuda and pts.dtype == torch.float32 and pts.is_contiguous() and pts.dim() == 3 and pts.shape[2] == 3):
+            raise ValueError("points must be a contiguous fp32 (B,N,3) device tensor")
+        B, N, _ = pts.shape
+        dev = pts.device
+        cc = crop_center.to(device=dev, dtype=torch.float32).contiguous()
+        h = _lib.handle(dev.index or 0)
+        fp, FH, FW = _nhwc_ptr(self.im_feat_list[-1], 256)
+        tp, TH, TW = _nhwc_ptr(self.tmpx, 64)
+        out = torch.empty_like(pts)
+        _lib.check(_lib.lib.chore_gen_surface_step_fused(h, pts.data_ptr(), cc.data_ptr(), B, N, fp, FH, FW, tp, TH, TW, fwd_dtype,
+                                                         self._heads_arena(dev).data_ptr(), self._cam6, int(k), float(threshold),
+                                                         out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_gen_surface_step_fused")
+        return out
+
     def query_grad_points(self, points, crop_center, g_df=None, g_pca=None, g_parts=None, g_centers=None):
         """d(sum_k <g_k, output_k>) / d points of the LAST stack's field at `points`, straight from chore_query_bwd_points: no
         autograd graph, for loops that need nothing but this gradient (Generator.approx_surface).  g_* like the outputs of

@@ -88,8 +88,15 @@ class Generator:
             cc = query_input["crop_center"]
             thr = float(self.threshold)
             df_only = hasattr(model, "query_df") and not os.environ.get("CHORE_GEN_ALL_HEADS")
+            fused = hasattr(model, "surface_step")
             for it in range(num_steps):
                 stream = torch.cuda.current_stream(dev).cuda_stream
+                if fused and df_only and it < num_steps - 1:
+                    new = model.surface_step(s, cc, k, thr)      # the whole step in one launch (same bits as the four below)
+                    if new is not None:
+                        s = new
+                        continue
+                    fused = False
                 if df_only and it < num_steps - 1:
                     df = model.query_df(s, cc)        # only the last step's other predictions are read (generator.py:78-79)
                 else:

@@ -329,6 +329,13 @@ int chore_gen_resample(chore_handle* h, const float* samples, int B, int N, cons
 int chore_gen_clamp_mask(chore_handle* h, const float* df, int k, float thr, int B, int N, float* g, chore_stream_t stream);
 int chore_gen_surface_step(chore_handle* h, const float* points, const float* grad, const float* df, int k, float thr, int B,
                            int N, float* out, chore_stream_t stream);
+/* the four launches above (chore_query_fwd -> chore_gen_clamp_mask -> chore_query_bwd_points -> chore_gen_surface_step) as
+ * one, with the same result bit for bit: arguments as chore_query_fwd; only with the fp16 x 3 heads (dtype CHORE_F16X3, or
+ * the maps' type | CHORE_HEADS_X3).  out_points (B,N,3) must not alias points. */
+int chore_gen_surface_step_fused(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                                 const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                                 const void* heads_arena, const float* cam6_host, int k, float thr, float* out_points,
+                                 chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Image preparation of the test loader on the device  (replaces, from the decoded uint8 images on,

@@ -144,3 +144,33 @@ def test_approx_surface_direct_path_equals_autograd_path(gen, name, monkeypatch)
         assert torch.equal(a, b)
     step = (ref.detach() - pts).norm(dim=-1).max()
     assert float((got.detach() - ref.detach()).abs().max()) <= 1e-6 * float(step)
+
+
+@pytest.mark.parametrize("mode,name", [("bf16", "human"), ("fp16x3", "object")])
+def test_fused_surface_step_equals_the_four_launches(opt, mode, name, monkeypatch):
+    """chore_gen_surface_step_fused (forward of the distance head, its own upstream gradient, backward, projection in the
+    backward-to-points kernel) against chore_query_fwd -> chore_gen_clamp_mask -> chore_query_bwd_points ->
+    chore_gen_surface_step: the same bits after 3 steps, for the 32- and the 64-point tiles, points outside the image included"""
+    import copy
+    from chore_amd.model import CHORE
+    from chore_amd.recon.generator import Generator
+    from chore_amd.utils import synth
+    o = copy.copy(opt)
+    o.compute_dtype = mode
+    net = CHORE(o).cuda().eval()
+    synth.load_synth_weights(net, seed=0)
+    gen2 = Generator(net, None, threshold=2.0, filter_val=0.004, device=torch.device("cuda"))
+    for B, N in ((1, 3000), (2, 20000)):
+        with torch.no_grad():
+            net.filter(torch.from_numpy(synth.synth_images(B, 128, 128, 0)).cuda())
+        q = {"crop_center": torch.tensor([synth.CROP_CENTER] * B).cuda()}
+        pts = gen2.init_samples(N, B)          # frames 1.. keep the unit cube: mostly outside the image
+        assert net.surface_step(pts, q["crop_center"], 0, 2.0) is not None
+        monkeypatch.setenv("CHORE_GEN_FOUR_LAUNCHES", "1")
+        ref, ref_preds = gen2.approx_surface(net, pts.clone(), 4, q, name)
+        monkeypatch.delenv("CHORE_GEN_FOUR_LAUNCHES")
+        got, got_preds = gen2.approx_surface(net, pts.clone(), 4, q, name)
+        assert torch.isfinite(got).all() and float((got.detach() - pts).abs().max()) > 1e-3
+        assert torch.equal(got.detach(), ref.detach())
+        for a, b in zip(got_preds, ref_preds):
+            assert torch.equal(a, b)
