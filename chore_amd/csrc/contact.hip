@@ -157,34 +157,44 @@ __global__ __launch_bounds__(TILE) void contact_nn_kernel(const float* __restric
                                                           const int* __restrict__ lab_c, int lab_c_stride, int Nc,
                                                           int P, const int* __restrict__ n_part,
                                                           unsigned long long* __restrict__ key) {
-    __shared__ float cx[TILE], cy[TILE], cz[TILE];
-    __shared__ int cl[TILE];                  // label, or -1 if the candidate does not take part
+    __shared__ f32x4 cand[TILE];              // x, y, z and the label's bits (-1: the candidate does not take part): one 16-byte read
     const int b = blockIdx.z;
     const int q = blockIdx.x * TILE + threadIdx.x;
     const int c0 = blockIdx.y * TILE;
+    // contact points are a small share of both clouds: most (query tile, candidate chunk) pairs have no query or no candidate
+    // that takes part and leave here, before the chunk is staged (block-uniform exits; what they skip contributes nothing)
+    int l = 0;
+    bool mine = false;
+    if (q < Nq) {
+        l = lab_q[(size_t)b * lab_q_stride + q];
+        const int* np = n_part + ((size_t)b * P + l) * 2;
+        mine = sel_q[(size_t)b * Nq + q] && np[0] > 0 && np[1] > 0;
+    }
+    if (!__syncthreads_or(mine)) return;
+    int lc = -1;
     {
         const int c = c0 + threadIdx.x;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (c < Nc) {
             const float* p = C + ((size_t)b * Nc + c) * 3;
-            cx[threadIdx.x] = p[0]; cy[threadIdx.x] = p[1]; cz[threadIdx.x] = p[2];
-            cl[threadIdx.x] = sel_c[(size_t)b * Nc + c] ? lab_c[(size_t)b * lab_c_stride + c] : -1;
-        } else {
-            cl[threadIdx.x] = -1;
+            v[0] = p[0]; v[1] = p[1]; v[2] = p[2];
+            lc = sel_c[(size_t)b * Nc + c] ? lab_c[(size_t)b * lab_c_stride + c] : -1;
         }
+        v[3] = __int_as_float(lc);
+        cand[threadIdx.x] = v;
     }
-    __syncthreads();
-    if (q >= Nq) return;
-    const int l = lab_q[(size_t)b * lab_q_stride + q];
-    const int* np = n_part + ((size_t)b * P + l) * 2;
-    if (!(sel_q[(size_t)b * Nq + q] && np[0] > 0 && np[1] > 0)) return;
+    if (!__syncthreads_or(lc >= 0)) return;
+    if (!mine) return;
     const float* p = Q + ((size_t)b * Nq + q) * 3;
     const float x = p[0], y = p[1], z = p[2];
     float best = 3.0e38f;
     int bi = -1;
     const int n = min(TILE, Nc - c0);
+#pragma unroll 4
     for (int j = 0; j < n; ++j) {
-        if (cl[j] == l) {
-            const float dx = x - cx[j], dy = y - cy[j], dz = z - cz[j];
+        const f32x4 v = cand[j];
+        if (__float_as_int(v[3]) == l) {
+            const float dx = x - v[0], dy = y - v[1], dz = z - v[2];
             const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
             if (d < best) { best = d; bi = c0 + j; }
         }
@@ -270,12 +280,13 @@ __global__ __launch_bounds__(TILE) void contact_bwd_kernel(const float* __restri
         }
         cn[threadIdx.x] = j;
     }
-    __syncthreads();
+    const int lo = blockIdx.x * TILE;
+    const bool any = __syncthreads_or(cn[threadIdx.x] >= lo && cn[threadIdx.x] < lo + TILE);    // a candidate that points into this tile?
     if (q >= Nq) return;
     const float* p = Q + ((size_t)b * Nq + q) * 3;
     const float x = p[0], y = p[1], z = p[2];
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    const int n = min(TILE, Nc - c0);
+    const int n = any ? min(TILE, Nc - c0) : 0;
     for (int k = 0; k < n; ++k) {
         if (cn[k] == q) {   // r = candidate k has q as its nearest neighbour: d m_r / d q = -2 (r - q)
             gx -= cw[k] * (cx[k] - x); gy -= cw[k] * (cy[k] - y); gz -= cw[k] * (cz[k] - z);
@@ -362,21 +373,25 @@ extern "C" int chore_contact_bwd(chore_handle* h, const float* hum, const float*
                                  int No, int P, const float* g_loss, const void* workspace, float* d_hum, float* d_obj,
                                  chore_stream_t stream) {
     CHORE_ENTER(h);
-    if (!hum || !obj || !label_h || !g_loss || !workspace || !d_hum || !d_obj)
+    if (!hum || !obj || !label_h || !g_loss || !workspace || (!d_hum && !d_obj))
         CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: null argument");
     if (B <= 0 || Nh <= 0 || No <= 0 || P <= 0 || P > CP_MAX)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_contact_bwd: bad sizes");
     hipStream_t s = (hipStream_t)stream;
     CWs w = contact_ws(const_cast<void*>(workspace), B, Nh, No, P);
     const int th = (Nh + TILE - 1) / TILE, to = (No + TILE - 1) / TILE;
-    hipLaunchKernelGGL(contact_bwd_kernel, dim3(th, to, B), dim3(TILE), 0, s, hum, Nh, 0, obj, w.nn_o, w.label_o, No, No, P,
-                       w.n_part, w.npairs, g_loss, w.part_h);
-    hipLaunchKernelGGL(contact_bwd_kernel, dim3(to, th, B), dim3(TILE), 0, s, obj, No, 1, hum, w.nn_h, label_h, 0, Nh, P,
-                       w.n_part, w.npairs, g_loss, w.part_o);
-    hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(th, B), dim3(TILE), 0, s, hum, w.nn_h, label_h, 0, Nh, 0, obj, No, P,
-                       w.n_part, w.npairs, g_loss, w.part_h, to, d_hum);
-    hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(to, B), dim3(TILE), 0, s, obj, w.nn_o, w.label_o, No, No, 1, hum, Nh, P,
-                       w.n_part, w.npairs, g_loss, w.part_o, th, d_obj);
+    if (d_hum) {        // (NULL: that cloud is a constant of the caller, e.g. the body in optimize_smpl_object)
+        hipLaunchKernelGGL(contact_bwd_kernel, dim3(th, to, B), dim3(TILE), 0, s, hum, Nh, 0, obj, w.nn_o, w.label_o, No, No, P,
+                           w.n_part, w.npairs, g_loss, w.part_h);
+        hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(th, B), dim3(TILE), 0, s, hum, w.nn_h, label_h, 0, Nh, 0, obj, No, P,
+                           w.n_part, w.npairs, g_loss, w.part_h, to, d_hum);
+    }
+    if (d_obj) {
+        hipLaunchKernelGGL(contact_bwd_kernel, dim3(to, th, B), dim3(TILE), 0, s, obj, No, 1, hum, w.nn_h, label_h, 0, Nh, P,
+                           w.n_part, w.npairs, g_loss, w.part_o);
+        hipLaunchKernelGGL(contact_bwd_finish_kernel, dim3(to, B), dim3(TILE), 0, s, obj, w.nn_o, w.label_o, No, No, 1, hum, Nh, P,
+                           w.n_part, w.npairs, g_loss, w.part_o, th, d_obj);
+    }
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -104,11 +104,16 @@ class _ContactFn(torch.autograd.Function):
         h = _lib.handle(dev.index or 0)
         B, Nh, _ = hum.shape
         No = obj.shape[1]
-        d_hum, d_obj = torch.empty_like(hum), torch.empty_like(obj)
+        # a cloud that is a constant of the caller (the body in optimize_smpl_object) gets no gradient: NULL skips its kernels
+        d_hum = torch.empty_like(hum) if ctx.needs_input_grad[0] else None
+        d_obj = torch.empty_like(obj) if ctx.needs_input_grad[1] else None
+        if d_hum is None and d_obj is None:
+            return (None,) * 7
         g = g.float().contiguous()
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib.chore_contact_bwd(h, hum.data_ptr(), obj.data_ptr(), lab.data_ptr(), B, Nh, No, ctx.P,
-                                              g.data_ptr(), ws.data_ptr(), d_hum.data_ptr(), d_obj.data_ptr(), stream),
+                                              g.data_ptr(), ws.data_ptr(), None if d_hum is None else d_hum.data_ptr(),
+                                              None if d_obj is None else d_obj.data_ptr(), stream),
                    h, "chore_contact_bwd")
         return d_hum, d_obj, None, None, None, None, None
 

@@ -245,7 +245,8 @@ size_t chore_contact_workspace_bytes(int B, int Nh, int No, int P);
 int chore_contact_fwd(chore_handle* h, const float* hum, const float* obj, const float* df_hum_o,
                       const float* df_obj_h, const int* label_h, const float* part_logits, int B, int Nh, int No,
                       int P, float thres, float* loss, void* workspace, chore_stream_t stream);
-/* g_loss: 1 float on the device (upstream gradient) -> d_hum (B,Nh,3), d_obj (B,No,3) */
+/* g_loss: 1 float on the device (upstream gradient) -> d_hum (B,Nh,3), d_obj (B,No,3); one of the two may be NULL (not
+ * computed) */
 int chore_contact_bwd(chore_handle* h, const float* hum, const float* obj, const int* label_h, int B, int Nh,
                       int No, int P, const float* g_loss, const void* workspace, float* d_hum, float* d_obj,
                       chore_stream_t stream);
