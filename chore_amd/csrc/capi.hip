@@ -189,8 +189,10 @@ int chore_query_bwd_points(chore_handle* h, const float* points, const float* cr
     a.dpoints = dpoints;
     if (nan_check_on()) {
         nan_scan(points, (size_t)B * N * 3, 8, (hipStream_t)stream);
-        nan_scan(g_df, (size_t)B * 2 * N, 9, (hipStream_t)stream); nan_scan(g_pca, (size_t)B * 9 * N, 10, (hipStream_t)stream);
-        nan_scan(g_parts, (size_t)B * 14 * N, 11, (hipStream_t)stream); nan_scan(g_centers, (size_t)B * 6 * N, 12, (hipStream_t)stream);
+        if (g_df) nan_scan(g_df, (size_t)B * 2 * N, 9, (hipStream_t)stream);
+        if (g_pca) nan_scan(g_pca, (size_t)B * 9 * N, 10, (hipStream_t)stream);
+        if (g_parts) nan_scan(g_parts, (size_t)B * 14 * N, 11, (hipStream_t)stream);
+        if (g_centers) nan_scan(g_centers, (size_t)B * 6 * N, 12, (hipStream_t)stream);
         rc = x3 ? launch_query_bwd_x3(h, dtype, a, (hipStream_t)stream)
                 : (dtype == CHORE_F32 ? launch_query_bwd_f32(h, a, (hipStream_t)stream) : launch_query_bwd_f32_bf16maps(h, a, (hipStream_t)stream));
         nan_scan(dpoints, (size_t)B * N * 3, 13, (hipStream_t)stream);
@@ -211,6 +213,8 @@ int chore_gen_surface_step_fused(chore_handle* h, const float* points, const flo
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena, cam6_host);
     if (rc) return rc;
+    for (int i = 0; i < HEAD_NUM; ++i) { a.g[i] = nullptr; a.out[i] = nullptr; }
+    a.in_img = nullptr;
     a.dpoints = out_points;
     a.surf_k = k;
     a.surf_thr = thr;
