@@ -14,7 +14,7 @@
 template <int PTS>
 struct QueryBwdSmemT {
     float X[PTS * XS];             // forward: feature tile; backward: d(feature) tile
-    float P[HEAD_NUM][32 * PTS];   // per-head partial of one 32-row block, [row][pt]
+    float P[2][HEAD_NUM][32 * PTS];   // per-head partial of one 32-row block, [row][pt]; two buffers: one barrier per block
     PtTableT<PTS> tab;
     float dfk[PTS];                // SURF: the clamped distance of every point
 };
@@ -331,8 +331,11 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
             }
         }
         }
-        if (active || rb == 0) {
-            float* P = sm.P[head];
+        // block rb goes to buffer rb & 1: the barrier below separates its writes from its reduction, and the reduction of
+        // block rb - 1 (other buffer) from the writes of block rb + 1 -- one barrier per block instead of two, and a wave
+        // multiplies its next block while the others still add
+        if (active || rb < 2) {
+            float* P = sm.P[rb & 1][head];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, half);
@@ -345,12 +348,13 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         for (int e = 0; e < (32 * PTS) / NT_; ++e) {
             const int idx = e * NT_ + tid;  // row-major [row][pt]
             const int row = idx / PTS, pt = idx % PTS;
-            const float s = ((sm.P[0][idx] + sm.P[1][idx]) + sm.P[2][idx]) + sm.P[3][idx];
+            const float (*Pb)[32 * PTS] = sm.P[rb & 1];
+            const float s = ((Pb[0][idx] + Pb[1][idx]) + Pb[2][idx]) + Pb[3][idx];
             const int k = rb * 32 + row;
             if (k < QF_KPAD) sm.X[pt * XS + k] = s;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     if constexpr (TRAIN) {   // the d(323-vector) tile, consumed by the feature-map scatter
         for (int i = tid; i < PTS * (QF_KPAD / 4); i += NT_) {
