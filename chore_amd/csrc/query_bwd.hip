@@ -470,6 +470,15 @@ static int launch_query_bwd_n(chore_handle* h, const QueryArgs& a, hipStream_t s
 
 bool query_small_tiles(int B, int N);   // query_fwd.hip: 32-point tiles when 64-point tiles would not fill the CUs
 
+// fp16 x 3 backward, a few rounds of workgroups: a round of 64-point tiles takes 82 us, one of 32-point tiles 46 us (measured,
+// one workgroup per CU either way), so e.g. 20 000 points (313 tiles = 2 rounds, the second a fifth full) finish sooner as
+// 625 small tiles (3 rounds): 165 -> 137 us; from ~10 rounds on the 64-point tiles win on every count
+static bool x3_bwd_prefers_small(int B, int N) {
+    const long long t64 = (long long)B * ((N + 63) / 64), t32 = (long long)B * ((N + 31) / 32);
+    const long long r64 = (t64 + 255) / 256, r32 = (t32 + 255) / 256;
+    return r32 * 455 < r64 * 825;
+}
+
 template <typename T, int NCB>
 static int launch_query_surf_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
@@ -487,7 +496,8 @@ static int launch_query_surf_n(chore_handle* h, const QueryArgs& a, hipStream_t 
 }
 template <typename T>
 static int launch_query_surf_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
-    return query_small_tiles(a.B, a.N) ? launch_query_surf_n<T, 1>(h, a, s) : launch_query_surf_n<T, 2>(h, a, s);     // as the backward
+    return (query_small_tiles(a.B, a.N) || x3_bwd_prefers_small(a.B, a.N)) ? launch_query_surf_n<T, 1>(h, a, s)
+                                                                              : launch_query_surf_n<T, 2>(h, a, s);     // as the backward
 }
 int launch_query_surface_step(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
     return dtype == CHORE_F32 ? launch_query_surf_t<float>(h, a, s) : launch_query_surf_t<unsigned short>(h, a, s);
@@ -515,7 +525,7 @@ template <typename T, bool TRAIN, bool X3 = false>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if constexpr (!TRAIN) {
         static const bool x3_small = getenv("CHORE_QUERY_X3_BWD_SMALL") != nullptr;
-        if (query_small_tiles(a.B, a.N) || (X3 && x3_small)) return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
+        if (query_small_tiles(a.B, a.N) || (X3 && (x3_small || x3_bwd_prefers_small(a.B, a.N)))) return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
     }
     // the training variants are bound by their staging stores: measured slower with eight waves (39.4 vs 38.6 ms per step)
     // fp16 x 3: four waves with two column blocks each, like the forward (the eight-wave kernel fetches every weight
