@@ -148,6 +148,7 @@ struct Img {
     }
 };
 
+constexpr int SIL_U = 8;     // pixels of a line whose loads are in flight together
 // The 64 lanes of a wave share one walk: lane l takes the positions d0_from + l, + 64, ... along the edge.
 __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v0, float u1, float v1, float u2, float v2,
                               float eps, int lane, float& g0, float& g1) {
@@ -183,9 +184,16 @@ __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v
         if (im.fim[im.at(axis, d0, d1_in)] == fn) {          // 'out': beyond the edge up to the image border
             const int lim = direction > 0 ? size - 1 : 0;
             const int lo = max(min(d1_out, lim), 0), hi = min(max(d1_out, lim), size - 1);
-            for (int d1 = lo; d1 <= hi; ++d1) {
-                const size_t q = im.at(axis, d0, d1);
-                push(d1, (im.alpha[q] - a_in) * im.grad[q]);
+            for (int d1 = lo; d1 <= hi; d1 += SIL_U) {      // SIL_U pixels' loads requested together, pushed in pixel order
+                float al[SIL_U], gr[SIL_U];
+#pragma unroll
+                for (int u = 0; u < SIL_U; ++u) {
+                    const size_t q = im.at(axis, d0, min(d1 + u, hi));
+                    al[u] = im.alpha[q]; gr[u] = im.grad[q];
+                }
+#pragma unroll
+                for (int u = 0; u < SIL_U; ++u)
+                    if (d1 + u <= hi) push(d1 + u, (al[u] - a_in) * gr[u]);
             }
         }
         float c2;                                            // 'in': this face's pixels up to the opposite edge
@@ -194,10 +202,17 @@ __device__ void sil_edge_walk(const Img& im, int fn, int axis, float u0, float v
         if (!(fabsf(c2) <= 3.0e38f)) continue;
         const int lim = direction > 0 ? (int)ceilf(c2) : (int)floorf(c2);
         const int lo = max(min(d1_in, lim), 0), hi = min(max(d1_in, lim), size - 1);
-        for (int d1 = lo; d1 <= hi; ++d1) {
-            const size_t q = im.at(axis, d0, d1);
-            if (im.fim[q] != fn) continue;
-            push(d1, (im.alpha[q] - a_out) * im.grad[q]);
+        for (int d1 = lo; d1 <= hi; d1 += SIL_U) {
+            float al[SIL_U], gr[SIL_U];
+            int fm[SIL_U];
+#pragma unroll
+            for (int u = 0; u < SIL_U; ++u) {
+                const size_t q = im.at(axis, d0, min(d1 + u, hi));
+                fm[u] = im.fim[q]; al[u] = im.alpha[q]; gr[u] = im.grad[q];
+            }
+#pragma unroll
+            for (int u = 0; u < SIL_U; ++u)
+                if (d1 + u <= hi && fm[u] == fn) push(d1 + u, (al[u] - a_out) * gr[u]);
         }
     }
 }
