@@ -2,15 +2,15 @@
 //
 // Replaces SMPL_Layer.forward (lib_smpl/smplpytorch/smplpytorch/pytorch/smpl_layer.py:72-175) and
 // its autograd: ~500 tiny ATen launches per call in the reference (52 batch_rodrigues, 51 chained
-// 4x4 matmuls, 52 bmm, a (V*3 x 459) blend-shape matmul) become 2 kernels forward, 4 backward.
+// 4x4 matmuls, 52 bmm, a (V*3 x 459) blend-shape matmul) become 2 kernels forward, 3 backward.
 //   * pose kernel (one workgroup per frame): 52 Rodrigues rotations through the reference's quaternion
 //     path (angle = ||theta + 1e-8||, rodrigues_layer.py:41-52), joint locations J = JT + JS*beta
 //     (J_regressor folded into JT/JS at pack time), the kinematic chain and the skinning transforms.
 //   * vertex kernel: thread = one coordinate of a vertex; the pose blend shapes are stored p-major
 //     ([459][V*3]) so the 38 MB matrix streams once, fully coalesced and 27 rows at a time, for a
 //     group of up to 4 frames whose pose maps and transforms sit in LDS.
-//   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), two
-//     fixed-order reduction kernels (dA = W^T dT; d pose_map = P^T d v_posed with d beta = S^T d v_posed)
+//   * backward: vertex kernel (recomputes the blend, emits d v_posed and d T per vertex), one
+//     launch of fixed-order reductions (dA = W^T dT; d pose_map = P^T d v_posed with d beta = S^T d v_posed)
 //     and the pose kernel backward (reverse kinematic chain, Rodrigues Jacobian by forward-mode
 //     dual numbers).  All reductions are tree reductions in a fixed order: deterministic.
 // Gradients are produced for pose, betas and trans (what the fitting optimises,
@@ -439,11 +439,11 @@ __device__ __forceinline__ void block_reduce(float (&a)[NACC], double* sh /*[256
 }
 
 // dA[b][j][e] = sum_v W[v][j] dT[b][v][e]          grid (J, B)
-__global__ __launch_bounds__(256) void lbs_dA_kernel(Dims d, const float* __restrict__ model, float* __restrict__ work, int B) {
-    __shared__ double sh[256];
+__device__ __forceinline__ void lbs_dA_body(Dims d, const float* __restrict__ model, float* __restrict__ work, int B, int j, int b,
+                                            double* sh) {
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
-    const int j = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     float a[12];
 #pragma unroll
     for (int e = 0; e < 12; ++e) a[e] = 0.f;
@@ -471,11 +471,11 @@ __global__ __launch_bounds__(256) void lbs_dA_kernel(Dims d, const float* __rest
 // dpm[b][p] = sum_i PT[p][i] gvp[b][i]  (p < NP)  and  dbv[b][n] = sum_i S[i][n] gvp[b][i]  (row NP + n, from the transposed
 // copy ST)             grid (NP + NB, ceil(B/FB)).  A thread's sum runs over i = tid, tid + 256, ... in that order; the loads of
 // DPM_U steps are issued together (one at a time: 81 dependent round trips, 33 + 25 us for the two former kernels)
-__global__ __launch_bounds__(256) void lbs_dpm_kernel(Dims d, const float* __restrict__ model, float* __restrict__ work, int B) {
-    __shared__ double sh[256];
+__device__ __forceinline__ void lbs_dpm_body(Dims d, const float* __restrict__ model, float* __restrict__ work, int B, int p, int grp,
+                                             double* sh) {
     const Arena ar = arena_layout(d);
     const Work wk = work_layout(d, B);
-    const int p = blockIdx.x, b0 = blockIdx.y * FB, nf = min(FB, B - b0), tid = threadIdx.x;
+    const int b0 = grp * FB, nf = min(FB, B - b0), tid = threadIdx.x;
     const size_t V3 = (size_t)d.V * 3;
     const float* row = p < d.NP ? model + ar.PT + (size_t)p * V3 : model + ar.ST + (size_t)(p - d.NP) * V3;
     const float* gv[FB];
@@ -507,6 +507,15 @@ __global__ __launch_bounds__(256) void lbs_dpm_kernel(Dims d, const float* __res
             if (p < d.NP) work[wk.dpm + (size_t)(b0 + f) * d.NP + p] = r[f];
             else work[wk.dbv + (size_t)(b0 + f) * d.NB + (p - d.NP)] = r[f];
         }
+}
+
+// the two reductions over the vertices in one launch (they are independent): blocks [0, J) x B the skinning transforms,
+// blocks [J, J + NP + NB) x ceil(B / FB) the pose map and the betas                       grid (J + NP + NB, B)
+__global__ __launch_bounds__(256) void lbs_reduce_kernel(Dims d, const float* __restrict__ model, float* __restrict__ work, int B) {
+    __shared__ double sh[256];
+    const int x = blockIdx.x, y = blockIdx.y;
+    if (x < d.J) lbs_dA_body(d, model, work, B, x, y, sh);
+    else if (y < (B + FB - 1) / FB) lbs_dpm_body(d, model, work, B, x - d.J, y, sh);
 }
 
 // pose kernel backward: reverse chain, Rodrigues Jacobian, betas through J, trans
@@ -784,9 +793,7 @@ int chore_smpl_lbs_bwd(chore_handle* h, const void* arena, int V, int J, int num
     hipLaunchKernelGGL(lbs_vertex_bwd_kernel, dim3((V + 255) / 256, B), dim3(256), std::max((size_t)J * 12 * sizeof(float), 256 * sizeof(double)), s, d, m, scale, w,
                        B, v_posed, g_verts);
     CHORE_LAUNCH_CHECK(h, s);
-    hipLaunchKernelGGL(lbs_dA_kernel, dim3(J, B), dim3(256), 0, s, d, m, w, B);
-    CHORE_LAUNCH_CHECK(h, s);
-    hipLaunchKernelGGL(lbs_dpm_kernel, dim3(d.NP + num_betas, (B + FB - 1) / FB), dim3(256), 0, s, d, m, w, B);
+    hipLaunchKernelGGL(lbs_reduce_kernel, dim3(J + d.NP + num_betas, B), dim3(256), 0, s, d, m, w, B);
     CHORE_LAUNCH_CHECK(h, s);
     hipLaunchKernelGGL(lbs_pose_bwd_kernel, dim3(B), dim3(64), 0, s, d, m, pose, scale, (const float*)w, B, g_verts, g_joints,
                        dpose, dbetas, dtrans);
