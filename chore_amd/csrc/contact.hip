@@ -151,16 +151,23 @@ __global__ void contact_pairs_kernel(int B, int P, CWs w) {
 // frame spread over ~320 blocks) and merges its minimum with a 64-bit atomicMin on (distance bits << 32 | index):
 // distances are non-negative, so the bit pattern orders like the value, and equal distances resolve to the
 // smaller index -- the same first-minimum a sequential scan finds, whatever order the blocks run in.
-__global__ __launch_bounds__(TILE) void contact_nn_kernel(const float* __restrict__ Q, const int* __restrict__ sel_q,
-                                                          const int* __restrict__ lab_q, int lab_q_stride, int Nq,
-                                                          const float* __restrict__ C, const int* __restrict__ sel_c,
-                                                          const int* __restrict__ lab_c, int lab_c_stride, int Nc,
-                                                          int P, const int* __restrict__ n_part,
-                                                          unsigned long long* __restrict__ key) {
+struct NNSide {      // one direction of the pairing: queries of one cloud against candidates of the other
+    const float* Q; const int* sel_q; const int* lab_q; int lab_q_stride, Nq;
+    const float* C; const int* sel_c; const int* lab_c; int lab_c_stride, Nc;
+    unsigned long long* key;
+};
+// both directions in one launch (they are independent): blockIdx.y = direction, blockIdx.x = query tile + tiles * chunk
+__global__ __launch_bounds__(TILE) void contact_nn_kernel(NNSide s0, NNSide s1, int P, const int* __restrict__ n_part) {
     __shared__ f32x4 cand[TILE];              // x, y, z and the label's bits (-1: the candidate does not take part): one 16-byte read
+    const NNSide& sd = blockIdx.y ? s1 : s0;
+    const float* __restrict__ Q = sd.Q; const int* __restrict__ sel_q = sd.sel_q; const int* __restrict__ lab_q = sd.lab_q;
+    const float* __restrict__ C = sd.C; const int* __restrict__ sel_c = sd.sel_c; const int* __restrict__ lab_c = sd.lab_c;
+    const int lab_q_stride = sd.lab_q_stride, Nq = sd.Nq, lab_c_stride = sd.lab_c_stride, Nc = sd.Nc;
+    unsigned long long* __restrict__ key = sd.key;
+    const int tq = (Nq + TILE - 1) / TILE;
     const int b = blockIdx.z;
-    const int q = blockIdx.x * TILE + threadIdx.x;
-    const int c0 = blockIdx.y * TILE;
+    const int q = (blockIdx.x % tq) * TILE + threadIdx.x;
+    const int c0 = (blockIdx.x / tq) * TILE;
     // contact points are a small share of both clouds: most (query tile, candidate chunk) pairs have no query or no candidate
     // that takes part and leave here, before the chunk is staged (block-uniform exits; what they skip contributes nothing)
     int l = 0;
@@ -355,10 +362,11 @@ extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float*
         hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)w.key_h,
                            0xffffffffu, n);
     }
-    hipLaunchKernelGGL(contact_nn_kernel, dim3(th, to, B), dim3(TILE), 0, s, hum, w.sel_h, label_h, 0, Nh,
-                       obj, w.sel_o, w.label_o, No, No, P, w.n_part, w.key_h);
-    hipLaunchKernelGGL(contact_nn_kernel, dim3(to, th, B), dim3(TILE), 0, s, obj, w.sel_o, w.label_o, No, No,
-                       hum, w.sel_h, label_h, 0, Nh, P, w.n_part, w.key_o);
+    {
+        const NNSide s0{hum, w.sel_h, label_h, 0, Nh, obj, w.sel_o, w.label_o, No, No, w.key_h};
+        const NNSide s1{obj, w.sel_o, w.label_o, No, No, hum, w.sel_h, label_h, 0, Nh, w.key_o};
+        hipLaunchKernelGGL(contact_nn_kernel, dim3(th * to, 2, B), dim3(TILE), 0, s, s0, s1, P, w.n_part);
+    }
     hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * Nh + 255) / 256)), dim3(256), 0, s, w.key_h,
                        (size_t)B * Nh, w.nn_h, w.m_h);
     hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * No + 255) / 256)), dim3(256), 0, s, w.key_o,
