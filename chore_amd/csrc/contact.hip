@@ -68,9 +68,10 @@ CWs contact_ws(void* base, int B, int Nh, int No, int P) {
 
 // plain fill instead of hipMemsetAsync: the step is recorded into hipGraphs, and byte-memset nodes of odd sizes
 // replayed unreliably there (sporadic GPU memory faults), kernel nodes do not
-__global__ void contact_fill_kernel(unsigned* __restrict__ p, unsigned v, size_t n) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void contact_fill_kernel(unsigned* __restrict__ p, unsigned v, size_t n, unsigned* __restrict__ p1, unsigned v1, size_t n1) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // two ranges in one launch
     if (i < n) p[i] = v;
+    else if (i < n + n1) p1[i - n] = v1;
 }
 
 // ---- 1. masks, labels, contact counts ---------------------------------------------------------------
@@ -210,10 +211,17 @@ __global__ __launch_bounds__(TILE) void contact_nn_kernel(NNSide s0, NNSide s1, 
         atomicMin(key + (size_t)b * Nq + q, ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi);
 }
 
-__global__ void contact_unpack_kernel(const unsigned long long* __restrict__ key, size_t n, int* __restrict__ nn,
-                                      float* __restrict__ mind) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// both clouds' keys in one launch: elements [0, n0) of the first set, then [0, n1) of the second
+__global__ void contact_unpack_kernel(const unsigned long long* __restrict__ key0, size_t n0, int* __restrict__ nn0,
+                                      float* __restrict__ mind0, const unsigned long long* __restrict__ key1, size_t n1,
+                                      int* __restrict__ nn1, float* __restrict__ mind1) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n0 + n1) return;
+    const bool second = i >= n0;
+    if (second) i -= n0;
+    const unsigned long long* key = second ? key1 : key0;
+    int* nn = second ? nn1 : nn0;
+    float* mind = second ? mind1 : mind0;
     const unsigned long long k = key[i];
     const bool none = k == ~0ull;
     nn[i] = none ? -1 : (int)(unsigned)(k & 0xffffffffu);
@@ -347,9 +355,11 @@ extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float*
     hipStream_t s = (hipStream_t)stream;
     CWs w = contact_ws(workspace, B, Nh, No, P);
     // counters: cnt, n_part (contiguous up to npairs)
-    {
+    {   // the counters to 0 and the nearest-neighbour keys to "none", one launch
         const size_t n = ((char*)w.npairs - (char*)w.cnt) / 4 + 1;   // cnt, n_part, npairs
-        hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)w.cnt, 0u, n);
+        const size_t nk = ((char*)w.part_h - (char*)w.key_h) / 4;    // key_h and key_o
+        hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + nk + 255) / 256)), dim3(256), 0, s, (unsigned*)w.cnt, 0u, n,
+                           (unsigned*)w.key_h, 0xffffffffu, nk);
     }
     const int Nm = Nh > No ? Nh : No;
     dim3 gm((Nm + 255) / 256, B);
@@ -358,19 +368,12 @@ extern "C" int chore_contact_fwd(chore_handle* h, const float* hum, const float*
     hipLaunchKernelGGL(contact_pairs_kernel, dim3(1), dim3(256), 0, s, B, P, w);
     const int th = (Nh + TILE - 1) / TILE, to = (No + TILE - 1) / TILE;
     {
-        const size_t n = ((char*)w.part_h - (char*)w.key_h) / 4;     // key_h and key_o
-        hipLaunchKernelGGL(contact_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)w.key_h,
-                           0xffffffffu, n);
-    }
-    {
         const NNSide s0{hum, w.sel_h, label_h, 0, Nh, obj, w.sel_o, w.label_o, No, No, w.key_h};
         const NNSide s1{obj, w.sel_o, w.label_o, No, No, hum, w.sel_h, label_h, 0, Nh, w.key_o};
         hipLaunchKernelGGL(contact_nn_kernel, dim3(th * to, 2, B), dim3(TILE), 0, s, s0, s1, P, w.n_part);
     }
-    hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * Nh + 255) / 256)), dim3(256), 0, s, w.key_h,
-                       (size_t)B * Nh, w.nn_h, w.m_h);
-    hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * No + 255) / 256)), dim3(256), 0, s, w.key_o,
-                       (size_t)B * No, w.nn_o, w.m_o);
+    hipLaunchKernelGGL(contact_unpack_kernel, dim3((unsigned)(((size_t)B * (Nh + No) + 255) / 256)), dim3(256), 0, s, w.key_h,
+                       (size_t)B * Nh, w.nn_h, w.m_h, w.key_o, (size_t)B * No, w.nn_o, w.m_o);
     hipLaunchKernelGGL(contact_pair_sum_kernel, dim3(B * P * 2), dim3(256), 0, s, label_h, B, Nh, No, P, w);
     hipLaunchKernelGGL(contact_finish_kernel, dim3(1), dim3(64), 0, s, B, P, w, loss);
     CHORE_LAUNCH_CHECK(h, s);
