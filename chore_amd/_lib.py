@@ -116,6 +116,7 @@ SIGNATURES = {
     "chore_fit_obj_terms_fwd": (c_int, [c_void_p] * 5 + [c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_fit_obj_terms_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                         c_void_p, c_void_p]),
+    "chore_fit_rot_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int, c_longlong, c_void_p, c_void_p]),
     "chore_fit_stop_rule": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "chore_train_loss_workspace_bytes": (c_size_t, []),
     "chore_train_loss": (c_int, [c_void_p] * 11 + [c_int, c_int, c_float, c_void_p, c_float] + [c_void_p] * 5 + [c_int, c_void_p,

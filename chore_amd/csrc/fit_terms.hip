@@ -321,6 +321,18 @@ __global__ __launch_bounds__(256) void obj_terms_bwd_kernel(const float* __restr
     }
 }
 
+// ---- the SO(3) perturbation of a step: out = rot + scale * noise[k], then k += 1   (decopose_axis, recon_fit_base.py:374-384,
+//      with the per-step draws laid out up front; k is the device-side step counter a recorded graph advances) ----
+__global__ __launch_bounds__(256) void rot_noise_kernel(const float* __restrict__ rot, const float* __restrict__ noise,
+                                                        long long* __restrict__ k, float scale, int n /*B*9*/, long long steps,
+                                                        float* __restrict__ out) {
+    const long long kk = *k;
+    const long long kc = kk < 0 ? 0 : (kk >= steps ? steps - 1 : kk);
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = rot[i] + scale * noise[(size_t)kc * n + i];
+    __syncthreads();
+    if (threadIdx.x == 0) *k = kk + 1;
+}
+
 int check_smpl(chore_handle* h, const SmplTermArgs& a, const char* who) {
     if (!a.pose || !a.pose_init || !a.J || !a.cc || !a.bmean || !a.bprec || !a.hmean || !a.lprec || !a.rprec)
         CHORE_FAIL(h, CHORE_EINVAL, "%s: null argument", who);
@@ -463,6 +475,16 @@ int chore_fit_obj_terms_bwd(chore_handle* h, const float* diff, const float* obj
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(obj_terms_bwd_kernel, dim3((N + 255) / 256, B), dim3(256), 0, st, diff, obj_s, scale0, up_scale, up_ocent, B, N,
                        dobject, dcenters, dscale);
+    CHORE_LAUNCH_CHECK(h, st);
+    return CHORE_OK;
+}
+
+int chore_fit_rot_noise(chore_handle* h, const float* rot, const float* noise, int64_t* k, float scale, int B, int64_t steps,
+                        float* out, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!rot || !noise || !k || !out || B < 1 || steps < 1) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_rot_noise: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(rot_noise_kernel, dim3(1), dim3(256), 0, st, rot, noise, (long long*)k, scale, B * 9, (long long)steps, out);
     CHORE_LAUNCH_CHECK(h, st);
     return CHORE_OK;
 }

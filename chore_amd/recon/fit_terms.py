@@ -222,3 +222,34 @@ def obj_terms(object, centers, obj_s, smpl_center, scale0):
     """-> (scale, ocent): mean((obj_s - scale0)^2) and
     mse(mean(object, 1), smpl_center + mean(centers[:, 3:], -1)).sum(-1).mean()"""
     return _ObjTermsFn.apply(object, centers, obj_s, smpl_center.detach().float().contiguous(), scale0)
+
+
+class _RotNoiseFn(torch.autograd.Function):
+    """rot + scale * noise[k]; k += 1 (in place, on the device).  The gradient passes to rot unchanged."""
+
+    @staticmethod
+    def forward(ctx, rot, noise, k, scale):
+        dev = rot.device
+        h = _lib.handle(dev.index or 0)
+        r = rot.float().contiguous()
+        out = torch.empty_like(r)
+        _lib.check(_lib.lib.chore_fit_rot_noise(h, r.data_ptr(), noise.data_ptr(), k.data_ptr(), float(scale), r.shape[0],
+                                                noise.shape[0], out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h,
+                   "chore_fit_rot_noise")
+        return out      # (k is an integer counter outside autograd: nothing to mark)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None, None, None
+
+
+def rot_noise_supported(rot, noise, k):
+    return (not TORCH_TERMS and rot.is_cuda and rot.dtype == torch.float32 and noise.is_cuda and noise.dtype == torch.float32 and
+            noise.is_contiguous() and noise.dim() == 4 and tuple(noise.shape[1:]) == tuple(rot.shape) and k.dtype == torch.int64 and
+            k.numel() == 1 and k.is_cuda)
+
+
+def rot_noise(rot, noise, k, scale=1e-4):
+    """rot + scale * noise[k] for the (steps,B,3,3) table of draws, advancing the device counter k -- the argument of
+    project_so3 in decopose_axis"""
+    return _RotNoiseFn.apply(rot, noise, k, scale)

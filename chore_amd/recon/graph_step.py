@@ -147,6 +147,7 @@ class EagerStep:
         self.armed = torch.zeros((), dtype=torch.bool, device=dev)   # the early-stop rule is live in this outer iteration
         self.stop = torch.zeros((), dtype=torch.bool, device=dev)    # latched: the reference has returned
         self.loss = torch.zeros((), device=dev)
+        self.seed = torch.ones((), device=dev)            # d loss / d loss: handed to backward() (it fills a fresh one per call otherwise)
 
     def zero_grads(self):
         """what optimizer.zero_grad() did in the reference's torch (zero in place; the tensors stay: a recorded graph
@@ -171,7 +172,7 @@ class EagerStep:
         if isinstance(self.opt, FusedAdam):
             # two launches: Adam on all tensors (the latched flag freezes the parameters), then the stop rule + step counter
             loss = self.loss_fn(_OnePlusDecay(self.denom))
-            loss.backward()
+            loss.backward(self.seed if loss.dtype == self.seed.dtype and loss.dim() == 0 else None)
             self.opt.step(self.stop)
             lv = loss.detach()
             if lv.dtype != torch.float32:

@@ -216,7 +216,7 @@ class ReconFitterBehave(ReconFitterBase):
         return self.copy_smpl_params(split, smpl), scale
 
     # ---- object + joint -----------------------------------------------------------------------------
-    def forward_step(self, model, smpl, data_dict, obj_R, obj_t, obj_s, phase, noise=None):
+    def forward_step(self, model, smpl, data_dict, obj_R, obj_t, obj_s, phase, noise=None, rot_noisy=None):
         const = data_dict.get("smpl_const")     # optimize_smpl_object: the body does not move, see there
         if const is None:
             smpl.forget()
@@ -224,7 +224,8 @@ class ReconFitterBehave(ReconFitterBase):
         else:
             smpl_verts = const["verts"]
         loss_dict = {}
-        R = self.decopose_axis(obj_R, noise=noise)
+        # rot_noisy: obj_R + 1e-4 * this step's draw, already formed (fit_terms.rot_noise) = the argument of decopose_axis's projection
+        R = self.project_so3(rot_noisy) if rot_noisy is not None else self.decopose_axis(obj_R, noise=noise)
         if phase == "sil":      # none of its terms reads the field (the reference queries the object points all the same, :171)
             sil = data_dict["silhouette"]
             obj_losses = sil.mask_loss(R, obj_t, obj_s)[0] if hasattr(sil, "mask_loss") else sil(R, obj_t, obj_s)[0]
@@ -331,6 +332,9 @@ class ReconFitterBehave(ReconFitterBase):
 
         def loss_of(phase):
             def f(decay):
+                if fit_terms.rot_noise_supported(obj_R, noise, k):      # the step's perturbed parameter and k += 1, one launch
+                    return self.sum_dict(self.forward_step(model, split, data_dict, obj_R, obj_t, obj_s, phase,
+                                                           rot_noisy=fit_terms.rot_noise(obj_R, noise, k)), wd, decay)
                 nz = noise.index_select(0, k).squeeze(0)
                 k.add_(1)
                 return self.sum_dict(self.forward_step(model, split, data_dict, obj_R, obj_t, obj_s, phase, noise=nz), wd, decay)

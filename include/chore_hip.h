@@ -554,6 +554,11 @@ int chore_fit_obj_terms_fwd(chore_handle* h, const float* object, const float* c
 int chore_fit_obj_terms_bwd(chore_handle* h, const float* diff, const float* obj_s, float scale0, const float* up_scale,
                             const float* up_ocent, int B, int N, float* dobject, float* dcenters, float* dscale,
                             chore_stream_t stream);
+/* the perturbation of the raw rotation parameter of a step (ReconFitterBase.decopose_axis, recon/recon_fit_base.py:374-384:
+ * rot + 1e-4 * U[0,1)), with the draws of all steps laid out up front: out (B,3,3) = rot + scale * noise[*k] with noise
+ * (steps,B,3,3), then *k += 1 (k: device int64, the step counter a recorded graph advances; clamped into [0, steps)) */
+int chore_fit_rot_noise(chore_handle* h, const float* rot, const float* noise, int64_t* k, float scale, int B, int64_t steps,
+                        float* out, chore_stream_t stream);
 
 /* debug aid: with CHORE_NAN_CHECK=1 in the environment chore_query_fwd / chore_query_bwd_points scan their inputs and
  * outputs for non-finite values (extra launches on the caller's stream); out32[0..15] = counts per site (0 points, 1-4 the
