@@ -409,3 +409,23 @@ def test_fused_adam_step_equals_torch_adam():
         assert abs(la - lb) <= 2e-6 * abs(lb) and abs(pva - pvb) <= 2e-6 * abs(pvb)
     for a, b in zip(pa, pb):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
+def test_rot_noise_operator():
+    """chore_fit_rot_noise: rot + 1e-4 * noise[k] bit for bit as the tensor expression, the device counter advanced by one per
+    call, the gradient passed through to rot"""
+    from chore_amd.recon import fit_terms
+    rs = np.random.RandomState(2)
+    B, S = 3, 5
+    rot = torch.from_numpy(rs.standard_normal((B, 3, 3)).astype(np.float32)).cuda().requires_grad_(True)
+    noise = torch.from_numpy(rs.uniform(0, 1, (S, B, 3, 3)).astype(np.float32)).cuda()
+    k = torch.zeros(1, dtype=torch.long, device="cuda")
+    assert fit_terms.rot_noise_supported(rot, noise, k)
+    for step in range(S):
+        out = fit_terms.rot_noise(rot, noise, k)
+        assert int(k) == step + 1
+        assert torch.equal(out.detach(), rot.detach() + 1e-4 * noise[step])
+    w = torch.from_numpy(rs.standard_normal((B, 3, 3)).astype(np.float32)).cuda()
+    k.zero_()
+    (fit_terms.rot_noise(rot, noise, k) * w).sum().backward()
+    assert torch.equal(rot.grad, w)
