@@ -228,7 +228,7 @@ def profile_enable(device_index: int, on: bool):
 def profile_read(device_index: int):
     """-> {class: dict(ms, flops, bytes, launches)} accumulated since profile_enable"""
     h = handle(device_index)
-    n = 24
+    n = 48
     names = (c_char_p * n)()
     ms, fl, by = (ctypes.c_double * n)(), (ctypes.c_double * n)(), (ctypes.c_double * n)()
     la = (c_int64 * n)()

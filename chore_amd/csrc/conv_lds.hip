@@ -25,7 +25,7 @@
 //     vectors covering full 128-byte lines (the first version stored 2-byte elements and spent
 //     37 % of the convolution time there).  GroupNorm partial sums of the
 //     stored values are reduced in a fixed order.
-#include "enc_common.h"
+#include "conv_common.h"
 
 // Ablation switches for kernel experiments (scripts/conv_ablate.sh) exist only in builds with -DCHORE_CONV_ABLATE=1; in
 // the shipped library DBG(a) is the constant 0 and every switch below folds away.
@@ -38,119 +38,14 @@
 #define DBG(a) 0
 #endif
 
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
-typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+using namespace conv_detail;
 
 namespace {
 
 constexpr int TH = 8, TW = 32;   // tile
 constexpr int ROWB = 80;         // LDS patch row: 64 B of channels + 16 B pad (5 slots: odd)
-constexpr int KGC = 2;           // k-groups per chunk
 constexpr int SCR_LD = 68;       // scratch row stride in floats (64 channels + 4: conflict-free b128 reads)
 
-template <typename T> struct CT;
-template <> struct CT<float> { static constexpr int VE = 4, KGE = 8; };
-template <> struct CT<bf16_t> { static constexpr int VE = 8, KGE = 16; };
-template <> struct CT<x3_t> { static constexpr int VE = 8, KGE = 16; };   // VE: channels per staging slot (two 16-byte loads)
-
-
-template <typename T>
-__device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* sh, bool use_gn) {
-    if (!use_gn) return raw;
-    u32x4 o;
-    if constexpr (sizeof(T) == 4) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t = fmaf(__uint_as_float(raw[j]), sc[j], sh[j]);
-            o[j] = __float_as_uint(t > 0.f ? t : 0.f);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(raw[j] << 16), hi = __uint_as_float(raw[j] & 0xffff0000u);
-            float x = fmaf(lo, sc[2 * j], sh[2 * j]), y = fmaf(hi, sc[2 * j + 1], sh[2 * j + 1]);
-            x = x > 0.f ? x : 0.f;
-            y = y > 0.f ? y : 0.f;
-            o[j] = pack2bf(x, y);
-        }
-    }
-    return o;
-}
-
-// fp16 x 3 staging: 8 fp32 channels (two vectors) -> GroupNorm + ReLU -> fp16 hi and lo vectors
-__device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
-                                         u32x4& lo) {
-    float t[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { t[j] = __uint_as_float(r0[j]); t[4 + j] = __uint_as_float(r1[j]); }
-    if (use_gn) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float y = fmaf(t[j], sc[j], sh[j]);
-            t[j] = y > 0.f ? y : 0.f;
-        }
-    }
-    f16x8_t h, l;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h[j] = (_Float16)t[j];
-        l[j] = (_Float16)(t[j] - (float)h[j]);
-    }
-    hi = __builtin_bit_cast(u32x4, h);
-    lo = __builtin_bit_cast(u32x4, l);
-}
-
-__device__ __forceinline__ void mfma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {
-    const f16x8_t a0 = __builtin_bit_cast(f16x8_t, ah), a1 = __builtin_bit_cast(f16x8_t, al);
-    const f16x8_t b0 = __builtin_bit_cast(f16x8_t, bh), b1 = __builtin_bit_cast(f16x8_t, bl);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc, 0, 0, 0);   // small terms first
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc, 0, 0, 0);
-}
-
-template <typename T>
-__device__ __forceinline__ void mfma(f32x16& acc, const u32x4& av, const u32x4& bw) {
-    if constexpr (sizeof(T) == 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av),
-                                                      __builtin_bit_cast(bf16x8_t, bw), acc, 0, 0, 0);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(av[i]), __uint_as_float(bw[i]), acc, 0, 0, 0);
-    }
-}
-
-// 8 consecutive channels <-> registers
-template <typename T> __device__ __forceinline__ void load8(const T* p, float (&v)[8]);
-template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
-    const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
-    v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-}
-template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
-    const u32x4 a = *(const u32x4*)p;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        v[2 * j] = __uint_as_float(a[j] << 16);
-        v[2 * j + 1] = __uint_as_float(a[j] & 0xffff0000u);
-    }
-}
-// store 8 channels; v is replaced by the values as stored (rounded to T)
-template <typename T> __device__ __forceinline__ void store8(T* p, float (&v)[8]);
-template <> __device__ __forceinline__ void store8<float>(float* p, float (&v)[8]) {
-    f32x4 a = {v[0], v[1], v[2], v[3]}, b = {v[4], v[5], v[6], v[7]};
-    *(f32x4*)p = a;
-    *(f32x4*)(p + 4) = b;
-}
-template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)[8]) {
-    u32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        o[j] = pack2bf(v[2 * j], v[2 * j + 1]);
-        v[2 * j] = __uint_as_float(o[j] << 16);
-        v[2 * j + 1] = __uint_as_float(o[j] & 0xffff0000u);
-    }
-    *(u32x4*)p = o;
-}
 
 // TPS = taps per K-step: 3 (one kernel row) for large grids; 9 (the whole chunk) for the small maps, where a
 // workgroup's time is a chain of dependent weight fetches and fewer, longer steps mean fewer round trips
@@ -318,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     if (use_gn && !(DBG(a) & 64)) {
         // GroupNorm affine of this image's input channels from the producers' exact group totals
         for (int ci = tid; ci < Cin; ci += 256)
-            gn_scale_shift(a.in_st, b, Cin, ci, a.H * a.W, a.gamma, a.beta, ss_lds[2 * ci], ss_lds[2 * ci + 1]);
+            gn_scale_shift(a.in_st, a.B, b, Cin, ci, a.H * a.W, a.gamma, a.beta, ss_lds[2 * ci], ss_lds[2 * ci + 1]);
     }
     __syncthreads();   // ss_lds visible, scratch free
     write_patch(preq[0], chunk_of(0) * CC);
@@ -562,15 +457,15 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 const int gs = a.st_raw_C / GN_GROUPS;
                 const float s1 = group_lane_sum(t[0], gs), s2 = group_lane_sum(t[1], gs);
                 GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
-                if (tid % gs == 0) stat_add(&o->sum, s1);
-                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, s2);
+                if (tid % gs == 0) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells(a.B), s2);
             }
             if (a.st_out) {
                 const int gs = a.st_out_C / GN_GROUPS;
                 const float s1 = group_lane_sum(t[2], gs), s2 = group_lane_sum(t[3], gs);
                 GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
-                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, s1);
-                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, s2);
+                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, act_hi_cells(a.B), s2);
             }
         }
     }
@@ -642,6 +537,12 @@ static bool is_small_grid(int dtype, int B, int H, int W, int Cin, int Cout, int
     return nt <= 64 && nch % PD_SMALL == 0 && (long)B * tiles_of(H, W) * (Cout / nt) < 384;
 }
 
+// CHORE_CONV_LDS=1: every layer on conv_lds_kernel (A/B measurements against the specialised-wave kernel)
+bool conv_use_pc() {
+    static const bool off = getenv("CHORE_CONV_LDS") != nullptr;
+    return !off;
+}
+
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
     if (conv_small_eligible(dtype, taps, H, W, Cin, Cout)) return ConvPlan{32, 1, H * (W / 32), 0, Cin};
     const int nt = choose_nt(dtype, B, H, W, Cout);
@@ -662,10 +563,14 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
     if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
+    if (dtype == CHORE_F16X3 && !a_in.res2.p && conv_use_pc()) {   // specialised-wave kernel (conv_pc.hip)
+        const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+        if (pp.th) return launch_conv_pc(h, taps, pp, a_in, s);
+    }
     ConvArgs a = a_in;
 #if CHORE_CONV_ABLATE
     static const int dbg = getenv("CHORE_CONV_DBG") ? atoi(getenv("CHORE_CONV_DBG")) : 0;
-    a.dbg = dbg;
+    a.dbg = (a_in.dbg & (1 << 30)) ? (a_in.dbg & ~(1 << 30)) : dbg;   // bit 30: the caller's switches (scripts/probes/conv_bench.hip)
 #endif
     const int nt = choose_nt(dtype, a.B, a.H, a.W, a.Cout);
     const bool small_grid = is_small_grid(dtype, a.B, a.H, a.W, a.in.C, a.Cout, nt);

@@ -1,0 +1,585 @@
+// conv_pc.hip -- 3x3 / 1x1 convolution of the encoder as an implicit GEMM with SPECIALISED WAVES (every conv of ConvBlock,
+// model/net_util.py:346-396, and the 1x1 convs of the stack tail, model/HGFilters.py:128-142,167-183).  Same arithmetic,
+// same ConvArgs contract and the same packed weights as conv_lds_kernel; what differs is who does what inside a workgroup.
+//
+// Why.  conv_lds_kernel runs every phase with all four waves: load -> GroupNorm/ReLU/hi-lo split -> LDS -> barrier -> MFMAs.
+// A per-phase breakdown (profiles/r03_conv_phase_breakdown.txt) shows the phases simply add up -- staging 10.7 us + MFMAs
+// 14.4 us of a 47 us launch at 128^2, and two co-resident workgroups run in lockstep, so the hardware overlaps nothing --
+// and the layers on the 64^2 maps launch 128 workgroups on a 256-CU part.
+//
+// Here a workgroup is 8 waves, two per SIMD:
+//   * waves 0-3 (consumers) only read fragments from LDS and issue MFMAs;
+//   * waves 4-7 (producers) only move data: activations global -> registers -> GroupNorm + ReLU (+ fp16 hi / lo split)
+//     -> the OTHER patch buffer, the next K-step's weight fragments -> the OTHER ring slot, residual rows -> registers.
+//   The matrix pipe and the vector ALU of a SIMD are separate issue ports, so the producer's arithmetic runs beside the
+//   consumer's MFMAs.  One s_barrier per K-step (raw: the producers' global loads stay in flight across it).
+//   * tile = TH x 32 pixels x NT channels with TH = 8 or 4: the 4-row tile doubles the workgroup count on the 64^2 maps.
+//   * epilogue: the accumulators go through an LDS image of the whole tile, then ALL 512 threads add the residuals
+//     (fetched during the last chunk), store 16-byte vectors and reduce the GroupNorm statistics in a fixed order.
+#include "conv_common.h"
+
+#ifndef CHORE_CONV_ABLATE
+#define CHORE_CONV_ABLATE 0
+#endif
+#if CHORE_CONV_ABLATE
+#define PDBG(a) ((a).dbg)
+#else
+#define PDBG(a) 0
+#endif
+
+using namespace conv_detail;
+
+namespace {
+
+constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
+
+// TH rows x 32 pixels x NT channels; K-step = TPS taps of one 32-channel chunk
+template <int TAPS, int TH_, int NT_, int TPS_> struct PGeo {
+    static constexpr int TH = TH_, NT = NT_, TPS = TPS_;
+    static constexpr int PAD = (TAPS == 9) ? 1 : 0;
+    static constexpr int PW = PTW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
+    static constexpr int RB = 144;                                  // LDS patch row: 64 B hi + 64 B lo + 16 B pad (9 slots: odd)
+    static constexpr int PATCHB = ROWS * RB;
+    static constexpr int KROWS = TAPS / TPS;                        // K-steps per chunk
+    static constexpr int NB = NT / 32;
+    static constexpr int SB1 = TPS * KGC * NB * 1024;               // bytes of one operand plane of a K-step
+    static constexpr int SBYTES = 2 * SB1;                          // hi plane, then lo plane
+    static constexpr int NBW = NT >= 64 ? 2 : 1;                    // channel blocks per consumer wave
+    static constexpr int WAVES_N = NB / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
+    static constexpr int SCR_LD = NT + 4;                           // epilogue image: floats per pixel
+    static constexpr int G8 = NT / 8;                               // 8-channel groups per pixel
+    static constexpr int NU = TH * PTW * G8 / 512;                  // (pixel, 8 channels) units per thread in the epilogue
+    static constexpr size_t main_bytes(int Cin) { return (size_t)2 * PATCHB + 2 * SBYTES + (size_t)Cin * 8 + (size_t)ROWS * 4 + 16; }
+    static constexpr size_t epi_bytes() { return (size_t)TH * PTW * SCR_LD * 4 + (size_t)4 * 8 * NT * 4; }
+    static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
+    static_assert(MB >= 1 && WAVES_M * MB == TH, "tile rows must divide over the consumer waves");
+    static_assert(NU >= 1, "epilogue units");
+};
+
+// event counts in LDS (see sem_ready / sem_done in the kernel)
+__device__ __forceinline__ void sem_signal(unsigned* sem, int lane) {
+    asm volatile("" ::: "memory");   // the LDS traffic before it is issued before it (the LDS keeps the order)
+    if (lane == 0) __hip_atomic_fetch_add(sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void sem_wait(const unsigned* sem, unsigned need) {
+    while (*(const volatile unsigned*)sem < need) __builtin_amdgcn_s_sleep(1);
+    asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void wg_barrier() {
+    // LDS traffic of this wave done, then the workgroup barrier; vector-memory loads stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int TAPS, int TH_, int NT_, int TPS_>
+__global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
+    static_assert(IS_X3<T>, "conv_pc_kernel: fp16 x 3 operands");
+    using G = PGeo<TAPS, TH_, NT_, TPS_>;
+    constexpr int TH = G::TH, NT = G::NT, TPS = G::TPS, PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, RB = G::RB;
+    constexpr int PATCHB = G::PATCHB, KROWS = G::KROWS, SB1 = G::SB1, SBYTES = G::SBYTES;
+    constexpr int NBW = G::NBW, WAVES_N = G::WAVES_N, MB = G::MB, SCR_LD = G::SCR_LD, G8 = G::G8, NU = G::NU;
+    constexpr int KGE = 16, CC = 32;                    // channels per k-group / per chunk
+    constexpr int NTASK = ROWS * 4;                     // staging tasks per chunk: (patch row, 8 channels)
+    constexpr int NVP0 = (NTASK + 511) / 512;           // tasks per thread when all 512 threads stage (first chunk)
+    constexpr int NVP = (NTASK + 255) / 256;            // tasks per producer thread per chunk
+    constexpr int RPS = (NVP + KROWS - 1) / KROWS;      // of them per K-step
+    constexpr int SVEC = SBYTES / 16, SBV = (SVEC + 255) / 256, SV1 = SB1 / 16;
+    constexpr int NKS = TPS * KGC;                      // MFMA k-steps per K-step
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* patch = smem;                                  // [2][ROWS][RB]
+    char* bst = smem + 2 * PATCHB;                       // [2][SBYTES]
+    float* ss_lds = (float*)(bst + 2 * SBYTES);          // [Cin][2]
+    int* rowoff_lds = (int*)(ss_lds + 2 * a.in.C);       // [ROWS] element offset of the patch row's pixel, -1 outside the image
+    // producer -> consumer and consumer -> producer event counts of the main loop (one increment per wave and K-step).
+    // The LDS executes a CU's requests in order: whoever sees a count sees everything its writer did before it.
+    unsigned* sem_ready = (unsigned*)(rowoff_lds + ROWS);
+    unsigned* sem_done = sem_ready + 1;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int cw = wid & 3;                              // consumer wave index (producers: unused)
+    const int wn = cw % WAVES_N, wm = cw / WAVES_N;
+    const int tiles_x = (a.W + PTW - 1) / PTW;
+    // XCD-aware placement (as conv_lds_kernel): every XCD takes a contiguous range of (image, pixel tile, channel tile)
+    const int ntn = a.Cout / NT, tiles = tiles_x * ((a.H + TH - 1) / TH);
+    int lid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = lid & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (lid >> 3);
+    }
+    const int n_tile = lid % ntn, tileb = lid / ntn, tile = tileb % tiles, b = tileb / tiles;
+    const int ty0 = (tile / tiles_x) * TH, tx0 = (tile % tiles_x) * PTW;
+    const int Cin = a.in.C;
+    const bool use_gn = a.in_st != nullptr;
+    const int NKG = Cin / KGE, NB = a.Cout / 32;
+    const int NCH = Cin / CC;
+    const int S = NCH * KROWS;
+    const float* in_b = (const float*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
+
+    const int crot = (tile * 5 + n_tile * 3) % NCH;
+    auto chunk_of = [&](int ci) -> int { int x = ci + crot; return x >= NCH ? x - NCH : x; };
+
+    auto row_offset = [&](int row) -> int {
+        const int y = ty0 + row / PW - PAD, x = tx0 + row % PW - PAD;
+        const bool ok = (row < ROWS) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
+        return ok ? (y * a.W + x) * a.in.cs : -1;
+    };
+    // one staging task: 8 fp32 channels of one patch row -> GroupNorm + ReLU -> fp16 hi / lo -> LDS
+    auto load_task = [&](u32x4 (&r)[2], int off, int c0, int v) {
+        const u32x4* p = (const u32x4*)(in_b + (off >= 0 ? off : 0) + c0 + v * 8);
+        r[0] = p[0];
+        r[1] = p[1];
+    };
+    auto put_task = [&](const u32x4 (&r)[2], int off, int c0, int row, int v, int pbuf) {
+        float sc[8], sh[8];
+        {   // (scale, shift) pairs of the 8 channels: 64 contiguous bytes
+            const f32x4* q = (const f32x4*)(ss_lds + (c0 + v * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t = q[j];
+                sc[2 * j] = t[0]; sh[2 * j] = t[1]; sc[2 * j + 1] = t[2]; sh[2 * j + 1] = t[3];
+            }
+        }
+        u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+        if (off >= 0) xform_x3(r[0], r[1], sc, sh, use_gn, hi, lo);
+        char* d = patch + pbuf * PATCHB + row * RB + v * 16;
+        *(u32x4*)d = hi;
+        *(u32x4*)(d + 64) = lo;
+    };
+
+    // weight slice of K-step (chunk c, kernel row krow): [plane][t][kg][nb][lane] vectors
+    const u32x4* wbase = (const u32x4*)a.wpk + (size_t)(n_tile * (NT / 32)) * 64;
+    const size_t wkg = (size_t)NB * 64;   // vectors between consecutive k-groups
+    const int ptid = tid & 255;
+    int woff[SBV];
+#pragma unroll
+    for (int j = 0; j < SBV; ++j) {
+        const int i0 = (ptid + j * 256 < SVEC) ? ptid + j * 256 : SVEC - 1;
+        const int i = i0 % SV1;
+        constexpr int PER_KG = (NT / 32) * 64;
+        const int t = i / (KGC * PER_KG), kg = (i / PER_KG) % KGC, r = i % PER_KG;
+        woff[j] = (t * NKG + kg) * (int)wkg + r;
+        if (i0 >= SV1) woff[j] += TAPS * NKG * (int)wkg;   // the lo plane follows the complete hi plane in memory
+    }
+    auto load_w = [&](u32x4 (&rb)[SBV], int s) {
+        const int c = chunk_of(s / KROWS), krow = s % KROWS;
+        const u32x4* wb = wbase + (size_t)(krow * TPS * NKG + c * KGC) * wkg;   // wave-uniform
+#pragma unroll
+        for (int j = 0; j < SBV; ++j) rb[j] = wb[woff[j]];
+    };
+    auto write_w = [&](const u32x4 (&rb)[SBV], int slot) {
+#pragma unroll
+        for (int j = 0; j < SBV; ++j) {
+            const int i = ptid + j * 256;
+            if (i < SVEC) *(u32x4*)(bst + slot * SBYTES + i * 16) = rb[j];
+        }
+    };
+
+    // ---------------- prologue: everybody stages chunk 0; producers fetch the first weights ----------------
+    u32x4 p0[NVP0][2];
+    int off0[NVP0];
+#pragma unroll
+    for (int j = 0; j < NVP0; ++j) {
+        const int i = tid + j * 512;
+        off0[j] = row_offset(i >> 2);
+        load_task(p0[j], off0[j], chunk_of(0) * CC, i & 3);
+    }
+    u32x4 wreg[SBV];
+    if (producer) load_w(wreg, 0);
+    for (int r = tid; r < ROWS; r += 512) rowoff_lds[r] = row_offset(r);
+    if (tid < 2) sem_ready[tid] = 0u;
+    for (int ci = tid; ci < Cin; ci += 512) {
+        float sc = 1.f, sh = 0.f;
+        if (use_gn) gn_scale_shift(a.in_st, a.B, b, Cin, ci, a.H * a.W, a.gamma, a.beta, sc, sh);
+        ss_lds[2 * ci] = sc;
+        ss_lds[2 * ci + 1] = sh;
+    }
+    wg_barrier();
+#pragma unroll
+    for (int j = 0; j < NVP0; ++j) {
+        const int i = tid + j * 512;
+        if (i < NTASK) put_task(p0[j], off0[j], chunk_of(0) * CC, i >> 2, i & 3, 0);
+    }
+
+    // epilogue coordinates (needed early: the residual rows are requested before the main loop ends)
+    constexpr float ASCALE = 1.0f / (float)(1 << X3_WSHIFT);   // undoes the weight scaling of the fp16 x 3 packing
+    const int g8 = tid % G8;
+    const int nv = n_tile * NT + g8 * 8;                        // this thread's 8 channels
+    const size_t img = (size_t)b * a.H * a.W;
+    const float* res_p = a.res.p ? (const float*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    u32x4 rq[NU][2];
+    auto fetch_res = [&]() {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+            const int p = (tid + 512 * j) / G8;
+            const int y = ty0 + p / PTW, x = tx0 + p % PTW;
+            const bool ok = (y < a.H) && (x < a.W);
+            const size_t pix = (size_t)y * a.W + x;
+            const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                rq[j][k] = (res_p && ok) ? *((const u32x4*)(res_p + pix * a.res.cs) + k) : z;
+            }
+        }
+    };
+
+    f32x16 acc[MB][NBW];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int q = 0; q < NBW; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][q][r] = 0.f;
+
+    if (producer) {
+        // =========================== producers ===========================
+        // K-step s stages a part of chunk (s / KROWS + 1): tasks ptid + 256 * (krow * RPS + j), j < RPS.  The loads of a
+        // part -- and of a K-step's weights -- are issued NSET K-steps before they are needed (one register set per K-step
+        // of the window): a K-step is ~1 us of MFMAs and a global round trip under load is 2 us.
+        constexpr int NSET = KROWS > 2 ? KROWS : 2;
+        u32x4 pset[NSET][RPS][2], wset[NSET][SBV];
+        int oset[NSET][RPS];
+        auto load_part = [&](u32x4 (&pr)[RPS][2], int (&po)[RPS], int s) {
+            const int c0 = chunk_of(s / KROWS + 1) * CC, krow = s % KROWS;
+#pragma unroll
+            for (int j = 0; j < RPS; ++j) {
+                const int i = ptid + 256 * (krow * RPS + j);
+                const int row = (i >> 2) < ROWS ? (i >> 2) : ROWS - 1;
+                po[j] = rowoff_lds[row];
+                load_task(pr[j], po[j], c0, i & 3);
+            }
+        };
+        auto put_part = [&](const u32x4 (&pr)[RPS][2], const int (&po)[RPS], int s) {
+            const int cn = s / KROWS + 1, krow = s % KROWS;
+            const int c0 = chunk_of(cn) * CC;
+#pragma unroll
+            for (int j = 0; j < RPS; ++j) {
+                const int i = ptid + 256 * (krow * RPS + j);
+                if (krow * RPS + j < NVP && i < NTASK) put_task(pr[j], po[j], c0, i >> 2, i & 3, cn & 1);
+            }
+        };
+        // steady state without branches around loads (a branch makes the compiler's vmcnt bookkeeping give up and wait for
+        // everything in flight): indices past the end are clamped, the redundant loads are never used
+        auto stage_step = [&](int s, u32x4 (&ps)[RPS][2], int (&po)[RPS], u32x4 (&ws)[SBV]) {
+            sem_wait(sem_done, 4u * s);        // the consumers have left K-step s - 1: its ring slot and the other patch buffer are free
+            if (!(PDBG(a) & 1)) write_w(ws, (s + 1) & 1);
+            if (!(PDBG(a) & 1)) load_w(ws, s + 1 + NSET < S ? s + 1 + NSET : S - 1);
+            if (!(PDBG(a) & 32)) put_part(ps, po, s);
+            sem_signal(sem_ready, lane);       // what K-step s + 1 reads is in LDS (this wave's share)
+            const int sn = s + NSET;
+            if (!(PDBG(a) & 2)) load_part(ps, po, sn / KROWS + 1 < NCH ? sn : (NCH - 2) * KROWS + sn % KROWS);
+        };
+        write_w(wreg, 0);
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) {
+            load_w(wset[u], u + 1 < S ? u + 1 : S - 1);
+            if (NCH > 1) load_part(pset[u], oset[u], u / KROWS + 1 < NCH ? u : u % KROWS);
+        }
+        wg_barrier();   // chunk 0 and K-step 0 are in LDS
+        if constexpr (KROWS > 1) {
+#pragma unroll 1
+            for (int c = 0; c < NCH - 1; ++c) {               // chunks with a successor to stage
+#pragma unroll
+                for (int u = 0; u < KROWS; ++u) stage_step(c * KROWS + u, pset[u], oset[u], wset[u]);
+            }
+        } else {
+            int c = 0;
+#pragma unroll 1
+            for (; c + 1 < NCH - 1; c += 2) {
+                stage_step(c, pset[0], oset[0], wset[0]);
+                stage_step(c + 1, pset[1], oset[1], wset[1]);
+            }
+            if (c < NCH - 1) stage_step(c, pset[0], oset[0], wset[0]);   // c is even here
+        }
+        // last chunk: nothing left to stage; the residual rows are requested now
+        if (NU <= 4) fetch_res();
+#pragma unroll
+        for (int u = 0; u < KROWS; ++u) {
+            const int s = (NCH - 1) * KROWS + u;
+            if (u + 1 < KROWS) {
+                sem_wait(sem_done, 4u * s);
+                write_w(wset[(KROWS > 1) ? u : 0], (s + 1) & 1);
+                sem_signal(sem_ready, lane);
+            }
+        }
+    } else {
+        // =========================== consumers ===========================
+        const int half = lane >> 5, px = lane & 31;
+        const char* a_ptr = patch + ((wm * MB) * PW + px) * RB + 16 * half;
+        const char* b_ptr = bst + (wn * NBW) * 1024 + lane * 16;
+        wg_barrier();   // chunk 0 and K-step 0 are in LDS
+        __builtin_amdgcn_s_setprio(1);   // the matrix pipe first: the producers' arithmetic fills what is left
+        // One flat stream of k-steps (a k-step = one MFMA K of one tap): the fragments of k-step i + 1 are requested before
+        // the MFMAs of k-step i are issued -- also across a K-step boundary, after the producers' count says the next
+        // K-step's operands are in LDS -- so the matrix pipe never waits for an LDS round trip or a rendezvous.
+        u32x4 af[2][MB], afl[2][MB], bf[2][NBW], bfl[2][NBW];
+        // fragment loads in the order the MFMAs want them (small terms first: a_lo b_hi, then a_hi b_lo, a_hi b_hi)
+        auto load_frag = [&](int fs, int s, int ks) {
+            const int krow = s % KROWS, pbuf = (s / KROWS) & 1;
+            const char* bs = b_ptr + (s & 1) * SBYTES;
+            const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 3) ? (krow * PW) * RB : 0);
+            const int t = ks / KGC, kg = ks % KGC;
+            const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
+#pragma unroll
+            for (int q = 0; q < NBW; ++q) bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) afl[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + 64 + kg * 32);
+#pragma unroll
+            for (int m = 0; m < MB; ++m) af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + kg * 32);
+#pragma unroll
+            for (int q = 0; q < NBW; ++q) bfl[fs][q] = *(const u32x4*)(bs + SB1 + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+        };
+        constexpr int NRD = 2 * (MB + NBW), NMF = 3 * MB * NBW;     // LDS reads / MFMAs of one k-step
+        static_assert(NKS % 2 == 0, "fragment double buffer: even k-steps per K-step");
+        auto mfma_step = [&](int s, bool last) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                bool pre = true;
+                if (ks + 1 < NKS) load_frag((ks + 1) & 1, s, ks + 1);
+                else if (!last) {
+                    sem_wait(sem_ready, 4u * (s + 1));
+                    load_frag(0, s + 1, 0);
+                } else pre = false;
+                if (PDBG(a) & 4) continue;
+                // the three terms of a product go to the same accumulator in a fixed order; the accumulators take turns
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NBW; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, afl[ks & 1][m]),
+                                                                           __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NBW; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[ks & 1][m]),
+                                                                           __builtin_bit_cast(f16x8_t, bfl[ks & 1][q]), acc[m][q], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+#pragma unroll
+                    for (int q = 0; q < NBW; ++q)
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[ks & 1][m]),
+                                                                           __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+                // issue order: one MFMA, one read of the next k-step's fragments, ... (the reads ride in the matrix pipe's shadow)
+                if (pre) {
+#pragma unroll
+                    for (int i = 0; i < (NRD < NMF ? NRD : NMF); ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            sem_signal(sem_done, lane);   // every read of K-step s has been issued: its ring slot (and patch buffer) may be refilled
+        };
+        load_frag(0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+        for (int s = 0; s < S - 1; ++s) mfma_step(s, false);
+        if (NU <= 4) fetch_res();                             // in flight during the last MFMA block
+        mfma_step(S - 1, true);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    wg_barrier();   // all fragment reads done: the patch buffers and the ring are dead
+    if (PDBG(a) & 8) return;
+
+    // ---------------- epilogue: accumulators -> LDS image of the tile -> all threads store ----------------
+    float* scr = (float*)smem;                                 // [TH * 32 pixels][SCR_LD]
+    float* red = (float*)smem + TH * PTW * SCR_LD;             // [4 kinds][8 waves][NT]
+    if (!producer) {
+        const int half = lane >> 5, px = lane & 31;
+#pragma unroll
+        for (int q = 0; q < NBW; ++q) {
+            const int ch = (wn * NBW + q) * 32 + px;
+            const float bias = a.bias ? a.bias[n_tile * NT + ch] : 0.f;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    scr[((wm * MB + m) * PTW + mfma32_row(r, half)) * SCR_LD + ch] = acc[m][q][r] * ASCALE + bias;
+        }
+    }
+    if (NU > 4) fetch_res();
+    wg_barrier();
+
+    float* out_p = (float*)a.out.p + img * a.out.cs + a.out.co + nv;
+    float* raw_p = a.raw.p ? (float*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
+    const bool want_stats = (a.st_raw || a.st_out) && !(PDBG(a) & 256);
+    float sr[8], qr[8], so[8], qo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        const int p = (tid + 512 * j) / G8;                    // pixel of the tile
+        const int y = ty0 + p / PTW, x = tx0 + p % PTW;
+        float f[8];
+        {
+            const f32x4 lo = *(const f32x4*)(scr + p * SCR_LD + g8 * 8), hi = *(const f32x4*)(scr + p * SCR_LD + g8 * 8 + 4);
+            f[0] = lo[0]; f[1] = lo[1]; f[2] = lo[2]; f[3] = lo[3]; f[4] = hi[0]; f[5] = hi[1]; f[6] = hi[2]; f[7] = hi[3];
+        }
+        if (y < a.H && x < a.W) {
+            const size_t pix = (size_t)y * a.W + x;
+            if (raw_p) {
+                float g[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = f[e];
+                store8<float>(raw_p + pix * a.raw.cs, g);
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
+                }
+            }
+            if (res_p) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { f[k] += __uint_as_float(rq[j][0][k]); f[4 + k] += __uint_as_float(rq[j][1][k]); }
+            }
+            store8<float>(out_p + pix * a.out.cs, f);
+            if (want_stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { so[e] += f[e]; qo[e] += f[e] * f[e]; }
+            }
+        }
+    }
+
+    if (want_stats) {   // uniform over the grid
+        // lanes with equal (lane % G8) hold the same 8 channels: fixed-order butterfly over the rest
+#pragma unroll
+        for (int o = G8; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sr[e] += __shfl_xor(sr[e], o, 64); qr[e] += __shfl_xor(qr[e], o, 64);
+                so[e] += __shfl_xor(so[e], o, 64); qo[e] += __shfl_xor(qo[e], o, 64);
+            }
+        }
+        if (lane < G8) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[(0 * 8 + wid) * NT + lane * 8 + e] = sr[e];
+                red[(1 * 8 + wid) * NT + lane * 8 + e] = qr[e];
+                red[(2 * 8 + wid) * NT + lane * 8 + e] = so[e];
+                red[(3 * 8 + wid) * NT + lane * 8 + e] = qo[e];
+            }
+        }
+        wg_barrier();
+        if (tid < NT) {
+            float t[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int w = 0; w < 8; ++w) t[k] += red[(k * 8 + w) * NT + tid];
+            const int cg = n_tile * NT + tid;
+            if (PDBG(a) & 16) return;
+            // channels -> GroupNorm groups of the tensor the slice belongs to; the (up to) four sums of a group leave from
+            // different lanes of the group, concurrently (see conv_lds_kernel)
+#if CHORE_CONV_ABLATE
+            if (PDBG(a) & (512 | 4096 | 16384 | 32768)) {   // experiments on how the sums leave the workgroup
+                for (int k = 0; k < 2; ++k) {
+                    GroupStat* st = k ? a.st_out : a.st_raw;
+                    if (!st) continue;
+                    const int gs = (k ? a.st_out_C : a.st_raw_C) / GN_GROUPS, co = k ? a.st_out_co : a.st_raw_co;
+                    const float s1 = group_lane_sum(t[2 * k], gs), s2 = group_lane_sum(t[2 * k + 1], gs);
+                    GroupStat* o = st + (size_t)b * GN_GROUPS + (co + cg) / gs;
+                    const bool l1 = tid % gs == 0, l2 = tid % gs == (gs > 1 ? 1 : 0);
+                    if (PDBG(a) & 512) {             // plain stores
+                        if (l1) { ((float*)o)[0] = s1; ((float*)o)[1] = s2; }
+                    } else if (PDBG(a) & 4096) {     // one 64-bit no-return atomic per sum
+                        if (l1) __hip_atomic_fetch_add((long long*)&o->sum.lo, (long long)((double)s1 * 0x1p20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (l2) __hip_atomic_fetch_add((long long*)&o->sq.lo, (long long)((double)s2 * 0x1p20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {                         // two limbs: 16384 = high limbs in another table (4 KB away), 32768 = low limb only
+                        for (int u = 0; u < 2; ++u) {
+                            if (!(u ? l2 : l1)) continue;
+                            StatCell* c = u ? &o->sq : &o->sum;
+                            const double d = (double)(u ? s2 : s1) * 0x1p40, hh = floor(d * 0x1p-32);
+                            const long long hi = (long long)hh;
+                            const unsigned long long lo = (unsigned long long)(d - hh * 0x1p32);
+                            (void)__hip_atomic_fetch_add(&c->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (PDBG(a) & 16384) (void)__hip_atomic_fetch_add(&c->hi + 2 * a.B * GN_GROUPS * 2, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+                return;
+            }
+#endif
+            if (a.st_raw) {
+                const int gs = a.st_raw_C / GN_GROUPS;
+                const float s1 = group_lane_sum(t[0], gs), s2 = group_lane_sum(t[1], gs);
+                GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
+                if (tid % gs == 0) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells(a.B), s2);
+            }
+            if (a.st_out) {
+                const int gs = a.st_out_C / GN_GROUPS;
+                const float s1 = group_lane_sum(t[2], gs), s2 = group_lane_sum(t[3], gs);
+                GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
+                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, act_hi_cells(a.B), s2);
+            }
+        }
+    }
+}
+
+template <typename T, int TAPS, int TH, int NT, int TPS>
+int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+    using G = PGeo<TAPS, TH, NT, TPS>;
+    const size_t smem = G::smem_bytes(a.in.C);
+    if (smem > 160 * 1024) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS", smem);
+    bool& attr = CHORE_ONCE_FLAG(h);
+    if (!attr) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    const int tiles = ((a.W + PTW - 1) / PTW) * ((a.H + TH - 1) / TH);
+    dim3 grid(tiles * (a.Cout / NT) * a.B);
+    hipLaunchKernelGGL((conv_pc_kernel<T, TAPS, TH, NT, TPS>), grid, dim3(512), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+}  // namespace
+
+// tile configuration of the specialised-wave kernel for a layer: th = 0 -> not covered (the caller uses conv_lds_kernel)
+PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force) {
+    PcPlan p{0, 0, 0};
+    if (dtype != CHORE_F16X3 || Cin % 32 || Cout % 32 || W % 32) return p;
+    if (force) {   // development: th * 1000 + nt (e.g. 8064), tps follows
+        p.th = force / 1000; p.nt = force % 1000;
+        p.tps = taps == 1 ? 1 : ((p.th == 4 && p.nt == 32) ? 9 : 3);
+        return p;
+    }
+    const long px_tiles8 = (long)B * ((H + 7) / 8) * (W / 32);
+    if (taps == 1) {
+        if (Cout % 128 == 0) { p.th = 8; p.nt = 128; p.tps = 1; }
+        else if (Cout % 64 == 0) { p.th = 8; p.nt = 64; p.tps = 1; }
+        return p;
+    }
+    // 3x3: the widest channel tile that still gives every CU a workgroup; 4-row tiles when 8-row tiles leave CUs idle
+    if (Cout % 64 == 0 && px_tiles8 * (Cout / 64) >= 256) { p.th = 8; p.nt = 64; p.tps = 3; }
+    else if (px_tiles8 * (Cout / 32) >= 256) { p.th = 8; p.nt = 32; p.tps = 3; }
+    else if (H % 4 == 0 && Cout % 64 == 0 && px_tiles8 * 2 * (Cout / 64) >= 256) { p.th = 4; p.nt = 64; p.tps = 3; }
+    else if (H % 4 == 0) { p.th = 4; p.nt = 32; p.tps = 9; }
+    else { p.th = 8; p.nt = 32; p.tps = 3; }
+    return p;
+}
+
+int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {
+    if (a.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: a second residual is not supported (conv_lds_kernel has it)");
+    const int key = taps * 100000 + p.th * 10000 + p.nt * 10 + p.tps;
+    switch (key) {
+        case 9 * 100000 + 8 * 10000 + 64 * 10 + 3: return launch_pc_t<x3_t, 9, 8, 64, 3>(h, a, s);
+        case 9 * 100000 + 8 * 10000 + 32 * 10 + 3: return launch_pc_t<x3_t, 9, 8, 32, 3>(h, a, s);
+        case 9 * 100000 + 4 * 10000 + 64 * 10 + 3: return launch_pc_t<x3_t, 9, 4, 64, 3>(h, a, s);
+        case 9 * 100000 + 4 * 10000 + 32 * 10 + 9: return launch_pc_t<x3_t, 9, 4, 32, 9>(h, a, s);
+        case 9 * 100000 + 4 * 10000 + 32 * 10 + 3: return launch_pc_t<x3_t, 9, 4, 32, 3>(h, a, s);
+        case 1 * 100000 + 8 * 10000 + 128 * 10 + 1: return launch_pc_t<x3_t, 1, 8, 128, 1>(h, a, s);
+        case 1 * 100000 + 8 * 10000 + 64 * 10 + 1: return launch_pc_t<x3_t, 1, 8, 64, 1>(h, a, s);
+    }
+    CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: no kernel for taps=%d th=%d nt=%d tps=%d", taps, p.th, p.nt, p.tps);
+}

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     }
     if (use_gn)
         for (int ci = tid; ci < CIN; ci += 256)
-            gn_scale_shift(a.in_st, b, CIN, ci, a.H * a.W, a.gamma, a.beta, ss[2 * ci], ss[2 * ci + 1]);
+            gn_scale_shift(a.in_st, a.B, b, CIN, ci, a.H * a.W, a.gamma, a.beta, ss[2 * ci], ss[2 * ci + 1]);
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NSLOT; ++j) {
@@ -304,15 +304,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
                 const float s1 = group_lane_sum(tsum[0], gs), s2 = group_lane_sum(tsum[1], gs);
                 // the group's sums go out from different lanes of the group, concurrently (conv_lds.hip, same place)
                 GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + ch) / gs;
-                if (tid % gs == 0) stat_add(&o->sum, s1);
-                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, s2);
+                if (tid % gs == 0) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells(a.B), s2);
             }
             if (a.st_out) {
                 const int gs = a.st_out_C / GN_GROUPS;
                 const float s1 = group_lane_sum(tsum[2], gs), s2 = group_lane_sum(tsum[3], gs);
                 GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + ch) / gs;
-                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, s1);
-                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, s2);
+                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, act_hi_cells(a.B), s2);
             }
         }
     }

@@ -27,7 +27,7 @@ bool make_dims(Dims& d, int dtype, int B, int H, int W, int Cin, int Cout) {
     if ((dtype != CHORE_F32 && dtype != CHORE_BF16) || B <= 0 || H <= 0 || W <= 0) return false;
     if (Cout % 128 || Cin % 32 || Cin > 256 || Cout > 256) return false;      // slices of Cout/4 channels, whole groups
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.C1 = Cout / 2; d.C2 = Cout / 4;
-    d.px = (size_t)B * H * W; d.es = dtype == CHORE_F32 ? 4 : 2; d.nb = (size_t)B * GN_GROUPS * sizeof(GroupStat);
+    d.px = (size_t)B * H * W; d.es = dtype == CHORE_F32 ? 4 : 2; d.nb = act_stats_bytes(B);
     d.down = Cin != Cout;
     return true;
 }
@@ -71,7 +71,7 @@ int side_stream(chore_handle* h) {
 
 View mkview(const void* p, int cs, int co, int C) { View v; v.p = const_cast<void*>(p); v.cs = cs; v.co = co; v.C = C; return v; }
 
-size_t gn_acc_bytes(int B, int C) { return ((size_t)B * GN_GROUPS + C) * sizeof(GroupStat); }
+size_t gn_acc_bytes(int B, int C) { return chore_gn_relu_bwd_workspace_bytes(B, C); }   // two tables of cells (enc_common.h)
 
 }  // namespace
 
@@ -83,7 +83,7 @@ size_t chore_convblock_saved_bytes(int dtype, int B, int H, int W, int Cin, int 
     return saved_layout(d, nullptr).bytes;
 }
 // byte offset of the statistics of y inside `saved` (chore_gn_stats_bytes(B) of them): what the NEXT block's x_stats wants
-size_t chore_convblock_out_stats_offset(int B) { return 3 * (size_t)B * GN_GROUPS * sizeof(GroupStat); }
+size_t chore_convblock_out_stats_offset(int B) { return 3 * act_stats_bytes(B); }
 
 size_t chore_convblock_workspace_bytes(int dtype, int B, int H, int W, int Cin, int Cout) {
     Dims d;

@@ -33,7 +33,7 @@ constexpr int GN_GROUPS = 32;
 constexpr int GN_SPLITS_MAX = 64;
 
 // ---- exact, order-independent GroupNorm statistics -------------------------------------------------
-// Every producer adds its partial sums per (image, GroupNorm group) into a 128-bit fixed-point accumulator
+// Every producer adds its partial sums per (image, GroupNorm group) into a two-limb fixed-point accumulator
 // (unit 2^-40) with 64-bit integer atomics.  (Per group, not per channel: device-scope atomics execute at the
 // memory side and their COUNT is what a producer kernel pays for -- a per-channel version spent 10-30 % of
 // every producer on them.)  Integer addition is associative, so the totals -- and everything
@@ -42,40 +42,44 @@ constexpr int GN_SPLITS_MAX = 64;
 // totals into the per-(image,channel) affine  relu(x*scale+shift)  in its own prologue.
 struct StatCell { unsigned long long lo; long long hi; };
 struct GroupStat { StatCell sum, sq; };   // per (image, group): sum and sum of squares of the stored values
-
-__device__ __forceinline__ void stat_add(StatCell* c, float x) {
+// value = (hi * 2^32 + lo) * 2^-40 with lo a sum of 32-bit pieces: no carry between the limbs, so an add is two
+// NO-RETURN atomics and the wave does not wait for a round trip to the memory side.  (The first version kept a proper
+// 128-bit integer: its low add had to return the old value for the carry and every producer kernel ended with ~5 us of
+// waiting for those returns.)  lo cannot overflow before 2^32 adds.
+// The two limbs of a cell must NOT sit next to each other: two atomics from one lane into the same 16 bytes queue behind
+// each other at the memory side (measured: + 9 us on a 47 us convolution, profiles/r03_conv_phase_breakdown.txt).  Every
+// accumulator array of n cells is therefore allocated as TWO tables of n cells, the low limbs are added into table 0 and
+// the high limbs into the same cell of table 1, `hi_cells` (>= n, a multiple of 256 cells = 4 KB where it matters) later.
+__device__ __forceinline__ void stat_add(StatCell* c, size_t hi_cells, float x) {
     const double d = (double)x * 0x1p40;             // exact (power-of-two scaling)
-    const double h = floor(d * 0x1p-64);             // exact split of the <= 53 significant bits
+    const double h = floor(d * 0x1p-32);             // exact split of the <= 53 significant bits
     const long long hi = (long long)h;
-    const unsigned long long lo = (unsigned long long)(d - h * 0x1p64);
-    const unsigned long long old = atomicAdd(&c->lo, lo);
-    const long long carry = (old + lo < old) ? 1 : 0;
-    if (hi + carry != 0) atomicAdd((unsigned long long*)&c->hi, (unsigned long long)(hi + carry));
+    const unsigned long long lo = (unsigned long long)(d - h * 0x1p32);   // in [0, 2^32)
+    (void)__hip_atomic_fetch_add(&c->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (hi != 0) (void)__hip_atomic_fetch_add(&c[hi_cells].hi, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double stat_read(const StatCell& c) {
-    unsigned long long lo = c.lo;
-    long long hi = c.hi;
-    const bool neg = hi < 0;
-    if (neg) {   // two's-complement negate so that small negative totals keep their low bits
-        lo = ~lo + 1ull;
-        hi = ~hi + (lo == 0ull ? 1 : 0);
-    }
-    const double v = ((double)hi * 0x1p64 + (double)lo) * 0x1p-40;
-    return neg ? -v : v;
+__device__ __forceinline__ double stat_read(const StatCell* c, size_t hi_cells) {
+    const unsigned long long lo = c->lo;
+    const long long top = c[hi_cells].hi + (long long)(lo >> 32);
+    return ((double)top * 0x1p32 + (double)(lo & 0xffffffffull)) * 0x1p-40;
 }
+// statistics of an activation tensor: [2 tables][B][32] GroupStat
+inline size_t act_stats_bytes(int B) { return (size_t)2 * B * GN_GROUPS * sizeof(GroupStat); }
+__host__ __device__ inline size_t act_hi_cells(int B) { return (size_t)B * GN_GROUPS * 2; }
 // sum over the gs (power of two <= 8) consecutive channels of a group held by gs consecutive lanes: fixed tree
 __device__ __forceinline__ float group_lane_sum(float v, int gs) {
     for (int o = 1; o < gs; o <<= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
 // scale/shift of channel c of image b: GroupNorm(32 groups, eps 1e-5, biased variance) folded to an affine
-__device__ __forceinline__ void gn_scale_shift(const GroupStat* st, int b, int C, int c, int HW,
+__device__ __forceinline__ void gn_scale_shift(const GroupStat* st, int B, int b, int C, int c, int HW,
                                                const float* gamma, const float* beta, float& scale, float& shift) {
     const int gs = C / GN_GROUPS;
-    const GroupStat s = st[(size_t)b * GN_GROUPS + c / gs];
+    const GroupStat* g = st + (size_t)b * GN_GROUPS + c / gs;
+    const double ssum = stat_read(&g->sum, act_hi_cells(B)), ssq = stat_read(&g->sq, act_hi_cells(B));
     const double n = (double)HW * gs;
-    const double mean = stat_read(s.sum) / n;
-    double var = stat_read(s.sq) / n - mean * mean;
+    const double mean = ssum / n;
+    double var = ssq / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
     scale = rstd * gamma[c];
@@ -135,6 +139,13 @@ struct ConvPlan { int nt, th, ntiles, tps, small_cin; };   // N tile, tile heigh
 bool conv_small_eligible(int dtype, int taps, int H, int W, int Cin, int Cout);
 int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s);
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // tile configuration launch_conv will use
+
+// specialised-wave convolution (conv_pc.hip, fp16 x 3 operands): th rows x 32 pixels x nt channels per workgroup, tps taps per
+// K-step; th = 0: the layer is not covered and launch_conv uses conv_lds_kernel
+struct PcPlan { int th, nt, tps; };
+PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
+int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
+bool conv_use_pc();
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);

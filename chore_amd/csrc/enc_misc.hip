@@ -170,8 +170,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
         a = group_lane_sum(a, gs);
         q = group_lane_sum(q, gs);
         GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
-        if (tid % gs == 0) stat_add(&o->sum, a);
-        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, q);
+        if (tid % gs == 0) stat_add(&o->sum, act_hi_cells((int)gridDim.y), a);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells((int)gridDim.y), q);
     }
 }
 
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict_
                                                             int ycs, int yco, int C, int HW) {
     __shared__ float ss[512];
     const int b = blockIdx.y, tid = threadIdx.x;
-    if (tid < C) gn_scale_shift(st, b, C, tid, HW, gamma, beta, ss[2 * tid], ss[2 * tid + 1]);
+    if (tid < C) gn_scale_shift(st, (int)gridDim.y, b, C, tid, HW, gamma, beta, ss[2 * tid], ss[2 * tid + 1]);
     __syncthreads();
     const int tpr = C / 4;
     const size_t total4 = (size_t)HW * tpr;
@@ -400,8 +400,8 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
         a = group_lane_sum(a, gs);
         q = group_lane_sum(q, gs);
         GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
-        if (tid % gs == 0) stat_add(&o->sum, a);
-        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, q);
+        if (tid % gs == 0) stat_add(&o->sum, act_hi_cells((int)gridDim.y), a);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells((int)gridDim.y), q);
     }
 }
 

@@ -174,19 +174,34 @@ struct RunCtx {
 
 // one class per kernel instantiation, named like the kernel in a rocprofv3 trace so that bench.py's live
 // hipEvent numbers can be checked against profiles/*_kernel_stats.csv line by line
-enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_NUM = K_CONV_FIRST + 11 };
+enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_PC_FIRST = K_CONV_FIRST + 11, K_NUM = K_PC_FIRST + 7 };
 const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "map_stats_kernel<T,C,PoolOp>",
                                          "map_stats_kernel<T,C,UpAddOp>", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
                                          "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
                                          "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
                                          "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>", "conv_small_kernel<T,64,ROWS>",
-                                         "conv_small_kernel<T,128,ROWS>", "conv_small_kernel<T,256,ROWS>"};
+                                         "conv_small_kernel<T,128,ROWS>", "conv_small_kernel<T,256,ROWS>",
+                                         "conv_pc_kernel<T,9,8,64,3>", "conv_pc_kernel<T,9,8,32,3>", "conv_pc_kernel<T,9,4,64,3>",
+                                         "conv_pc_kernel<T,9,4,32,9>", "conv_pc_kernel<T,9,4,32,3>", "conv_pc_kernel<T,1,8,128,1>",
+                                         "conv_pc_kernel<T,1,8,64,1>"};
 inline int conv_class(const ConvPlan& p, int taps) {
     if (p.tps == 0) return K_CONV_FIRST + 8 + (p.small_cin == 64 ? 0 : (p.small_cin == 128 ? 1 : 2));
     const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
     if (taps == 1) return K_CONV_FIRST + 5 + ni;
     if (p.tps == 9) return K_CONV_FIRST + 3 + (ni - 1);
     return K_CONV_FIRST + ni;
+}
+// class of the kernel launch_conv will pick for a layer (the specialised-wave kernel where it covers the layer)
+inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+    if (dtype == CHORE_F16X3 && conv_use_pc() && !conv_small_eligible(dtype, taps, H, W, Cin, Cout)) {
+        const PcPlan pp = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
+        if (pp.th) {
+            if (taps == 1) return K_PC_FIRST + (pp.nt == 128 ? 5 : 6);
+            if (pp.th == 8) return K_PC_FIRST + (pp.nt == 64 ? 0 : 1);
+            return K_PC_FIRST + (pp.nt == 64 ? 2 : (pp.tps == 9 ? 3 : 4));
+        }
+    }
+    return conv_class(conv_plan(dtype, taps, B, H, W, Cin, Cout), taps);
 }
 
 enum StepKind { S_KERNEL = 0, S_RECORD, S_WAIT, S_MEMSET };
@@ -260,7 +275,7 @@ struct Builder {
     void new_stats(Buf& b) {
         b.st_valid = true;
         b.st_off = stat_top;
-        stat_top += align_up((size_t)B * GN_GROUPS * sizeof(GroupStat), 256);
+        stat_top += align_up(act_stats_bytes(B), 256);
     }
 
     static void* ptr(RunCtx& r, const Buf& b) {
@@ -346,7 +361,7 @@ struct Builder {
                     " cout=" + std::to_string(c.cout) + " HxW=" + std::to_string(c.in.H) + "x" + std::to_string(c.in.W);
         {
             const double px = (double)B * c.in.H * c.in.W;
-            cur_class = conv_class(conv_plan(dtype, c.taps, B, c.in.H, c.in.W, c.in_C, c.cout), c.taps);
+            cur_class = conv_class_of(dtype, c.taps, B, c.in.H, c.in.W, c.in_C, c.cout);
             cur_flops = 2.0 * c.taps * c.in_C * c.cout * px;
             cur_bytes = px * es() * (c.in_C + c.cout * (1 + (c.has_raw ? 1 : 0) + (c.has_res ? 1 : 0) + (c.has_res2 ? 1 : 0)));
         }

@@ -15,7 +15,7 @@ size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout) {
     return packed_conv_bytes(dtype, taps, Cin, Cout);
 }
 
-size_t chore_gn_stats_bytes(int B) { return (size_t)B * GN_GROUPS * sizeof(GroupStat); }
+size_t chore_gn_stats_bytes(int B) { return act_stats_bytes(B); }
 
 // statistics of x (B,HW,C) for GroupNorm(32, C): stats is zeroed and filled
 // (zeroed != 0: the caller hands in zeroed accumulators, e.g. a slice of an arena cleared once per pass)

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
         __syncthreads();                                  // previous tile fully consumed
         if (use_gn && b != cur_b) {
-            if (tid < CT32) gn_scale_shift(a.st, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            if (tid < CT32) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
             __syncthreads();
         }
         cur_b = b;
@@ -148,7 +148,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
                 const unsigned a0 = (unsigned)(size_t)(img + (row0 + 8 * h + rsel) * CT32 + csel);
                 asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:256" : "=v"(hi) : "v"(a0));   // +4 rows x 64 B
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // the wait carries the two results as operands: an MFMA that uses them cannot be scheduled above it (a bare
+                // "memory" clobber does not order a register-only MFMA -- it read the destination before the data arrived)
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi) : : "memory");
                 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
                 const u64x2 v = {lo, hi};
                 return __builtin_bit_cast(tb_bf16x8, v);
@@ -249,7 +251,7 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
         const int ty0 = (tt / tiles_x) * TH, tx0 = (tt % tiles_x) * TW;
         __syncthreads();                                   // previous tile fully consumed
         if (use_gn && b != cur_b) {
-            if (tid < 64) gn_scale_shift(a.st, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            if (tid < 64) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
             __syncthreads();
         }
         cur_b = b;
@@ -458,9 +460,13 @@ __global__ void stem_wgrad_finish_kernel(const float* __restrict__ part, int S, 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm + ReLU backward
 // ------------------------------------------------------------------------------------------------
+// accumulator cells of a GroupNorm backward ((B*32 + C) GroupStat = two cells each), rounded up to 4 KB: where the table
+// of the high limbs starts
+static inline size_t gn_bwd_hi_cells(int B, int C) { return (((size_t)B * GN_GROUPS + C) * 2 + 255) / 256 * 256; }
 struct GnBwdAcc {                 // exact accumulators, zeroed by the caller
     GroupStat* grp;               // [B][32]: sum = S1 = sum(g*gamma), sq = S2 = sum(g*gamma*xhat)
     GroupStat* chan;              // [C]:     sum = dbeta, sq = dgamma
+    size_t hc;                    // cells between a low limb and its high limb (the second table, enc_common.h)
 };
 
 template <typename T>
@@ -473,10 +479,11 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     const int b = blockIdx.y, s = blockIdx.x, tid = threadIdx.x;
     const int gs = C / GN_GROUPS;
     if (tid < C) {
-        const GroupStat g = st[(size_t)b * GN_GROUPS + tid / gs];
+        const GroupStat* gst = st + (size_t)b * GN_GROUPS + tid / gs;
+        const double ssum = stat_read(&gst->sum, act_hi_cells((int)gridDim.y)), ssq = stat_read(&gst->sq, act_hi_cells((int)gridDim.y));
         const double n = (double)HW * gs;
-        const double mean = stat_read(g.sum) / n;
-        double var = stat_read(g.sq) / n - mean * mean;
+        const double mean = ssum / n;
+        double var = ssq / n - mean * mean;
         if (var < 0.0) var = 0.0;
         const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
         const float scale = rstd * gamma[tid];
@@ -537,12 +544,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
         for (int i = 0; i < P; ++i)
 #pragma unroll
             for (int k = 0; k < 4; ++k) t[k] += red[k][i * C + tid];
-        stat_add(&acc.chan[tid].sum, t[0]);
-        stat_add(&acc.chan[tid].sq, t[1]);
+        stat_add(&acc.chan[tid].sum, acc.hc, t[0]);
+        stat_add(&acc.chan[tid].sq, acc.hc, t[1]);
         const float g1 = group_lane_sum(t[2], gs), g2 = group_lane_sum(t[3], gs);
         GroupStat* o = acc.grp + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
-        if (tid % gs == 0) stat_add(&o->sum, g1);
-        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, g2);
+        if (tid % gs == 0) stat_add(&o->sum, acc.hc, g1);
+        if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, acc.hc, g2);
     }
 }
 
@@ -557,24 +564,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const int gs = C / GN_GROUPS;
     if (tid < C) {
         const int gi = tid / gs;
-        const GroupStat g = st[(size_t)b * GN_GROUPS + gi];
+        const GroupStat* gst = st + (size_t)b * GN_GROUPS + gi;
+        const double ssum = stat_read(&gst->sum, act_hi_cells((int)gridDim.y)), ssq = stat_read(&gst->sq, act_hi_cells((int)gridDim.y));
         const double n = (double)HW * gs;
-        const double mean = stat_read(g.sum) / n;
-        double var = stat_read(g.sq) / n - mean * mean;
+        const double mean = ssum / n;
+        double var = ssq / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        const GroupStat ga = acc.grp[(size_t)b * GN_GROUPS + gi];
+        const GroupStat* ga = acc.grp + (size_t)b * GN_GROUPS + gi;
         const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
         const float scale = rstd * gamma[tid];
         pc[7 * tid] = (float)mean;
         pc[7 * tid + 1] = rstd;
         pc[7 * tid + 2] = gamma[tid];
-        pc[7 * tid + 3] = (float)(stat_read(ga.sum) / n);
-        pc[7 * tid + 4] = (float)(stat_read(ga.sq) / n);
+        pc[7 * tid + 3] = (float)(stat_read(&ga->sum, acc.hc) / n);
+        pc[7 * tid + 4] = (float)(stat_read(&ga->sq, acc.hc) / n);
         pc[7 * tid + 5] = scale;
         pc[7 * tid + 6] = beta[tid] - (float)mean * scale;
         if (blockIdx.x == 0 && b == 0) {     // the parameter gradients: totals over the whole batch
-            dbeta[tid] = (float)stat_read(acc.chan[tid].sum);
-            dgamma[tid] = (float)stat_read(acc.chan[tid].sq);
+            dbeta[tid] = (float)stat_read(&acc.chan[tid].sum, acc.hc);
+            dgamma[tid] = (float)stat_read(&acc.chan[tid].sq, acc.hc);
         }
     }
     __syncthreads();
@@ -641,6 +649,7 @@ int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stat
     GnBwdAcc acc;
     acc.grp = (GroupStat*)workspace;
     acc.chan = acc.grp + (size_t)B * GN_GROUPS;
+    acc.hc = gn_bwd_hi_cells(B, C);
     int S = HW / 128;          // pixels per share: 128 measured a little faster than 64 / 256 on the training step
     if (S < 1) S = 1;
     if (S > GN_SPLITS_MAX) S = GN_SPLITS_MAX;
@@ -811,7 +820,7 @@ int chore_stem_bwd_weight(chore_handle* h, int dtype, const float* images, int B
     return CHORE_OK;
 }
 
-size_t chore_gn_relu_bwd_workspace_bytes(int B, int C) { return ((size_t)B * GN_GROUPS + C) * sizeof(GroupStat); }
+size_t chore_gn_relu_bwd_workspace_bytes(int B, int C) { return (gn_bwd_hi_cells(B, C) + ((size_t)B * GN_GROUPS + C) * 2) * sizeof(StatCell); }
 
 // da = gradient w.r.t. relu(groupnorm(x)) -> dx, dgamma (C), dbeta (C)
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,

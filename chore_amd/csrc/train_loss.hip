@@ -18,6 +18,8 @@
 
 namespace {
 
+constexpr size_t LOSS_HI_CELLS = 16;   // cells between a low limb and its high limb (two tables, enc_common.h)
+
 struct LossArgs {
     const float *df, *pca, *parts, *centers;                       // predictions (B,2,N) (B,9,N) (B,14,N) (B,6,N)
     const float *df_h, *df_o, *pca_gt, *body_center, *obj_center;   // (B,N) (B,N) (B,9,N) (B,3) (B,3,N)
@@ -26,7 +28,7 @@ struct LossArgs {
     int B, N;
     float max_dist, scale;
     float w[6];
-    StatCell* acc;                                                  // [6], zeroed
+    StatCell* acc;                                                  // [6] low limbs, the high limbs LOSS_HI_CELLS cells later; zeroed
     float* losses;                                                  // [6] h, o, parts, pca, smpl, obj (scaled), then [6] = their sum
     int accumulate;
 };
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void train_loss_kernel(LossArgs a) {
     __syncthreads();
     if (threadIdx.x < 6) {
         const int k = threadIdx.x;
-        stat_add(&a.acc[k], ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k]);
+        stat_add(&a.acc[k], LOSS_HI_CELLS, ((red[0][k] + red[1][k]) + red[2][k]) + red[3][k]);
     }
 }
 
@@ -120,7 +122,7 @@ __global__ void train_loss_finish_kernel(LossArgs a) {
     const double norm[6] = {a.w[0] / B, a.w[1] / B, a.w[2] / B, a.w[3] / (9.0 * B * N), a.w[5] / (3.0 * B * N), a.w[4] / (3.0 * B * N)};
     float total = 0.f;
     for (int k = 0; k < 6; ++k) {
-        const float v = (float)(stat_read(a.acc[k]) * norm[k]) * a.scale;
+        const float v = (float)(stat_read(&a.acc[k], LOSS_HI_CELLS) * norm[k]) * a.scale;
         a.losses[k] = a.accumulate ? a.losses[k] + v : v;
         total += v;
     }
@@ -131,7 +133,7 @@ __global__ void train_loss_finish_kernel(LossArgs a) {
 
 extern "C" {
 
-size_t chore_train_loss_workspace_bytes(void) { return 256; }
+size_t chore_train_loss_workspace_bytes(void) { return (LOSS_HI_CELLS + 6) * sizeof(StatCell) + 160; }
 
 // losses (device, 7 floats): the six terms in the reference's order h, o, parts, pca, smpl, obj and their sum, all times
 // `scale` (1 / number of stacks); accumulate != 0 adds to what is there (the stacks of one step).  g_*: gradients of
@@ -156,7 +158,7 @@ int chore_train_loss(chore_handle* h, const float* df, const float* pca, const f
     a.B = B; a.N = N; a.max_dist = max_dist; a.scale = scale;
     for (int k = 0; k < 6; ++k) a.w[k] = weights[k];
     a.acc = (StatCell*)workspace; a.losses = losses; a.accumulate = accumulate;
-    CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, 6 * sizeof(StatCell), s));
+    CHORE_HIP_CHECK(h, hipMemsetAsync(workspace, 0, (LOSS_HI_CELLS + 6) * sizeof(StatCell), s));
     hipLaunchKernelGGL(train_loss_kernel, dim3((N + 255) / 256, B), dim3(256), 0, s, a);
     hipLaunchKernelGGL(train_loss_finish_kernel, dim3(1), dim3(64), 0, s, a);
     CHORE_LAUNCH_CHECK(h, s);

@@ -225,12 +225,12 @@ def test_conv_block_operator(dtype, cin, cout, shape):
                 continue
             assert p.grad is not None, (i, n)
             check(p.grad, ref[n].grad, dtype, f"block{i}.{n}")
-    # the statistics handed on are those of a fresh statistics pass over y1 (128-bit fixed-point sums of per-workgroup
-    # fp32 partials in both: equal up to the grouping of those partials)
+    # the statistics handed on are those of a fresh statistics pass over y1 (two-limb fixed-point sums of per-workgroup
+    # fp32 partials in both: equal up to the grouping of those partials).  Layout (csrc/enc_common.h): two tables of
+    # 16-byte cells, value = (table1.hi * 2^32 + table0.lo) * 2^-40
     def decode(t):
-        w = t.cpu().numpy().view(np.uint64).astype(np.float64).reshape(-1, 2)
-        v = w[:, 0] + w[:, 1] * 2.0 ** 64
-        return np.where(w[:, 1] >= 2.0 ** 63, v - 2.0 ** 128, v)
+        w = t.cpu().numpy().view(np.uint64).reshape(2, -1, 2)
+        return w[0, :, 0].astype(np.float64) + w[1, :, 1].view(np.int64).astype(np.float64) * 2.0 ** 32
     a, b = decode(s1), decode(ops.gn_stats(y1.detach())[:s1.numel()])
     assert np.abs(a - b).max() <= 1e-6 * np.abs(b).max()
 
