@@ -34,8 +34,8 @@ namespace {
 constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
 
 // TH rows x 32 pixels x NT channels; K-step = TPS taps of one 32-channel chunk
-template <int TAPS, int TH_, int NT_, int TPS_> struct PGeo {
-    static constexpr int TH = TH_, NT = NT_, TPS = TPS_;
+template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_> struct PGeo {
+    static constexpr int TH = TH_, NT = NT_, TPS = TPS_, NSLOT = NSLOT_;   // NSLOT: K-steps of weights resident in the LDS ring
     static constexpr int PAD = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = PTW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
     static constexpr int RB = 144;                                  // LDS patch row: 64 B hi + 64 B lo + 16 B pad (9 slots: odd)
@@ -49,22 +49,28 @@ template <int TAPS, int TH_, int NT_, int TPS_> struct PGeo {
     static constexpr int SCR_LD = NT + 4;                           // epilogue image: floats per pixel
     static constexpr int G8 = NT / 8;                               // 8-channel groups per pixel
     static constexpr int NU = TH * PTW * G8 / 512;                  // (pixel, 8 channels) units per thread in the epilogue
-    static constexpr size_t main_bytes(int Cin) { return (size_t)2 * PATCHB + 2 * SBYTES + (size_t)Cin * 8 + (size_t)ROWS * 4 + 16; }
-    static constexpr size_t epi_bytes() { return (size_t)TH * PTW * SCR_LD * 4 + (size_t)4 * 8 * NT * 4; }
+    static constexpr size_t main_bytes(int Cin) { return (size_t)2 * PATCHB + (size_t)NSLOT * SBYTES + (size_t)Cin * 8 + (size_t)ROWS * 4 + 48; }
+    // epilogue: the tile image, then (over it) the statistics partials [512 / G8][4 NT] + [512 / (4 NT)][4 NT] floats
+    static constexpr size_t epi_bytes() {
+        return (size_t)TH * PTW * SCR_LD * 4 > (size_t)(512 * 32 + 512) * 4 ? (size_t)TH * PTW * SCR_LD * 4 : (size_t)(512 * 32 + 512) * 4;
+    }
     static size_t smem_bytes(int Cin) { return main_bytes(Cin) > epi_bytes() ? main_bytes(Cin) : epi_bytes(); }
     static_assert(MB >= 1 && WAVES_M * MB == TH, "tile rows must divide over the consumer waves");
     static_assert(NU >= 1, "epilogue units");
 };
 
-// event counts in LDS (see sem_ready / sem_done in the kernel)
-__device__ __forceinline__ void sem_signal(unsigned* sem, int lane) {
+// Progress counts in LDS (sem_ready / sem_done in the kernel): one word per wave of a role = the number of K-steps that
+// wave has finished; a waiter needs the MINIMUM over the four waves (with a ring deeper than two slots the waves of a role
+// drift apart by several K-steps: a sum would let a fast wave vouch for a slow one).
+__device__ __forceinline__ void sem_signal(unsigned* sem, int wave, unsigned count, int lane) {
     asm volatile("" ::: "memory");   // the LDS traffic before it is issued before it (the LDS keeps the order)
-    if (lane == 0) __hip_atomic_fetch_add(sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) *(volatile unsigned*)(sem + wave) = count;
     asm volatile("" ::: "memory");
 }
-__device__ __forceinline__ void sem_wait(const unsigned* sem, unsigned need) {
-    while (*(const volatile unsigned*)sem < need) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
+__device__ __forceinline__ unsigned sem_min(const unsigned* sem) {
+    const u32x4 v = *(const volatile u32x4*)sem;
+    const unsigned a = v[0] < v[1] ? v[0] : v[1], b = v[2] < v[3] ? v[2] : v[3];
+    return a < b ? a : b;
 }
 
 __device__ __forceinline__ void wg_barrier() {
@@ -75,10 +81,11 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int TAPS, int TH_, int NT_, int TPS_>
+template <typename T, int TAPS, int TH_, int NT_, int TPS_, int NSLOT_>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     static_assert(IS_X3<T>, "conv_pc_kernel: fp16 x 3 operands");
-    using G = PGeo<TAPS, TH_, NT_, TPS_>;
+    using G = PGeo<TAPS, TH_, NT_, TPS_, NSLOT_>;
+    constexpr int NSLOT = G::NSLOT;
     constexpr int TH = G::TH, NT = G::NT, TPS = G::TPS, PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, RB = G::RB;
     constexpr int PATCHB = G::PATCHB, KROWS = G::KROWS, SB1 = G::SB1, SBYTES = G::SBYTES;
     constexpr int NBW = G::NBW, WAVES_N = G::WAVES_N, MB = G::MB, SCR_LD = G::SCR_LD, G8 = G::G8, NU = G::NU;
@@ -86,22 +93,36 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     constexpr int NTASK = ROWS * 4;                     // staging tasks per chunk: (patch row, 8 channels)
     constexpr int NVP0 = (NTASK + 511) / 512;           // tasks per thread when all 512 threads stage (first chunk)
     constexpr int NVP = (NTASK + 255) / 256;            // tasks per producer thread per chunk
-    constexpr int RPS = (NVP + KROWS - 1) / KROWS;      // of them per K-step
+    // ... per K-step: the last K-step of a chunk stages nothing, so that a chunk's patch is complete one K-step early
+    constexpr int RPS = KROWS > 1 ? (NVP + KROWS - 2) / (KROWS - 1) : NVP;
+    constexpr int LASTK = (NVP - 1) / RPS;              // last K-step of a chunk with staging work
     constexpr int SVEC = SBYTES / 16, SBV = (SVEC + 255) / 256, SV1 = SB1 / 16;
     constexpr int NKS = TPS * KGC;                      // MFMA k-steps per K-step
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* patch = smem;                                  // [2][ROWS][RB]
-    char* bst = smem + 2 * PATCHB;                       // [2][SBYTES]
-    float* ss_lds = (float*)(bst + 2 * SBYTES);          // [Cin][2]
+    char* bst = smem + 2 * PATCHB;                       // [NSLOT][SBYTES]
+    float* ss_lds = (float*)(bst + NSLOT * SBYTES);      // [Cin][2]
     int* rowoff_lds = (int*)(ss_lds + 2 * a.in.C);       // [ROWS] element offset of the patch row's pixel, -1 outside the image
     // producer -> consumer and consumer -> producer event counts of the main loop (one increment per wave and K-step).
     // The LDS executes a CU's requests in order: whoever sees a count sees everything its writer did before it.
-    unsigned* sem_ready = (unsigned*)(rowoff_lds + ROWS);
-    unsigned* sem_done = sem_ready + 1;
+    unsigned* sem_ready = (unsigned*)(((size_t)(rowoff_lds + ROWS) + 15) & ~(size_t)15);   // [4] producer waves
+    unsigned* sem_done = sem_ready + 4;                                                     // [4] consumer waves
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if CHORE_CONV_ABLATE
+    // phase stamps of one consumer and one producer wave of the workgroup in the middle of the grid: shader clock and 100 MHz wall clock
+    auto stamp = [&](int i) {
+        if (a.dbg_ticks && blockIdx.x == gridDim.x / 2 && (tid == 0 || tid == 256)) {
+            a.dbg_ticks[(tid ? 16 : 0) + 2 * i] = __builtin_readcyclecounter();
+            a.dbg_ticks[(tid ? 16 : 0) + 2 * i + 1] = wall_clock64();
+        }
+    };
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(0);
     const bool producer = wid >= 4;
     const int cw = wid & 3;                              // consumer wave index (producers: unused)
     const int wn = cw % WAVES_N, wm = cw / WAVES_N;
@@ -190,10 +211,15 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         off0[j] = row_offset(i >> 2);
         load_task(p0[j], off0[j], chunk_of(0) * CC, i & 3);
     }
-    u32x4 wreg[SBV];
-    if (producer) load_w(wreg, 0);
+    // the ring starts with K-steps 0 .. NSLOT - 2
+    constexpr int NPRO = NSLOT - 1;
+    u32x4 wpro[NPRO][SBV];
+    if (producer) {
+#pragma unroll
+        for (int u = 0; u < NPRO; ++u) load_w(wpro[u], u < S ? u : S - 1);
+    }
     for (int r = tid; r < ROWS; r += 512) rowoff_lds[r] = row_offset(r);
-    if (tid < 2) sem_ready[tid] = 0u;
+    if (tid < 8) sem_ready[tid] = 0u;
     for (int ci = tid; ci < Cin; ci += 512) {
         float sc = 1.f, sh = 0.f;
         if (use_gn) gn_scale_shift(a.in_st, a.B, b, Cin, ci, a.H * a.W, a.gamma, a.beta, sc, sh);
@@ -239,12 +265,16 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 
     if (producer) {
         // =========================== producers ===========================
-        // K-step s stages a part of chunk (s / KROWS + 1): tasks ptid + 256 * (krow * RPS + j), j < RPS.  The loads of a
-        // part -- and of a K-step's weights -- are issued NSET K-steps before they are needed (one register set per K-step
-        // of the window): a K-step is ~1 us of MFMAs and a global round trip under load is 2 us.
-        constexpr int NSET = KROWS > 2 ? KROWS : 2;
-        u32x4 pset[NSET][RPS][2], wset[NSET][SBV];
-        int oset[NSET][RPS];
+        // Producer step s (one per K-step of the consumers, at most one ahead of their K-step s in starting):
+        //   * K-step s + NSLOT - 1's weights -> ring slot (s + NSLOT - 1) % NSLOT, free since the consumers left K-step s - 1;
+        //   * a part of the NEXT chunk's patch -> the other patch buffer (tasks ptid + 256 * (k * RPS + j), k = s % KROWS).
+        // So a producer step has NSLOT - 1 K-steps of MFMAs to finish, not one: its latency (global round trips, the
+        // arithmetic of the split, LDS writes) hides behind the ring, only its throughput counts.
+        // The global loads of both are issued U steps before their use, one register set per position in the unrolled loop.
+        constexpr int U = KROWS > 1 ? KROWS : 2;
+        u32x4 pset[U][RPS][2], wset[U][SBV];
+        int oset[U][RPS];
+        unsigned done_seen = 0;
         auto load_part = [&](u32x4 (&pr)[RPS][2], int (&po)[RPS], int s) {
             const int c0 = chunk_of(s / KROWS + 1) * CC, krow = s % KROWS;
 #pragma unroll
@@ -264,68 +294,71 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 if (krow * RPS + j < NVP && i < NTASK) put_task(pr[j], po[j], c0, i >> 2, i & 3, cn & 1);
             }
         };
-        // steady state without branches around loads (a branch makes the compiler's vmcnt bookkeeping give up and wait for
+        // steady state without branches around LOADS (a branch makes the compiler's vmcnt bookkeeping give up and wait for
         // everything in flight): indices past the end are clamped, the redundant loads are never used
         auto stage_step = [&](int s, u32x4 (&ps)[RPS][2], int (&po)[RPS], u32x4 (&ws)[SBV]) {
-            sem_wait(sem_done, 4u * s);        // the consumers have left K-step s - 1: its ring slot and the other patch buffer are free
-            if (!(PDBG(a) & 1)) write_w(ws, (s + 1) & 1);
-            if (!(PDBG(a) & 1)) load_w(ws, s + 1 + NSET < S ? s + 1 + NSET : S - 1);
-            if (!(PDBG(a) & 32)) put_part(ps, po, s);
-            sem_signal(sem_ready, lane);       // what K-step s + 1 reads is in LDS (this wave's share)
-            const int sn = s + NSET;
-            if (!(PDBG(a) & 2)) load_part(ps, po, sn / KROWS + 1 < NCH ? sn : (NCH - 2) * KROWS + sn % KROWS);
+            if (done_seen < (unsigned)s) {     // every consumer wave has left K-step s - 1
+                do { done_seen = sem_min(sem_done); if (done_seen >= (unsigned)s) break; __builtin_amdgcn_s_sleep(1); } while (true);
+                asm volatile("" ::: "memory");
+            }
+            const int u = s + NSLOT - 1;
+            if (u < S && !(PDBG(a) & 1)) write_w(ws, u % NSLOT);
+            if (!(PDBG(a) & 1)) load_w(ws, u + U < S ? u + U : S - 1);
+            if (s / KROWS + 1 < NCH && !(PDBG(a) & 32)) put_part(ps, po, s);
+            sem_signal(sem_ready, cw, (unsigned)s + 1u, lane);   // this wave's share of producer steps 0 .. s is in LDS
+            const int sn = s + U;
+            if (!(PDBG(a) & 2)) load_part(ps, po, sn / KROWS + 1 < NCH ? sn : (NCH > 1 ? (NCH - 2) * KROWS + sn % KROWS : 0));
         };
-        write_w(wreg, 0);
+        if (NU <= 4) fetch_res();              // the residual rows: an input of the launch, requested once, used at the very end
 #pragma unroll
-        for (int u = 0; u < NSET; ++u) {
-            load_w(wset[u], u + 1 < S ? u + 1 : S - 1);
-            if (NCH > 1) load_part(pset[u], oset[u], u / KROWS + 1 < NCH ? u : u % KROWS);
+        for (int u = 0; u < NPRO; ++u)
+            if (u < S) write_w(wpro[u], u);
+#pragma unroll
+        for (int j = 0; j < U; ++j) {
+            // set j holds the weights of the first K-step u >= NSLOT - 1 with u % U == j
+            const int u0 = NPRO + ((j - NPRO) % U + U) % U;
+            load_w(wset[j], u0 < S ? u0 : S - 1);
+            load_part(pset[j], oset[j], j / KROWS + 1 < NCH ? j : (NCH > 1 ? j % KROWS : 0));
         }
-        wg_barrier();   // chunk 0 and K-step 0 are in LDS
+        wg_barrier();   // chunk 0 and the first K-steps are in LDS
+        stamp(1);
+        if (PDBG(a) & 2048) __builtin_amdgcn_s_setprio(1);
         if constexpr (KROWS > 1) {
 #pragma unroll 1
-            for (int c = 0; c < NCH - 1; ++c) {               // chunks with a successor to stage
+            for (int c = 0; c < NCH; ++c) {
 #pragma unroll
-                for (int u = 0; u < KROWS; ++u) stage_step(c * KROWS + u, pset[u], oset[u], wset[u]);
+                for (int k = 0; k < KROWS; ++k) stage_step(c * KROWS + k, pset[k], oset[k], wset[(k + NPRO) % U]);
             }
         } else {
             int c = 0;
 #pragma unroll 1
-            for (; c + 1 < NCH - 1; c += 2) {
-                stage_step(c, pset[0], oset[0], wset[0]);
-                stage_step(c + 1, pset[1], oset[1], wset[1]);
+            for (; c + 1 < NCH; c += 2) {
+                stage_step(c, pset[0], oset[0], wset[NPRO % 2]);
+                stage_step(c + 1, pset[1], oset[1], wset[(NPRO + 1) % 2]);
             }
-            if (c < NCH - 1) stage_step(c, pset[0], oset[0], wset[0]);   // c is even here
-        }
-        // last chunk: nothing left to stage; the residual rows are requested now
-        if (NU <= 4) fetch_res();
-#pragma unroll
-        for (int u = 0; u < KROWS; ++u) {
-            const int s = (NCH - 1) * KROWS + u;
-            if (u + 1 < KROWS) {
-                sem_wait(sem_done, 4u * s);
-                write_w(wset[(KROWS > 1) ? u : 0], (s + 1) & 1);
-                sem_signal(sem_ready, lane);
-            }
+            if (c < NCH) stage_step(c, pset[0], oset[0], wset[NPRO % 2]);   // c is even here
         }
     } else {
         // =========================== consumers ===========================
         const int half = lane >> 5, px = lane & 31;
         const char* a_ptr = patch + ((wm * MB) * PW + px) * RB + 16 * half;
         const char* b_ptr = bst + (wn * NBW) * 1024 + lane * 16;
-        wg_barrier();   // chunk 0 and K-step 0 are in LDS
-        __builtin_amdgcn_s_setprio(1);   // the matrix pipe first: the producers' arithmetic fills what is left
+        wg_barrier();   // chunk 0 and the first K-steps are in LDS
+        stamp(1);
+        if (!(PDBG(a) & 64)) __builtin_amdgcn_s_setprio(1);   // the matrix pipe first: the producers' arithmetic fills what is left
         // One flat stream of k-steps (a k-step = one MFMA K of one tap): the fragments of k-step i + 1 are requested before
         // the MFMAs of k-step i are issued -- also across a K-step boundary, after the producers' count says the next
         // K-step's operands are in LDS -- so the matrix pipe never waits for an LDS round trip or a rendezvous.
         u32x4 af[2][MB], afl[2][MB], bf[2][NBW], bfl[2][NBW];
+        unsigned ready_seen = 0;
         // fragment loads in the order the MFMAs want them (small terms first: a_lo b_hi, then a_hi b_lo, a_hi b_hi)
-        auto load_frag = [&](int fs, int s, int ks) {
+        auto load_frag = [&](int fs, int s, int slot, int ks) {
             const int krow = s % KROWS, pbuf = (s / KROWS) & 1;
-            const char* bs = b_ptr + (s & 1) * SBYTES;
-            const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 3) ? (krow * PW) * RB : 0);
+            const char* bs = b_ptr + slot * SBYTES;
+            const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 3) ? (krow * PW) * RB : ((TPS == 1 && TAPS == 9) ? ((krow / 3) * PW + krow % 3) * RB : 0));
             const int t = ks / KGC, kg = ks % KGC;
             const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
+            if (PDBG(a) & 128) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
 #pragma unroll
@@ -337,14 +370,24 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         };
         constexpr int NRD = 2 * (MB + NBW), NMF = 3 * MB * NBW;     // LDS reads / MFMAs of one k-step
         static_assert(NKS % 2 == 0, "fragment double buffer: even k-steps per K-step");
+        int slot = 0;
         auto mfma_step = [&](int s, bool last) {
+            const int nslot = slot + 1 == NSLOT ? 0 : slot + 1;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 bool pre = true;
-                if (ks + 1 < NKS) load_frag((ks + 1) & 1, s, ks + 1);
+                if (ks + 1 < NKS) load_frag((ks + 1) & 1, s, slot, ks + 1);
                 else if (!last) {
-                    sem_wait(sem_ready, 4u * (s + 1));
-                    load_frag(0, s + 1, 0);
+                    // K-step s + 1 needs producer steps 0 .. s - NSLOT + 2 (its weights) and, when it opens a chunk, the steps
+                    // that staged the chunk's patch (the last of them: LASTK of the previous chunk)
+                    const int sn = s + 1;
+                    int need = sn - NSLOT + 2;
+                    if (sn % KROWS == 0) { const int np = sn - KROWS + LASTK + 1; need = need > np ? need : np; }
+                    if ((int)ready_seen < need) {
+                        do { ready_seen = sem_min(sem_ready); if ((int)ready_seen >= need) break; __builtin_amdgcn_s_sleep(1); } while (true);
+                        asm volatile("" ::: "memory");
+                    }
+                    load_frag(0, sn, nslot, 0);
                 } else pre = false;
                 if (PDBG(a) & 4) continue;
                 // the three terms of a product go to the same accumulator in a fixed order; the accumulators take turns
@@ -377,9 +420,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, NMF, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            sem_signal(sem_done, lane);   // every read of K-step s has been issued: its ring slot (and patch buffer) may be refilled
+            sem_signal(sem_done, cw, (unsigned)s + 1u, lane);   // every read of K-steps 0 .. s has been issued: ring slots and patch buffers up to there may be refilled
+            slot = nslot;
         };
-        load_frag(0, 0, 0);
+        load_frag(0, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
         for (int s = 0; s < S - 1; ++s) mfma_step(s, false);
@@ -387,12 +431,13 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         mfma_step(S - 1, true);
         __builtin_amdgcn_s_setprio(0);
     }
+    stamp(2);
     wg_barrier();   // all fragment reads done: the patch buffers and the ring are dead
+    stamp(3);
     if (PDBG(a) & 8) return;
 
     // ---------------- epilogue: accumulators -> LDS image of the tile -> all threads store ----------------
     float* scr = (float*)smem;                                 // [TH * 32 pixels][SCR_LD]
-    float* red = (float*)smem + TH * PTW * SCR_LD;             // [4 kinds][8 waves][NT]
     if (!producer) {
         const int half = lane >> 5, px = lane & 31;
 #pragma unroll
@@ -448,97 +493,78 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         }
     }
 
+    stamp(4);
     if (want_stats) {   // uniform over the grid
-        // lanes with equal (lane % G8) hold the same 8 channels: fixed-order butterfly over the rest
-#pragma unroll
-        for (int o = G8; o < 64; o <<= 1) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                sr[e] += __shfl_xor(sr[e], o, 64); qr[e] += __shfl_xor(qr[e], o, 64);
-                so[e] += __shfl_xor(so[e], o, 64); qo[e] += __shfl_xor(qo[e], o, 64);
-            }
-        }
-        if (lane < G8) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                red[(0 * 8 + wid) * NT + lane * 8 + e] = sr[e];
-                red[(1 * 8 + wid) * NT + lane * 8 + e] = qr[e];
-                red[(2 * 8 + wid) * NT + lane * 8 + e] = so[e];
-                red[(3 * 8 + wid) * NT + lane * 8 + e] = qo[e];
-            }
+        // 512 threads x (4 sums x 8 channels) -> per-channel totals through LDS, in a fixed order: every thread parks its 32
+        // partial sums as a row segment of part[thread / G8][kind * NT + channel]; the columns are added up in NSEG
+        // segments of 32 rows by all threads, the segments by one thread per column.  (The first version ran a 3-round
+        // butterfly over the 32 registers: 96 cross-lane moves per thread, 4 us of a 45 us launch.)
+        constexpr int RL = 4 * NT, NROW = 512 / G8, NSEG = 512 / RL, RPSEG = NROW / NSEG;
+        static_assert(NSEG >= 1 && RPSEG * NSEG == NROW, "statistics reduction geometry");
+        wg_barrier();                                          // every thread is done with the tile image
+        float* part = (float*)smem;                            // [NROW][RL]
+        float* red2 = part + NROW * RL;                        // [NSEG][RL]
+        {
+            float* pr = part + (tid / G8) * RL + g8 * 8;
+            *(f32x4*)(pr) = f32x4{sr[0], sr[1], sr[2], sr[3]};           *(f32x4*)(pr + 4) = f32x4{sr[4], sr[5], sr[6], sr[7]};
+            *(f32x4*)(pr + NT) = f32x4{qr[0], qr[1], qr[2], qr[3]};      *(f32x4*)(pr + NT + 4) = f32x4{qr[4], qr[5], qr[6], qr[7]};
+            *(f32x4*)(pr + 2 * NT) = f32x4{so[0], so[1], so[2], so[3]};  *(f32x4*)(pr + 2 * NT + 4) = f32x4{so[4], so[5], so[6], so[7]};
+            *(f32x4*)(pr + 3 * NT) = f32x4{qo[0], qo[1], qo[2], qo[3]};  *(f32x4*)(pr + 3 * NT + 4) = f32x4{qo[4], qo[5], qo[6], qo[7]};
         }
         wg_barrier();
+        {
+            const int col = tid % RL, seg = tid / RL;
+            const float* pc = part + (seg * RPSEG) * RL + col;
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < RPSEG; ++r) t += pc[r * RL];
+            red2[seg * RL + col] = t;
+        }
+        wg_barrier();
+        stamp(5);
         if (tid < NT) {
-            float t[4] = {0.f, 0.f, 0.f, 0.f};
+            // thread = channel; t[kind]: kinds 0 / 1 = sum / sum of squares of `raw`, 2 / 3 of `out`
+            float t[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k) {
+                t[k] = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) t[k] += red[(k * 8 + w) * NT + tid];
-            const int cg = n_tile * NT + tid;
-            if (PDBG(a) & 16) return;
-            // channels -> GroupNorm groups of the tensor the slice belongs to; the (up to) four sums of a group leave from
-            // different lanes of the group, concurrently (see conv_lds_kernel)
-#if CHORE_CONV_ABLATE
-            if (PDBG(a) & (512 | 4096 | 16384 | 32768)) {   // experiments on how the sums leave the workgroup
-                for (int k = 0; k < 2; ++k) {
-                    GroupStat* st = k ? a.st_out : a.st_raw;
-                    if (!st) continue;
-                    const int gs = (k ? a.st_out_C : a.st_raw_C) / GN_GROUPS, co = k ? a.st_out_co : a.st_raw_co;
-                    const float s1 = group_lane_sum(t[2 * k], gs), s2 = group_lane_sum(t[2 * k + 1], gs);
-                    GroupStat* o = st + (size_t)b * GN_GROUPS + (co + cg) / gs;
-                    const bool l1 = tid % gs == 0, l2 = tid % gs == (gs > 1 ? 1 : 0);
-                    if (PDBG(a) & 512) {             // plain stores
-                        if (l1) { ((float*)o)[0] = s1; ((float*)o)[1] = s2; }
-                    } else if (PDBG(a) & 4096) {     // one 64-bit no-return atomic per sum
-                        if (l1) __hip_atomic_fetch_add((long long*)&o->sum.lo, (long long)((double)s1 * 0x1p20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if (l2) __hip_atomic_fetch_add((long long*)&o->sq.lo, (long long)((double)s2 * 0x1p20), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    } else {                         // two limbs: 16384 = high limbs in another table (4 KB away), 32768 = low limb only
-                        for (int u = 0; u < 2; ++u) {
-                            if (!(u ? l2 : l1)) continue;
-                            StatCell* c = u ? &o->sq : &o->sum;
-                            const double d = (double)(u ? s2 : s1) * 0x1p40, hh = floor(d * 0x1p-32);
-                            const long long hi = (long long)hh;
-                            const unsigned long long lo = (unsigned long long)(d - hh * 0x1p32);
-                            (void)__hip_atomic_fetch_add(&c->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (PDBG(a) & 16384) (void)__hip_atomic_fetch_add(&c->hi + 2 * a.B * GN_GROUPS * 2, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                }
-                return;
+                for (int g = 0; g < NSEG; ++g) t[k] += red2[g * RL + k * NT + tid];
             }
-#endif
-            if (a.st_raw) {
-                const int gs = a.st_raw_C / GN_GROUPS;
-                const float s1 = group_lane_sum(t[0], gs), s2 = group_lane_sum(t[1], gs);
-                GroupStat* o = a.st_raw + (size_t)b * GN_GROUPS + (a.st_raw_co + cg) / gs;
+            if (PDBG(a) & 16) return;
+            // Channels -> GroupNorm groups of the tensor the slice belongs to.  All adds of the workgroup leave from ONE wave
+            // (per tensor: the group's sum from its first lane, the sum of squares from its second, one instruction each):
+            // atomics of different instructions that hit one cache line queue at the memory side -- spread over four waves the
+            // same adds cost 3 us more (profiles/r03_conv_phase_breakdown.txt).
+            const int cg = n_tile * NT + tid;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                GroupStat* st = k ? a.st_out : a.st_raw;
+                if (!st) continue;
+                const int gs = (k ? a.st_out_C : a.st_raw_C) / GN_GROUPS, co = k ? a.st_out_co : a.st_raw_co;
+                const float s1 = group_lane_sum(t[2 * k], gs), s2 = group_lane_sum(t[2 * k + 1], gs);
+                GroupStat* o = st + (size_t)b * GN_GROUPS + (co + cg) / gs;
                 if (tid % gs == 0) stat_add(&o->sum, act_hi_cells(a.B), s1);
                 if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells(a.B), s2);
-            }
-            if (a.st_out) {
-                const int gs = a.st_out_C / GN_GROUPS;
-                const float s1 = group_lane_sum(t[2], gs), s2 = group_lane_sum(t[3], gs);
-                GroupStat* o = a.st_out + (size_t)b * GN_GROUPS + (a.st_out_co + cg) / gs;
-                if (tid % gs == (gs > 3 ? 2 : 0)) stat_add(&o->sum, act_hi_cells(a.B), s1);
-                if (tid % gs == (gs > 3 ? 3 : (gs > 1 ? 1 : 0))) stat_add(&o->sq, act_hi_cells(a.B), s2);
             }
         }
     }
 }
 
-template <typename T, int TAPS, int TH, int NT, int TPS>
+template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT>
 int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = PGeo<TAPS, TH, NT, TPS>;
+    using G = PGeo<TAPS, TH, NT, TPS, NSLOT>;
     const size_t smem = G::smem_bytes(a.in.C);
     if (smem > 160 * 1024) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS", smem);
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr = true;
     }
     const int tiles = ((a.W + PTW - 1) / PTW) * ((a.H + TH - 1) / TH);
     dim3 grid(tiles * (a.Cout / NT) * a.B);
-    hipLaunchKernelGGL((conv_pc_kernel<T, TAPS, TH, NT, TPS>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -547,39 +573,54 @@ int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 
 // tile configuration of the specialised-wave kernel for a layer: th = 0 -> not covered (the caller uses conv_lds_kernel)
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force) {
-    PcPlan p{0, 0, 0};
+    PcPlan p{0, 0, 0, 0};
     if (dtype != CHORE_F16X3 || Cin % 32 || Cout % 32 || W % 32) return p;
-    if (force) {   // development: th * 1000 + nt (e.g. 8064), tps follows
+    auto ring = [&](PcPlan& q) {   // taps per K-step and ring depth of a tiling (what fits 160 KB of LDS)
+        // (measured, profiles/r03_conv_phase_breakdown.txt: rings of single taps with 4 - 6 slots are no faster than two slots of
+        // whole kernel rows -- the consumers pay per K-step for the hand-over -- except where only single taps fit: 128 channels)
+        if (taps == 1) { q.tps = 1; q.nslot = 2; return; }
+        if (q.nt == 128) { q.tps = 1; q.nslot = 3; }
+        else if (q.th == 4 && q.nt == 32) { q.tps = 9; q.nslot = 2; }
+        else { q.tps = 3; q.nslot = 2; }
+    };
+    if (force) {   // development: th * 1000 + nt (e.g. 8064)
         p.th = force / 1000; p.nt = force % 1000;
-        p.tps = taps == 1 ? 1 : ((p.th == 4 && p.nt == 32) ? 9 : 3);
+        ring(p);
         return p;
     }
     const long px_tiles8 = (long)B * ((H + 7) / 8) * (W / 32);
     if (taps == 1) {
-        if (Cout % 128 == 0) { p.th = 8; p.nt = 128; p.tps = 1; }
-        else if (Cout % 64 == 0) { p.th = 8; p.nt = 64; p.tps = 1; }
+        if (Cout % 128 == 0) { p.th = 8; p.nt = 128; }
+        else if (Cout % 64 == 0) { p.th = 8; p.nt = 64; }
+        else return p;
+        ring(p);
         return p;
     }
     // 3x3: the widest channel tile that still gives every CU a workgroup; 4-row tiles when 8-row tiles leave CUs idle
-    if (Cout % 64 == 0 && px_tiles8 * (Cout / 64) >= 256) { p.th = 8; p.nt = 64; p.tps = 3; }
-    else if (px_tiles8 * (Cout / 32) >= 256) { p.th = 8; p.nt = 32; p.tps = 3; }
-    else if (H % 4 == 0 && Cout % 64 == 0 && px_tiles8 * 2 * (Cout / 64) >= 256) { p.th = 4; p.nt = 64; p.tps = 3; }
-    else if (H % 4 == 0) { p.th = 4; p.nt = 32; p.tps = 9; }
-    else { p.th = 8; p.nt = 32; p.tps = 3; }
+    if (Cout % 128 == 0 && px_tiles8 * (Cout / 128) >= 256) { p.th = 8; p.nt = 128; }
+    else if (Cout % 64 == 0 && px_tiles8 * (Cout / 64) >= 256) { p.th = 8; p.nt = 64; }
+    else if (px_tiles8 * (Cout / 32) >= 256) { p.th = 8; p.nt = 32; }
+    else if (H % 4 == 0 && Cout % 64 == 0 && px_tiles8 * 2 * (Cout / 64) >= 256) { p.th = 4; p.nt = 64; }
+    else if (H % 4 == 0) { p.th = 4; p.nt = 32; }
+    else { p.th = 8; p.nt = 32; }
+    ring(p);
     return p;
 }
 
 int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {
     if (a.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: a second residual is not supported (conv_lds_kernel has it)");
-    const int key = taps * 100000 + p.th * 10000 + p.nt * 10 + p.tps;
+    const int key = ((taps * 10 + p.th) * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
+#define PC_CASE(TAPS, TH, NT, TPS, NSLOT) \
+    case ((TAPS * 10 + TH) * 1000 + NT) * 100 + TPS * 10 + NSLOT: return launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)
     switch (key) {
-        case 9 * 100000 + 8 * 10000 + 64 * 10 + 3: return launch_pc_t<x3_t, 9, 8, 64, 3>(h, a, s);
-        case 9 * 100000 + 8 * 10000 + 32 * 10 + 3: return launch_pc_t<x3_t, 9, 8, 32, 3>(h, a, s);
-        case 9 * 100000 + 4 * 10000 + 64 * 10 + 3: return launch_pc_t<x3_t, 9, 4, 64, 3>(h, a, s);
-        case 9 * 100000 + 4 * 10000 + 32 * 10 + 9: return launch_pc_t<x3_t, 9, 4, 32, 9>(h, a, s);
-        case 9 * 100000 + 4 * 10000 + 32 * 10 + 3: return launch_pc_t<x3_t, 9, 4, 32, 3>(h, a, s);
-        case 1 * 100000 + 8 * 10000 + 128 * 10 + 1: return launch_pc_t<x3_t, 1, 8, 128, 1>(h, a, s);
-        case 1 * 100000 + 8 * 10000 + 64 * 10 + 1: return launch_pc_t<x3_t, 1, 8, 64, 1>(h, a, s);
+        PC_CASE(9, 8, 128, 1, 3);
+        PC_CASE(9, 8, 64, 3, 2);
+        PC_CASE(9, 8, 32, 3, 2);
+        PC_CASE(9, 4, 64, 3, 2);
+        PC_CASE(9, 4, 32, 9, 2);
+        PC_CASE(1, 8, 128, 1, 2);
+        PC_CASE(1, 8, 64, 1, 2);
     }
-    CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: no kernel for taps=%d th=%d nt=%d tps=%d", taps, p.th, p.nt, p.tps);
+#undef PC_CASE
+    CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: no kernel for taps=%d th=%d nt=%d tps=%d nslot=%d", taps, p.th, p.nt, p.tps, p.nslot);
 }

@@ -101,6 +101,7 @@ struct ConvArgs {
     // the tensor `raw` / `out` belong to; *_C = channels of that tensor (group size = C/32), *_co = offset of this slice
     GroupStat* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0;
     GroupStat* st_out = nullptr; int st_out_C = 0, st_out_co = 0;
+    unsigned long long* dbg_ticks = nullptr;   // CHORE_CONV_ABLATE builds: phase time stamps of workgroup 0 (conv_pc.hip)
     int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
 };
@@ -141,8 +142,8 @@ int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t
 ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // tile configuration launch_conv will use
 
 // specialised-wave convolution (conv_pc.hip, fp16 x 3 operands): th rows x 32 pixels x nt channels per workgroup, tps taps per
-// K-step; th = 0: the layer is not covered and launch_conv uses conv_lds_kernel
-struct PcPlan { int th, nt, tps; };
+// K-step, nslot K-steps of weights resident in LDS; th = 0: the layer is not covered and launch_conv uses conv_lds_kernel
+struct PcPlan { int th, nt, tps, nslot; };
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
 int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();

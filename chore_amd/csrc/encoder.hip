@@ -181,9 +181,9 @@ const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_a
                                          "conv_lds_kernel<T,9,32,9>", "conv_lds_kernel<T,1,128,1>",
                                          "conv_lds_kernel<T,1,64,1>", "conv_lds_kernel<T,1,32,1>", "conv_small_kernel<T,64,ROWS>",
                                          "conv_small_kernel<T,128,ROWS>", "conv_small_kernel<T,256,ROWS>",
-                                         "conv_pc_kernel<T,9,8,64,3>", "conv_pc_kernel<T,9,8,32,3>", "conv_pc_kernel<T,9,4,64,3>",
-                                         "conv_pc_kernel<T,9,4,32,9>", "conv_pc_kernel<T,9,4,32,3>", "conv_pc_kernel<T,1,8,128,1>",
-                                         "conv_pc_kernel<T,1,8,64,1>"};
+                                         "conv_pc_kernel<T,9,8,128,1,3>", "conv_pc_kernel<T,9,8,64,3,2>",
+                                         "conv_pc_kernel<T,9,8,32,3,2>", "conv_pc_kernel<T,9,4,64,3,2>", "conv_pc_kernel<T,9,4,32,9,2>",
+                                         "conv_pc_kernel<T,1,8,128,1,2>", "conv_pc_kernel<T,1,8,64,1,2>"};
 inline int conv_class(const ConvPlan& p, int taps) {
     if (p.tps == 0) return K_CONV_FIRST + 8 + (p.small_cin == 64 ? 0 : (p.small_cin == 128 ? 1 : 2));
     const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
@@ -197,8 +197,8 @@ inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int 
         const PcPlan pp = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
         if (pp.th) {
             if (taps == 1) return K_PC_FIRST + (pp.nt == 128 ? 5 : 6);
-            if (pp.th == 8) return K_PC_FIRST + (pp.nt == 64 ? 0 : 1);
-            return K_PC_FIRST + (pp.nt == 64 ? 2 : (pp.tps == 9 ? 3 : 4));
+            if (pp.th == 8) return K_PC_FIRST + (pp.nt == 128 ? 0 : (pp.nt == 64 ? 1 : 2));
+            return K_PC_FIRST + (pp.nt == 64 ? 3 : 4);
         }
     }
     return conv_class(conv_plan(dtype, taps, B, H, W, Cin, Cout), taps);
@@ -234,7 +234,7 @@ struct Program {
     size_t stats_off = 0, stats_bytes = 0;
     int n_events = 0, n_streams = 1;
     size_t ws_bytes = 0;
-    std::vector<hipEvent_t> events;       // created on first run
+    std::vector<hipEvent_t> events;       // created on first run: [group][n_events]
 };
 
 struct Builder {
@@ -589,11 +589,25 @@ struct Builder {
     }
 };
 
+constexpr int MAX_GROUPS = 8;
 struct EncCache {
     std::vector<std::unique_ptr<Program>> progs;
     Profile prof;
-    hipStream_t aux[MAX_STREAMS] = {nullptr};   // [0] unused (caller's stream)
+    hipStream_t aux[MAX_GROUPS][MAX_STREAMS] = {};   // [0][0] unused (caller's stream)
+    hipEvent_t fork_ev = nullptr, join_ev[MAX_GROUPS] = {};
 };
+
+// CHORE_ENC_GROUPS=G encodes the batch as G independent groups of B / G images, each a chain of launches of its own on its
+// own streams.  The idea: a launch of specialised-wave workgroups (one per CU) lasts as long as ONE workgroup lives, whether
+// it has 256 workgroups or 64, so the chains of half batches could overlap.  Measured (B = 4, fp16x3): G = 1 5.6 ms, G = 2
+// 6.9 ms, G = 4 10.7 ms per step with only 2.6 ms of host time at G = 2 -- the device does not run the chains side by side
+// (six and more streams share the hardware queues).  Off by default; kept as a switch.
+int enc_groups(int B) {
+    static const int want = getenv("CHORE_ENC_GROUPS") ? atoi(getenv("CHORE_ENC_GROUPS")) : 1;
+    int g = want < 1 ? 1 : (want > MAX_GROUPS ? MAX_GROUPS : want);
+    while (g > 1 && B % g) --g;
+    return g;
+}
 
 Program* get_program(chore_handle* h, const chore_encoder_cfg& cfg, int B, int H, int W, int dtype, int n_out,
                      bool want_normx) {
@@ -637,8 +651,12 @@ extern "C" {
 void chore_encoder_cache_free(chore_handle* h) {
     if (h && h->enc_cache) {
         EncCache* c = (EncCache*)h->enc_cache;
-        for (int i = 1; i < MAX_STREAMS; ++i)
-            if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+        for (int g = 0; g < MAX_GROUPS; ++g)
+            for (int i = 0; i < MAX_STREAMS; ++i)
+                if (c->aux[g][i]) (void)hipStreamDestroy(c->aux[g][i]);
+        if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+        for (hipEvent_t e : c->join_ev)
+            if (e) (void)hipEventDestroy(e);
         for (auto& p : c->progs)
             for (hipEvent_t e : p->events) (void)hipEventDestroy(e);
         for (hipEvent_t e : c->prof.ev) (void)hipEventDestroy(e);
@@ -715,7 +733,8 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
 size_t chore_encoder_workspace_bytes(const chore_encoder_cfg* cfg, int B, int H, int W, int dtype) {
     if (!cfg || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return 0;
     if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) return 0;
-    return plan_workspace(*cfg, B, H, W, dtype);
+    const int G = enc_groups(B);
+    return (size_t)G * align_up(plan_workspace(*cfg, B / G, H, W, dtype), 256);
 }
 
 int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float* images, int B, int H, int W,
@@ -731,75 +750,104 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
         CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad n_stack_out");
     for (int i = 0; i < n_stack_out; ++i)
         if (!feat_out[i]) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: null feat_out[%d]", i);
-    Program* P = get_program(h, *cfg, B, H, W, dtype, n_stack_out, normx != nullptr);
-    if (workspace_bytes < P->ws_bytes)
-        CHORE_FAIL(h, CHORE_ENOMEM, "chore_encode_fwd: workspace %zu < %zu bytes", workspace_bytes, P->ws_bytes);
+    const int G = enc_groups(B), Bg = B / G;
+    Program* P = get_program(h, *cfg, Bg, H, W, dtype, n_stack_out, normx != nullptr);
+    const size_t ws_group = align_up(P->ws_bytes, 256);
+    if (workspace_bytes < (size_t)G * ws_group)
+        CHORE_FAIL(h, CHORE_ENOMEM, "chore_encode_fwd: workspace %zu < %zu bytes", workspace_bytes, (size_t)G * ws_group);
     EncCache* cache = (EncCache*)h->enc_cache;
-    hipStream_t streams[MAX_STREAMS];
-    streams[0] = (hipStream_t)stream;
-    for (int i = 1; i < P->n_streams; ++i) {   // auxiliary streams / events are created once, not per call
-        if (!cache->aux[i]) CHORE_HIP_CHECK(h, hipStreamCreateWithFlags(&cache->aux[i], hipStreamNonBlocking));
-        streams[i] = cache->aux[i];
-    }
-    while ((int)P->events.size() < P->n_events) {
+    static const bool debug_sync = getenv("CHORE_DEBUG_SYNC") != nullptr;
+    Profile& prof = cache->prof;
+    const bool serial = prof.on || debug_sync;   // attribution / debugging: everything on the caller's stream
+    hipStream_t streams[MAX_GROUPS][MAX_STREAMS];
+    for (int g = 0; g < G; ++g)
+        for (int i = 0; i < P->n_streams; ++i) {   // auxiliary streams / events are created once, not per call
+            if (g == 0 && i == 0) { streams[0][0] = (hipStream_t)stream; continue; }
+            if (!cache->aux[g][i]) CHORE_HIP_CHECK(h, hipStreamCreateWithFlags(&cache->aux[g][i], hipStreamNonBlocking));
+            streams[g][i] = cache->aux[g][i];
+        }
+    while ((int)P->events.size() < G * P->n_events) {
         hipEvent_t e;
         CHORE_HIP_CHECK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         P->events.push_back(e);
     }
-    RunCtx r;
-    r.h = h; r.dtype = dtype; r.s = streams[0]; r.arena = (const char*)arena;
-    for (int i = 0; i < MAX_STREAMS; ++i) r.pool_base[i] = (char*)workspace + P->pool_off[i];
-    r.stats = (char*)workspace + P->stats_off;
-    r.images = images; r.feats = feat_out; r.tmpx = tmpx; r.normx = normx;
-    static const bool debug_sync = getenv("CHORE_DEBUG_SYNC") != nullptr;
-    Profile& prof = cache->prof;
-    const bool serial = prof.on || debug_sync;   // attribution / debugging: everything on the caller's stream
+    if (G > 1 && !serial) {   // the other groups' chains start where the caller's stream is now
+        if (!cache->fork_ev) CHORE_HIP_CHECK(h, hipEventCreateWithFlags(&cache->fork_ev, hipEventDisableTiming));
+        CHORE_HIP_CHECK(h, hipEventRecord(cache->fork_ev, (hipStream_t)stream));
+        for (int g = 1; g < G; ++g) CHORE_HIP_CHECK(h, hipStreamWaitEvent(streams[g][0], cache->fork_ev, 0));
+    }
     if (prof.on) {
-        const size_t need = 2 * P->steps.size();
+        const size_t need = 2 * P->steps.size() * G;
         while (prof.ev.size() < need) {
             hipEvent_t e;
             CHORE_HIP_CHECK(h, hipEventCreate(&e));
             prof.ev.push_back(e);
         }
     }
-    for (size_t i = 0; i < P->steps.size(); ++i) {
-        Step& st = P->steps[i];
-        hipStream_t ss = serial ? streams[0] : streams[st.stream];
-        if (st.kind == S_RECORD) {
-            if (!serial) CHORE_HIP_CHECK(h, hipEventRecord(P->events[st.event], ss));
-            continue;
+    // element sizes of the caller's tensors (feature maps and tmpx / normx in the activation type)
+    const size_t es = esize(dtype);
+    const size_t img_stride = (size_t)cfg->in_channels * H * W;                          // floats per image
+    const size_t feat_stride = (size_t)(H / 4) * (W / 4) * cfg->hourglass_dim * es;      // bytes per image
+    const size_t tmpx_stride = (size_t)(H / 2) * (W / 2) * 64 * es, normx_stride = (size_t)(H / 4) * (W / 4) * 128 * es;
+    for (int g = 0; g < G; ++g) {
+        void* feats_g[16];
+        for (int i = 0; i < n_stack_out; ++i) feats_g[i] = (char*)feat_out[i] + (size_t)g * Bg * feat_stride;
+        RunCtx r;
+        r.h = h; r.dtype = dtype; r.s = streams[g][0]; r.arena = (const char*)arena;
+        char* ws = (char*)workspace + (size_t)g * ws_group;
+        for (int i = 0; i < MAX_STREAMS; ++i) r.pool_base[i] = ws + P->pool_off[i];
+        r.stats = ws + P->stats_off;
+        r.images = images + (size_t)g * Bg * img_stride;
+        r.feats = feats_g;
+        r.tmpx = (char*)tmpx + (size_t)g * Bg * tmpx_stride;
+        r.normx = normx ? (char*)normx + (size_t)g * Bg * normx_stride : nullptr;
+        hipEvent_t* ev = P->events.data() + (size_t)g * P->n_events;
+        hipEvent_t* pev = prof.on ? prof.ev.data() + (size_t)g * 2 * P->steps.size() : nullptr;
+        for (size_t i = 0; i < P->steps.size(); ++i) {
+            Step& st = P->steps[i];
+            hipStream_t ss = serial ? (hipStream_t)stream : streams[g][st.stream];
+            if (st.kind == S_RECORD) {
+                if (!serial) CHORE_HIP_CHECK(h, hipEventRecord(ev[st.event], ss));
+                continue;
+            }
+            if (st.kind == S_WAIT) {
+                if (!serial) CHORE_HIP_CHECK(h, hipStreamWaitEvent(ss, ev[st.event], 0));
+                continue;
+            }
+            if (st.kind == S_MEMSET) {
+                CHORE_HIP_CHECK(h, hipMemsetAsync(r.stats, 0, P->stats_bytes, ss));
+                continue;
+            }
+            r.s = ss;
+            if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(pev[2 * i], ss));
+            st.fn(r);
+            if (r.rc) return r.rc;
+            if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(pev[2 * i + 1], ss));
+            if (debug_sync) {
+                fprintf(stderr, "[chore] group %d step %s\n", g, st.label.c_str());
+                hipError_t e = hipStreamSynchronize(ss);
+                if (e != hipSuccess) CHORE_FAIL(h, CHORE_EHIP, "step '%s' failed: %s", st.label.c_str(), hipGetErrorString(e));
+            }
         }
-        if (st.kind == S_WAIT) {
-            if (!serial) CHORE_HIP_CHECK(h, hipStreamWaitEvent(ss, P->events[st.event], 0));
-            continue;
-        }
-        if (st.kind == S_MEMSET) {
-            CHORE_HIP_CHECK(h, hipMemsetAsync(r.stats, 0, P->stats_bytes, ss));
-            continue;
-        }
-        r.s = ss;
-        if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i], ss));
-        st.fn(r);
-        if (r.rc) return r.rc;
-        if (prof.on) CHORE_HIP_CHECK(h, hipEventRecord(prof.ev[2 * i + 1], ss));
-        if (debug_sync) {
-            fprintf(stderr, "[chore] step %s\n", st.label.c_str());
-            hipError_t e = hipStreamSynchronize(ss);
-            if (e != hipSuccess) CHORE_FAIL(h, CHORE_EHIP, "step '%s' failed: %s", st.label.c_str(), hipGetErrorString(e));
+        if (g > 0 && !serial) {   // the caller's stream continues after every group
+            if (!cache->join_ev[g]) CHORE_HIP_CHECK(h, hipEventCreateWithFlags(&cache->join_ev[g], hipEventDisableTiming));
+            CHORE_HIP_CHECK(h, hipEventRecord(cache->join_ev[g], streams[g][0]));
+            CHORE_HIP_CHECK(h, hipStreamWaitEvent((hipStream_t)stream, cache->join_ev[g], 0));
         }
     }
     if (prof.on) {
-        CHORE_HIP_CHECK(h, hipStreamSynchronize(streams[0]));
-        for (size_t i = 0; i < P->steps.size(); ++i) {
-            const Step& st = P->steps[i];
-            if (st.kind != S_KERNEL) continue;
-            float ms = 0.f;
-            CHORE_HIP_CHECK(h, hipEventElapsedTime(&ms, prof.ev[2 * i], prof.ev[2 * i + 1]));
-            prof.ms[st.klass] += ms;
-            prof.flops[st.klass] += st.flops;
-            prof.bytes[st.klass] += st.bytes;
-            prof.launches[st.klass] += 1;
-        }
+        CHORE_HIP_CHECK(h, hipStreamSynchronize((hipStream_t)stream));
+        for (int g = 0; g < G; ++g)
+            for (size_t i = 0; i < P->steps.size(); ++i) {
+                const Step& st = P->steps[i];
+                if (st.kind != S_KERNEL) continue;
+                float ms = 0.f;
+                CHORE_HIP_CHECK(h, hipEventElapsedTime(&ms, prof.ev[(g * P->steps.size() + i) * 2], prof.ev[(g * P->steps.size() + i) * 2 + 1]));
+                prof.ms[st.klass] += ms;
+                prof.flops[st.klass] += st.flops;
+                prof.bytes[st.klass] += st.bytes;
+                prof.launches[st.klass] += 1;
+            }
     }
     return CHORE_OK;
 }

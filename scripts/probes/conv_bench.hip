@@ -36,6 +36,7 @@ int main(int argc, char** argv) {
     const int B = 4;
     chore_handle hh;
     chore_handle* h = &hh;
+    setenv("CHORE_CONV_LDS", "1", 1);   // launch_conv = conv_lds_kernel here; the specialised-wave kernel is called directly
     CK(hipSetDevice(0));
     hipStream_t s;
     CK(hipStreamCreate(&s));
@@ -51,12 +52,11 @@ int main(int argc, char** argv) {
         {"c1   32^2 256->128", 9, 32, 32, 256, 128, true, true},
         {"c2   32^2 128->64 ", 9, 32, 32, 128, 64, true, true},
     };
-    const int dbgs[] = {0, 16, 512, 4096, 16384, 32768, 256, 8, 8 | 4, 8 | 32, 8 | 4 | 32, 8 | 4 | 32 | 64, 128 | 8, 8 | 1 | 2, 8 | 1 | 2 | 32, 1024};
-    const char* dbgn[] = {"full", "-atom", "plainst", "1atom64", "hi-far", "lo-only", "-stats", "-epi", "-epi-mfma", "-epi-publish", "-epi-mfma-pub", "..-gn", "prologue only",
-                          "-epi-loads", "-epi-ld-pub", "-res"};
+    const int dbgs[] = {0, 16, 256, 8, 8 | 4, 8 | 32, 8 | 1 | 2, 8 | 1 | 2 | 32, 1 << 29};
+    const char* dbgn[] = {"full", "-atom", "-stats", "-epi", "-epi-mfma", "-epi-publish", "-epi-loads", "-epi-ld-pub", "full again"};
     const size_t esz = dtype == CHORE_BF16 ? 2 : 4;
     printf("dtype %d, B %d, %d launches per number (us per launch)\n", dtype, B, iters);
-    printf("%-20s %-9s %5s", "layer", "kernel", "WGs");
+    printf("%-20s %-13s %5s", "layer", "kernel", "WGs");
     for (const char* n : dbgn) printf(" %13s", n);
     printf("   GFLOP  TF(full)\n");
     int si = 0;
@@ -109,23 +109,26 @@ int main(int argc, char** argv) {
         a.B = B; a.H = sh.H; a.W = sh.W; a.Cout = sh.Cout;
         const ConvPlan pl = conv_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout);
         const int wgs = pl.tps == 0 ? -1 : B * pl.ntiles * (sh.Cout / pl.nt);
+        unsigned long long* dticks;
+        CK(hipMalloc(&dticks, 32 * 8));
+        a.dbg_ticks = dticks;
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0));
         CK(hipEventCreate(&e1));
         const double gflop = 2.0 * sh.taps * sh.Cin * sh.Cout * (double)px * 1e-9;
         // variant 0 = conv_lds_kernel (or conv_small), then the forced tilings of conv_pc_kernel: th * 1000 + nt
-        const int forces9[] = {0, 8064, 8032, 4064, 4032};
-        const int forces1[] = {0, 8128, 8064};
+        const int forces9[] = {0, 1, 8128, 8064, 8032, 4064, 4032};   // 1 = the tiling conv_pc_plan picks
+        const int forces1[] = {0, 1, 8128, 8064};
         const int* forces = sh.taps == 9 ? forces9 : forces1;
-        const int nforce = sh.taps == 9 ? 5 : 3;
+        const int nforce = sh.taps == 9 ? 7 : 4;
         std::vector<float> ref_out(nout), ref_raw(px * sh.Cout), got(nout);
         for (int fi = 0; fi < nforce; ++fi) {
             const int force = forces[fi];
-            PcPlan pp{0, 0, 0};
+            PcPlan pp{0, 0, 0, 0};
             int vw = wgs;
             if (force) {
-                pp = conv_pc_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force);
-                if (sh.Cout % pp.nt || sh.H % pp.th) continue;
+                pp = conv_pc_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force == 1 ? 0 : force);
+                if (!pp.th || sh.Cout % pp.nt || sh.H % pp.th) continue;
                 vw = B * (sh.H / pp.th) * (sh.W / 32) * (sh.Cout / pp.nt);
             }
             auto run = [&](int dbg) -> int {
@@ -149,11 +152,10 @@ int main(int argc, char** argv) {
                     for (size_t i = 0; i < px * sh.Cout; ++i) err_raw = fmax(err_raw, fabs((double)got[i] - ref_raw[i]));
                 }
             }
-            printf("%-20s %-9s %5d", sh.name, force ? (std::string("pc") + std::to_string(force)).c_str() : "lds", vw);
+            printf("%-20s %-13s %5d", sh.name, force ? (std::string(force == 1 ? "auto" : "pc") + std::to_string(pp.th * 1000 + pp.nt) + "/" + std::to_string(pp.tps) + "/" + std::to_string(pp.nslot)).c_str() : "lds", vw);
+            for (int i = 0; i < 400; ++i) run(0);   // clocks up before the first timed variant (it read 5 us high without)
             double full_us = 0;
             for (size_t di = 0; di < sizeof(dbgs) / sizeof(dbgs[0]); ++di) {
-                if (!force && (dbgs[di] == 512 || dbgs[di] == 4096 || dbgs[di] == 16384 || dbgs[di] == 32768)) { printf(" %13s", "-"); continue; }
-                if (force && !(dbgs[di] == 0 || dbgs[di] == 16 || dbgs[di] == 512 || dbgs[di] == 4096 || dbgs[di] == 16384 || dbgs[di] == 32768 || dbgs[di] == 256 || dbgs[di] == 8 || dbgs[di] == (8 | 4) || dbgs[di] == (8 | 32) || dbgs[di] == (8 | 1 | 2) || dbgs[di] == (8 | 1 | 2 | 32))) { printf(" %13s", "-"); continue; }
                 for (int i = 0; i < 5; ++i)
                     if (run(dbgs[di])) { fprintf(stderr, "%s\n", h->err.c_str()); return 1; }
                 CK(hipEventRecord(e0, s));
@@ -167,6 +169,19 @@ int main(int argc, char** argv) {
                 printf(" %13.2f", us);
             }
             printf("  %6.2f  %7.1f", gflop, gflop / full_us * 1e-3);
+            if (force) {   // phase stamps of the last full launch (workgroup in the middle of the grid)
+                run(getenv("STAMP_DBG") ? atoi(getenv("STAMP_DBG")) : 0);
+                CK(hipStreamSynchronize(s));
+                unsigned long long tk[32];
+                CK(hipMemcpy(tk, dticks, sizeof(tk), hipMemcpyDeviceToHost));
+                for (int w = 0; w < 2; ++w) {
+                    const unsigned long long* q = tk + 16 * w;
+                    const double ghz = (double)(q[2 * 4] - q[0]) / ((double)(q[2 * 4 + 1] - q[1]) * 10.0);
+                    printf("  [%s %.2f GHz us:", w ? "prod" : "cons", ghz);
+                    for (int i = 1; i <= 5; ++i) printf(" %.2f", (double)(q[2 * i + 1] - q[2 * i - 1]) * 0.01);
+                    printf(" | loop %.0f cyc @ %.2f GHz]", (double)(q[4] - q[2]), (double)(q[4] - q[2]) / ((double)(q[5] - q[3]) * 10.0));
+                }
+            }
             if (force) printf("  maxerr out %.3g raw %.3g (max |out| %.3g)", err_out, err_raw, mag);
             printf("\n");
             fflush(stdout);
