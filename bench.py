@@ -1,7 +1,13 @@
 #!/usr/bin/env python
 """bench.py -- the benchmarks of the CHORE field-query / fitting hot path on MI355X, one JSON line each.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode query|fit|train]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode all|query|fit|train]
+
+--mode all (default, what the driver runs): the line of --mode query (the K timed steps are query steps) and, measured after
+    the timed region by the same functions, the sub-records "fit" (metric 2) and "train" (metric 3), each with its own value,
+    roofline and cpu_baseline, plus query_fwd_bwd_points_per_s (metric 1(ii): forward + backward to the points).  With
+    N > 1 the "train" record is DDP over RCCL and carries the all-reduce share (a synced step against a no_sync() step);
+    the "fit" record is the frame-sharded fit (8 frames per GPU, one gather).
 
 --mode query (default; BASELINE.json metric 1, configs[1]): per GPU ONE STEP = HGFilters encode of 4 synthetic 512x512
     5-channel images + one 20 000-point MLP field query per image = `CHORE.filter(images); CHORE.query(points, crop_center)`
@@ -55,7 +61,10 @@ sys.path.insert(0, REPO)
 PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0}
 TNAME = {"bf16": "unsigned short", "fp32": "float", "fp16x3": "x3_t"}
 HEADS_FLOP_PER_POINT = 600832.0
-ENCODER_FLOP_PER_IMAGE = 258.25e9
+ENCODER_FLOP_PER_IMAGE = 258.25e9            # the reference graph (training: l, bl, al separate), SURVEY 8(d)
+# eval merges l / bl / al of stacks 0-3 into one 1x1 convolution (csrc/encoder.hip): 2 x 4 convolutions of
+# 2 * 256 * 256 * 128^2 FLOP per image are not executed
+ENCODER_FLOP_PER_IMAGE_EVAL = ENCODER_FLOP_PER_IMAGE - 8 * 2.0 * 256 * 256 * 128 * 128
 
 
 def chore_opt(dtype):
@@ -303,6 +312,23 @@ def mode_query(args, ctx):
                 other_modes[mode] = {"ms_per_step": t2, "value": B * N / t2 * 1e3, "unit": "points/s",
                                      "field_err": field_errors(net2.get_preds())["all"]}
                 del net2
+    # metric 1(ii): forward + backward to the points (the generator's projection step, recon/generator.py:50-79)
+    pg = points.clone().requires_grad_(True)
+
+    def fwd_bwd():
+        pg.grad = None
+        net.query(pg, crop_center=cc)
+        torch.clamp(net.get_preds()[0][:, 0], max=2.0).sum().backward()
+    for _ in range(3):
+        fwd_bwd()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fwd_bwd()
+    e1.record()
+    torch.cuda.synchronize()
+    fb_ms = e0.elapsed_time(e1) / 10
     out = None
     if rank == 0:
         kernels = {}
@@ -360,7 +386,9 @@ def mode_query(args, ctx):
                                            "4 x 768 points); stated tolerances: chore_amd/utils/field_check.py"})
         out.update({"roofline": roof, "other_modes": other_modes, "encode_ms": enc_ms, "query_ms": qry_ms,
                     "query_only_points_per_s": B * N / qry_ms * 1e3,
-                    "encode_tflops": B * ENCODER_FLOP_PER_IMAGE / enc_ms / 1e9, "kernels": kernels})
+                    "query_fwd_bwd_points_per_s": B * N / fb_ms * 1e3, "query_fwd_bwd_ms": fb_ms,
+                    "encode_tflops": B * ENCODER_FLOP_PER_IMAGE_EVAL / enc_ms / 1e9,
+                    "encode_flop_per_image": ENCODER_FLOP_PER_IMAGE_EVAL, "kernels": kernels})
         if ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_query()
             out["cpu_baseline_torch"] = cpu_baseline_query_torch()
@@ -446,10 +474,15 @@ def mode_fit(args, ctx):
         fwd_pts = 100 * 6890 + 50 * 6000 + 50 * 3000 + 100 * (6000 + 6890)
         bwd_pts = 100 * 6890 + 50 * 6000 + 100 * 6000
         flops = B * (fwd_pts + bwd_pts) * HEADS_FLOP_PER_POINT / 300
+        hd = "fp32" if args.dtype == "fp32" else "fp16x3"          # arithmetic of the heads (query kernels)
         out = base_line(args, ctx, "ms per fit iteration (SMPL-H LBS + field queries + loss terms + Adam; whole fit_recon chain run)",
                         iter_ms, "ms", elapsed, False, args.dtype,
-                        {"workload": "BASELINE configs[%d]: fit_recon chain on %d frame(s) per GPU, 300 Adam iterations = optimize_smpl "
-                                     "%s + optimize_smpl_object %s" % (2 if ctx.world == 1 else 4, B, SMPL_ITERS, OBJECT_ITERS),
+                        {"workload": "%s: fit_recon chain on %d frame(s) per GPU, 300 Adam iterations = optimize_smpl "
+                                     "%s + optimize_smpl_object %s" % (
+                                         "BASELINE configs[2]" if (ctx.world == 1 and B == 1) else
+                                         ("BASELINE configs[4] (64 frames on 8 GPUs)" if ctx.world * B == 64 else
+                                          "the per-GPU share of BASELINE configs[4] (8 frames per GPU)" if B == 8 else "frame-sharded fit"),
+                                         B, SMPL_ITERS, OBJECT_ITERS),
                          "frames_per_gpu": B, "frames": B * ctx.world, "adam_iterations_per_step": iters // max(args.steps, 1),
                          "inner_iteration": "eager" if args.eager else "hipGraph replay (chore_amd/recon/graph_step.py)",
                          "early_stop": "off (a fixed 300 iterations are timed)",
@@ -462,9 +495,13 @@ def mode_fit(args, ctx):
                     "frames_per_s_whole_chain": ctx.world * B * args.steps / elapsed,
                     "roofline": {"kernel": "whole fit iteration (field queries dominate: query_fwd_f32_kernel / query_bwd_f32_kernel, "
                                            "32-point tiles)", "bound": "mfma", "achieved": flops / iter_ms / 1e9,
-                                 "peak": PEAK_TFLOPS["fp32"], "unit": "TFLOP/s", "frac": flops / iter_ms / 1e9 / PEAK_TFLOPS["fp32"],
+                                 "peak": PEAK_TFLOPS[hd], "unit": "TFLOP/s", "frac": flops / iter_ms / 1e9 / PEAK_TFLOPS[hd],
+                                 "frac_of_fp32_mfma_peak": flops / iter_ms / 1e9 / PEAK_TFLOPS["fp32"],
                                  "traffic": None, "flops_per_iteration": flops,
-                                 "note": "algorithmic FLOPs of the heads only (600 832 per point forward, the same again backward)"},
+                                 "note": "algorithmic FLOPs of the heads only (600 832 per point forward, the same again backward) "
+                                         "against the peak of the unit the heads run on: the fp16 matrix cores with hi/lo split "
+                                         "operands (three MFMAs per product) unless the mode is fp32; a fit iteration is a chain "
+                                         "of ~30-60 small dependent launches, not a matrix-core workload"},
                     "gathered": {k: list(v.shape) for k, v in fitted.items()}})
         if ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_fit()
@@ -507,6 +544,13 @@ def mode_train(args, ctx):
         last["err"] = error
 
     elapsed = ctx.timed(step, args.steps, args.warmup)
+    nosync = None
+    if ctx.world > 1:
+        # the same steps without the gradient all-reduce: what the collective (and its overlap with the backward) costs
+        def step_nosync():
+            with model.no_sync():
+                step()
+        nosync = ctx.timed(step_nosync, args.steps, 1)
     out = None
     if rank == 0:
         flops = 3.0 * (B * ENCODER_FLOP_PER_IMAGE + 5 * B * N * HEADS_FLOP_PER_POINT)     # 3.82 TFLOP at B=4
@@ -517,6 +561,11 @@ def mode_train(args, ctx):
                          "images_per_gpu": B, "points_per_image": N, "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
                          "grad_allreduce": "torch DDP over RCCL (backend nccl), find_unused_parameters=True" if ctx.world > 1
                                            else "none (1 GPU)"})
+        if nosync is not None:
+            out["allreduce"] = {"ms_per_step_synced": ms, "ms_per_step_no_sync": nosync / args.steps * 1e3,
+                                "share_of_step": max(0.0, 1.0 - nosync / elapsed), "bytes_per_step": 4 * sum(p.numel() for p in net.parameters()),
+                                "how": "K steps under DistributedDataParallel.no_sync() against K synced steps (bucketed all-reduce "
+                                       "overlapped with the backward by torch DDP, RCCL over xGMI)"}
         out.update({"images_per_s": ctx.world * B * args.steps / elapsed, "final_loss": float(last["err"].detach()),
                     "parameters": sum(p.numel() for p in net.parameters()),
                     "roofline": {"kernel": "whole training step (all kernels)", "bound": "mfma", "achieved": flops / ms / 1e9,
@@ -527,12 +576,34 @@ def mode_train(args, ctx):
     return out
 
 
+def mode_all(args, ctx):
+    """the query line with the fit and training records inside (what the driver's one command measures)"""
+    import copy
+    out = mode_query(args, ctx)
+    subs = {}
+    for name, fn, over in (("fit", mode_fit, dict(steps=1, warmup=1, dtype="fp16x3", mode="fit")),
+                           ("train", mode_train, dict(steps=5, warmup=2, dtype="bf16", mode="train"))):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        if ctx.cuda:
+            torch.cuda.empty_cache()
+        subs[name] = fn(a, ctx)
+    if ctx.rank == 0:
+        for name, rec in subs.items():
+            out[name] = {k: rec[k] for k in rec if k not in ("n_gpus", "data", "scaling", "vs_baseline")}
+        out["records"] = {"fit": "BASELINE metric 2 (ms per fit iteration), configs[2] / configs[4]: same function as --mode fit, 1 step after "
+                                 "1 warm-up chain", "train": "BASELINE metric 3 (training steps/s), configs[3]: same function as --mode train, "
+                                                             "5 steps after 2 warm-up steps"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--mode", default="query", choices=["query", "fit", "train"])
+    ap.add_argument("--mode", default="all", choices=["all", "query", "fit", "train"])
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16x3"],
                     help="default: fp16x3 for query / fit (meets the 1e-4 field tolerance), bf16 for train")
     ap.add_argument("--batch", type=int, default=4)
@@ -542,7 +613,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()
-    defaults = {"query": (20, 5), "fit": (3, 1), "train": (10, 3)}[args.mode]
+    defaults = {"all": (20, 5), "query": (20, 5), "fit": (3, 1), "train": (10, 3)}[args.mode]
     if args.dtype is None:
         args.dtype = "bf16" if args.mode == "train" else "fp16x3"
     args.steps = defaults[0] if args.steps is None else args.steps
@@ -554,13 +625,23 @@ def main():
         # the distributed skeleton without the device work: used by the CPU test of the N > 1 launch path
         elapsed = ctx.timed(lambda: time.sleep(0.001 * (1 + ctx.rank)), args.steps, args.warmup)
         if ctx.rank == 0:
-            print(json.dumps(base_line(args, ctx, "dry run", args.steps / elapsed, "steps/s", elapsed, True, "none",
-                                       {"workload": "dry run (no device work)"})), flush=True)
+            line = base_line(args, ctx, "dry run", args.steps / elapsed, "steps/s", elapsed, True, "none",
+                             {"workload": "dry run (no device work)"})
+            if args.mode == "all":      # the shape of the real line: the sub-records and their keys (tests/test_bench_launch.py)
+                sub = {"metric": "dry run", "value": 0.0, "unit": "-", "steps": 0, "warmup": 0, "ms_per_step": 0.0,
+                       "higher_is_better": True, "dtype": "none", "config": {"workload": "dry run"},
+                       "roofline": {"bound": "mfma", "achieved": 0.0, "peak": 1.0, "unit": "TFLOP/s", "frac": 0.0, "traffic": None},
+                       "cpu_baseline": {"value": 0.0, "unit": "-", "cores": 0, "kind": "port", "sample": "dry run"}}
+                line.update({"roofline": dict(sub["roofline"]), "cpu_baseline": dict(sub["cpu_baseline"]), "fit": dict(sub),
+                             "train": dict(sub), "query_fwd_bwd_points_per_s": 0.0})
+                if ctx.world > 1:
+                    line["train"]["allreduce"] = {"ms_per_step_synced": 0.0, "ms_per_step_no_sync": 0.0, "share_of_step": 0.0}
+            print(json.dumps(line), flush=True)
         ctx.close()
         return
     if not ctx.cuda:
         raise SystemExit("bench.py needs a GPU (there is no CPU path); --dry-run exercises the launch skeleton only")
-    out = {"query": mode_query, "fit": mode_fit, "train": mode_train}[args.mode](args, ctx)
+    out = {"all": mode_all, "query": mode_query, "fit": mode_fit, "train": mode_train}[args.mode](args, ctx)
     if ctx.rank == 0:
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -22,3 +22,37 @@ def test_bench_self_launch_two_ranks():
         assert k in d, k
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["ms_per_step"] >= 2.0       # MAX over ranks: rank 1 sleeps 2 ms per step
+
+
+SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "dtype", "config", "roofline")
+ROOF_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic")
+
+
+def _check_all_schema(d, world):
+    """the schema of the default (--mode all) line: the query record with the fit and train records inside"""
+    for k in ROOF_KEYS:
+        assert k in d["roofline"], k
+    assert "query_fwd_bwd_points_per_s" in d
+    for name in ("fit", "train"):
+        sub = d[name]
+        for k in SUB_KEYS:
+            assert k in sub, (name, k)
+        for k in ROOF_KEYS:
+            assert k in sub["roofline"], (name, k)
+        if world == 1:
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in sub["cpu_baseline"], (name, k)
+    if world > 1:       # a SCALE run measures a collective: the training record carries the all-reduce share
+        for k in ("ms_per_step_synced", "ms_per_step_no_sync", "share_of_step"):
+            assert k in d["train"]["allreduce"], k
+
+
+def test_default_mode_schema_one_and_two_ranks():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for world in (1, 2):
+        out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", str(world), "--dry-run", "--steps", "2",
+                              "--warmup", "1"], capture_output=True, text=True, timeout=300, env=env, cwd=REPO)
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        _check_all_schema(json.loads(lines[0]), world)
