@@ -14,8 +14,9 @@
 //     and every lane tests only those whose box meets the tile.  No list, no dropped faces, the winner is the
 //     smallest depth and, among equal depths, the smallest triangle index: deterministic.
 //     (5 000 triangles x 65 536 pixels is 0.3 G box tests per image: ~20 us.)
-//   * the backward keeps the reference's one-thread-per-triangle walk (its sum order is part of the result) and
-//     reads the alpha / gradient images through a per-image row pointer.
+//   * the backward walks the same edges over the same pixels as the reference (which gives a triangle to ONE thread), but
+//     a workgroup owns a triangle, a wave one (edge, axis) walk and a lane one edge position, eight pixels of a scan line
+//     in flight; the per-vertex sums are combined by a fixed butterfly, so the result is deterministic.
 // Degenerate edges (a zero denominator makes the crossing coordinate non-finite) are skipped, like the
 // restatement in oracle/silhouette.py does; with real-valued vertices they have measure zero.
 #include "common.h"

@@ -18,6 +18,7 @@ import torch.nn as nn
 
 from .const import BODY_POSE_NUM, GLOBAL_POSE_NUM, HAND_POSE_NUM, SMPL_HAND_POSE_NUM, TOP_BETA_NUM
 from .smpl_layer import SMPL_Layer
+from ..utils.paths import SMPL_ASSETS_ROOT, SMPL_MODEL_ROOT  # noqa: F401  (lib_smpl/smpl_generator.py:15 imports both from here)
 
 
 def _as_layer(model, gender="male", num_betas=10):

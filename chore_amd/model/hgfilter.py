@@ -100,7 +100,6 @@ class HGFilter(_Params):
                 self.add_module(f"bl{i}", _conv(256, 256, 1, True))
                 self.add_module(f"al{i}", _conv(hd, 256, 1, True))
         self._packed = {}  # dtype -> (version key, arena tensor)
-        self._plist = None
         self._work = {}    # (B,H,W,dtype) -> workspace tensor
 
     # ---------------------------------------------------------------------------------------
@@ -112,14 +111,14 @@ class HGFilter(_Params):
         """(storage address, version counter) of every parameter: an in-place update, a swapped tensor or a moved module
         all change it.  A write through `p.data` (EMA / averaging code, nn.init on .data) bumps no version counter and
         is invisible here -- call invalidate_packed() after such writes (load_state_dict and .to() do it themselves)."""
-        if self._plist is None:
-            self._plist = list(self.parameters())
-        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self._plist)
+        # the live parameter list, every call (~0.1 ms for the 486 tensors): a REPLACED Parameter object (m.weight =
+        # nn.Parameter(...), load_state_dict(assign=True) through an outer wrapper, a parametrization) is a different
+        # tensor with another address, so it changes the key; a cached list would keep looking at the old object
+        return (str(device),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def invalidate_packed(self):
         """forget the repacked (MFMA-fragment order) copies of the weights; the next forward packs again"""
         self._packed = {}
-        self._plist = None
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)

@@ -15,6 +15,7 @@ and the openpose json (:305-320).  The device path needs none of that I/O: the f
 """
 import json
 import os
+import zlib
 import pickle as pkl
 
 import numpy as np
@@ -300,11 +301,11 @@ class SyntheticAssets(FitAssets):
     def load_mocap(self, file):
         if file in self._mocap:
             return self._mocap[file]
-        rs = np.random.RandomState(abs(hash(os.path.basename(os.path.dirname(file)))) % (2 ** 31))
+        rs = np.random.RandomState(zlib.crc32(os.path.basename(os.path.dirname(file)).encode()) & 0x7fffffff)   # stable across processes (str hashes are salted)
         return rs.standard_normal(72) * 0.2, rs.standard_normal(10) * 0.5
 
     def load_kpts(self, file):
         if file in self._kpts:
             return self._kpts[file]
-        rs = np.random.RandomState(abs(hash(file)) % (2 ** 31))
+        rs = np.random.RandomState(zlib.crc32(file.encode()) & 0x7fffffff)
         return np.concatenate([rs.uniform(300, 1700, (25, 2)), rs.uniform(0, 1, (25, 1))], -1)

@@ -19,6 +19,7 @@ from ..lib_smpl.const import SMPL_PARTS_NUM, SMPL_POSE_PRAMS_NUM  # noqa: F401
 from ..lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatchSplitParams
 from ..model.camera import KinectColorCamera
 from . import fit_terms
+from ..utils.paths import BEHAVE_PATH, RECON_PATH, SMPL_ASSETS_ROOT  # noqa: F401  (names the reference's scripts import from here, recon_fit_base.py:39-45)
 
 
 # 14 body-part colours of the visualisations (recon/opt_utils.py:13-28)
@@ -176,7 +177,7 @@ def sample_surface(verts, faces, count, rs):
 
 
 class ReconFitterBase:
-    def __init__(self, seq_folder=None, device="cuda:0", debug=False, obj_name=None, outpath=None, args=None,
+    def __init__(self, seq_folder=None, device="cuda:0", debug=False, obj_name=None, outpath=RECON_PATH, args=None,
                  assets=None):
         """the reference's argument list (recon_fit_base.py:48-52) + `assets`: where the files it reads come from
         (recon/assets.py; default: the folders of ./PATHS.yml like the reference).  Everything loaded here -- template

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
 from . import fit_terms
 from .graph_step import EagerStep, GraphedStep
-from .recon_fit_base import ReconFitterBase
+from .recon_fit_base import RECON_PATH, ReconFitterBase  # noqa: F401  (recon_fit_coco.py:15 imports RECON_PATH from here)
 
 
 class ReconFitterBehave(ReconFitterBase):

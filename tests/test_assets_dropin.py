@@ -106,8 +106,13 @@ def test_dropin_aliases_resolve_from_a_reference_checkout():
     still come from the checkout (config.config_loader)"""
     code = ("import chore_amd.dropin as d; d.install(); "
             "from model import CHORE; from model.camera import KinectColorCamera; from recon.generator import Generator; "
-            "from recon.recon_fit_base import ReconFitterBase; from recon.recon_fit_behave import ReconFitterBehave, recon_fit; "
-            "from lib_smpl.const import SMPL_POSE_PRAMS_NUM; from lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch; "
+            "from recon.recon_fit_base import ReconFitterBase, RECON_PATH, BEHAVE_PATH, SMPL_ASSETS_ROOT; "
+            "from recon.recon_fit_behave import ReconFitterBehave, recon_fit, RECON_PATH as RP2; "
+            "from recon.recon_fit_coco import ReconFitterCoco; "
+            "from lib_smpl.const import SMPL_POSE_PRAMS_NUM; "
+            "from lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch, SMPL_MODEL_ROOT, SMPL_ASSETS_ROOT as SA2; "
+            "import inspect; assert RECON_PATH == RP2 and RECON_PATH is not None and SMPL_ASSETS_ROOT == 'assets' == SA2; "
+            "assert inspect.signature(ReconFitterBase.__init__).parameters['outpath'].default == RECON_PATH; "
             "import config.config_loader as cl; "
             "print(CHORE.__module__, Generator.__module__, ReconFitterBase.__module__, cl.__file__)")
     env = dict(os.environ, PYTHONPATH=REPO)
