@@ -26,5 +26,5 @@ for k in sorted(set(f) | set(w)):
     out[k] = {"launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 for k, v in out.items():
-    if "conv_lds" in k or "map_stats" in k or "stem" in k or "query" in k:
+    if "conv_" in k or "map_stats" in k or "stem" in k or "query" in k:
         print("%-70s n=%4d read %8.2f MB write %8.2f MB" % (k[:70], v["launches"], v["read_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))

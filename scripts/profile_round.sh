@@ -13,11 +13,11 @@ repo=$(pwd)
 out=$repo/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-timeout 600 python bench.py --dtype $dt --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
+timeout 900 python bench.py --steps 20 --warmup 5 > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 cd /tmp
 rm -rf /tmp/prof_$tag /tmp/profs_$tag
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag --output-format csv -- \
-    python $repo/bench.py --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
+    python $repo/bench.py --mode query --dtype $dt --steps 10 --warmup 3 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof.err
 f=$(find /tmp/prof_$tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/${tag}_kernel_stats.csv
 f=$(find /tmp/prof_$tag -name "*kernel_trace.csv" | head -1)
 [ -n "$f" ] && python $repo/scripts/prof_summary.py $f 60 > $out/${tag}_kernel_trace_summary.txt
@@ -36,3 +36,5 @@ for pmc in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_
     [ -n "$f" ] && python $repo/scripts/pmc_summary.py $f > $out/${tag}_pmc_pass$i.txt
 done
 cd $repo
+# HBM-side traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE) of every kernel -> what bench.py's roofline.traffic reads
+[ -f $out/${tag}_pmc_pass1.txt ] && [ -f $out/${tag}_pmc_pass2.txt ] && python scripts/pmc_traffic.py $out/${tag}_pmc_pass1.txt $out/${tag}_pmc_pass2.txt $out/pmc_traffic_${dt}.json > $out/${tag}_pmc_traffic_summary.txt
