@@ -58,8 +58,8 @@ sys.path.insert(0, REPO)
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md.  fp16x3 issues three fp16 MFMAs per algorithmic product: its
 # algorithmic FLOPs are priced against the full fp16 peak (a kernel doing nothing but MFMAs would show frac = 1/3)
-PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0}
-TNAME = {"bf16": "unsigned short", "fp32": "float", "fp16x3": "x3_t"}
+PEAK_TFLOPS = {"bf16": 2500.0, "fp32": 157.3, "fp16x3": 2500.0, "fp16": 2500.0}
+TNAME = {"bf16": "unsigned short", "fp32": "float", "fp16x3": "x3_t", "fp16": "h16_t"}
 HEADS_FLOP_PER_POINT = 600832.0
 ENCODER_FLOP_PER_IMAGE = 258.25e9            # the reference graph (training: l, bl, al separate), SURVEY 8(d)
 # eval merges l / bl / al of stacks 0-3 into one 1x1 convolution (csrc/encoder.hip): 2 x 4 convolutions of
@@ -302,7 +302,7 @@ def mode_query(args, ctx):
         if rank == 0 and B == 4 and N == 20000:
             step()
             field_err = field_errors(net.get_preds())
-            for mode in ("bf16", "fp16x3", "fp32"):
+            for mode in ("fp16", "bf16", "fp16x3", "fp32"):
                 if mode == args.dtype:
                     continue
                 net2, _, _, _, step2 = make(mode, 0)
@@ -347,8 +347,8 @@ def mode_query(args, ctx):
             traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
         # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
         # 32-point tiles when 64-point tiles would not fill the CUs)
-        x3 = args.dtype in ("fp16x3", "bf16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)
-        qt = "float" if args.dtype == "fp16x3" else tname
+        x3 = args.dtype in ("fp16x3", "bf16", "fp16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)
+        qt = "float" if args.dtype == "fp16x3" else ("qh16_t" if args.dtype == "fp16" else tname)
         if B * ((N + 63) // 64) <= 256:
             qname = "query_fwd_f32_kernel<%s, 1, false, %s>" % (qt, "true" if x3 else "false")
         elif x3:        # fp16 x 3 heads: four waves, two column blocks each (the eight-wave kernel is bound by the L1 there)
@@ -376,6 +376,8 @@ def mode_query(args, ctx):
                                                  "split operands, fp32 accumulation (fp32-grade: meets the 1e-4 field tolerance); "
                                                  "BASELINE names bf16 for this config -- that mode is in other_modes with its error",
                                        "bf16": "bf16 feature maps and MFMA operands in the encoder, fp32 accumulation (a 1e-2 mode); heads fp32-grade",
+                                       "fp16": "IEEE half feature maps (BASELINE configs[4]'s 'fp16 fields'); convolutions as two fp16 MFMAs per "
+                                               "product (activation x weight hi, lo), fp32 accumulation (a 1e-3 mode); heads fp32-grade",
                                        "fp32": "fp32 tensors, native fp32 MFMA"}[args.dtype],
                          "images_per_gpu": B, "points_per_image": N, "image": "512x512x5",
                          "heads_dtype": "fp32 results on the fp16 matrix cores, hi/lo split operands" if args.dtype != "fp32"
@@ -604,7 +606,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="all", choices=["all", "query", "fit", "train"])
-    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16x3"],
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16x3", "fp16"],
                     help="default: fp16x3 for query / fit (meets the 1e-4 field tolerance), bf16 for train")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--points", type=int, default=20000)

@@ -15,7 +15,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_siz
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
 
-F32, BF16, F16X3 = 0, 1, 2
+F32, BF16, F16X3, F16 = 0, 1, 2, 3
 HEADS_X3 = 0x100      # OR into a query dtype: heads on the fp16 matrix cores with split operands (include/chore_hip.h)
 
 

@@ -105,13 +105,32 @@ static void nan_scan(const float* p, size_t n, int slot, hipStream_t s) {
     static unsigned seq = 0;
     if (p && n) hipLaunchKernelGGL(nan_scan_kernel, dim3(64), dim3(256), 0, s, p, n, slot, ++seq);
 }
+// ---- CHORE_LDS_POISON (common.h) ----
+__global__ __launch_bounds__(1024) void lds_poison_kernel(unsigned pattern) {
+    extern __shared__ unsigned lds_poison_mem[];
+    for (int i = threadIdx.x; i < 160 * 1024 / 4; i += 1024) lds_poison_mem[i] = pattern;
+    __syncthreads();
+    if (lds_poison_mem[(threadIdx.x * 37) % (160 * 256)] != pattern) __builtin_trap();   // keeps the stores
+}
+void chore_lds_poison(hipStream_t s, const char* file, int line) {
+    static const unsigned pattern = (unsigned)strtoul(getenv("CHORE_LDS_POISON"), nullptr, 0) ? (unsigned)strtoul(getenv("CHORE_LDS_POISON"), nullptr, 0) : 0x7fc00000u;
+    static const char* only = getenv("CHORE_LDS_POISON_FILE");
+    static const int lo = getenv("CHORE_LDS_POISON_LINE_LO") ? atoi(getenv("CHORE_LDS_POISON_LINE_LO")) : 0;
+    static const int hi = getenv("CHORE_LDS_POISON_LINE_HI") ? atoi(getenv("CHORE_LDS_POISON_LINE_HI")) : 1 << 30;
+    if (only && !strstr(file, only)) return;
+    if (line < lo || line > hi) return;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)lds_poison_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(512), dim3(1024), 160 * 1024, s, pattern);      // one 160 KB workgroup per CU, twice over
+}
+
 extern "C" int chore_debug_nan_counts(unsigned* out32) {
     return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_nan_counts), sizeof(unsigned) * 32) == hipSuccess ? 0 : -2;
 }
 
 // split a query dtype into the map type and the heads mode (include/chore_hip.h: CHORE_HEADS_X3)
 static inline bool query_x3(int& dtype) {
-    const bool x3 = dtype == CHORE_F16X3 || (dtype & CHORE_HEADS_X3);
+    const bool x3 = dtype == CHORE_F16X3 || dtype == CHORE_F16 || (dtype & CHORE_HEADS_X3);      // fp16 maps: always with these heads
     dtype = dtype == CHORE_F16X3 ? CHORE_F32 : (dtype & ~CHORE_HEADS_X3);
     return x3;
 }
@@ -123,7 +142,7 @@ static int fill_query_args(chore_handle* h, QueryArgs& a, const float* points, c
         CHORE_FAIL(h, CHORE_EINVAL, "query: null argument");
     if (B <= 0 || N <= 0 || FH < 2 || FW < 2 || TH < 2 || TW < 2) CHORE_FAIL(h, CHORE_EINVAL, "query: bad shape");
     if (B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "query: B > 65535");
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "query: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "query: bad dtype");
     memset(&a, 0, sizeof(a));
     a.points = points; a.crop_center = crop_center; a.B = B; a.N = N;
     a.feat = feat; a.FH = FH; a.FW = FW; a.tmpx = tmpx; a.TH = TH; a.TW = TW;
@@ -166,6 +185,7 @@ int chore_sample_features(chore_handle* h, const float* points, const float* cro
                           chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!features) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: null output");
+    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: fp16 maps are an inference mode (chore_query_fwd)");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, feat /*unused*/,
                              cam6_host);
@@ -244,6 +264,7 @@ int chore_query_fwd_train(chore_handle* h, const float* points, const float* cro
                           float* centers, uint8_t* in_img, void* staging, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers || !staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: null output");
+    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: fp16 maps are an inference mode");
     QueryArgs a;
     const bool x3 = query_x3(dtype);
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
@@ -262,6 +283,7 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
                           int have_forward, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
+    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: fp16 maps are an inference mode");
     QueryArgs a;
     const bool x3 = query_x3(dtype);
     if (x3 && !have_forward) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: the fp16 x 3 heads need the staged forward");

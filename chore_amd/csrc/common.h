@@ -65,9 +65,20 @@ inline bool chore_debug_sync() {
     static const bool v = getenv("CHORE_DEBUG_SYNC") != nullptr;
     return v;
 }
+// CHORE_LDS_POISON=<pattern>: after EVERY kernel launch of the library a kernel fills the LDS of every CU with a bit pattern
+// (default: quiet NaNs).  LDS keeps what the previous workgroup on the CU left there, so a kernel that reads LDS it has not
+// written gives results that depend on what ran before it -- on a GPU shared with another process that is another
+// process's data, and runs stop reproducing.  With the poison such a read shows up as a NaN (or a changed result) in a
+// single process.  CHORE_LDS_POISON_FILE / _LINE_LO / _LINE_HI restrict the poison to launch sites (bisection).
+extern "C" void chore_lds_poison(hipStream_t s, const char* file, int line);
+inline bool chore_lds_poison_on() {
+    static const bool v = getenv("CHORE_LDS_POISON") != nullptr;
+    return v;
+}
 #define CHORE_LAUNCH_CHECK(h, stream)                                                         \
     do {                                                                                      \
         CHORE_HIP_CHECK(h, hipGetLastError());                                                \
+        if (chore_lds_poison_on()) chore_lds_poison(stream, __FILE__, __LINE__);              \
         if (chore_debug_sync()) {                                                             \
             fprintf(stderr, "[chore] launched at %s:%d\n", __FILE__, __LINE__);               \
             CHORE_HIP_CHECK(h, hipStreamSynchronize(stream));                                 \

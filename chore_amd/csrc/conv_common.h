@@ -115,4 +115,16 @@ template <> __device__ __forceinline__ void store8<bf16_t>(bf16_t* p, float (&v)
     *(u32x4*)p = o;
 }
 
+template <> __device__ __forceinline__ void load8<h16_t>(const h16_t* p, float (&v)[8]) {
+    const f16x8_t a = *(const f16x8_t*)p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (float)a[j];
+}
+template <> __device__ __forceinline__ void store8<h16_t>(h16_t* p, float (&v)[8]) {
+    f16x8_t o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o[j] = (_Float16)v[j]; v[j] = (float)o[j]; }
+    *(f16x8_t*)p = o;
+}
+
 }  // namespace conv_detail

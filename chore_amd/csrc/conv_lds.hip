@@ -552,7 +552,7 @@ ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) 
 
 int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipStream_t s) {
     const int cc = dtype == CHORE_F32 ? 16 : 32;
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "conv: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "conv: bad dtype");
     if (a_in.in.C % cc || a_in.in.C > 256) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cin=%d", a_in.in.C);
     if (a_in.Cout % 32) CHORE_FAIL(h, CHORE_EINVAL, "conv: unsupported Cout=%d", a_in.Cout);
     if (a_in.B > 65535) CHORE_FAIL(h, CHORE_EINVAL, "conv: B too large");
@@ -562,10 +562,15 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
-    if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
+    if (dtype != CHORE_F16 && conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
+    if (dtype == CHORE_F16) {   // fp16 tensors: the specialised-wave kernel is the only implementation
+        const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+        if (!pp.th || a_in.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv: layer not covered in the fp16 mode (Cin=%d Cout=%d)", a_in.in.C, a_in.Cout);
+        return launch_conv_pc(h, dtype, taps, pp, a_in, s);
+    }
     if (dtype == CHORE_F16X3 && !a_in.res2.p && conv_use_pc()) {   // specialised-wave kernel (conv_pc.hip)
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
-        if (pp.th) return launch_conv_pc(h, taps, pp, a_in, s);
+        if (pp.th) return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }
     ConvArgs a = a_in;
 #if CHORE_CONV_ABLATE
@@ -588,7 +593,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
 // ------------------------------------------------------------------------------------------------
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout) {
     const int kge = dtype == CHORE_F32 ? 8 : 16;
-    return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024 * (dtype == CHORE_F16X3 ? 2 : 1);   // fp16 x 3: hi plane + lo plane
+    return (size_t)taps * (Cin / kge) * (Cout / 32) * 1024 * ((dtype == CHORE_F16X3 || dtype == CHORE_F16) ? 2 : 1);   // fp16 x 3 / fp16: hi plane + lo plane
 }
 
 // transposed = 1 packs the weights of the DATA-GRADIENT convolution of a layer whose forward weights are
@@ -663,13 +668,13 @@ __global__ void pack_conv_multi_kernel(PackJobs j) {
 int launch_pack_conv_multi(chore_handle* h, int dtype, PackJobs& j, hipStream_t s) {
     unsigned blocks = 0;
     for (int k = 0; k < j.n; ++k) {
-        j.job[k].nvec = packed_conv_bytes(dtype, j.job[k].taps, j.job[k].Cin, j.job[k].Cout) / 16 / (dtype == CHORE_F16X3 ? 2 : 1);
+        j.job[k].nvec = packed_conv_bytes(dtype, j.job[k].taps, j.job[k].Cin, j.job[k].Cout) / 16 / ((dtype == CHORE_F16X3 || dtype == CHORE_F16) ? 2 : 1);
         j.job[k].blocks = (unsigned)((j.job[k].nvec + 255) / 256);
         blocks += j.job[k].blocks;
     }
     blocks += (unsigned)((j.zero_vecs + 255) / 256);
     if (!blocks) return CHORE_OK;
-    if (dtype == CHORE_F16X3) hipLaunchKernelGGL(pack_conv_multi_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, j);
+    if (dtype == CHORE_F16X3 || dtype == CHORE_F16) hipLaunchKernelGGL(pack_conv_multi_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, j);
     else if (dtype == CHORE_F32) hipLaunchKernelGGL(pack_conv_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, j);
     else hipLaunchKernelGGL(pack_conv_multi_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, j);
     CHORE_LAUNCH_CHECK(h, s);
@@ -678,9 +683,10 @@ int launch_pack_conv_multi(chore_handle* h, int dtype, PackJobs& j, hipStream_t 
 
 int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, const float* w, void* dst,
                      hipStream_t s, int transposed) {
-    const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16 / (dtype == CHORE_F16X3 ? 2 : 1);   // per plane
+    const bool two_planes = dtype == CHORE_F16X3 || dtype == CHORE_F16;      // the fp16 mode reads the fp16 x 3 weight format
+    const size_t nvec = packed_conv_bytes(dtype, taps, Cin, Cout) / 16 / (two_planes ? 2 : 1);   // per plane
     const unsigned blocks = (unsigned)((nvec + 255) / 256);
-    if (dtype == CHORE_F16X3)
+    if (two_planes)
         hipLaunchKernelGGL(pack_conv_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, taps, Cin, Cout, w, (u32x4*)dst, nvec,
                            transposed);
     else if (dtype == CHORE_F32)

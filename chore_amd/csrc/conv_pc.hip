@@ -34,11 +34,11 @@ namespace {
 constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
 
 // TH rows x 32 pixels x NT channels; K-step = TPS taps of one 32-channel chunk
-template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_> struct PGeo {
+template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_ = true> struct PGeo {
     static constexpr int TH = TH_, NT = NT_, TPS = TPS_, NSLOT = NSLOT_;   // NSLOT: K-steps of weights resident in the LDS ring
     static constexpr int PAD = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = PTW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
-    static constexpr int RB = 144;                                  // LDS patch row: 64 B hi + 64 B lo + 16 B pad (9 slots: odd)
+    static constexpr int RB = X3_ ? 144 : 80;                       // LDS patch row: 64 B hi [+ 64 B lo] + 16 B pad (9 / 5 slots: odd)
     static constexpr int PATCHB = ROWS * RB;
     static constexpr int KROWS = TAPS / TPS;                        // K-steps per chunk
     static constexpr int NB = NT / 32;
@@ -83,8 +83,13 @@ __device__ __forceinline__ void wg_barrier() {
 
 template <typename T, int TAPS, int TH_, int NT_, int TPS_, int NSLOT_>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
-    static_assert(IS_X3<T>, "conv_pc_kernel: fp16 x 3 operands");
-    using G = PGeo<TAPS, TH_, NT_, TPS_, NSLOT_>;
+    // T = x3_t: fp32 tensors, activations split into fp16 hi + lo while they are staged, three MFMAs per product;
+    // T = h16_t ("fp16 fields"): fp16 tensors, one activation plane, two MFMAs per product (a * w_lo, a * w_hi)
+    static_assert(IS_X3<T> || IS_H16<T>, "conv_pc_kernel: fp16 x 3 or fp16 operands");
+    constexpr bool X3 = IS_X3<T>;
+    using ST = typename std::conditional<X3, float, unsigned short>::type;     // element type in memory
+    constexpr int LVI = X3 ? 2 : 1;                     // 16-byte loads per 8 channels
+    using G = PGeo<TAPS, TH_, NT_, TPS_, NSLOT_, X3>;
     constexpr int NSLOT = G::NSLOT;
     constexpr int TH = G::TH, NT = G::NT, TPS = G::TPS, PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, RB = G::RB;
     constexpr int PATCHB = G::PATCHB, KROWS = G::KROWS, SB1 = G::SB1, SBYTES = G::SBYTES;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     const int NKG = Cin / KGE, NB = a.Cout / 32;
     const int NCH = Cin / CC;
     const int S = NCH * KROWS;
-    const float* in_b = (const float*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
+    const ST* in_b = (const ST*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
 
     const int crot = (tile * 5 + n_tile * 3) % NCH;
     auto chunk_of = [&](int ci) -> int { int x = ci + crot; return x >= NCH ? x - NCH : x; };
@@ -152,12 +157,12 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         return ok ? (y * a.W + x) * a.in.cs : -1;
     };
     // one staging task: 8 fp32 channels of one patch row -> GroupNorm + ReLU -> fp16 hi / lo -> LDS
-    auto load_task = [&](u32x4 (&r)[2], int off, int c0, int v) {
+    auto load_task = [&](u32x4 (&r)[LVI], int off, int c0, int v) {
         const u32x4* p = (const u32x4*)(in_b + (off >= 0 ? off : 0) + c0 + v * 8);
-        r[0] = p[0];
-        r[1] = p[1];
+#pragma unroll
+        for (int k = 0; k < LVI; ++k) r[k] = p[k];
     };
-    auto put_task = [&](const u32x4 (&r)[2], int off, int c0, int row, int v, int pbuf) {
+    auto put_task = [&](const u32x4 (&r)[LVI], int off, int c0, int row, int v, int pbuf) {
         float sc[8], sh[8];
         {   // (scale, shift) pairs of the 8 channels: 64 contiguous bytes
             const f32x4* q = (const f32x4*)(ss_lds + (c0 + v * 8) * 2);
@@ -168,10 +173,26 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             }
         }
         u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
-        if (off >= 0) xform_x3(r[0], r[1], sc, sh, use_gn, hi, lo);
         char* d = patch + pbuf * PATCHB + row * RB + v * 16;
-        *(u32x4*)d = hi;
-        *(u32x4*)(d + 64) = lo;
+        if constexpr (X3) {
+            if (off >= 0) xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo);
+            *(u32x4*)d = hi;
+            *(u32x4*)(d + 64) = lo;
+        } else {
+            if (off >= 0) {
+                if (use_gn) {   // relu(x * scale + shift) in fp32, rounded to fp16 once
+                    const f16x8_t x = __builtin_bit_cast(f16x8_t, r[0]);
+                    f16x8_t y;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = fmaf((float)x[j], sc[j], sh[j]);
+                        y[j] = (_Float16)(t > 0.f ? t : 0.f);
+                    }
+                    hi = __builtin_bit_cast(u32x4, y);
+                } else hi = r[0];
+            }
+            *(u32x4*)d = hi;
+        }
     };
 
     // weight slice of K-step (chunk c, kernel row krow): [plane][t][kg][nb][lane] vectors
@@ -203,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     };
 
     // ---------------- prologue: everybody stages chunk 0; producers fetch the first weights ----------------
-    u32x4 p0[NVP0][2];
+    u32x4 p0[NVP0][LVI];
     int off0[NVP0];
 #pragma unroll
     for (int j = 0; j < NVP0; ++j) {
@@ -238,8 +259,8 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     const int g8 = tid % G8;
     const int nv = n_tile * NT + g8 * 8;                        // this thread's 8 channels
     const size_t img = (size_t)b * a.H * a.W;
-    const float* res_p = a.res.p ? (const float*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
-    u32x4 rq[NU][2];
+    const ST* res_p = a.res.p ? (const ST*)a.res.p + img * a.res.cs + a.res.co + nv : nullptr;
+    u32x4 rq[NU][LVI];
     auto fetch_res = [&]() {
 #pragma unroll
         for (int j = 0; j < NU; ++j) {
@@ -249,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             const size_t pix = (size_t)y * a.W + x;
             const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < LVI; ++k) {
                 rq[j][k] = (res_p && ok) ? *((const u32x4*)(res_p + pix * a.res.cs) + k) : z;
             }
         }
@@ -272,10 +293,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         // arithmetic of the split, LDS writes) hides behind the ring, only its throughput counts.
         // The global loads of both are issued U steps before their use, one register set per position in the unrolled loop.
         constexpr int U = KROWS > 1 ? KROWS : 2;
-        u32x4 pset[U][RPS][2], wset[U][SBV];
+        u32x4 pset[U][RPS][LVI], wset[U][SBV];
         int oset[U][RPS];
         unsigned done_seen = 0;
-        auto load_part = [&](u32x4 (&pr)[RPS][2], int (&po)[RPS], int s) {
+        auto load_part = [&](u32x4 (&pr)[RPS][LVI], int (&po)[RPS], int s) {
             const int c0 = chunk_of(s / KROWS + 1) * CC, krow = s % KROWS;
 #pragma unroll
             for (int j = 0; j < RPS; ++j) {
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 load_task(pr[j], po[j], c0, i & 3);
             }
         };
-        auto put_part = [&](const u32x4 (&pr)[RPS][2], const int (&po)[RPS], int s) {
+        auto put_part = [&](const u32x4 (&pr)[RPS][LVI], const int (&po)[RPS], int s) {
             const int cn = s / KROWS + 1, krow = s % KROWS;
             const int c0 = chunk_of(cn) * CC;
 #pragma unroll
@@ -296,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         };
         // steady state without branches around LOADS (a branch makes the compiler's vmcnt bookkeeping give up and wait for
         // everything in flight): indices past the end are clamped, the redundant loads are never used
-        auto stage_step = [&](int s, u32x4 (&ps)[RPS][2], int (&po)[RPS], u32x4 (&ws)[SBV]) {
+        auto stage_step = [&](int s, u32x4 (&ps)[RPS][LVI], int (&po)[RPS], u32x4 (&ws)[SBV]) {
             if (done_seen < (unsigned)s) {     // every consumer wave has left K-step s - 1
                 do { done_seen = sem_min(sem_done); if (done_seen >= (unsigned)s) break; __builtin_amdgcn_s_sleep(1); } while (true);
                 asm volatile("" ::: "memory");
@@ -361,14 +382,16 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             if (PDBG(a) & 128) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+            if constexpr (X3) {
 #pragma unroll
-            for (int m = 0; m < MB; ++m) afl[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + 64 + kg * 32);
+                for (int m = 0; m < MB; ++m) afl[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + 64 + kg * 32);
+            }
 #pragma unroll
             for (int m = 0; m < MB; ++m) af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + kg * 32);
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bfl[fs][q] = *(const u32x4*)(bs + SB1 + ((t * KGC + kg) * (NT / 32) + q) * 1024);
         };
-        constexpr int NRD = 2 * (MB + NBW), NMF = 3 * MB * NBW;     // LDS reads / MFMAs of one k-step
+        constexpr int NRD = (X3 ? 2 : 1) * MB + 2 * NBW, NMF = (X3 ? 3 : 2) * MB * NBW;     // LDS reads / MFMAs of one k-step
         static_assert(NKS % 2 == 0, "fragment double buffer: even k-steps per K-step");
         int slot = 0;
         auto mfma_step = [&](int s, bool last) {
@@ -391,12 +414,14 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 } else pre = false;
                 if (PDBG(a) & 4) continue;
                 // the three terms of a product go to the same accumulator in a fixed order; the accumulators take turns
+                if constexpr (X3) {
 #pragma unroll
-                for (int m = 0; m < MB; ++m)
+                    for (int m = 0; m < MB; ++m)
 #pragma unroll
-                    for (int q = 0; q < NBW; ++q)
-                        acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, afl[ks & 1][m]),
-                                                                           __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+                        for (int q = 0; q < NBW; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, afl[ks & 1][m]),
+                                                                               __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+                }
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -454,8 +479,9 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     if (NU > 4) fetch_res();
     wg_barrier();
 
-    float* out_p = (float*)a.out.p + img * a.out.cs + a.out.co + nv;
-    float* raw_p = a.raw.p ? (float*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
+    ST* out_p = (ST*)a.out.p + img * a.out.cs + a.out.co + nv;
+    ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
+    using ET = typename std::conditional<X3, float, h16_t>::type;       // store8 / load8 element tag
     const bool want_stats = (a.st_raw || a.st_out) && !(PDBG(a) & 256);
     float sr[8], qr[8], so[8], qo[8];
 #pragma unroll
@@ -475,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 float g[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) g[e] = f[e];
-                store8<float>(raw_p + pix * a.raw.cs, g);
+                store8<ET>((ET*)(raw_p + pix * a.raw.cs), g);
                 if (want_stats) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
@@ -483,9 +509,15 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             }
             if (res_p) {
 #pragma unroll
-                for (int k = 0; k < 4; ++k) { f[k] += __uint_as_float(rq[j][0][k]); f[4 + k] += __uint_as_float(rq[j][1][k]); }
+                for (int k = 0; k < 4; ++k) {
+                    if constexpr (X3) { f[k] += __uint_as_float(rq[j][0][k]); f[4 + k] += __uint_as_float(rq[j][LVI - 1][k]); }
+                    else {
+                        const f16x8_t rh = __builtin_bit_cast(f16x8_t, rq[j][0]);
+                        f[2 * k] += (float)rh[2 * k]; f[2 * k + 1] += (float)rh[2 * k + 1];
+                    }
+                }
             }
-            store8<float>(out_p + pix * a.out.cs, f);
+            store8<ET>((ET*)(out_p + pix * a.out.cs), f);
             if (want_stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { so[e] += f[e]; qo[e] += f[e] * f[e]; }
@@ -553,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 
 template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT>
 int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = PGeo<TAPS, TH, NT, TPS, NSLOT>;
+    using G = PGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>>;
     const size_t smem = G::smem_bytes(a.in.C);
     if (smem > 160 * 1024) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS", smem);
     bool& attr = CHORE_ONCE_FLAG(h);
@@ -574,7 +606,7 @@ int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 // tile configuration of the specialised-wave kernel for a layer: th = 0 -> not covered (the caller uses conv_lds_kernel)
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force) {
     PcPlan p{0, 0, 0, 0};
-    if (dtype != CHORE_F16X3 || Cin % 32 || Cout % 32 || W % 32) return p;
+    if ((dtype != CHORE_F16X3 && dtype != CHORE_F16) || Cin % 32 || Cout % 32) return p;
     auto ring = [&](PcPlan& q) {   // taps per K-step and ring depth of a tiling (what fits 160 KB of LDS)
         // (measured, profiles/r03_conv_phase_breakdown.txt: rings of single taps with 4 - 6 slots are no faster than two slots of
         // whole kernel rows -- the consumers pay per K-step for the hand-over -- except where only single taps fit: 128 channels)
@@ -607,11 +639,12 @@ PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout,
     return p;
 }
 
-int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {
+int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {
     if (a.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: a second residual is not supported (conv_lds_kernel has it)");
     const int key = ((taps * 10 + p.th) * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
 #define PC_CASE(TAPS, TH, NT, TPS, NSLOT) \
-    case ((TAPS * 10 + TH) * 1000 + NT) * 100 + TPS * 10 + NSLOT: return launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)
+    case ((TAPS * 10 + TH) * 1000 + NT) * 100 + TPS * 10 + NSLOT:                                              \
+        return dtype == CHORE_F16 ? launch_pc_t<h16_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s) : launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)
     switch (key) {
         PC_CASE(9, 8, 128, 1, 3);
         PC_CASE(9, 8, 64, 3, 2);

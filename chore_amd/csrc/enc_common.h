@@ -7,6 +7,8 @@
 #include "common.h"
 
 typedef unsigned short bf16_t;
+// IEEE half storage (CHORE_F16): a distinct type so that templates can tell it from bf16
+struct h16_t { unsigned short u; };
 
 // "fp16 x 3" element type (CHORE_F16X3): fp32 tensors in memory, every product a*w of a convolution evaluated on the fp16
 // matrix cores as hi(a) hi(w) + lo(a) hi(w) + hi(a) lo(w) with hi = fp16(x), lo = fp16(x - hi) and fp32 accumulation.
@@ -17,6 +19,9 @@ typedef unsigned short bf16_t;
 struct x3_t { float v; };
 constexpr int X3_WSHIFT = 8;
 template <typename T> struct Store { using type = T; };
+template <typename T> struct IsH16 { static constexpr bool value = false; };
+template <> struct IsH16<h16_t> { static constexpr bool value = true; };
+template <typename T> constexpr bool IS_H16 = IsH16<T>::value;
 template <> struct Store<x3_t> { using type = float; };
 template <typename T> struct IsX3 { static constexpr bool value = false; };
 template <> struct IsX3<x3_t> { static constexpr bool value = true; };
@@ -133,6 +138,24 @@ template <> struct Vec4<bf16_t> {
         return r;
     }
 };
+template <> struct Vec4<h16_t> {
+    typedef _Float16 hx4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ f32x4 ld(const h16_t* p) {
+        const hx4 v = *(const hx4*)p;
+        f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        return r;
+    }
+    static __device__ __forceinline__ void st(h16_t* p, f32x4 v) {
+        const hx4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *(hx4*)p = o;
+    }
+    static __device__ __forceinline__ f32x4 st_round(h16_t* p, f32x4 v) {
+        const hx4 o = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *(hx4*)p = o;
+        f32x4 r = {(float)o[0], (float)o[1], (float)o[2], (float)o[3]};
+        return r;
+    }
+};
 #endif
 
 struct ConvPlan { int nt, th, ntiles, tps, small_cin; };   // N tile, tile height, tiles per image, taps per K-step (tps 0: conv_small_kernel)
@@ -145,7 +168,7 @@ ConvPlan conv_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);
 // K-step, nslot K-steps of weights resident in LDS; th = 0: the layer is not covered and launch_conv uses conv_lds_kernel
 struct PcPlan { int th, nt, tps, nslot; };
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
-int launch_conv_pc(chore_handle* h, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
+int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);

@@ -109,8 +109,15 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
     const int OH = H / 2, OW = W / 2;
     dim3 grid((OW + STEM_T - 1) / STEM_T, (OH + STEM_T - 1) / STEM_T, B);
     const size_t smem = (size_t)Cin * STEM_P * STEM_P * sizeof(float);
-    bool* attr[2] = {&CHORE_ONCE_FLAG(h), &CHORE_ONCE_FLAG(h)};
-    if (dtype == CHORE_F32) {
+    bool* attr[3] = {&CHORE_ONCE_FLAG(h), &CHORE_ONCE_FLAG(h), &CHORE_ONCE_FLAG(h)};
+    if (dtype == CHORE_F16) {
+        if (!*attr[2]) {
+            CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)stem_kernel<h16_t>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            *attr[2] = true;
+        }
+        hipLaunchKernelGGL(stem_kernel<h16_t>, grid, dim3(256), smem, s, images, B, Cin, H, W, wk, bias, (h16_t*)out);
+    } else if (dtype == CHORE_F32) {
         if (!*attr[0]) {
             CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)stem_kernel<float>,
                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -179,7 +186,9 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Gr
     if (x.C % GN_GROUPS || x.C > 256 || x.C < 32) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
     const int S = gn_splits(HW);
     dim3 grid(S, B);
-    if (dtype == CHORE_F32)
+    if (dtype == CHORE_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<h16_t>, grid, dim3(256), 0, s, (const h16_t*)x.p, x.cs, x.co, x.C, HW, S, st);
+    else if (dtype == CHORE_F32)
         hipLaunchKernelGGL(gn_stats_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, x.C, HW, S, st);
     else
         hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, x.C, HW, S,
@@ -224,7 +233,10 @@ int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupS
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 1024) blocks = 1024;
     dim3 grid(blocks, B);
-    if (dtype == CHORE_F32)
+    if (dtype == CHORE_F16)
+        hipLaunchKernelGGL(gn_apply_relu_kernel<h16_t>, grid, dim3(256), 0, s, (const h16_t*)x.p, x.cs, x.co, st, gamma,
+                           beta, (h16_t*)y.p, y.cs, y.co, x.C, HW);
+    else if (dtype == CHORE_F32)
         hipLaunchKernelGGL(gn_apply_relu_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, st, gamma,
                            beta, (float*)y.p, y.cs, y.co, x.C, HW);
     else
@@ -433,6 +445,7 @@ static int launch_pool_t(chore_handle* h, const View& x, const View& y, int B, i
 
 int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, GroupStat* st,
                     hipStream_t s) {
+    if (dtype == CHORE_F16) return launch_pool_t<h16_t>(h, x, y, B, H, W, st, s);
     return dtype == CHORE_F32 ? launch_pool_t<float>(h, x, y, B, H, W, st, s)
                               : launch_pool_t<bf16_t>(h, x, y, B, H, W, st, s);
 }
@@ -451,6 +464,7 @@ static int launch_upadd_t(chore_handle* h, const View& a, const View& low, const
 // y may alias a (in-place add): every element is read and written by the same thread
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,
                  GroupStat* st, hipStream_t s) {
+    if (dtype == CHORE_F16) return launch_upadd_t<h16_t>(h, a, low, y, B, H, W, st, s);
     return dtype == CHORE_F32 ? launch_upadd_t<float>(h, a, low, y, B, H, W, st, s)
                               : launch_upadd_t<bf16_t>(h, a, low, y, B, H, W, st, s);
 }

@@ -14,7 +14,7 @@
 namespace {
 
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-size_t esize(int dtype) { return dtype == CHORE_BF16 ? 2 : 4; }
+size_t esize(int dtype) { return (dtype == CHORE_BF16 || dtype == CHORE_F16) ? 2 : 4; }
 // element type the non-convolution kernels see: fp16 x 3 keeps fp32 tensors, only the convolutions split their operands
 int sdt(int dtype) { return dtype == CHORE_F16X3 ? CHORE_F32 : dtype; }
 
@@ -193,7 +193,7 @@ inline int conv_class(const ConvPlan& p, int taps) {
 }
 // class of the kernel launch_conv will pick for a layer (the specialised-wave kernel where it covers the layer)
 inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
-    if (dtype == CHORE_F16X3 && conv_use_pc() && !conv_small_eligible(dtype, taps, H, W, Cin, Cout)) {
+    if ((dtype == CHORE_F16 || (dtype == CHORE_F16X3 && conv_use_pc())) && (dtype == CHORE_F16 || !conv_small_eligible(dtype, taps, H, W, Cin, Cout))) {
         const PcPlan pp = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
         if (pp.th) {
             if (taps == 1) return K_PC_FIRST + (pp.nt == 128 ? 5 : 6);
@@ -666,7 +666,7 @@ void chore_encoder_cache_free(chore_handle* h) {
 }
 
 size_t chore_encoder_arena_bytes(const chore_encoder_cfg* cfg, int dtype) {
-    if (!cfg || (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3)) return 0;
+    if (!cfg || (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16)) return 0;
     return make_layout(*cfg, dtype).total;
 }
 
@@ -675,7 +675,7 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
     CHORE_ENTER(h);
     if (int rc = check_cfg(h, cfg)) return rc;
     if (!descs || !arena) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: null argument");
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_encoder_pack: bad dtype");
     const WLayout L = make_layout(*cfg, dtype);
     std::unordered_map<std::string, const chore_weight_desc*> by_name;
     for (int i = 0; i < n_descs; ++i)
@@ -732,7 +732,7 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
 
 size_t chore_encoder_workspace_bytes(const chore_encoder_cfg* cfg, int B, int H, int W, int dtype) {
     if (!cfg || B <= 0 || H <= 0 || W <= 0 || H % 16 || W % 16) return 0;
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) return 0;
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16) return 0;
     const int G = enc_groups(B);
     return (size_t)G * align_up(plan_workspace(*cfg, B / G, H, W, dtype), 256);
 }
@@ -745,7 +745,7 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     if (!images || !arena || !workspace || !tmpx) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: null argument");
     if (B <= 0 || B > 65535 || H % 16 || W % 16 || H < 16 || W < 16)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad shape B=%d H=%d W=%d (H, W multiples of 16)", B, H, W);
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad dtype");
     if (n_stack_out < 0 || n_stack_out > cfg->num_stack || (n_stack_out > 0 && !feat_out))
         CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: bad n_stack_out");
     for (int i = 0; i < n_stack_out; ++i)

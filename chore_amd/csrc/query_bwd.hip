@@ -500,6 +500,7 @@ static int launch_query_surf_t(chore_handle* h, const QueryArgs& a, hipStream_t 
                                                                               : launch_query_surf_n<T, 2>(h, a, s);     // as the backward
 }
 int launch_query_surface_step(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    if (dtype == CHORE_F16) return launch_query_surf_t<qh16_t>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_surf_t<float>(h, a, s) : launch_query_surf_t<unsigned short>(h, a, s);
 }
 
@@ -566,6 +567,7 @@ int launch_query_bwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream
     return launch_query_bwd_t<unsigned short, false>(h, a, s);
 }
 int launch_query_bwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    if (dtype == CHORE_F16) return launch_query_bwd_t<qh16_t, false, true>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_bwd_t<float, false, true>(h, a, s) : launch_query_bwd_t<unsigned short, false, true>(h, a, s);
 }
 

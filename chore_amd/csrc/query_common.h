@@ -102,6 +102,27 @@ template <> struct MapLoad<unsigned short> {  // bf16 storage
     static __device__ __forceinline__ float cvt1(Raw1 v, int odd) { return __uint_as_float(odd ? (v & 0xffff0000u) : (v << 16)); }
 };
 
+// IEEE half storage (CHORE_F16, "fp16 fields"): same containers as bf16, another conversion
+struct qh16_t { unsigned short u; };
+template <> struct MapLoad<qh16_t> {
+    static __device__ __forceinline__ float h2f(unsigned bits16) { return (float)__builtin_bit_cast(_Float16, (unsigned short)bits16); }
+    static __device__ __forceinline__ f32x4 load4(const qh16_t* p) {
+        const u16x4 v = *(const u16x4*)p;
+        return f32x4{h2f(v[0]), h2f(v[1]), h2f(v[2]), h2f(v[3])};
+    }
+    static __device__ __forceinline__ float load1(const qh16_t* p) { return h2f(p->u); }
+    typedef unsigned Raw4 __attribute__((ext_vector_type(2)));
+    typedef unsigned Raw1;
+    static __device__ __forceinline__ Raw4 raw4(const qh16_t* p) { return *(const Raw4*)p; }
+    static __device__ __forceinline__ Raw1 raw1(const qh16_t* p) { return *(const unsigned*)((uintptr_t)p & ~(uintptr_t)3); }
+    static __device__ __forceinline__ Raw4 zero4() { return Raw4{0u, 0u}; }
+    static __device__ __forceinline__ Raw1 zero1() { return 0u; }
+    static __device__ __forceinline__ f32x4 cvt4(Raw4 v) {
+        return f32x4{h2f(v[0] & 0xffffu), h2f(v[0] >> 16), h2f(v[1] & 0xffffu), h2f(v[1] >> 16)};
+    }
+    static __device__ __forceinline__ float cvt1(Raw1 v, int odd) { return h2f(odd ? (v >> 16) : (v & 0xffffu)); }
+};
+
 __device__ __forceinline__ float interp4(float a, float b, float c, float d, const float* w) {
     // fma(se,w3, fma(sw,w2, fma(ne,w1, nw*w0))): the chain ATen's CPU grid_sampler executes
     // (pinned bit for bit by tests/golden/query_index.npz)

@@ -522,5 +522,6 @@ int launch_query_fwd_f32_bf16maps(chore_handle* h, const QueryArgs& a, hipStream
     return launch_query_fwd_t<unsigned short>(h, a, s);
 }
 int launch_query_fwd_x3(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s) {      // dtype: the maps' type
+    if (dtype == CHORE_F16) return launch_query_fwd_t<qh16_t, true>(h, a, s);
     return dtype == CHORE_F32 ? launch_query_fwd_t<float, true>(h, a, s) : launch_query_fwd_t<unsigned short, true>(h, a, s);
 }

@@ -26,12 +26,13 @@ from .. import _lib
 from .camera import KinectColorCamera
 from .hgfilter import HGFilter
 
-_DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3}
+_DT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F16X3, "fp16": _lib.F16}
 # what the query kernels see: the fp16 x 3 encoder keeps fp32 feature maps; the inference query (forward and backward
 # to the points) of the fp16x3 AND the bf16 mode runs the heads on the fp16 matrix cores with split operands
 # (csrc/heads_x3.h: fp32-grade results); the fp32 mode keeps the native fp32 MFMA
-_QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32}
-_QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16 | _lib.HEADS_X3, "fp16x3": _lib.F16X3}
+# "fp16" ("fp16 fields", BASELINE configs[4]): IEEE half feature maps, two MFMAs per product in the encoder, the same heads
+_QDT = {"fp32": _lib.F32, "bf16": _lib.BF16, "fp16x3": _lib.F32, "fp16": _lib.F32}
+_QDT_FWD = {"fp32": _lib.F32, "bf16": _lib.BF16 | _lib.HEADS_X3, "fp16x3": _lib.F16X3, "fp16": _lib.F16}
 
 
 def _nhwc_ptr(t, C):
@@ -294,6 +295,13 @@ class CHORE(nn.Module):
                 if m.bias is not None:
                     nn.init.constant_(m.bias.data, 0.0)
 
+    def _fwd_dtype(self, dtype):
+        """the dtype word of the inference query entry points: map type | heads mode.  CHORE_HEADS_FP32=1 (A/B switch): the
+        native fp32 MFMA for the heads -- not with fp16 maps, which only the split-operand kernels read"""
+        if os.environ.get("CHORE_HEADS_FP32") and self.compute_dtype != "fp16":
+            return dtype
+        return _QDT_FWD[self.compute_dtype]
+
     # ---- packed weights ---------------------------------------------------------------------
     def _head_modules(self):
         return (("df", self.df), ("part_predictor", self.part_predictor), ("pca_predictor", self.pca_predictor),
@@ -346,8 +354,8 @@ class CHORE(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
             # training: the layer-by-layer differentiable forward (model/hgfilter_train.py)
             from .hgfilter_train import forward_train
-            if self.compute_dtype == "fp16x3":
-                raise NotImplementedError("compute_dtype 'fp16x3' is an inference mode (train in 'fp32' or 'bf16')")
+            if self.compute_dtype in ("fp16x3", "fp16"):
+                raise NotImplementedError("compute_dtype '%s' is an inference mode (train in 'fp32' or 'bf16')" % self.compute_dtype)
             tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
             feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt)
             feats = feats[-n_out:]
@@ -405,7 +413,7 @@ class CHORE(nn.Module):
             else:
                 # CHORE_HEADS_FP32=1: the native fp32 MFMA for the heads in every mode (A/B switch)
                 df, pca, parts, centers = _QueryFn.apply(pts, cc, feat, self.tmpx, arena, self._cam6, dtype,
-                                                         dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype])
+                                                         self._fwd_dtype(dtype))
             B, _, N = df.shape
             self.intermediate_preds_list.append((df, pca.view(B, 3, 3, N), parts, centers))
         self.preds = self.intermediate_preds_list[-1]
@@ -426,7 +434,7 @@ class CHORE(nn.Module):
         fp, FH, FW = _nhwc_ptr(self.im_feat_list[-1], 256)
         tp, TH, TW = _nhwc_ptr(self.tmpx, 64)
         dtype = _QDT[self.compute_dtype]
-        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        fwd_dtype = self._fwd_dtype(dtype)
         df = torch.empty(B, 2, N, device=dev, dtype=torch.float32)
         _lib.check(_lib.lib.chore_query_fwd(h, pts.data_ptr(), cc.data_ptr(), B, N, fp, FH, FW, tp, TH, TW, fwd_dtype,
                                             self._heads_arena(dev).data_ptr(), self._cam6, df.data_ptr(), None, None, None, None,
@@ -439,7 +447,7 @@ class CHORE(nn.Module):
         (chore_gen_surface_step_fused).  None if the mode has no fused step (the fp32-MFMA heads): the caller composes it
         from query_df / query_grad_points."""
         dtype = _QDT[self.compute_dtype]
-        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        fwd_dtype = self._fwd_dtype(dtype)
         if not (fwd_dtype == _lib.F16X3 or (fwd_dtype & _lib.HEADS_X3)) or os.environ.get("CHORE_GEN_FOUR_LAUNCHES"):
             return None
         if not self.im_feat_list:
@@ -479,7 +487,7 @@ class CHORE(nn.Module):
         gs = [None if g is None else g.detach().reshape(B, -1, N).float().contiguous() for g in (g_df, g_pca, g_parts, g_centers)]
         ptr = [None if g is None else g.data_ptr() for g in gs]
         dtype = _QDT[self.compute_dtype]
-        fwd_dtype = dtype if os.environ.get("CHORE_HEADS_FP32") else _QDT_FWD[self.compute_dtype]
+        fwd_dtype = self._fwd_dtype(dtype)
         dpoints = torch.empty_like(pts)
         _lib.check(_lib.lib.chore_query_bwd_points(h, pts.data_ptr(), cc.data_ptr(), B, N, fp, FH, FW, tp, TH, TW, fwd_dtype,
                                                    self._heads_arena(dev).data_ptr(), self._cam6, ptr[0], ptr[1], ptr[2], ptr[3],

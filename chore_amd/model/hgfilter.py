@@ -168,7 +168,7 @@ class HGFilter(_Params):
         dev = images.device
         images = images.contiguous().float()
         n_out = self.num_modules if n_stack_out is None else n_stack_out
-        tdt = torch.bfloat16 if dtype == _lib.BF16 else torch.float32
+        tdt = torch.bfloat16 if dtype == _lib.BF16 else (torch.float16 if dtype == _lib.F16 else torch.float32)
         arena = self.packed_arena(dtype, dev)
         cfg = self.cfg()
         h = _lib.handle(dev.index or 0)

@@ -40,7 +40,9 @@ enum {
 };
 
 /* storage / MFMA-operand type of feature maps and packed weights */
-enum { CHORE_F32 = 0, CHORE_BF16 = 1, CHORE_F16X3 = 2 };
+enum { CHORE_F32 = 0, CHORE_BF16 = 1, CHORE_F16X3 = 2, CHORE_F16 = 3 };
+/* CHORE_F16 ("fp16 fields", inference only): IEEE half feature maps; the encoder's convolutions multiply the fp16 activation
+ * by the weight's fp16 hi and lo parts (two MFMAs per product, fp32 accumulation); the heads run as under CHORE_HEADS_X3. */
 /* query entry points (chore_query_fwd / _bwd_points / _fwd_train / _bwd_train, chore_heads_wgrad): OR into the map type
  * to run the MLP heads on the fp16 matrix cores with hi/lo split operands (fp32-grade results, see csrc/heads_x3.h)
  * instead of the native fp32 MFMA.  CHORE_F16X3 there means CHORE_F32 | CHORE_HEADS_X3. */

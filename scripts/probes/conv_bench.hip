@@ -133,7 +133,7 @@ int main(int argc, char** argv) {
             }
             auto run = [&](int dbg) -> int {
                 a.dbg = dbg | (1 << 30);
-                return force ? launch_conv_pc(h, sh.taps, pp, a, s) : launch_conv(h, dtype, sh.taps, a, s);
+                return force ? launch_conv_pc(h, dtype, sh.taps, pp, a, s) : launch_conv(h, dtype, sh.taps, a, s);
             };
             // correctness against variant 0 (same arithmetic, another summation order over the chunks)
             CK(hipMemsetAsync(dout, 0, nout * esz, s));

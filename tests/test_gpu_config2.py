@@ -65,6 +65,22 @@ def test_fp16x3_mode_fields_within_1e4_of_reference(opt, preds32):
     assert torch.equal(preds[0] == 5.0, preds32[0] == 5.0)
 
 
+def test_fp16_mode_fields_within_stated_tolerance(opt, preds32):
+    """"fp16 fields" (BASELINE configs[4]): half feature maps, two MFMAs per product in the encoder -- on the golden points
+    against the reference and over all 4 x 20 000 points against the fp32 mode"""
+    from chore_amd.utils.field_check import TOL, field_errors
+    preds = run_mode(opt, "fp16")
+    err = field_errors(preds)
+    t = TOL["fp16"]
+    for name in ("df", "pca", "parts", "centers"):
+        for k in t:
+            assert err[name][k] < t[k], (name, k, err[name])
+    for name, a, b in zip(("df", "pca", "parts", "centers"), preds, preds32):
+        d = (a.double() - b.double()).abs()
+        assert float(d.max()) < t["max_abs"] and float(d.mean()) < t["mean_abs"], (name, float(d.max()), float(d.mean()))
+    assert torch.equal(preds[0] == 5.0, preds32[0] == 5.0)
+
+
 def test_bf16_mode_fields_within_stated_tolerance(opt, preds32):
     from chore_amd.utils.field_check import TOL, field_errors
     preds16 = run_mode(opt, "bf16")

@@ -88,6 +88,20 @@ def test_encoder_bf16_within_stated_tolerance(net16):
         assert rel_max(a, b) < 8e-2, (name, rel_max(a, b))
 
 
+def test_encoder_fp16_modes_on_a_ragged_shape(opt, net32):
+    """64 x 96 image (maps 32 x 48 ... 4 x 6: ragged 32-pixel tiles, maps smaller than a tile) in the two modes that run the
+    specialised-wave convolution: fp16x3 (eval, fp32-grade) and fp16 (half feature maps, a 1e-3 mode)"""
+    g = golden("encoder_64x96.npz")
+    import copy
+    for mode, tol_max, tol_l2 in (("fp16x3", 2e-4, 1e-4), ("fp16", 2e-2, 4e-3)):
+        net = make_net(copy.copy(opt), mode)
+        outs, tmpx, normx = encode(net, g["images"], train=False)
+        assert net.tmpx.dtype == (torch.float16 if mode == "fp16" else torch.float32)
+        for name, a, b in (("tmpx", tmpx, g["tmpx"]), ("normx", normx, g["normx"]), ("out_last", outs[-1], g["out_last"])):
+            assert rel_max(a, b) < tol_max, (mode, name, rel_max(a, b))
+            assert rel_l2(a, b) < tol_l2, (mode, name, rel_l2(a, b))
+
+
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_encoder_512_checksums(net32, net16, mode):
     """BASELINE size (512x512) against per-channel statistics and crops of the reference output"""

@@ -203,6 +203,33 @@ def test_bf16_maps_query(net, synth_sd):
 
 
 @pytest.mark.parametrize("B,N", [(1, 2048), (2, 333), (4, 20000)])
+def test_fp16_maps_query_forward_and_backward(net, B, N):
+    """fp16 feature maps ("fp16 fields"): values and the gradient to the points are those of the fp16 x 3 mode on the
+    half-rounded maps held in fp32 -- the gather converts exactly, everything after it is the same arithmetic"""
+    from chore_amd.utils import synth
+    rs = np.random.RandomState(23)
+    feat = torch.from_numpy(rs.standard_normal((B, 256, 128, 128)).astype(np.float32)).half()
+    tmpx = torch.from_numpy(rs.standard_normal((B, 64, 256, 256)).astype(np.float32)).half()
+    pts = synth.synth_points(B, N, seed=4)
+    cc = torch.from_numpy(np.tile(np.array([synth.CROP_CENTER], np.float32), (B, 1))).cuda()
+    res = {}
+    for mode, tdt in (("fp16x3", torch.float32), ("fp16", torch.float16)):
+        net.compute_dtype = mode
+        try:
+            net.im_feat_list = [nhwc(feat.float().numpy(), tdt)]
+            net.tmpx = nhwc(tmpx.float().numpy(), tdt)
+            p = torch.from_numpy(pts).cuda().requires_grad_(True)
+            net.query(p, crop_center=cc)
+            df, pca, parts, centers = net.get_preds()
+            (torch.clamp(df, max=2.0).sum() + 0.3 * pca.sum() + 0.1 * parts.square().sum() + centers.sum()).backward()
+            res[mode] = [t.detach().clone() for t in (df, pca, parts, centers, p.grad)]
+        finally:
+            net.compute_dtype = "fp32"
+    for a, b in zip(res["fp16"], res["fp16x3"]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,N", [(1, 2048), (2, 333), (4, 20000)])
 def test_fp16x3_heads_forward(net, synth_sd, B, N):
     """the fp16 x 3 mode's query forward -- fp32 maps, the heads as three fp16 MFMAs per product on hi/lo split operands
     (csrc/heads_x3.h) -- against the oracle on seeded maps: 5e-5 absolute (the north-star bound is 1e-4), the OUT_DIST
