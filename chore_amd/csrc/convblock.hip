@@ -91,11 +91,9 @@ size_t chore_convblock_workspace_bytes(int dtype, int B, int H, int W, int Cin, 
     const size_t fwd = pack_layout(d, dtype, 0, false).end;
     size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, d.C1) + gn_acc_bytes(B, d.C2));
     o = pack_layout(d, dtype, o, true).end;
-    size_t part = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, d.C1);
-    const size_t p2 = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, d.C1, d.C2), p3 = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, d.C2, d.C2);
-    const size_t p4 = d.down ? chore_conv2d_wgrad_workspace_bytes(1, B, H, W, Cin, Cout) : 0;
-    part = part > p2 ? part : p2; part = part > p3 ? part : p3; part = part > p4 ? part : p4;
-    o += al(part);
+    // the four weight gradients keep their shares' partials until ONE launch sums all of them: a region each
+    o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, d.C1)) + al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, d.C1, d.C2)) +
+         al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, d.C2, d.C2)) + (d.down ? al(chore_conv2d_wgrad_workspace_bytes(1, B, H, W, Cin, Cout)) : 0);
     o += al(d.px * (size_t)(Cin > d.C1 ? Cin : d.C1) * d.es);      // da
     o += al(d.px * d.C2 * d.es) + al(d.px * d.C1 * d.es);           // d(o2), d(o1)
     if (d.down) o += al(d.px * Cin * d.es);                          // gradient through the downsample branch
@@ -203,11 +201,11 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     const size_t zero_bytes = o;
     const PackOff pk = pack_layout(d, dtype, o, true);
     o = pk.end;
-    size_t part = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, C1);
-    const size_t p2 = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, C1, C2), p3 = chore_conv2d_wgrad_workspace_bytes(9, B, H, W, C2, C2);
-    const size_t p4 = d.down ? chore_conv2d_wgrad_workspace_bytes(1, B, H, W, Cin, Cout) : 0;
-    part = part > p2 ? part : p2; part = part > p3 ? part : p3; part = part > p4 ? part : p4;
-    char* wpart = ws + o; o += al(part);
+    char* wpart1 = ws + o; o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, C1));
+    char* wpart2 = ws + o; o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, C1, C2));
+    char* wpart3 = ws + o; o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, C2, C2));
+    char* wpartd = ws + o; if (d.down) o += al(chore_conv2d_wgrad_workspace_bytes(1, B, H, W, Cin, Cout));
+    WgradFinishJobs fin;             // the four ordered sums over the shares: one launch at the end of the side chain
     char* da = ws + o; o += al(d.px * (size_t)(Cin > C1 ? Cin : C1) * d.es);
     char* do2 = ws + o; o += al(d.px * C2 * d.es);
     char* do1 = ws + o; o += al(d.px * C1 * d.es);
@@ -258,20 +256,21 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     if ((rc = release(0))) return rc;        // dy, the workspace clear
     // ---- conv3: its output gradient is the last slice of dy ----
     if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o2, B, H, W, C2, sv.s2, gb[4], gb[5], dyb + (size_t)off3 * d.es, Cout, C2, dw3,
-                                     nullptr, wpart, s2))) return rc;
-    if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpart, s2)))
+                                     nullptr, wpart3, s2, &fin))) return rc;
+    if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpartd, s2, &fin)))
         return rc;
     if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o2, sv.s2, gb[4], gb[5], da, B, HW, C2, do2, dg3, db3, acc3, 1,
                                dyb + (size_t)off2 * d.es, Cout, s))) return rc;          // + the concat's gradient of o2
     // ---- conv2 ----
     if ((rc = release(1))) return rc;        // d(o2)
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart, s2))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart2, s2, &fin))) return rc;
     if ((rc = dgrad(9, mkview(do2, C2, 0, C2), w2, pk.w2, C1, C2, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o1, sv.s1, gb[2], gb[3], da, B, HW, C1, do1, dg2, db2, acc2, 1, dyb, Cout, s))) return rc;
     // ---- conv1 (and the downsample branch): both normalise x ----
     if ((rc = release(2))) return rc;        // d(o1)
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart, s2))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart1, s2, &fin))) return rc;
+    if ((rc = launch_wgrad_finish_multi(h, fin, s2))) return rc;
     const void* skip = dy;          // identity residual: dy itself flows to x
     int skip_cs = Cout;
     if (d.down) {

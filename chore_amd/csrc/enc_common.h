@@ -198,9 +198,17 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Gr
 int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                      const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
                      int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s);
+// the ordered sums over the shares' partials of up to four weight gradients, deferred into one launch (a ConvBlock's)
+struct WgradFinishJobs {
+    int n = 0;
+    struct J { const float* part; const float* part_bias; float* dw; float* dbias; int S, Cout, Cin, taps, ct; } j[4];
+};
+// defer: the partial-sum kernel only; the job is appended and launch_wgrad_finish_multi finishes all of them (every job
+// needs its own workspace then)
 int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                            const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
-                           float* dw, float* dbias, void* workspace, hipStream_t s);
+                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer = nullptr);
+int launch_wgrad_finish_multi(chore_handle* h, const WgradFinishJobs& jobs, hipStream_t s);
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
                          const float* beta, const View& y, int B, int HW, hipStream_t s);

@@ -341,9 +341,9 @@ static bool wgrad_use64(int dtype, int taps, int Cin, int Cout) {
 }
 
 // dW (O,C,kh,kw) = sum over the shares, in order
-__global__ void wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int S, int Cout,
-                                    int Cin, int taps, float* __restrict__ dw, float* __restrict__ dbias, int ct) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void wgrad_finish_body(size_t i, const float* __restrict__ part, const float* __restrict__ part_bias,
+                                                  int S, int Cout, int Cin, int taps, float* __restrict__ dw,
+                                                  float* __restrict__ dbias, int ct) {
     const size_t n = (size_t)Cout * Cin * taps;
     if (i < n) {
         // thread index follows the PARTIAL layout [o tile][c tile][tap][o % ct][c % ct]: coalesced reads of every share
@@ -368,6 +368,17 @@ __global__ void wgrad_finish_kernel(const float* __restrict__ part, const float*
         for (int k = 0; k < S; ++k) s += part_bias[(size_t)k * Cout + i];
         dbias[i] = s;
     }
+}
+__global__ void wgrad_finish_kernel(const float* __restrict__ part, const float* __restrict__ part_bias, int S, int Cout,
+                                    int Cin, int taps, float* __restrict__ dw, float* __restrict__ dbias, int ct) {
+    wgrad_finish_body((size_t)blockIdx.x * blockDim.x + threadIdx.x, part, part_bias, S, Cout, Cin, taps, dw, dbias, ct);
+}
+// up to four of them in one launch (blockIdx.y = job): same sums, same order
+__global__ void wgrad_finish_multi_kernel(WgradFinishJobs jobs) {
+    const WgradFinishJobs::J& j = jobs.j[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)j.Cout * j.Cin * j.taps) return;       // (Cout <= Cout * Cin * taps: the bias entries are covered)
+    wgrad_finish_body(i, j.part, j.part_bias, j.S, j.Cout, j.Cin, j.taps, j.dw, j.dbias, j.ct);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -676,8 +687,9 @@ int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stat
 // the weight gradient with a channel-strided dy (dy_stride = channels of the tensor dy is a slice of; dy already offset)
 int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                            const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
-                           float* dw, float* dbias, void* workspace, hipStream_t s) {
+                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer) {
     if (!x || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: null argument");
+    if (defer && defer->n >= 4) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: more than four deferred sums");
     if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || Cin > 256)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: unsupported taps=%d Cin=%d Cout=%d", taps, Cin, Cout);
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
@@ -704,6 +716,7 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
         if (taps == 9) hipLaunchKernelGGL(wgrad64_kernel<9>, dim3(a.S * npairs), dim3(256), smem64, s, a);
         else hipLaunchKernelGGL(wgrad64_kernel<1>, dim3(a.S * npairs), dim3(256), smem64, s, a);
         CHORE_LAUNCH_CHECK(h, s);
+        if (defer) { defer->j[defer->n++] = {a.part, a.part_bias, dw, dbias, a.S, Cout, Cin, taps, ct}; return CHORE_OK; }
         const size_t n = (size_t)Cout * Cin * taps;
         hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
                            Cin, taps, dw, dbias, ct);
@@ -730,9 +743,22 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
     if (dtype == CHORE_F32) { if (taps == 9) LAUNCH_WG(float, 9); else LAUNCH_WG(float, 1); }
     else { if (taps == 9) LAUNCH_WG(bf16_t, 9); else LAUNCH_WG(bf16_t, 1); }
 #undef LAUNCH_WG
+    if (defer) { CHORE_LAUNCH_CHECK(h, s); defer->j[defer->n++] = {a.part, a.part_bias, dw, dbias, a.S, Cout, Cin, taps, ct}; return CHORE_OK; }
     const size_t n = (size_t)Cout * Cin * taps;
     hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
                        Cin, taps, dw, dbias, ct);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+int launch_wgrad_finish_multi(chore_handle* h, const WgradFinishJobs& jobs, hipStream_t s) {
+    if (jobs.n <= 0) return CHORE_OK;
+    size_t nmax = 0;
+    for (int k = 0; k < jobs.n; ++k) {
+        const size_t n = (size_t)jobs.j[k].Cout * jobs.j[k].Cin * jobs.j[k].taps;
+        nmax = n > nmax ? n : nmax;
+    }
+    hipLaunchKernelGGL(wgrad_finish_multi_kernel, dim3((unsigned)((nmax + 255) / 256), jobs.n), dim3(256), 0, s, jobs);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -161,6 +161,7 @@ class _ConvGN(torch.autograd.Function):
         ctx.save_for_backward(x, wf, *([st, g, b] if gamma is not None else []))
         ctx.acc = _bwd_acc(B, Cin, dev) if gamma is not None else None
         if want_stats:
+            ctx.set_materialize_grads(False)     # no zero tensor for the statistics' (unused) gradient slot
             ctx.mark_non_differentiable(st_y)
             return y, st_y
         return y
@@ -221,6 +222,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.down = wd is not None
         off, nb = L.chore_convblock_out_stats_offset(B), L.chore_gn_stats_bytes(B)
         y_stats = saved[off:off + nb]
+        ctx.set_materialize_grads(False)     # no zero tensor per block for the statistics' (unused) gradient slot
         ctx.mark_non_differentiable(y_stats)
         return y, y_stats
 
@@ -289,6 +291,7 @@ class _UpAdd(torch.autograd.Function):
                                             None if st is None else st.data_ptr(), stream), h, "chore_upadd_fwd")
         ctx.shape = (B, H, W, C)
         if want_stats:
+            ctx.set_materialize_grads(False)     # no zero tensor for the statistics' (unused) gradient slot
             ctx.mark_non_differentiable(st)
             return y, st
         return y
@@ -316,6 +319,7 @@ class _AvgPool2(torch.autograd.Function):
                                                stream), h, "chore_avgpool2_fwd")
         ctx.shape = tuple(x.shape)
         if want_stats:
+            ctx.set_materialize_grads(False)     # no zero tensor for the statistics' (unused) gradient slot
             ctx.mark_non_differentiable(st)
             return y, st
         return y
