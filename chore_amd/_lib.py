@@ -13,7 +13,8 @@ import torch  # noqa: F401  -- FIRST: PyTorch ships its own libamdhip64; loading
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int64, c_longlong, c_size_t, c_uint8, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libchore_hip.so")
+# CHORE_HIP_LIB: another build of the same library (A/B runs of two kernel versions on one GPU box)
+LIB_PATH = os.environ.get("CHORE_HIP_LIB") or os.path.join(_HERE, "csrc", "libchore_hip.so")
 
 F32, BF16, F16X3, F16 = 0, 1, 2, 3
 HEADS_X3 = 0x100      # OR into a query dtype: heads on the fp16 matrix cores with split operands (include/chore_hip.h)
@@ -159,6 +160,8 @@ SIGNATURES = {
     "chore_prep_resize_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
     "chore_prep_crop_compose": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                         c_int, c_void_p, c_void_p]),
+    "chore_prep_crop_compose_mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, ctypes.c_double,
+                                             ctypes.c_double, ctypes.c_double, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "chore_collision_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "chore_collision_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p]),

@@ -1,4 +1,6 @@
 // image_prep.hip -- the image preparation of the test loader on the device.
+// (use_mean_center=True, the COCO loader: the float64 canvas of pad_image test_data.py:133-160 and cv2's generic float
+// resize -- see prep_compose_mean_kernel below.)
 //
 // Replaces, from the decoded uint8 images on, TestData.prepare_image_crop (/root/reference/data/test_data.py:59-125,
 // use_mean_center=False) = BaseDataset.masks2bbox (data/base_data.py:92-112) + cv2.resize to the 2048-px space (:82-84)
@@ -99,6 +101,66 @@ __global__ void prep_compose_kernel(Src rgb, Src pm, Src om, int ch, int cw, int
     out[4 * plane + q] = (float)((double)o / 255.0);
 }
 
+// ---- use_mean_center=True ------------------------------------------------------------------------------------------
+// pad_image pastes the uint8 image into a zero float64 canvas so that the crop centre lands on the mean crop centre, the
+// crop is then taken from the canvas, and cv2.resize runs its generic float path (float weights, double products, the
+// horizontal pass first).  Nothing is materialised here: a canvas pixel is a translated, clipped source pixel.
+struct Canvas {                 // canvas rectangle [cx1, cx2) x [cy1, cy2) <- source starting at (sx1, sy1); zero elsewhere
+    int ch, cw, cx1, cy1, cx2, cy2, sx1, sy1;
+};
+struct SrcM {
+    const unsigned char* p;
+    int h, w, C;
+    Canvas cv;
+    int x1, y1, nx, ny, p1, p2;        // the crop of the CANVAS (base_data.py:131-162)
+    __device__ __forceinline__ double at(int y, int x, int k) const {
+        const int cx = x - p1, cy = y - p2;
+        if (cx < 0 || cx >= nx || cy < 0 || cy >= ny) return 0.0;
+        const int X = x1 + cx, Y = y1 + cy;                           // canvas pixel
+        if (X < cv.cx1 || X >= cv.cx2 || Y < cv.cy1 || Y >= cv.cy2) return 0.0;
+        return (double)p[((size_t)(cv.sy1 + Y - cv.cy1) * w + (cv.sx1 + X - cv.cx1)) * C + k];
+    }
+};
+__device__ __forceinline__ void lin_coef_f(int d, int n_src, int n_dst, bool clamp_weights, int& s, float& f) {
+    const double scale = (double)n_src / (double)n_dst;
+    f = (float)(((double)d + 0.5) * scale - 0.5);
+    s = (int)floorf(f);
+    f = f - (float)s;
+    if (clamp_weights) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    }
+}
+__device__ __forceinline__ double resize_sample_f64(const SrcM& s, int ch, int cw, int dh, int dw, int dy, int dx, int k) {
+    if (cw == dw && ch == dh) return s.at(dy, dx, k);
+    if (cw == 2 * dw && ch == 2 * dh)
+        return __dmul_rn(__dadd_rn(__dadd_rn(__dadd_rn(s.at(2 * dy, 2 * dx, k), s.at(2 * dy, 2 * dx + 1, k)), s.at(2 * dy + 1, 2 * dx, k)),
+                                   s.at(2 * dy + 1, 2 * dx + 1, k)), 0.25);
+    int sx, sy;
+    float fx, fy;
+    lin_coef_f(dx, cw, dw, true, sx, fx);
+    lin_coef_f(dy, ch, dh, false, sy, fy);
+    const double a0 = (double)(1.0f - fx), a1 = (double)fx, b0 = (double)(1.0f - fy), b1 = (double)fy;
+    const int sx1 = min(sx + 1, cw - 1);
+    const int y0 = clampi(sy, 0, ch - 1), y1 = clampi(sy + 1, 0, ch - 1);
+    const double r0 = __dadd_rn(__dmul_rn(s.at(y0, sx, k), a0), __dmul_rn(s.at(y0, sx1, k), a1));
+    const double r1 = __dadd_rn(__dmul_rn(s.at(y1, sx, k), a0), __dmul_rn(s.at(y1, sx1, k), a1));
+    return __dadd_rn(__dmul_rn(r0, b0), __dmul_rn(r1, b1));
+}
+__global__ void prep_compose_mean_kernel(SrcM rgb, SrcM pm, SrcM om, int ch, int cw, int S, float* __restrict__ out) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (dx >= S) return;
+    const double p = resize_sample_f64(pm, ch, cw, S, S, dy, dx, 0) / 255.0, o = resize_sample_f64(om, ch, cw, S, S, dy, dx, 0) / 255.0;
+    const bool keep = p > 0.5 || o > 0.5;
+    const size_t plane = (size_t)S * S, q = (size_t)dy * S + dx;
+    for (int k = 0; k < 3; ++k) {
+        const double v = resize_sample_f64(rgb, ch, cw, S, S, dy, dx, k) / 255.0;
+        out[k * plane + q] = keep ? (float)v : 0.f;
+    }
+    out[3 * plane + q] = (float)p;
+    out[4 * plane + q] = (float)o;
+}
+
 Src plain(const unsigned char* p, int h, int w, int C) { return Src{p, h, w, C, 0, 0, w, h, 0, 0}; }
 
 }  // namespace
@@ -147,6 +209,44 @@ int chore_prep_crop_compose(chore_handle* h, const unsigned char* rgb, const uns
         o{obj_mask, H, W, 1, x1, y1, nx, ny, p1, p2};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(prep_compose_kernel, dim3((S + 255) / 256, S), dim3(256), 0, s, r, p, o, ch, cw, S, images);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// use_mean_center=True: the images are first moved so that (cc_x, cc_y) -- the crop centre in the 2048-px space -- lands on
+// (mean_x, mean_y) (pad_image, test_data.py:133-160), the crop corners tl / br are those around the mean centre
+int chore_prep_crop_compose_mean(chore_handle* h, const unsigned char* rgb, const unsigned char* person_mask,
+                                 const unsigned char* obj_mask, int H, int W, double cc_x, double cc_y, double mean_x, double mean_y,
+                                 int tl_x, int tl_y, int br_x, int br_y, int S, float* images, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!rgb || !person_mask || !obj_mask || !images || H <= 0 || W <= 0 || S <= 0 || S > 65535)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_prep_crop_compose_mean: bad argument");
+    const int kw = 2048, kh = 1536;
+    Canvas cv;
+    const int tx = (int)(mean_x - cc_x), ty = (int)(mean_y - cc_y);            // astype(int): toward zero
+    const int bx = W + tx, by = H + ty;
+    cv.cw = bx > kw ? bx : kw; cv.ch = by > kh ? by : kh;
+    cv.cx1 = tx > 0 ? tx : 0; cv.cy1 = ty > 0 ? ty : 0;
+    cv.cx2 = bx < kw ? bx : kw; cv.cy2 = by < kh ? by : kh;
+    cv.sx1 = tx < 0 ? -tx : 0; cv.sy1 = ty < 0 ? -ty : 0;
+    const int sx2 = (W - (bx - kw)) < W ? (W - (bx - kw)) : W, sy2 = (H - (by - kh)) < H ? (H - (by - kh)) : H;
+    if (cv.cx2 - cv.cx1 != sx2 - cv.sx1 || cv.cy2 - cv.cy1 != sy2 - cv.sy1)    // numpy would refuse the assignment
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_prep_crop_compose_mean: paste rectangles differ (%d x %d vs %d x %d)", cv.cx2 - cv.cx1,
+                   cv.cy2 - cv.cy1, sx2 - cv.sx1, sy2 - cv.sy1);
+    // geometry of BaseDataset.crop on the canvas
+    const int CW = cv.cw, CH = cv.ch;
+    const int x1 = tl_x > 0 ? tl_x : 0, y1 = tl_y > 0 ? tl_y : 0;
+    const int x2 = br_x < CW - 1 ? br_x : CW - 1, y2 = br_y < CH - 1 ? br_y : CH - 1;
+    const int p1 = tl_x < 0 ? -tl_x : 0, p2 = tl_y < 0 ? -tl_y : 0;
+    const int p3 = br_x - CW + 1 > 0 ? br_x - CW + 1 : 0, p4 = br_y - CH + 1 > 0 ? br_y - CH + 1 : 0;
+    const int nx = x2 > x1 ? x2 - x1 : 0, ny = y2 > y1 ? y2 - y1 : 0;
+    const int cw = nx + p1 + p3, ch = ny + p2 + p4;
+    if (cw != ch || cw <= 0)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_prep_crop_compose_mean: the crop is %d x %d, not square", cw, ch);
+    SrcM r{rgb, H, W, 3, cv, x1, y1, nx, ny, p1, p2}, p{person_mask, H, W, 1, cv, x1, y1, nx, ny, p1, p2},
+        o{obj_mask, H, W, 1, cv, x1, y1, nx, ny, p1, p2};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(prep_compose_mean_kernel, dim3((S + 255) / 256, S), dim3(256), 0, s, r, p, o, ch, cw, S, images);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

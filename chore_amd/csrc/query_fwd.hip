@@ -194,6 +194,289 @@ __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp16 x 3 forward, TWO waves per head that split the head's OUTPUT channels ("split" kernel).
+//
+// The four-wave kernel above keeps a layer's activations in registers, so one wave walks the whole GEMM chain of its head:
+// 936 dependent MFMAs per 64-point tile with nothing else on its SIMD, every weight-fragment or LDS wait exposed (a tile
+// takes 42 us for 14 us of MFMA work).  Here a head has two waves: wave (head, c) owns row blocks 2c, 2c+1 -- 64 of the 128
+// hidden channels -- of every layer, for all points of the tile.  It needs only ITS half of each weight matrix (no fragment
+// is fetched twice: the L1 traffic per tile is that of the four-wave kernel) but all K channels of the previous layer, so
+// the layers exchange their activations through the LDS: after a layer each wave writes relu(.) of its 64 channels as
+// ready-made B fragments (hi / lo planes, the k order heads_x3.h packs the weights in), a barrier, and both waves of the
+// head read all eight K-steps from there.  The input tile is stored the same way (gather_tile_split: fp16 hi / lo planes
+// at gather time), so no k-loop converts anything: loads and MFMAs only, half the chain per wave, two waves per SIMD.
+// LDS: the input planes (86 KB at 64 points) and the exchange area (32 KB per head) share one region -- the input is dead
+// when layer 1 is done -- plus the point table: 135 KB.
+constexpr int XSH = 344;                 // halves per point row of an input plane (336 + 8: 688 B, conflict-free b128 rows)
+template <int PTS>
+struct QuerySplitSmemT {
+    static constexpr size_t XB = (size_t)2 * PTS * XSH * 2;                       // two planes of halves
+    static constexpr size_t EB = (size_t)HEAD_NUM * 4 * 2 * (PTS / 32) * 2 * 1024;  // [head][kb][s][cb][plane] x 1 KB
+    __attribute__((aligned(16))) char buf[XB > EB ? XB : EB];
+    PtTableT<PTS> tab;
+};
+
+template <typename T, int PTS>
+__device__ __forceinline__ void gather_tile_split(char* XH, char* XL, const PtTableT<PTS>& tab, const T* feat_b, const T* tmpx_b,
+                                                  int wid, int lane) {
+    using L = MapLoad<T>;
+    constexpr int NW = 8, U = PTS / NW;          // all of a wave's points (8 or 4) in flight at once: one HBM round trip
+    auto put = [&](char* row_h, char* row_l, int k, float v) {
+        const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
+        *(_Float16*)(row_h + 2 * k) = h;
+        *(_Float16*)(row_l + 2 * k) = l;
+    };
+    typename L::Raw4 fv[U][4];
+    typename L::Raw1 tv[U][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int pt = wid * U + u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int fo = tab.foff[k][pt];
+            const int to = tab.toff[k][pt];
+            fv[u][k] = (fo >= 0) ? L::raw4(feat_b + fo + lane * 4) : L::zero4();
+            tv[u][k] = (to >= 0) ? L::raw1(tmpx_b + to + lane) : L::zero1();
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int pt = wid * U + u;
+        float fw[4], tw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { fw[k] = tab.fw[k][pt]; tw[k] = tab.tw[k][pt]; }
+        const f32x4 c0 = L::cvt4(fv[u][0]), c1 = L::cvt4(fv[u][1]), c2 = L::cvt4(fv[u][2]), c3 = L::cvt4(fv[u][3]);
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 hh, ll;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float r = interp4(c0[c], c1[c], c2[c], c3[c], fw);
+            hh[c] = (_Float16)r;
+            ll[c] = (_Float16)(r - (float)hh[c]);
+        }
+        char* rh = XH + (size_t)pt * XSH * 2;
+        char* rl = XL + (size_t)pt * XSH * 2;
+        *(h4*)(rh + lane * 8) = hh;
+        *(h4*)(rl + lane * 8) = ll;
+        put(rh, rl, FEAT_C + 3 + lane, interp4(L::cvt1(tv[u][0], lane & 1), L::cvt1(tv[u][1], lane & 1), L::cvt1(tv[u][2], lane & 1),
+                                               L::cvt1(tv[u][3], lane & 1), tw));
+        if (lane < 3) put(rh, rl, FEAT_C + lane, tab.xyz[lane][pt]);
+        if (lane >= 3 && lane < 3 + (QX_KS1 * 16 - HEAD_IN)) put(rh, rl, HEAD_IN + lane - 3, 0.f);      // k = 323 .. 335
+    }
+}
+
+#ifdef CHORE_QUERY_STAMPS
+__device__ unsigned long long g_qstamps[4096 * 8];
+#define QSTAMP(i) do { if (tid == 0) { const int L_ = blockIdx.x + blockIdx.y * gridDim.x; if (L_ < 4096) g_qstamps[L_ * 8 + (i)] = wall_clock64(); } } while (0)
+extern "C" int chore_debug_query_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qstamps), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
+}
+#else
+#define QSTAMP(i) do { } while (0)
+#endif
+struct AFrag2 { u32x4 h[2], l[2]; };
+__device__ __forceinline__ void load_afrag2(AFrag2& f, const u32x4* A /*[rb][plane][lane] of this k-step, lane applied*/, int rb0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { f.h[i] = A[((rb0 + i) * 2) * 64]; f.l[i] = A[((rb0 + i) * 2 + 1) * 64]; }
+}
+
+template <typename T, int NCB>
+__global__ __launch_bounds__(512, 1) void query_fwd_x3_split_kernel(QueryArgs a) {
+    // The weight fragments of the three hidden layers are ONE stream of 21 + 8 + 8 k-steps through a ring of PF register
+    // slots: the loads run PF steps ahead of the MFMAs across the layer boundaries, so a layer's first fragments are
+    // already in registers when its barrier opens (a k-step of one wave lasts ~0.2 us, an L2 round trip ~1 us).
+    constexpr int PTS = 32 * NCB, PF = 7, NSTEP = QX_KS1 + 16;
+    static_assert(QX_KS1 % PF == 0, "the k loop of layer 1 is unrolled by the ring depth");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    QuerySplitSmemT<PTS>& sm = *reinterpret_cast<QuerySplitSmemT<PTS>*>(smem_raw);
+    char* XH = sm.buf;
+    char* XL = sm.buf + (size_t)PTS * XSH * 2;
+    u32x4* E = (u32x4*)sm.buf;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, col = lane & 31;
+    int b, tile_;
+    query_block(b, tile_);
+    const int n0 = tile_ * PTS;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+    QSTAMP(0);
+    if (tid < PTS) {
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW, nullptr);
+        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
+    }
+    __syncthreads();
+    QSTAMP(1);
+    const float* arena = (const float*)a.arena;
+    const int head = wid & 3, ch = wid >> 2, rb0 = 2 * ch;
+    const bool active = a.out[head] != nullptr;          // a head nobody asked for: its waves only keep the barriers
+    const u32x4* xbase = (const u32x4*)((const char*)arena + QX_OFF_BYTES);
+    const u32x4* A1 = xbase + (size_t)head * QX_KS1 * 4 * 2 * 64 + lane;
+    const u32x4* A23 = xbase + QX_L1_VEC + (size_t)head * 2 * 4 * 2 * 4 * 2 * 64 + lane;     // layers 2, 3: 16 consecutive k-steps
+    auto step_ptr = [&](int st) -> const u32x4* {        // fragment block of stream step st
+        return st < QX_KS1 ? A1 + (size_t)st * 4 * 2 * 64 : A23 + (size_t)(st - QX_KS1) * 4 * 2 * 64;
+    };
+    AFrag2 ring[PF];
+    // 16-bit maps: the ring's first loads fly under the gather; fp32 maps: the gather's 8 points x 4 taps in flight take the
+    // registers (an HBM round trip saved there is worth more than the one L2 round trip exposed here)
+    constexpr bool RING_EARLY = sizeof(T) == 2 || NCB == 1;
+    if (RING_EARLY && active) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_afrag2(ring[p], step_ptr(p), rb0);
+    }
+    const T* feat_b = (const T*)a.feat + (size_t)b * a.FH * a.FW * FEAT_C;
+    const T* tmpx_b = (const T*)a.tmpx + (size_t)b * a.TH * a.TW * TMPX_C;
+    gather_tile_split<T, PTS>(XH, XL, sm.tab, feat_b, tmpx_b, wid, lane);
+    if (!RING_EARLY && active) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) load_afrag2(ring[p], step_ptr(p), rb0);
+    }
+    __syncthreads();
+    QSTAMP(2);
+
+    f32x16 acc[2][NCB], nb[2];
+    auto mm = [&](const AFrag2& f, const u32x4 (&bh)[NCB], const u32x4 (&bl)[NCB]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = mfma3(f.h[i], f.l[i], bh[cb], bl[cb], acc[i][cb]);
+    };
+    auto fetch_bias = [&](int layer) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) nb[i] = scaled_bias(arena, head, layer, rb0 + i, half);
+    };
+    auto init_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[i][cb] = nb[i];
+    };
+    // relu(acc / 2^s) of this wave's two row blocks -> B fragments of K-blocks rb0, rb0 + 1 of the next layer
+    auto publish = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = relu(acc[i][cb][8 * s + j] * QX_INV);
+                    u32x4 hi, lo;
+                    split8(v, hi, lo);
+                    u32x4* dst = E + ((((size_t)(head * 4 + rb0 + i) * 2 + s) * NCB + cb) * 2) * 64 + lane;
+                    dst[0] = hi;
+                    dst[64] = lo;
+                }
+    };
+
+    // ---- layer 1: K = 336 from the input planes ----
+    if (active) {
+        fetch_bias(0);
+        init_acc();
+        fetch_bias(1);                   // the next layer's, in flight under this one
+        const char* xh0 = XH + (size_t)col * XSH * 2 + 16 * half;
+        const char* xl0 = XL + (size_t)col * XSH * 2 + 16 * half;
+#pragma unroll 1
+        for (int k0 = 0; k0 < QX_KS1; k0 += PF) {
+#pragma unroll
+            for (int p = 0; p < PF; ++p) {
+                const int ks = k0 + p;
+                u32x4 bh[NCB], bl[NCB];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    bh[cb] = *(const u32x4*)(xh0 + (size_t)cb * 32 * XSH * 2 + ks * 32);
+                    bl[cb] = *(const u32x4*)(xl0 + (size_t)cb * 32 * XSH * 2 + ks * 32);
+                }
+                mm(ring[p], bh, bl);
+                load_afrag2(ring[p], step_ptr(ks + PF), rb0);       // ks + PF < NSTEP always: runs into layer 2's fragments
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    __syncthreads();                     // every wave is done with the input planes: the exchange area may be written
+    QSTAMP(3);
+    if (active) publish();
+    __syncthreads();
+
+    // ---- layers 2, 3: K = 128 from the exchange area ----
+    u32x4 ah[8], al[8];                  // the output layer's fragments (requested when layer 3's MFMAs are done)
+#pragma unroll
+    for (int layer = 1; layer <= 2; ++layer) {
+        if (active) {
+            init_acc();
+            fetch_bias(layer + 1);
+            const u32x4* Eh = E + (size_t)head * 4 * 2 * NCB * 2 * 64 + lane;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {          // k-step t = (kb, s)
+                const int st = QX_KS1 + 8 * (layer - 1) + t;
+                u32x4 bh[NCB], bl[NCB];
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) {
+                    bh[cb] = Eh[((size_t)(t * NCB + cb) * 2) * 64];
+                    bl[cb] = Eh[((size_t)(t * NCB + cb) * 2 + 1) * 64];
+                }
+                mm(ring[st % PF], bh, bl);
+                if (st + PF < NSTEP) load_afrag2(ring[st % PF], step_ptr(st + PF), rb0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (layer == 2) {
+                const u32x4* A = xbase + QX_L1_VEC + QX_L23_VEC + (size_t)head * 4 * 2 * 2 * 64 + lane;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) { ah[t] = A[(t * 2) * 64]; al[t] = A[(t * 2 + 1) * 64]; }
+            }
+        }
+        __syncthreads();                 // both waves of every head have read the layer's input
+        if (active) publish();
+        __syncthreads();
+    }
+
+    QSTAMP(4);
+    // ---- output layer (one 32-row block): the head's two waves take a column block each ----
+    const int cb_o = NCB == 2 ? ch : 0;
+    if (!active || (NCB == 1 && ch != 0)) return;
+    f32x16 o = nb[0];                    // fetch_bias(3) with rb0 = 0: both waves need row block 0
+    if (rb0 != 0) o = scaled_bias(arena, head, 3, 0, half);
+    {
+        const u32x4* Eh = E + (size_t)head * 4 * 2 * NCB * 2 * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const u32x4 bh = Eh[((size_t)(t * NCB + cb_o) * 2) * 64], bl = Eh[((size_t)(t * NCB + cb_o) * 2 + 1) * 64];
+            o = mfma3(ah[t], al[t], bh, bl, o);
+        }
+    }
+    const int odim = head_out_dim(head);
+    float* outp = a.out[head] + (size_t)b * odim * a.N;
+    const int pt = cb_o * 32 + col, n = n0 + pt;
+    const bool inside = sm.tab.in_img[pt] != 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int chn = mfma32_row(r, half);
+        if (chn < odim && n < a.N) {
+            float v = o[r] * QX_INV;
+            if (head == 0 && !inside) v = 5.0f;
+            outp[(size_t)chn * a.N + n] = v;
+        }
+    }
+    QSTAMP(5);
+}
+
+template <typename T, int NCB>
+static int launch_query_fwd_split(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    bool& attr_set = CHORE_ONCE_FLAG(h);
+    constexpr int PTS = 32 * NCB;
+    const size_t smem = sizeof(QuerySplitSmemT<PTS>);
+    if (!attr_set) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_fwd_x3_split_kernel<T, NCB>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set = true;
+    }
+    dim3 grid((a.N + PTS - 1) / PTS, a.B);
+    hipLaunchKernelGGL((query_fwd_x3_split_kernel<T, NCB>), grid, dim3(512), smem, s, a);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pixel-aligned feature sample only (projection + 2x index + z_feat, no heads): the 323-vector per
 // point, point-major.  Same phase 1/2 code as the fused kernel, so it doubles as its probe.
 // ------------------------------------------------------------------------------------------------
@@ -469,6 +752,10 @@ template <typename T, bool X3 = false>
 static int launch_query_fwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     static const bool w4 = getenv("CHORE_QUERY_W4") != nullptr;     // A/B switches for large queries
     static const bool w8 = getenv("CHORE_QUERY_W8") != nullptr;
+    if constexpr (X3) {
+        static const bool nosplit = getenv("CHORE_QUERY_X3_NOSPLIT") != nullptr;      // A/B switch: the one-wave-per-head kernels
+        if (!nosplit) return query_small_tiles(a.B, a.N) ? launch_query_fwd_split<T, 1>(h, a, s) : launch_query_fwd_split<T, 2>(h, a, s);
+    }
     if (query_small_tiles(a.B, a.N)) return launch_query_fwd_n<T, 1, X3>(h, a, s);
     // (a single output asked for, CHORE.query_df: 32-point tiles do not pay -- a workgroup is placed with the registers of all
     // four waves, so the CU holds one whatever the three leaving waves free: 363 against 335 us at 8 x 20 000 points)

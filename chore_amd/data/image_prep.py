@@ -4,9 +4,11 @@ Counterpart of TestData.prepare_image_crop (/root/reference/data/test_data.py:59
 image and the two masks are decoded uint8 arrays: bounding box of the masks -> crop centre, resize to the 2048-px space,
 crop of `scale * 1200` px around the centre (zero padded), resize to the network input, /255, background masking,
 channel stacking.  All pixel work runs in libchore_hip.so (csrc/image_prep.hip: chore_prep_masks2bbox / _resize_u8 /
-_crop_compose); the host does the few scalar steps in numpy with the reference's expressions.  JPEG decoding, the
-keypoint / mocap based `fullbody_crop` scale (:167-200) and the use_mean_center variant of the COCO loader (float64
-canvas, :127-160) stay with the reference's host code.
+_crop_compose / _crop_compose_mean); the host does the few scalar steps in numpy with the reference's expressions.
+use_mean_center=True (the COCO loader, recon/recon_fit_coco.py:28): the patch is moved to the mean crop centre of the
+BEHAVE training set (pad_image :133-160 -- a float64 canvas in the reference, a translated clipped lookup here) and cv2's
+generic float resize applies.  JPEG decoding and the keypoint / mocap based `fullbody_crop` scale (:167-200) stay with the
+reference's host code.
 
     prep = ImagePrep(image_size=(512, 512), crop_size=1200)
     images, crop_center, resize_scale, old_center = prep.prepare(rgb_u8, person_u8, obj_u8, scale)
@@ -22,8 +24,8 @@ from .. import _lib
 
 class ImagePrep:
     def __init__(self, image_size=(512, 512), crop_size=1200, use_mean_center=False, device="cuda:0"):
-        if use_mean_center:
-            raise NotImplementedError("use_mean_center (COCO loader) pads on a float64 canvas: host code of the reference")
+        self.use_mean_center = bool(use_mean_center)
+        self.mean_crop_center = np.array([1008., 995.])      # test_data.py:32: computed from the BEHAVE training set
         if image_size[0] != image_size[1]:
             raise ValueError("the crop is square: image_size must be (S, S)")
         self.img_size, self.crop_size = tuple(image_size), float(crop_size)
@@ -80,6 +82,8 @@ class ImagePrep:
         crop_center = np.round(resize_scale * crop_center)
         rgb, pm, om = self.resize(rgb, newsize), self.resize(pm, newsize), self.resize(om, newsize)
         size = scale * np.array([self.crop_size, self.crop_size])
+        if self.use_mean_center:
+            return self._prepare_mean(rgb, pm, om, crop_center, size, resize_scale)
         tl = np.round(crop_center - size / 2).astype(int)
         br = np.round(crop_center + size / 2).astype(int)
         S = self.img_size[0]
@@ -90,3 +94,20 @@ class ImagePrep:
         _lib.check(_lib.lib.chore_prep_crop_compose(h, rgb.data_ptr(), pm.data_ptr(), om.data_ptr(), H, W, int(tl[0]), int(tl[1]),
                                                     int(br[0]), int(br[1]), S, images.data_ptr(), s), h, "chore_prep_crop_compose")
         return images, crop_center, resize_scale, crop_center.copy()
+
+    def _prepare_mean(self, rgb, pm, om, crop_center, size, resize_scale):
+        """use_mean_center=True: pad_image + change_crop_center (test_data.py:99-104,127-160), then crop / resize / compose"""
+        old_center = crop_center.copy()
+        mean = self.mean_crop_center.copy()
+        tl = np.round(mean - size / 2).astype(int)
+        br = np.round(mean + size / 2).astype(int)
+        S = self.img_size[0]
+        images = torch.empty(5, S, S, dtype=torch.float32, device=self.device)
+        h = _lib.handle(self.device.index or 0)
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        H, W = rgb.shape[:2]
+        _lib.check(_lib.lib.chore_prep_crop_compose_mean(h, rgb.data_ptr(), pm.data_ptr(), om.data_ptr(), H, W, float(old_center[0]),
+                                                         float(old_center[1]), float(mean[0]), float(mean[1]), int(tl[0]), int(tl[1]),
+                                                         int(br[0]), int(br[1]), S, images.data_ptr(), s), h,
+                   "chore_prep_crop_compose_mean")
+        return images, mean, resize_scale, old_center

@@ -362,6 +362,14 @@ int chore_prep_resize_u8(chore_handle* h, const unsigned char* src, int sh, int 
 int chore_prep_crop_compose(chore_handle* h, const unsigned char* rgb, const unsigned char* person_mask,
                             const unsigned char* obj_mask, int H, int W, int tl_x, int tl_y, int br_x, int br_y, int S,
                             float* images, chore_stream_t stream);
+/* use_mean_center=True (the COCO loader, recon/recon_fit_coco.py:28; data/test_data.py:127-160): the images are moved so
+ * that the crop centre (cc, in the 2048-px space) lands on the mean crop centre of the BEHAVE training set (pad_image's
+ * zero float64 canvas, at least 2048 x 1536, the pasted part clipped to that rectangle), the crop with corners tl / br is
+ * taken around the mean centre, and the resize is cv2's generic float path (float weights, double sums) -- restated in
+ * oracle/image_prep.py, UNPINNED like the 8-bit one. */
+int chore_prep_crop_compose_mean(chore_handle* h, const unsigned char* rgb, const unsigned char* person_mask,
+                                 const unsigned char* obj_mask, int H, int W, double cc_x, double cc_y, double mean_x, double mean_y,
+                                 int tl_x, int tl_y, int br_x, int br_y, int S, float* images, chore_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Interpenetration term of the joint fit  (replaces ReconFitterBase.smpl_obj_collision recon/recon_fit_base.py:610-624 =

@@ -72,7 +72,7 @@ def _prototypes():
 
 
 def _kind(c_type_text):
-    """'ptr' / 'int' / 'size' / 'float' / 'i64' of a C parameter or return type"""
+    """'ptr' / 'int' / 'size' / 'float' / 'double' / 'i64' of a C parameter or return type"""
     t = re.sub(r"\b[a-zA-Z_][a-zA-Z0-9_]*$", "", c_type_text).strip() if not c_type_text.endswith("*") else c_type_text
     t = t or c_type_text
     if "*" in t or "chore_stream_t" in t:
@@ -83,6 +83,8 @@ def _kind(c_type_text):
         return "i64"
     if "float" in t:
         return "float"
+    if "double" in t:
+        return "double"
     return "int"
 
 
@@ -91,7 +93,7 @@ def test_ctypes_signatures_match_the_header():
     against the prototype in include/chore_hip.h: a drifted signature corrupts the call silently"""
     from chore_amd import _lib
     kinds = {ctypes.c_int: "int", ctypes.c_size_t: "size", ctypes.c_float: "float", ctypes.c_longlong: "i64",
-             ctypes.c_int64: "i64", ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr"}
+             ctypes.c_int64: "i64", ctypes.c_void_p: "ptr", ctypes.c_char_p: "ptr", ctypes.c_double: "double"}
 
     def k(ct):
         return kinds.get(ct, "ptr")     # POINTER(...) types

@@ -72,3 +72,33 @@ def test_prepare_image_crop_matches_restatement(case):
     assert got.shape == (5, 512, 512) and got.dtype == np.float32
     assert np.array_equal(got, ref), (case, np.abs(got - ref).max())
     assert got[3].max() == 1.0 and (got[:3][:, (got[3] <= 0.5) & (got[4] <= 0.5)] == 0).all()
+
+
+@pytest.mark.parametrize("case", ["coco_landscape", "coco_portrait", "far_corner", "exact2x"])
+def test_prepare_image_crop_with_mean_center_matches_restatement(case):
+    """use_mean_center=True (the COCO loader, recon_fit_coco.py:28; test_data.py:127-160): pad_image's canvas, the crop around
+    the mean crop centre and the float resize -- bit for bit against the restatement, including a patch that is pushed
+    partly outside the 2048 x 1536 rectangle (clipped paste) and the 2 x 2 area fast path"""
+    from chore_amd.data import ImagePrep
+    rs = np.random.RandomState(11)
+    if case == "coco_landscape":
+        rgb, pm, om = _scene(rs, 480, 640, (200, 100, 330, 400), (300, 250, 420, 380))
+        scale = 1.07
+    elif case == "coco_portrait":
+        rgb, pm, om = _scene(rs, 640, 427, (100, 150, 300, 600), (250, 400, 400, 560))
+        scale = 0.93
+    elif case == "far_corner":       # subject in the top-left corner: the image is shifted far right / down and clipped
+        rgb, pm, om = _scene(rs, 1536, 2048, (20, 10, 300, 500), (250, 300, 420, 470))
+        scale = 1.2
+    else:
+        rgb, pm, om = _scene(rs, 480, 640, (200, 100, 330, 400), (300, 250, 420, 380))
+        scale = 1024 / 1200
+    prep = ImagePrep(image_size=(512, 512), crop_size=1200, use_mean_center=True)
+    images, center, rscale, old = prep.prepare(rgb, pm, om, scale)
+    ref, rcenter, rrscale, rold = oi.prepare_image_crop_mean_center(rgb, pm, om, scale)
+    assert np.array_equal(center, rcenter) and rscale == rrscale and np.array_equal(old, rold)
+    assert list(center) == [1008., 995.]
+    got = images.cpu().numpy()
+    assert got.shape == (5, 512, 512) and got.dtype == np.float32
+    assert np.array_equal(got, ref), (case, np.abs(got - ref).max())
+    assert got[3].max() > 0.9 and (got[:3][:, (got[3] <= 0.5) & (got[4] <= 0.5)] == 0).all()

@@ -29,3 +29,23 @@ def test_crop_and_compose_follow_the_reference_arithmetic():
     a = np.array([[200, 128]], np.uint8)
     bmin, bmax = oi.masks2bbox([a, a])                                     # 200+200 wraps to 144 (>127), 128+128 to 0
     assert list(bmin) == [0, 0] and list(bmax) == [1, 1]
+
+
+def test_mean_center_restatement_hand_cases():
+    """pad_image (test_data.py:133-160) and the float resize: hand-checkable cases"""
+    from oracle import image_prep as oi
+    img = (np.arange(12, dtype=np.uint8).reshape(3, 4) + 1)
+    # crop centre (2, 1) -> mean centre: the image lands with its pixel (1, 2) at (995, 1008) of a 1536 x 2048 canvas
+    c = oi.pad_image(img, np.array([2., 1.]))
+    assert c.shape == (1536, 2048) and c.dtype == np.float64
+    assert c[995, 1008] == img[1, 2] and c[994, 1006] == img[0, 0] and c.sum() == img.sum()
+    # a centre beyond the mean centre shifts the image up / left and clips it at the canvas origin
+    big = np.full((1536, 2048), 7, np.uint8)
+    c = oi.pad_image(big, np.array([1108., 1000.]))
+    assert c.shape == (1536, 2048) and c[0, 0] == 7 and c[1536 - 6, 0] == 7 and c[1536 - 5, 0] == 0 and c[0, 2048 - 100] == 0
+    # float resize: identity, exact 2 x 2 mean, and a 1 x 2 -> 1 x 4 upscale with cv2's pixel-centre weights
+    a = np.array([[0., 4.], [8., 12.]])
+    assert np.array_equal(oi.resize_linear_f64(a, (2, 2)), a)
+    assert np.array_equal(oi.resize_linear_f64(a, (1, 1)), [[6.]])
+    r = oi.resize_linear_f64(np.array([[0., 8.]]), (4, 1))
+    assert np.allclose(r, [[0., 2., 6., 8.]], atol=1e-6)
