@@ -1,6 +1,6 @@
 """N training passes in one process (gradients compared bit for bit with the first) while another process keeps the GPU busy"""
 import os, sys, subprocess, numpy as np, torch
-REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 if len(sys.argv) > 1 and sys.argv[1] == "noise":
     a = torch.randn(4096, 4096, device="cuda")
     while True:
