@@ -349,9 +349,12 @@ def mode_query(args, ctx):
         # 32-point tiles when 64-point tiles would not fill the CUs)
         x3 = args.dtype in ("fp16x3", "bf16", "fp16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)
         qt = "float" if args.dtype == "fp16x3" else ("qh16_t" if args.dtype == "fp16" else tname)
-        if B * ((N + 63) // 64) <= 256:
+        small = B * ((N + 63) // 64) <= 256
+        if x3 and not os.environ.get("CHORE_QUERY_X3_NOSPLIT"):     # fp16 x 3 heads: two waves per head (csrc/query_fwd.hip)
+            qname = "query_fwd_x3_split_kernel<%s, %d>" % (qt, 1 if small else 2)
+        elif small:
             qname = "query_fwd_f32_kernel<%s, 1, false, %s>" % (qt, "true" if x3 else "false")
-        elif x3:        # fp16 x 3 heads: four waves, two column blocks each (the eight-wave kernel is bound by the L1 there)
+        elif x3:        # four waves, two column blocks each (the eight-wave kernel is bound by the L1 there)
             qname = "query_fwd_f32_kernel<%s, 2, false, true>" % qt
         else:
             qname = "query_fwd_f32_w8_kernel<%s, false, false>" % qt
@@ -495,7 +498,7 @@ def mode_fit(args, ctx):
                          "sharding": "frames across ranks, no collective in the loop; one gather of the fitted parameters"})
         out.update({"chain_ms_per_step": per_step, "frame_iterations_per_s": ctx.world * B * 1e3 / iter_ms,
                     "frames_per_s_whole_chain": ctx.world * B * args.steps / elapsed,
-                    "roofline": {"kernel": "whole fit iteration (field queries dominate: query_fwd_f32_kernel / query_bwd_f32_kernel, "
+                    "roofline": {"kernel": "whole fit iteration (field queries dominate: query_fwd_x3_split_kernel / query_bwd_f32_kernel, "
                                            "32-point tiles)", "bound": "mfma", "achieved": flops / iter_ms / 1e9,
                                  "peak": PEAK_TFLOPS[hd], "unit": "TFLOP/s", "frac": flops / iter_ms / 1e9 / PEAK_TFLOPS[hd],
                                  "frac_of_fp32_mfma_peak": flops / iter_ms / 1e9 / PEAK_TFLOPS["fp32"],

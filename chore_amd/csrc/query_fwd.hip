@@ -221,7 +221,12 @@ __device__ __forceinline__ void gather_tile_split(char* XH, char* XL, const PtTa
                                                   int wid, int lane) {
     using L = MapLoad<T>;
     constexpr int NW = 8, U = PTS / NW;          // all of a wave's points (8 or 4) in flight at once: one HBM round trip
+    // The fp32 value is pinned in a register before it is split: left alone, the compiler folds the last fmaf of the
+    // interpolation into the conversion (v_fma_mixlo_f16: ONE rounding to half instead of fp32 then half), and on an exact tie
+    // the planes differ from the in-register split of the one-wave-per-head kernels -- the fused surface step, which
+    // recomputes its forward there, is checked against this kernel bit for bit (tests/test_gpu_generator.py).
     auto put = [&](char* row_h, char* row_l, int k, float v) {
+        asm volatile("" : "+v"(v));
         const _Float16 h = (_Float16)v, l = (_Float16)(v - (float)h);
         *(_Float16*)(row_h + 2 * k) = h;
         *(_Float16*)(row_l + 2 * k) = l;
@@ -250,7 +255,8 @@ __device__ __forceinline__ void gather_tile_split(char* XH, char* XL, const PtTa
         h4 hh, ll;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float r = interp4(c0[c], c1[c], c2[c], c3[c], fw);
+            float r = interp4(c0[c], c1[c], c2[c], c3[c], fw);
+            asm volatile("" : "+v"(r));
             hh[c] = (_Float16)r;
             ll[c] = (_Float16)(r - (float)hh[c]);
         }
@@ -268,6 +274,12 @@ __device__ __forceinline__ void gather_tile_split(char* XH, char* XL, const PtTa
 #ifdef CHORE_QUERY_STAMPS
 __device__ unsigned long long g_qstamps[4096 * 8];
 #define QSTAMP(i) do { if (tid == 0) { const int L_ = blockIdx.x + blockIdx.y * gridDim.x; if (L_ < 4096) g_qstamps[L_ * 8 + (i)] = wall_clock64(); } } while (0)
+__device__ unsigned short g_qx[2 * 64 * XSH];
+__device__ int g_qx_tile = -1;
+extern "C" int chore_debug_query_xdump(unsigned short* out, int tile) {
+    if (tile >= 0) return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_qx_tile), &tile, sizeof(int));
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qx), sizeof(unsigned short) * 2 * 64 * XSH);
+}
 extern "C" int chore_debug_query_stamps(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qstamps), sizeof(unsigned long long) * (n < 4096 * 8 ? n : 4096 * 8));
 }
@@ -332,6 +344,10 @@ __global__ __launch_bounds__(512, 1) void query_fwd_x3_split_kernel(QueryArgs a)
     }
     __syncthreads();
     QSTAMP(2);
+#ifdef CHORE_QUERY_STAMPS
+    if (b == 0 && tile_ == g_qx_tile)
+        for (int i = tid; i < 2 * PTS * XSH; i += 512) g_qx[i] = ((const unsigned short*)sm.buf)[i];
+#endif
 
     f32x16 acc[2][NCB], nb[2];
     auto mm = [&](const AFrag2& f, const u32x4 (&bh)[NCB], const u32x4 (&bl)[NCB]) {

@@ -381,3 +381,17 @@ def test_skipped_heads_change_nothing(opt, mode):
                                       g_centers=torch.zeros_like(centers))
         assert torch.isfinite(only).all() and float(only.abs().max()) > 0
         assert torch.equal(only, zeros)
+
+
+def test_split_forward_kernel_equals_the_one_wave_per_head_kernels_bit_for_bit():
+    """fp16 x 3 forward: the two-waves-per-head kernel (query_fwd_x3_split_kernel: input planes split into fp16 hi / lo at
+    gather time, activations exchanged through the LDS) against the one-wave-per-head kernels (CHORE_QUERY_X3_NOSPLIT=1, the
+    arithmetic the backward / surface-step kernels recompute): all four outputs, fp32 / bf16 / fp16 maps, 32- and 64-point
+    tiles, ragged tails -- identical bits (scripts/query_split_equal.py runs both in child processes: the switch is read once)"""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "query_split_equal.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if " equal " in ln]
+    assert len(lines) == 36 and all(" equal True" in ln for ln in lines), "\n".join(ln for ln in lines if "True" not in ln)
