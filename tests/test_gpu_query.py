@@ -6,6 +6,8 @@ Everything goes through the C-ABI (ctypes -> libchore_hip.so).  Expected values 
 Tolerances: projection, in_img, OUT_DIST mask and sampled features are BIT-EXACT; head outputs
 |err| <= 3e-5 (fp32 accumulation order differs from BLAS); gradients rel. 2e-4 of their scale.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
