@@ -14,9 +14,9 @@
 
 namespace {
 
-constexpr int FS_MAXT = 8;
+constexpr int FS_MAXT = 16;
 struct AdamTensors {
-    float* p[FS_MAXT]; const float* g[FS_MAXT]; float* m[FS_MAXT]; float* v[FS_MAXT];
+    float* p[FS_MAXT]; float* g[FS_MAXT]; const float* gn[FS_MAXT]; float* m[FS_MAXT]; float* v[FS_MAXT];
     int n[FS_MAXT];
     int nt;
 };
@@ -29,7 +29,12 @@ __global__ void fit_adam_kernel(AdamTensors t, const float* step, float lr, floa
     const float step_size = -(lr / bc1);
     const float bc2s = sqrtf(bc2);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < t.n[k]; i += gridDim.x * blockDim.x) {
-        const float g = t.g[k][i];
+        float g = t.g[k][i];
+        if (t.gn[k]) {                       // this step's gradient: .grad += new (what AccumulateGrad's add launch did)
+            g = g + t.gn[k][i];
+            t.g[k][i] = g;
+        }
+        if (!t.p[k]) continue;               // a leaf that only accumulates (stepped by a later phase's optimiser)
         float m = t.m[k][i], v = t.v[k][i];
         m = m + (g - m) * (1.0f - b1);
         v = v * b2 + (1.0f - b2) * g * g;
@@ -72,20 +77,24 @@ __global__ void fit_weighted_sum_bwd_kernel(LossTerms t, const float* denom, con
 
 extern "C" {
 
-// One Adam step on nt <= 8 fp32 device tensors (p, g, m, v: host arrays of device pointers, n: their lengths).  step: device
+// One Adam step on nt <= 16 fp32 device tensors (p, g, m, v: host arrays of device pointers, n: their lengths).  step: device
 // float, the number of steps taken so far (NOT incremented here: chore_fit_stop_rule does, after this launch); stop: device
 // byte, nonzero = leave the parameters alone.
-int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
-                        int nt, const float* step, float lr, float beta1, float beta2, float eps, const uint8_t* stop,
-                        chore_stream_t stream) {
-    CHORE_ENTER(h);
+// chore_fit_adam_step_acc: g[k] is the ACCUMULATED gradient (the parameter's .grad, read and written) and gnew[k] (or NULL)
+// this step's fresh gradient, added first -- the per-parameter `grad += new` launches of autograd's accumulation folded into
+// the update; p[k] / m[k] / v[k] NULL = a leaf that only accumulates.
+static int adam_step_impl(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
+                          float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
+                          const uint8_t* stop, chore_stream_t stream, const char* who) {
     if (!p || !g || !m || !v || !n || !step || !stop || nt <= 0 || nt > FS_MAXT)
-        CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step: bad argument (at most %d tensors)", FS_MAXT);
+        CHORE_FAIL(h, CHORE_EINVAL, "%s: bad argument (at most %d tensors)", who, FS_MAXT);
     AdamTensors t;
     int nmax = 0;
     for (int k = 0; k < nt; ++k) {
-        if (!p[k] || !g[k] || !m[k] || !v[k] || n[k] <= 0) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step: null tensor %d", k);
-        t.p[k] = p[k]; t.g[k] = g[k]; t.m[k] = m[k]; t.v[k] = v[k]; t.n[k] = n[k];
+        const bool acc_only = gnew && !p[k];
+        if (!g[k] || n[k] <= 0 || (!acc_only && (!p[k] || !m[k] || !v[k])) || (acc_only && !gnew[k]))
+            CHORE_FAIL(h, CHORE_EINVAL, "%s: null tensor %d", who, k);
+        t.p[k] = p[k]; t.g[k] = g[k]; t.gn[k] = gnew ? gnew[k] : nullptr; t.m[k] = m[k]; t.v[k] = v[k]; t.n[k] = n[k];
         nmax = n[k] > nmax ? n[k] : nmax;
     }
     t.nt = nt;
@@ -94,6 +103,19 @@ int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g,
     hipLaunchKernelGGL(fit_adam_kernel, dim3(bx, nt), dim3(256), 0, (hipStream_t)stream, t, step, lr, beta1, beta2, eps, stop);
     CHORE_LAUNCH_CHECK(h, (hipStream_t)stream);
     return CHORE_OK;
+}
+int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g, float* const* m, float* const* v, const int* n,
+                        int nt, const float* step, float lr, float beta1, float beta2, float eps, const uint8_t* stop,
+                        chore_stream_t stream) {
+    CHORE_ENTER(h);
+    return adam_step_impl(h, p, (float* const*)g, nullptr, m, v, n, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step");
+}
+int chore_fit_adam_step_acc(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
+                            float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
+                            const uint8_t* stop, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!gnew) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step_acc: gnew is NULL");
+    return adam_step_impl(h, p, g, gnew, m, v, n, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step_acc");
 }
 
 // the stop rule of one inner step: hit = |prev - loss| / prev < prev * tol;  stop |= hit & armed;  prev = loss unless stop was

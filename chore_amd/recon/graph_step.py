@@ -29,8 +29,8 @@ class FusedAdam:
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
         self.params = list(params)
-        if not 0 < len(self.params) <= 8 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.params):
-            raise ValueError("FusedAdam: 1..8 contiguous fp32 device tensors")
+        if not 0 < len(self.params) <= 16 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.params):
+            raise ValueError("FusedAdam: 1..16 contiguous fp32 device tensors")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = self.params[0].device
         self.step_t = torch.zeros((), device=dev)
@@ -62,6 +62,45 @@ class FusedAdam:
         _lib.check(_lib.lib.chore_fit_adam_step(h, pp, gg, mm, vv, nn, n, self.step_t.data_ptr(), self.lr, self.betas[0],
                                                 self.betas[1], self.eps, stop.data_ptr(),
                                                 torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step")
+
+
+    def step_acc(self, stop, leaves, new_grads):
+        """Adam with autograd's accumulation folded into the launch (chore_fit_adam_step_acc): leaves = the parameters of
+        this optimiser followed by the leaves that only accumulate; new_grads[i] = this step's gradient of leaves[i]
+        (torch.autograd.grad; None = the loss does not reach it).  Equals  leaf.grad += new  for every leaf, then step()."""
+        state = {id(p): (m, v) for p, m, v in zip(self.params, self.m, self.v)}
+        rows = []
+        for leaf, g in zip(leaves, new_grads):
+            if g is None and leaf.grad is None:
+                continue                                   # torch's Adam skips a parameter without a gradient
+            if leaf.grad is None:
+                leaf.grad = torch.zeros_like(leaf)        # 0 + new = new, bit for bit what the first accumulation stores
+            if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
+                g = g.float().contiguous()
+            mv = state.get(id(leaf))
+            if mv is None and g is None:
+                continue                                   # accumulate-only leaf, nothing new
+            rows.append((leaf if mv is not None else None, leaf.grad, g, mv))
+        if not rows:
+            return
+        if len(rows) > 16:
+            raise ValueError("FusedAdam.step_acc: at most 16 tensors")
+        key = tuple((0 if p is None else p.data_ptr(), a.data_ptr(), 0 if g is None else g.data_ptr()) for p, a, g, _ in rows)
+        if self._args is None or self._args[0] != key:
+            n = len(rows)
+            arr = lambda xs: (ctypes.c_void_p * n)(*xs)   # noqa: E731
+            self._keep = [g for _, _, g, _ in rows]
+            self._args = (key, arr([None if p is None else p.data_ptr() for p, _, _, _ in rows]), arr([a.data_ptr() for _, a, _, _ in rows]),
+                          arr([None if g is None else g.data_ptr() for _, _, g, _ in rows]),
+                          arr([None if mv is None else mv[0].data_ptr() for _, _, _, mv in rows]),
+                          arr([None if mv is None else mv[1].data_ptr() for _, _, _, mv in rows]),
+                          (ctypes.c_int * n)(*[a.numel() for _, a, _, _ in rows]), n)
+        _, pp, aa, gg, mm, vv, nn, n = self._args
+        dev = self.params[0].device
+        h = _lib.handle(dev.index or 0)
+        _lib.check(_lib.lib.chore_fit_adam_step_acc(h, pp, aa, gg, mm, vv, nn, n, self.step_t.data_ptr(), self.lr, self.betas[0],
+                                                    self.betas[1], self.eps, stop.data_ptr(),
+                                                    torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step_acc")
 
 
 class _WeightedSum(torch.autograd.Function):
@@ -127,6 +166,7 @@ class EagerStep:
         carry: parameters this phase does not step but whose .grad keeps accumulating (every leaf the loss reaches does in
         the reference, and a later phase's new Adam starts from those sums, recon_fit_behave.py:243-259)"""
         self.params = list(params)
+        self.carry = [p for p in carry if all(p is not q for q in self.params)]
         self.opt = opt if opt is not None else self._make_opt(lr, betas, capturable)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
         self._init_flags(self.params[0].device)
@@ -172,8 +212,18 @@ class EagerStep:
         if isinstance(self.opt, FusedAdam):
             # two launches: Adam on all tensors (the latched flag freezes the parameters), then the stop rule + step counter
             loss = self.loss_fn(_OnePlusDecay(self.denom))
-            loss.backward(self.seed if loss.dtype == self.seed.dtype and loss.dim() == 0 else None)
-            self.opt.step(self.stop)
+            seed = self.seed if loss.dtype == self.seed.dtype and loss.dim() == 0 else None
+            if os.environ.get("CHORE_FIT_BACKWARD_ACCUMULATE"):        # A/B switch: .backward() + one add launch per leaf
+                loss.backward(seed)
+                self.opt.step(self.stop)
+            else:
+                # this step's gradients as fresh tensors; `grad += new` of every leaf happens inside the Adam launch.  The
+                # leaves: the optimiser's parameters and `carry` -- every other leaf the loss reaches is not stepped by any
+                # later optimiser of the fit (the caller's contract, see __init__)
+                leaves = [p for p in self.opt.params] + [p for p in self.carry if all(p is not q for q in self.opt.params)]
+                leaves += [p for p in self.params if all(p is not q for q in leaves)]
+                grads = torch.autograd.grad(loss, leaves, seed, allow_unused=True)
+                self.opt.step_acc(self.stop, leaves, grads)
             lv = loss.detach()
             if lv.dtype != torch.float32:
                 lv = lv.float()
@@ -217,6 +267,7 @@ class GraphedStep(EagerStep):
         self.params = list(params)
         dev = self.params[0].device
         carry = [p for p in carry if all(p is not q for q in self.params)]
+        self.carry = carry
         for p in self.params + carry:
             if p.grad is None:       # a recorded backward must ADD into a tensor that exists (a missing .grad would be
                 p.grad = torch.zeros_like(p)   # replaced by a graph-private tensor and overwritten on every replay)

@@ -504,13 +504,21 @@ int chore_profile_read(chore_handle* h, int max_classes, const char** names, dou
                        double* bytes, int64_t* launches);
 
 /* The tail of one inner fitting step (reference recon/recon_fit_behave.py:143-160, 270-287): Adam -- the formulas of
- * torch.optim.Adam(capturable=True) -- on nt <= 8 small fp32 tensors in one launch, and the early-stop rule
+ * torch.optim.Adam(capturable=True) -- on nt <= 16 small fp32 tensors in one launch, and the early-stop rule
  * |prev - loss| / prev < prev * tol with its latch in another.  p / g / m / v: host arrays of device pointers, n: lengths;
  * step, prev, loss, loss_out: device floats; stop, armed: device bytes.  A set `stop` freezes the parameters (the moments and
  * the counter still advance).  chore_fit_stop_rule increments `step` (if not NULL): call it after chore_fit_adam_step. */
 int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g, float* const* m, float* const* v,
                         const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
                         const uint8_t* stop, chore_stream_t stream);
+/* the same update with autograd's gradient accumulation folded in: g[k] is the ACCUMULATED gradient (the parameter's .grad,
+ * read and written), gnew[k] (or NULL: nothing new) this step's fresh gradient, added to g[k] first -- the reference
+ * accumulates over the inner steps of an outer iteration (recon_fit_behave.py:117-118,143-146), which as tensor ops is one
+ * `grad += new` launch per parameter and step.  p[k] == NULL (then m[k], v[k] are ignored): a leaf that only accumulates
+ * (stepped by a later phase's optimiser, which starts from these sums).  nt <= 16. */
+int chore_fit_adam_step_acc(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
+                            float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2,
+                            float eps, const uint8_t* stop, chore_stream_t stream);
 int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
                         float* loss_out, float* step, chore_stream_t stream);
 /* the weighting of the fit's loss dictionary (recon_fit_behave.py:339-358): out = sum_k coeff[k] * loss[k] / denom over
