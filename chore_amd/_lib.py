@@ -102,8 +102,8 @@ SIGNATURES = {
     "chore_debug_nan_counts": (c_int, [c_void_p]),
     "chore_fit_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                     c_float, c_float, c_void_p, c_void_p]),
-    "chore_fit_adam_step_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float,
-                                        c_float, c_float, c_float, c_void_p, c_void_p]),
+    "chore_fit_adam_step_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                        c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
     "chore_fit_weighted_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_fit_weighted_sum_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_fit_smpl_terms_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -18,7 +18,8 @@ constexpr int FS_MAXT = 16;
 struct AdamTensors {
     float* p[FS_MAXT]; float* g[FS_MAXT]; const float* gn[FS_MAXT]; float* m[FS_MAXT]; float* v[FS_MAXT];
     int n[FS_MAXT];
-    int nt;
+    int cols[FS_MAXT], pstride[FS_MAXT];      // the PARAMETER as rows of `cols` elements `pstride` apart (a column slice of a
+    int nt;                                   // wider tensor); gradients and moments are dense.  cols == n: dense
 };
 
 __global__ void fit_adam_kernel(AdamTensors t, const float* step, float lr, float b1, float b2, float eps, const unsigned char* stop) {
@@ -41,7 +42,8 @@ __global__ void fit_adam_kernel(AdamTensors t, const float* step, float lr, floa
         t.m[k][i] = m; t.v[k][i] = v;
         if (!frozen) {
             const float denom = sqrtf(v) / (bc2s * step_size) + eps / step_size;
-            t.p[k][i] += m / denom;
+            const int c = t.cols[k];
+            t.p[k][c == t.n[k] ? i : (i / c) * t.pstride[k] + i % c] += m / denom;
         }
     }
 }
@@ -82,10 +84,12 @@ extern "C" {
 // byte, nonzero = leave the parameters alone.
 // chore_fit_adam_step_acc: g[k] is the ACCUMULATED gradient (the parameter's .grad, read and written) and gnew[k] (or NULL)
 // this step's fresh gradient, added first -- the per-parameter `grad += new` launches of autograd's accumulation folded into
-// the update; p[k] / m[k] / v[k] NULL = a leaf that only accumulates.
+// the update; p[k] / m[k] / v[k] NULL = a leaf that only accumulates.  cols / pstride (or NULL = dense): parameter k is a
+// column slice -- rows of cols[k] elements, pstride[k] apart -- of a wider tensor (the split SMPL parameters of a multi-frame
+// batch are views b[:, :2], p[:, 3:66], ... of the wrapper's storage); g, gnew, m, v are dense.
 static int adam_step_impl(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
-                          float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
-                          const uint8_t* stop, chore_stream_t stream, const char* who) {
+                          float* const* v, const int* n, const int* cols, const int* pstride, int nt, const float* step, float lr,
+                          float beta1, float beta2, float eps, const uint8_t* stop, chore_stream_t stream, const char* who) {
     if (!p || !g || !m || !v || !n || !step || !stop || nt <= 0 || nt > FS_MAXT)
         CHORE_FAIL(h, CHORE_EINVAL, "%s: bad argument (at most %d tensors)", who, FS_MAXT);
     AdamTensors t;
@@ -95,6 +99,9 @@ static int adam_step_impl(chore_handle* h, float* const* p, float* const* g, con
         if (!g[k] || n[k] <= 0 || (!acc_only && (!p[k] || !m[k] || !v[k])) || (acc_only && !gnew[k]))
             CHORE_FAIL(h, CHORE_EINVAL, "%s: null tensor %d", who, k);
         t.p[k] = p[k]; t.g[k] = g[k]; t.gn[k] = gnew ? gnew[k] : nullptr; t.m[k] = m[k]; t.v[k] = v[k]; t.n[k] = n[k];
+        t.cols[k] = (cols && cols[k] > 0) ? cols[k] : n[k];
+        t.pstride[k] = (cols && pstride) ? pstride[k] : t.cols[k];
+        if (n[k] % t.cols[k] || t.pstride[k] < t.cols[k]) CHORE_FAIL(h, CHORE_EINVAL, "%s: tensor %d: %d elements in rows of %d, stride %d", who, k, n[k], t.cols[k], t.pstride[k]);
         nmax = n[k] > nmax ? n[k] : nmax;
     }
     t.nt = nt;
@@ -108,14 +115,14 @@ int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g,
                         int nt, const float* step, float lr, float beta1, float beta2, float eps, const uint8_t* stop,
                         chore_stream_t stream) {
     CHORE_ENTER(h);
-    return adam_step_impl(h, p, (float* const*)g, nullptr, m, v, n, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step");
+    return adam_step_impl(h, p, (float* const*)g, nullptr, m, v, n, nullptr, nullptr, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step");
 }
 int chore_fit_adam_step_acc(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
-                            float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2, float eps,
-                            const uint8_t* stop, chore_stream_t stream) {
+                            float* const* v, const int* n, const int* cols, const int* pstride, int nt, const float* step, float lr,
+                            float beta1, float beta2, float eps, const uint8_t* stop, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!gnew) CHORE_FAIL(h, CHORE_EINVAL, "chore_fit_adam_step_acc: gnew is NULL");
-    return adam_step_impl(h, p, g, gnew, m, v, n, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step_acc");
+    return adam_step_impl(h, p, g, gnew, m, v, n, cols, pstride, nt, step, lr, beta1, beta2, eps, stop, stream, "chore_fit_adam_step_acc");
 }
 
 // the stop rule of one inner step: hit = |prev - loss| / prev < prev * tol;  stop |= hit & armed;  prev = loss unless stop was

@@ -22,6 +22,11 @@ from torch import optim
 from .. import _lib
 
 
+def _row_strided(p):
+    """dense, or a 2-D column slice (rows `stride(0)` apart, unit column stride) -- what chore_fit_adam_step_acc updates in place"""
+    return p.is_contiguous() or (p.dim() == 2 and p.stride(1) == 1 and p.stride(0) >= p.shape[1])
+
+
 class FusedAdam:
     """torch.optim.Adam(params, lr, betas, capturable=True) for a handful of small fp32 device tensors as ONE launch
     (chore_fit_adam_step, csrc/fit_step.hip), gated by the stepper's latched stop flag.  Same formulas, same state (step
@@ -29,13 +34,13 @@ class FusedAdam:
 
     def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8):
         self.params = list(params)
-        if not 0 < len(self.params) <= 16 or any(p.dtype != torch.float32 or not p.is_cuda or not p.is_contiguous() for p in self.params):
-            raise ValueError("FusedAdam: 1..16 contiguous fp32 device tensors")
+        if not 0 < len(self.params) <= 16 or any(p.dtype != torch.float32 or not p.is_cuda or not _row_strided(p) for p in self.params):
+            raise ValueError("FusedAdam: 1..16 fp32 device tensors, dense or column slices of a 2-D tensor")
         self.lr, self.betas, self.eps = float(lr), (float(betas[0]), float(betas[1])), float(eps)
         dev = self.params[0].device
         self.step_t = torch.zeros((), device=dev)
-        self.m = [torch.zeros_like(p) for p in self.params]
-        self.v = [torch.zeros_like(p) for p in self.params]
+        self.m = [torch.zeros(p.shape, dtype=p.dtype, device=p.device) for p in self.params]      # dense, whatever p's strides
+        self.v = [torch.zeros(p.shape, dtype=p.dtype, device=p.device) for p in self.params]
         self._args = None
 
     def state_tensors(self):
@@ -44,6 +49,8 @@ class FusedAdam:
     def step(self, stop):
         """stop: device bool scalar; the step counter is advanced by the stop-rule launch that follows (EagerStep._one)"""
         live = [(p, p.grad, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        if any(not p.is_contiguous() for p, _, _, _ in live):
+            raise ValueError("FusedAdam.step: column-slice parameters need step_acc")
         key = tuple((p.data_ptr(), g.data_ptr()) for p, g, _, _ in live)
         if self._args is None or self._args[0] != key:
             n = len(live)
@@ -74,12 +81,14 @@ class FusedAdam:
             if g is None and leaf.grad is None:
                 continue                                   # torch's Adam skips a parameter without a gradient
             if leaf.grad is None:
-                leaf.grad = torch.zeros_like(leaf)        # 0 + new = new, bit for bit what the first accumulation stores
+                leaf.grad = torch.zeros(leaf.shape, dtype=leaf.dtype, device=leaf.device)    # dense; 0 + new = new, bit for bit what the first accumulation stores
             if g is not None and (g.dtype != torch.float32 or not g.is_contiguous()):
                 g = g.float().contiguous()
             mv = state.get(id(leaf))
             if mv is None and g is None:
                 continue                                   # accumulate-only leaf, nothing new
+            if not leaf.grad.is_contiguous():
+                raise ValueError("FusedAdam.step_acc: .grad must be dense")
             rows.append((leaf if mv is not None else None, leaf.grad, g, mv))
         if not rows:
             return
@@ -94,11 +103,13 @@ class FusedAdam:
                           arr([None if g is None else g.data_ptr() for _, _, g, _ in rows]),
                           arr([None if mv is None else mv[0].data_ptr() for _, _, _, mv in rows]),
                           arr([None if mv is None else mv[1].data_ptr() for _, _, _, mv in rows]),
-                          (ctypes.c_int * n)(*[a.numel() for _, a, _, _ in rows]), n)
-        _, pp, aa, gg, mm, vv, nn, n = self._args
+                          (ctypes.c_int * n)(*[a.numel() for _, a, _, _ in rows]),
+                          (ctypes.c_int * n)(*[(a.numel() if (p is None or p.is_contiguous()) else p.shape[1]) for p, a, _, _ in rows]),
+                          (ctypes.c_int * n)(*[(a.numel() if (p is None or p.is_contiguous()) else p.stride(0)) for p, a, _, _ in rows]), n)
+        _, pp, aa, gg, mm, vv, nn, cc, ss, n = self._args
         dev = self.params[0].device
         h = _lib.handle(dev.index or 0)
-        _lib.check(_lib.lib.chore_fit_adam_step_acc(h, pp, aa, gg, mm, vv, nn, n, self.step_t.data_ptr(), self.lr, self.betas[0],
+        _lib.check(_lib.lib.chore_fit_adam_step_acc(h, pp, aa, gg, mm, vv, nn, cc, ss, n, self.step_t.data_ptr(), self.lr, self.betas[0],
                                                     self.betas[1], self.eps, stop.data_ptr(),
                                                     torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step_acc")
 
@@ -140,8 +151,9 @@ def weighted_sum(losses, coeffs, denom):
 
 
 def _fused_ok(params):
-    return (not os.environ.get("CHORE_FIT_TORCH_ADAM")) and 0 < len(params) <= 8 and all(
-        p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
+    strided_ok = not os.environ.get("CHORE_FIT_BACKWARD_ACCUMULATE")       # only the accumulate-in-Adam launch takes column slices
+    return (not os.environ.get("CHORE_FIT_TORCH_ADAM")) and 0 < len(params) <= 16 and all(
+        p.is_cuda and p.dtype == torch.float32 and (p.is_contiguous() or (strided_ok and _row_strided(p))) for p in params)
 
 
 class _OnePlusDecay:

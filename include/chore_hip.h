@@ -515,10 +515,12 @@ int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g,
  * read and written), gnew[k] (or NULL: nothing new) this step's fresh gradient, added to g[k] first -- the reference
  * accumulates over the inner steps of an outer iteration (recon_fit_behave.py:117-118,143-146), which as tensor ops is one
  * `grad += new` launch per parameter and step.  p[k] == NULL (then m[k], v[k] are ignored): a leaf that only accumulates
- * (stepped by a later phase's optimiser, which starts from these sums).  nt <= 16. */
+ * (stepped by a later phase's optimiser, which starts from these sums).  cols / pstride (host int arrays, or NULL = dense):
+ * parameter k is a column slice of a wider tensor -- rows of cols[k] elements, pstride[k] apart (the split SMPL parameters of a
+ * multi-frame batch, lib_smpl/wrapper_pytorch.py's SMPLPyTorchWrapperBatchSplitParams); g, gnew, m, v stay dense.  nt <= 16. */
 int chore_fit_adam_step_acc(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
-                            float* const* v, const int* n, int nt, const float* step, float lr, float beta1, float beta2,
-                            float eps, const uint8_t* stop, chore_stream_t stream);
+                            float* const* v, const int* n, const int* cols, const int* pstride, int nt, const float* step,
+                            float lr, float beta1, float beta2, float eps, const uint8_t* stop, chore_stream_t stream);
 int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
                         float* loss_out, float* step, chore_stream_t stream);
 /* the weighting of the fit's loss dictionary (recon_fit_behave.py:339-358): out = sum_k coeff[k] * loss[k] / denom over

@@ -411,6 +411,46 @@ def test_fused_adam_step_equals_torch_adam():
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+def test_fused_adam_on_column_slices_of_a_batch_equals_torch_adam():
+    """the split SMPL parameters of a multi-frame batch are column slices of the wrapper's storage (b[:, :2], p[:, 3:66], ...:
+    non-contiguous for B > 1, lib_smpl/wrapper_pytorch.py from_smpl): the accumulate-in-Adam launch updates them in place
+    through their row stride -- same trajectory as torch.optim.Adam(capturable=True) on the same views, the storage they
+    alias written through, gradients accumulating over the inner steps of an outer iteration"""
+    import os
+    from chore_amd.recon import graph_step as gs
+    res = {}
+    for mode in ("fused", "torch"):
+        torch.manual_seed(5)
+        B = 3
+        pose, betas = torch.randn(B, 72, device="cuda"), torch.randn(B, 10, device="cuda")
+        trans = torch.randn(B, 3, device="cuda")
+        views = [betas[:, :2], betas[:, 2:], pose[:, :3], pose[:, 3:66], trans]
+        assert not views[0].is_contiguous()
+        params = [torch.nn.Parameter(v) for v in views]             # like the wrapper: parameters that alias the storage
+        targets = [torch.randn(v.shape, device="cuda") for v in views]
+        if mode == "torch":
+            os.environ["CHORE_FIT_TORCH_ADAM"] = "1"
+        try:
+            prev = torch.tensor(300.0, device="cuda")
+
+            def loss_fn(decay):
+                return sum(((p - t) ** 2).sum() * (k + 1) for k, (p, t) in enumerate(zip(params, targets))) / (1 + decay)
+            st = gs.EagerStep(params[:4], 0.02, loss_fn, 0.001, prev, capturable=True, carry=[params[4]])
+            assert isinstance(st.opt, gs.FusedAdam) == (mode == "fused")
+            for it in range(4):
+                st.begin_outer(it, armed=False, zero=True)
+                for _ in range(3):
+                    st.step()
+        finally:
+            os.environ.pop("CHORE_FIT_TORCH_ADAM", None)
+        res[mode] = (pose.clone(), betas.clone(), trans.clone(), [p.grad.clone() for p in params])
+    for a, b in zip(res["fused"][:3], res["torch"][:3]):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    assert float((res["fused"][0][:, 66:] - res["torch"][0][:, 66:]).abs().max()) == 0       # the hand pose columns: nobody's
+    for a, b in zip(res["fused"][3], res["torch"][3]):                                          # accumulated gradients, the carried leaf too
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+
+
 def test_rot_noise_operator():
     """chore_fit_rot_noise: rot + 1e-4 * noise[k] bit for bit as the tensor expression, the device counter advanced by one per
     call, the gradient passed through to rot"""
