@@ -114,6 +114,13 @@ __host__ __device__ inline float bf2f(unsigned short b) {
 }
 
 // D-fragment row of the 32x32 MFMA family: row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+// MODE.FP16_OVFL (bit 23 of the wave's MODE register): with it set, a float -> half conversion that overflows gives +-65504
+// instead of +-inf.  The fp16 x 3 kernels split fp32 values into fp16 hi / lo pairs; with the bit set a pair represents every
+// |x| <= 131 008 exactly as before (hi saturates, lo takes the rest) and saturates beyond -- without it |x| >= 65 520 turned
+// into inf and, one MFMA later, NaN, where the fp32-MFMA path stays finite (scripts/probes/f16_ovfl_probe.hip).  Values in range
+// convert exactly as without the bit.  Every wave sets it on entry (MODE is per-wave state).
+__device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+
 __host__ __device__ inline int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
 // ----- heads (query) constants -----

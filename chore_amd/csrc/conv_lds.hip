@@ -68,6 +68,7 @@ constexpr int PD_SMALL = 2;
 
 template <typename T, int TAPS, int NT, int TPS_>
 __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
+    if constexpr (IS_X3<T> || IS_H16<T>) f16_saturate_mode();     // the fp16 x 3 / fp16 operand split never produces inf (common.h)
     constexpr bool X3 = IS_X3<T>;
     using ST = typename Store<T>::type;                 // element type in memory
     using G = Geo<TAPS, NT, TPS_, X3>;

@@ -83,6 +83,7 @@ __device__ __forceinline__ void wg_barrier() {
 
 template <typename T, int TAPS, int TH_, int NT_, int TPS_, int NSLOT_>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
+    if constexpr (IS_X3<T> || IS_H16<T>) f16_saturate_mode();     // the fp16 x 3 / fp16 operand split never produces inf (common.h)
     // T = x3_t: fp32 tensors, activations split into fp16 hi + lo while they are staged, three MFMAs per product;
     // T = h16_t ("fp16 fields"): fp16 tensors, one activation plane, two MFMAs per product (a * w_lo, a * w_hi)
     static_assert(IS_X3<T> || IS_H16<T>, "conv_pc_kernel: fp16 x 3 or fp16 operands");

@@ -56,6 +56,7 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, f32x1
 
 template <typename T, int CIN, int ROWS>
 __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
+    if constexpr (IS_X3<T> || IS_H16<T>) f16_saturate_mode();     // the fp16 x 3 / fp16 operand split never produces inf (common.h)
     using G = SGeo<T, CIN, ROWS>;
     constexpr bool X3 = G::X3;
     using ST = typename Store<T>::type;

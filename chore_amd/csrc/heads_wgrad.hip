@@ -165,6 +165,7 @@ __device__ __forceinline__ float chunk_scale_for(float m) {   // 2^(12 - floor(l
 }
 
 __global__ __launch_bounds__(256, 2) void heads_wgrad_x3_kernel(HeadsWgradArgs a) {
+    f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smx[];
     u32x4* LA = (u32x4*)smx;                       // [hi | lo][8][128]
     u32x4* LB = LA + 2 * HX_PLANE_VEC;

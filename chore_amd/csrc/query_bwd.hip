@@ -110,6 +110,7 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     static_assert(NW == 4 || (NW == 8 && NCB == 1), "eight waves = two column blocks of one 32-point block each");
     constexpr int PTS = 32 * NCB * (NW / 4), NT_ = NW * 64;
     static_assert(!TRAIN || PTS == 64, "the training staging is written for 64-point tiles");
+    if constexpr (X3) f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryBwdSmemT<PTS>& sm = *reinterpret_cast<QueryBwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;

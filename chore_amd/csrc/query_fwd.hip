@@ -30,6 +30,7 @@ template <typename T, int NCB, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
     static_assert(!TRAIN || NCB == 2, "the training staging is written for 64-point tiles");
     constexpr int PTS = 32 * NCB;
+    if constexpr (X3) f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(256, 1) void query_fwd_f32_kernel(QueryArgs a) {
 template <typename T, bool TRAIN = false, bool X3 = false>
 __global__ __launch_bounds__(512, 1) void query_fwd_f32_w8_kernel(QueryArgs a) {
     constexpr int PTS = 64;
+    if constexpr (X3) f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QueryFwdSmemT<PTS>& sm = *reinterpret_cast<QueryFwdSmemT<PTS>*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -299,6 +301,7 @@ __global__ __launch_bounds__(512, 1) void query_fwd_x3_split_kernel(QueryArgs a)
     // already in registers when its barrier opens (a k-step of one wave lasts ~0.2 us, an L2 round trip ~1 us).
     constexpr int PTS = 32 * NCB, PF = 7, NSTEP = QX_KS1 + 16;
     static_assert(QX_KS1 % PF == 0, "the k loop of layer 1 is unrolled by the ring depth");
+    f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     QuerySplitSmemT<PTS>& sm = *reinterpret_cast<QuerySplitSmemT<PTS>*>(smem_raw);
     char* XH = sm.buf;

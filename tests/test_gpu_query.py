@@ -397,3 +397,45 @@ def test_split_forward_kernel_equals_the_one_wave_per_head_kernels_bit_for_bit()
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if " equal " in ln]
     assert len(lines) == 36 and all(" equal True" in ln for ln in lines), "\n".join(ln for ln in lines if "True" not in ln)
+
+
+def test_fp16x3_heads_stay_finite_beyond_the_half_range(opt):
+    """an input feature beyond the IEEE-half range (|x| >= 65 520) used to become inf in the fp16 hi / lo split of the fp16 x 3
+    heads and NaN one MFMA later, where the fp32-MFMA path stays finite.  The split-operand kernels run with
+    MODE.FP16_OVFL set (csrc/common.h f16_saturate_mode): the pair saturates instead -- |x| <= 131 008 is still represented
+    exactly (hi = 65 504, lo = the rest).  Feature maps scaled to +-1e5: forward and backward to the points finite, and within
+    1e-3 of the fp32-MFMA heads' largest output (hidden activations beyond 131 008 saturate: this is a guard against NaN, not
+    a range extension)."""
+    import copy
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    g = golden("query_full.npz")
+    res = {}
+    for x3 in (True, False):
+        o = copy.copy(opt)
+        o.compute_dtype = "fp32"
+        net = CHORE(o).cuda().eval()
+        synth.load_synth_weights(net, seed=0)
+        for p in net.parameters():
+            p.requires_grad_(False)
+        feat = nhwc(g["feat"])
+        feat = feat * (1.0e5 / float(feat.abs().max()))
+        assert float(feat.abs().max()) > 9.9e4
+        net.im_feat_list, net.tmpx = [feat], nhwc(g["tmpx"])
+        pts = torch.from_numpy(g["points"]).cuda().requires_grad_(True)
+        cc = torch.from_numpy(g["crop_center"]).cuda()
+        if x3:
+            os.environ.pop("CHORE_HEADS_FP32", None)
+        else:
+            os.environ["CHORE_HEADS_FP32"] = "1"
+        try:
+            net.compute_dtype = "fp16x3" if x3 else "fp32"
+            net.query(pts, crop_center=cc)
+            preds = [p.detach().clone() for p in net.get_preds()]
+            (gp,) = torch.autograd.grad(net.get_preds()[0][:, 0].sum(), pts)
+        finally:
+            os.environ.pop("CHORE_HEADS_FP32", None)
+        assert all(torch.isfinite(p).all() for p in preds) and torch.isfinite(gp).all(), "x3" if x3 else "fp32"
+        res[x3] = preds
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
