@@ -587,7 +587,7 @@ def mode_all(args, ctx):
     out = mode_query(args, ctx)
     subs = {}
     for name, fn, over in (("fit", mode_fit, dict(steps=1, warmup=1, dtype="fp16x3", mode="fit")),
-                           ("train", mode_train, dict(steps=10, warmup=5, dtype="bf16", mode="train"))):
+                           ("train", mode_train, dict(steps=20, warmup=8, dtype="bf16", mode="train"))):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
@@ -599,7 +599,7 @@ def mode_all(args, ctx):
             out[name] = {k: rec[k] for k in rec if k not in ("n_gpus", "data", "scaling", "vs_baseline")}
         out["records"] = {"fit": "BASELINE metric 2 (ms per fit iteration), configs[2] / configs[4]: same function as --mode fit, 1 step after "
                                  "1 warm-up chain", "train": "BASELINE metric 3 (training steps/s), configs[3]: same function as --mode train, "
-                                                             "10 steps after 5 warm-up steps"}
+                                                             "20 steps after 8 warm-up steps"}
     return out
 
 
