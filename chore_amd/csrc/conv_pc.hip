@@ -381,16 +381,20 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             const int t = ks / KGC, kg = ks % KGC;
             const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
             if (PDBG(a) & 128) return;   // ablation: no fragment reads (the MFMAs run on whatever the registers hold)
+            if (!(PDBG(a) & 4096)) {   // ablation 4096: no B-fragment reads (what fetching the weight fragments from the L2 instead would leave on the LDS)
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+            }
             if constexpr (X3) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) afl[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + 64 + kg * 32);
             }
 #pragma unroll
             for (int m = 0; m < MB; ++m) af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + kg * 32);
+            if (!(PDBG(a) & 4096)) {
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bfl[fs][q] = *(const u32x4*)(bs + SB1 + ((t * KGC + kg) * (NT / 32) + q) * 1024);
+            }
         };
         constexpr int NRD = (X3 ? 2 : 1) * MB + 2 * NBW, NMF = (X3 ? 3 : 2) * MB * NBW;     // LDS reads / MFMAs of one k-step
         static_assert(NKS % 2 == 0, "fragment double buffer: even k-steps per K-step");

@@ -52,8 +52,8 @@ int main(int argc, char** argv) {
         {"c1   32^2 256->128", 9, 32, 32, 256, 128, true, true},
         {"c2   32^2 128->64 ", 9, 32, 32, 128, 64, true, true},
     };
-    const int dbgs[] = {0, 16, 256, 8, 8 | 4, 8 | 32, 8 | 1 | 2, 8 | 1 | 2 | 32, 1 << 29};
-    const char* dbgn[] = {"full", "-atom", "-stats", "-epi", "-epi-mfma", "-epi-publish", "-epi-loads", "-epi-ld-pub", "full again"};
+    const int dbgs[] = {0, 16, 256, 8, 8 | 4, 8 | 32, 8 | 1 | 2, 8 | 1 | 2 | 32, 4096 | 1, 8 | 4096 | 1, 1 << 29};
+    const char* dbgn[] = {"full", "-atom", "-stats", "-epi", "-epi-mfma", "-epi-publish", "-epi-loads", "-epi-ld-pub", "-Bfrag-w", "-epi-Bfrag-w", "full again"};
     const size_t esz = dtype == CHORE_BF16 ? 2 : 4;
     printf("dtype %d, B %d, %d launches per number (us per launch)\n", dtype, B, iters);
     printf("%-20s %-13s %5s", "layer", "kernel", "WGs");
