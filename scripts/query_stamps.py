@@ -1,4 +1,4 @@
-"""phase times of the split query-forward kernel (library built with -DCHORE_QUERY_STAMPS, CHORE_HIP_LIB pointing at it)"""
+"""phase times of the split query-forward kernel (scripts/build_variant.sh stamps query_fwd.hip -DCHORE_QUERY_STAMPS=1; CHORE_HIP_LIB=<that library>)"""
 import ctypes, os, sys, numpy as np, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R)
 from bench import chore_opt
