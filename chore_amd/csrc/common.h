@@ -119,7 +119,11 @@ __host__ __device__ inline float bf2f(unsigned short b) {
 // |x| <= 131 008 exactly as before (hi saturates, lo takes the rest) and saturates beyond -- without it |x| >= 65 520 turned
 // into inf and, one MFMA later, NaN, where the fp32-MFMA path stays finite (scripts/probes/f16_ovfl_probe.hip).  Values in range
 // convert exactly as without the bit.  Every wave sets it on entry (MODE is per-wave state).
+#ifdef CHORE_NO_F16_SATURATE      // A/B builds only (scripts/build_variant.sh)
+__device__ __forceinline__ void f16_saturate_mode() {}
+#else
 __device__ __forceinline__ void f16_saturate_mode() { __builtin_amdgcn_s_setreg(1 | (23 << 6) | (0 << 11), 1); }
+#endif
 
 __host__ __device__ inline int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
