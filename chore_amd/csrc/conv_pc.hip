@@ -412,7 +412,9 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                     int need = sn - NSLOT + 2;
                     if (sn % KROWS == 0) { const int np = sn - KROWS + LASTK + 1; need = need > np ? need : np; }
                     if ((int)ready_seen < need) {
+                        if (!(PDBG(a) & 64)) __builtin_amdgcn_s_setprio(0);      // never hold the priority while waiting for a lower-priority wave
                         do { ready_seen = sem_min(sem_ready); if ((int)ready_seen >= need) break; __builtin_amdgcn_s_sleep(1); } while (true);
+                        if (!(PDBG(a) & 64)) __builtin_amdgcn_s_setprio(1);
                         asm volatile("" ::: "memory");
                     }
                     load_frag(0, sn, nslot, 0);
@@ -591,8 +593,15 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT>
 int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     using G = PGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>>;
-    const size_t smem = G::smem_bytes(a.in.C);
+    size_t smem = G::smem_bytes(a.in.C);
     if (smem > 160 * 1024) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS", smem);
+    // ONE workgroup per CU, always.  The small fp16 tilings (79 KB of LDS, ~120 registers) fit twice; with two workgroups on
+    // a CU every SIMD holds two high-priority consumer waves, and when both poll for operands their producers -- priority 0
+    // on the same SIMD -- were observed to be starved for SECONDS: conv_pc_kernel<h16_t,9,8,32,3,2> at 256^2 took 25 s for a
+    // launch that takes 50 us (scripts/fp16_hang_probe.py; it resolves only when the driver's time slicing reshuffles the
+    // waves).  The hand-over by polling was designed and measured with one workgroup per CU (what the fp16 x 3 tilings always
+    // get); an LDS request of more than half the CU's 160 KB keeps it that way for every tiling.
+    if (smem < 81 * 1024) smem = 81 * 1024;
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,

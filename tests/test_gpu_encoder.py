@@ -311,3 +311,20 @@ def test_fused_loss_kernel_equals_tensor_op_loss(opt):
     for ga, gb in zip(a[2], b[2]):
         assert ga.shape == gb.shape
         assert float((ga - gb).abs().max()) <= 2e-6 * float(gb.abs().max())
+
+
+def test_fp16_mode_back_to_back_encodes_have_no_slow_launches():
+    """regression: with two workgroups of conv_pc_kernel's small fp16 tilings on one CU, two high-priority consumer waves per
+    SIMD polling for operands starved their producers -- single launches took 25 s (50 us normally), whole encodes seconds,
+    first seen as a 1 s-per-launch line in a profile.  conv_pc launches now always request more than half a CU's LDS (one
+    workgroup per CU) and no wave keeps its priority while it polls.  300 encodes queued back to back, each between two
+    events, in a child process with a timeout: none beyond 3x the median."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(repo, "scripts", "fp16_outlier_probe.py"), "fp16", "300"], capture_output=True,
+                         text=True, timeout=240)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("fp16")][-1]
+    assert "beyond 3x median: 0" in line, line
+    assert float(line.split("median")[1].split("ms")[0]) < 8.0, line
