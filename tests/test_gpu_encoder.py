@@ -7,6 +7,8 @@ Stated tolerances
   bf16 mode (bf16 storage + bf16 MFMA operands, fp32 accumulate and GroupNorm statistics):
                                 relative L2 error <= 2e-2 per tensor, max |err| <= 8e-2 * max|ref|.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
