@@ -563,7 +563,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
-    if (dtype != CHORE_F16 && conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
+    if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
     if (dtype == CHORE_F16) {   // fp16 tensors: the specialised-wave kernel is the only implementation
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
         if (!pp.th || a_in.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv: layer not covered in the fp16 mode (Cin=%d Cout=%d)", a_in.in.C, a_in.Cout);

@@ -18,6 +18,7 @@
 //   * the four partial tiles are added in wave order through LDS (deterministic), then bias, residuals, stores and the
 //     exact GroupNorm statistics of what was stored, like the big kernel.
 #include "enc_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
@@ -34,6 +35,7 @@ constexpr int RED_BYTES = 4 * 32 * RED_LD * 4;
 // (ROWS + 2)-for-ROWS; fewer rows: more workgroups.
 template <typename T, int CIN, int ROWS> struct SGeo {
     static constexpr bool X3 = IS_X3<T>;
+    static constexpr bool H16 = IS_H16<T>;                  // fp16 tensors: one activation plane, weights hi + lo (two MFMAs)
     static constexpr int KS = 4 / ROWS;
     static constexpr int NPX = (ROWS + 2) * PW;
     static constexpr int PB = CIN * 2 + 16;                 // bytes per pixel per operand plane (16-byte slots: odd count)
@@ -58,8 +60,8 @@ template <typename T, int CIN, int ROWS>
 __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     if constexpr (IS_X3<T> || IS_H16<T>) f16_saturate_mode();     // the fp16 x 3 / fp16 operand split never produces inf (common.h)
     using G = SGeo<T, CIN, ROWS>;
-    constexpr bool X3 = G::X3;
-    using ST = typename Store<T>::type;
+    constexpr bool X3 = G::X3, H16 = G::H16, WLO = X3 || H16;      // WLO: the weights come as hi + lo planes
+    using ST = typename std::conditional<H16, unsigned short, typename Store<T>::type>::type;
     constexpr int PB = G::PB, PLANE = G::PLANE, VPP = G::VPP, NSLOT = G::NSLOT, U = G::U, KS = G::KS, NPX = G::NPX;
     constexpr int LV = X3 ? 2 : 1;                          // 16-byte loads per 8-channel slot
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,6 +120,10 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
             if constexpr (X3) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) { f[k] = __uint_as_float(pre[j][0][k]); f[4 + k] = __uint_as_float(pre[j][1][k]); }
+            } else if constexpr (H16) {
+                const f16x8_t x = __builtin_bit_cast(f16x8_t, pre[j][0]);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f[k] = (float)x[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -138,6 +144,13 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
                 for (int k = 0; k < 8; ++k) { h[k] = (_Float16)f[k]; l[k] = (_Float16)(f[k] - (float)h[k]); }
                 hi = __builtin_bit_cast(u32x4, h);
                 lo = __builtin_bit_cast(u32x4, l);
+            } else if constexpr (H16) {
+                if (use_gn) {       // relu(x * scale + shift) in fp32, rounded to fp16 once (as conv_pc_kernel<h16_t>)
+                    f16x8_t h;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) h[k] = (_Float16)f[k];
+                    hi = __builtin_bit_cast(u32x4, h);
+                } else hi = pre[j][0];
             } else if (use_gn) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) hi[k] = pack2bf(f[2 * k], f[2 * k + 1]);
@@ -160,17 +173,17 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     const int wrow_ = wid / G::KS;
-    u32x4 b0[6], b1[6], l0[X3 ? 6 : 1], l1[X3 ? 6 : 1];       // two fragment sets, named statically (no indexed registers)
-    auto load_b = [&](u32x4 (&bq)[6], u32x4 (&bl)[X3 ? 6 : 1], int u) {
+    u32x4 b0[6], b1[6], l0[WLO ? 6 : 1], l1[WLO ? 6 : 1];     // two fragment sets, named statically (no indexed registers)
+    auto load_b = [&](u32x4 (&bq)[6], u32x4 (&bl)[WLO ? 6 : 1], int u) {
         const int c = u / 3, ky = u % 3;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const u32x4* p = wfrag(ky * 3 + k / 2, c * 2 + (k & 1));
             bq[k] = *p;
-            if constexpr (X3) bl[k] = *(p + lo_plane);
+            if constexpr (WLO) bl[k] = *(p + lo_plane);
         }
     };
-    auto unit = [&](const u32x4 (&bq)[6], const u32x4 (&bl)[X3 ? 6 : 1], int u) {
+    auto unit = [&](const u32x4 (&bq)[6], const u32x4 (&bl)[WLO ? 6 : 1], int u) {
         const int c = u / 3, ky = u % 3;
         const char* ap = patch + (((wrow_ + ky) * PW + px) * PB) + (c * 32 + 8 * half) * 2;
 #pragma unroll
@@ -181,6 +194,9 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
                 const u32x4 al = *(const u32x4*)(ap + PLANE + kx * PB + kg * 32);
                 acc = mfma_f16(al, bq[k], acc);             // small terms first
                 acc = mfma_f16(av, bl[k], acc);
+                acc = mfma_f16(av, bq[k], acc);
+            } else if constexpr (H16) {
+                acc = mfma_f16(av, bl[k], acc);             // a * w_lo, then a * w_hi
                 acc = mfma_f16(av, bq[k], acc);
             } else {
                 acc = mfma_bf16(av, bq[k], acc);
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wid * 32 + mfma32_row(r, half)) * RED_LD + px] = acc[r];
     __syncthreads();
-    constexpr float ASCALE = X3 ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;
+    constexpr float ASCALE = WLO ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;
     const int p = tid >> 3, g4 = (tid & 7) * 4;              // this thread: pixel p, channels g4 .. g4+3 of the tile
     const int cg = n_tile * 32 + g4;
     const bool want_stats = a.st_raw || a.st_out;
@@ -225,7 +241,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
         const size_t pix = ((size_t)b * a.H + y + row) * a.W + x0 + p;
         auto ld4 = [&](const View& v, float (&o)[4]) {
             const ST* q = (const ST*)v.p + pix * v.cs + v.co + cg;
-            if constexpr (sizeof(ST) == 2) {
+            if constexpr (H16) {
+                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                const h4_t r4 = *(const h4_t*)q;
+                o[0] = (float)r4[0]; o[1] = (float)r4[1]; o[2] = (float)r4[2]; o[3] = (float)r4[3];
+            } else if constexpr (sizeof(ST) == 2) {
                 const unsigned long long raw = *(const unsigned long long*)q;
                 o[0] = __uint_as_float((unsigned)(raw & 0xffffu) << 16);
                 o[1] = __uint_as_float((unsigned)(raw & 0xffff0000u));
@@ -238,7 +258,12 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
         };
         auto st4 = [&](const View& v, float (&o)[4]) {        // stores; o is replaced by the values as stored
             ST* q = (ST*)v.p + pix * v.cs + v.co + cg;
-            if constexpr (sizeof(ST) == 2) {
+            if constexpr (H16) {
+                typedef _Float16 h4_t __attribute__((ext_vector_type(4)));
+                const h4_t r4 = {(_Float16)o[0], (_Float16)o[1], (_Float16)o[2], (_Float16)o[3]};
+                *(h4_t*)q = r4;
+                o[0] = (float)r4[0]; o[1] = (float)r4[1]; o[2] = (float)r4[2]; o[3] = (float)r4[3];
+            } else if constexpr (sizeof(ST) == 2) {
                 const unsigned lo = pack2bf(o[0], o[1]), hi = pack2bf(o[2], o[3]);
                 *(unsigned long long*)q = (unsigned long long)lo | ((unsigned long long)hi << 32);
                 o[0] = __uint_as_float(lo << 16); o[1] = __uint_as_float(lo & 0xffff0000u);
@@ -365,7 +390,7 @@ int small_rows(int dtype, int H, int W, int Cin) {
     static const int r64c = getenv("CHORE_CONV_SMALL_ROWS64_C256") ? atoi(getenv("CHORE_CONV_SMALL_ROWS64_C256")) : -1;
     const bool x3 = dtype == CHORE_F16X3;
     int rows;
-    if (H * W <= 32 * 32) rows = r32 >= 0 ? r32 : (x3 ? 2 : 1);
+    if (H * W <= 32 * 32) rows = r32 >= 0 ? r32 : ((x3 || dtype == CHORE_F16) ? 2 : 1);
     else if (Cin == 256) rows = r64c >= 0 ? r64c : 0;
     else rows = r64 >= 0 ? r64 : 0;
     // LDS: (rows + 2) x 34 pixels x (2 Cin + 16) bytes per plane, two planes for fp16 x 3
@@ -386,7 +411,7 @@ int small_rows(int dtype, int H, int W, int Cin) {
 // fp16 x 3 only: the native-fp32 parity mode keeps the one kernel it was validated with.
 bool conv_small_eligible(int dtype, int taps, int H, int W, int Cin, int Cout) {
     static const bool off = getenv("CHORE_NO_CONV_SMALL") != nullptr;      // A/B switch
-    if (off || taps != 9 || (dtype != CHORE_BF16 && dtype != CHORE_F16X3)) return false;
+    if (off || taps != 9 || (dtype != CHORE_BF16 && dtype != CHORE_F16X3 && dtype != CHORE_F16)) return false;
     if (W % 32 || Cout % 32 || (Cin != 64 && Cin != 128 && Cin != 256) || H * W > 64 * 64) return false;
     return small_rows(dtype, H, W, Cin) > 0;
 }
@@ -394,5 +419,6 @@ bool conv_small_eligible(int dtype, int taps, int H, int W, int Cin, int Cout) {
 int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s) {
     if ((size_t)a.B * a.H * (a.W / 32) * (a.Cout / 32) > 0x7fffffffull) CHORE_FAIL(h, CHORE_EINVAL, "conv_small: grid too large");
     const int rows = small_rows(dtype, a.H, a.W, a.in.C);
+    if (dtype == CHORE_F16) return launch_small_c<h16_t>(h, rows, a, s);
     return dtype == CHORE_F16X3 ? launch_small_c<x3_t>(h, rows, a, s) : launch_small_c<bf16_t>(h, rows, a, s);
 }

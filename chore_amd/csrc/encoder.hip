@@ -193,7 +193,7 @@ inline int conv_class(const ConvPlan& p, int taps) {
 }
 // class of the kernel launch_conv will pick for a layer (the specialised-wave kernel where it covers the layer)
 inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
-    if ((dtype == CHORE_F16 || (dtype == CHORE_F16X3 && conv_use_pc())) && (dtype == CHORE_F16 || !conv_small_eligible(dtype, taps, H, W, Cin, Cout))) {
+    if ((dtype == CHORE_F16 || (dtype == CHORE_F16X3 && conv_use_pc())) && !conv_small_eligible(dtype, taps, H, W, Cin, Cout)) {
         const PcPlan pp = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
         if (pp.th) {
             if (taps == 1) return K_PC_FIRST + (pp.nt == 128 ? 5 : 6);
