@@ -185,7 +185,8 @@ int chore_sample_features(chore_handle* h, const float* points, const float* cro
                           chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!features) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: null output");
-    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: fp16 maps are an inference mode (chore_query_fwd)");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16)   // (also CHORE_F16 | CHORE_HEADS_X3 and CHORE_F16X3: the flag is not a map type here)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_sample_features: maps must be CHORE_F32 or CHORE_BF16 (fp16 maps are an inference mode: chore_query_fwd)");
     QueryArgs a;
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, feat /*unused*/,
                              cam6_host);
@@ -264,9 +265,11 @@ int chore_query_fwd_train(chore_handle* h, const float* points, const float* cro
                           float* centers, uint8_t* in_img, void* staging, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!df || !pca || !parts || !centers || !staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: null output");
-    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: fp16 maps are an inference mode");
     QueryArgs a;
     const bool x3 = query_x3(dtype);
+    // checked AFTER the heads flag is stripped: CHORE_F16 | CHORE_HEADS_X3 must not get past (the launchers below read fp32 or bf16)
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd_train: maps must be CHORE_F32 or CHORE_BF16 (fp16 maps are an inference mode)");
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
                              cam6_host);
     if (rc) return rc;
@@ -283,9 +286,11 @@ int chore_query_bwd_train(chore_handle* h, const float* points, const float* cro
                           int have_forward, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!staging) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: null staging");
-    if (dtype == CHORE_F16) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: fp16 maps are an inference mode");
     QueryArgs a;
     const bool x3 = query_x3(dtype);
+    // checked AFTER the heads flag is stripped: CHORE_F16 | CHORE_HEADS_X3 must not get past (the launchers below read fp32 or bf16)
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16)
+        CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: maps must be CHORE_F32 or CHORE_BF16 (fp16 maps are an inference mode)");
     if (x3 && !have_forward) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_bwd_train: the fp16 x 3 heads need the staged forward");
     int rc = fill_query_args(h, a, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena,
                              cam6_host);

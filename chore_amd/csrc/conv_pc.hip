@@ -62,13 +62,20 @@ template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_ = true> str
 // Progress counts in LDS (sem_ready / sem_done in the kernel): one word per wave of a role = the number of K-steps that
 // wave has finished; a waiter needs the MINIMUM over the four waves (with a ring deeper than two slots the waves of a role
 // drift apart by several K-steps: a sum would let a fast wave vouch for a slow one).
+// The counts are read and written through pointers that are LDS pointers BY TYPE (address space 3).  A volatile access through
+// a generic pointer is never narrowed to its address space by the compiler: until round 4 every count access was a FLAT
+// instruction with `sc0 sc1` -- a round trip through the vector-memory path of the CU, behind the producers' global loads --
+// followed by `s_waitcnt vmcnt(0) lgkmcnt(0)`, which stalled the consumers' MFMA stream at every K-step and drained the
+// producers' prefetched global loads at every step (profiles/r04_conv_phase_breakdown.txt).
+using lds_u32 = __attribute__((address_space(3))) unsigned;
+using lds_u32x4 = __attribute__((address_space(3))) u32x4;
 __device__ __forceinline__ void sem_signal(unsigned* sem, int wave, unsigned count, int lane) {
     asm volatile("" ::: "memory");   // the LDS traffic before it is issued before it (the LDS keeps the order)
-    if (lane == 0) *(volatile unsigned*)(sem + wave) = count;
+    if (lane == 0) *(volatile lds_u32*)(sem + wave) = count;
     asm volatile("" ::: "memory");
 }
 __device__ __forceinline__ unsigned sem_min(const unsigned* sem) {
-    const u32x4 v = *(const volatile u32x4*)sem;
+    const u32x4 v = *(const volatile lds_u32x4*)sem;
     const unsigned a = v[0] < v[1] ? v[0] : v[1], b = v[2] < v[3] ? v[2] : v[3];
     return a < b ? a : b;
 }
@@ -112,7 +119,11 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     int* rowoff_lds = (int*)(ss_lds + 2 * a.in.C);       // [ROWS] element offset of the patch row's pixel, -1 outside the image
     // producer -> consumer and consumer -> producer event counts of the main loop (one increment per wave and K-step).
     // The LDS executes a CU's requests in order: whoever sees a count sees everything its writer did before it.
-    unsigned* sem_ready = (unsigned*)(((size_t)(rowoff_lds + ROWS) + 15) & ~(size_t)15);   // [4] producer waves
+    // (the offset is computed as an integer from `smem`: a pointer that went through an integer cast loses its LDS address
+    // space, and every count access became a FLAT instruction -- a round trip through the vector-memory path with
+    // `s_waitcnt vmcnt(0) lgkmcnt(0)` behind it, which also drained the producers' prefetched global loads at every step)
+    const int sem_off = (2 * PATCHB + NSLOT * SBYTES + a.in.C * 8 + ROWS * 4 + 15) & ~15;
+    unsigned* sem_ready = (unsigned*)(smem + sem_off);                                      // [4] producer waves
     unsigned* sem_done = sem_ready + 4;                                                     // [4] consumer waves
 
     const int tid = threadIdx.x, lane = tid & 63;

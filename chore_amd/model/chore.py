@@ -386,6 +386,10 @@ class CHORE(nn.Module):
         head_params = [p for _, m in self._head_modules() for p in m.parameters()]
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))
+        if train and self.compute_dtype == "fp16":
+            # the training kernels read fp32 / bf16 maps; half maps would be read as fp32 (wrong values, reads past the buffer)
+            raise NotImplementedError("compute_dtype 'fp16' is an inference mode: query() with trainable heads or maps that "
+                                      "require grad needs 'fp32' or 'bf16' (freeze the parameters for inference)")
         self.intermediate_preds_list = []
         if pts.shape[1] == 0:     # no points: empty predictions (what the reference's torch ops return), nothing to launch
             B = pts.shape[0]

@@ -29,6 +29,8 @@ static float frand(unsigned& s) {
     return ((s >> 8) & 0xffff) / 32768.0f - 1.0f;
 }
 
+extern "C" void chore_lds_poison(hipStream_t, const char*, int) {}   // capi.hip is not linked into the probe
+
 int main(int argc, char** argv) {
     const int dtype = argc > 1 ? atoi(argv[1]) : CHORE_F16X3;
     const int iters = argc > 2 ? atoi(argv[2]) : 200;

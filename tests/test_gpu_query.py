@@ -264,6 +264,46 @@ def test_rejects_bad_inputs(net):
         net.query(torch.from_numpy(g["points"]).cuda(), crop_center=torch.from_numpy(g["crop_center"]).cuda())
 
 
+def test_fp16_mode_rejects_training_queries(opt):
+    """'fp16' is an inference mode: with trainable heads (or maps that require grad) query() must refuse -- the training
+    kernels read fp32 / bf16 maps and would read the half maps as fp32.  The C ABI refuses the map type
+    too, with or without the heads flag."""
+    import argparse
+    from chore_amd import _lib
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    o = argparse.Namespace(**vars(opt))
+    o.compute_dtype = "fp16"
+    n = CHORE(o).cuda().eval()
+    synth.load_synth_weights(n, seed=0)            # parameters keep requires_grad=True
+    rs = np.random.RandomState(5)
+    n.im_feat_list = [nhwc(rs.standard_normal((1, 256, 128, 128)).astype(np.float32), torch.float16)]
+    n.tmpx = nhwc(rs.standard_normal((1, 64, 256, 256)).astype(np.float32), torch.float16)
+    pts = torch.from_numpy(synth.synth_points(1, 256, seed=4)).cuda()
+    cc = torch.from_numpy(np.array([synth.CROP_CENTER], np.float32)).cuda()
+    with pytest.raises(NotImplementedError):
+        n.query(pts, crop_center=cc)
+    with torch.no_grad():                           # inference with the same (unfrozen) parameters is fine
+        n.query(pts, crop_center=cc)
+    assert torch.isfinite(n.get_preds()[0]).all()
+    for p in n.parameters():
+        p.requires_grad_(False)
+    n.query(pts.clone().requires_grad_(True), crop_center=cc)      # frozen heads, gradient to the points: the inference path
+    # the C ABI: fp16 maps are refused by the training entry points whatever the heads flag says
+    h = _lib.handle(0)
+    fp, FH, FW = n.im_feat_list[0].data_ptr(), 128, 128
+    tp, TH, TW = n.tmpx.data_ptr(), 256, 256
+    out = [torch.empty(1, c, 256, device="cuda") for c in (2, 9, 14, 6)]
+    inside = torch.empty(1, 256, dtype=torch.uint8, device="cuda")
+    staging = torch.empty(_lib.lib.chore_query_train_bytes(1, 256), dtype=torch.uint8, device="cuda")
+    for dt in (_lib.F16, _lib.F16 | _lib.HEADS_X3):
+        rc = _lib.lib.chore_query_fwd_train(h, pts.data_ptr(), cc.data_ptr(), 1, 256, fp, FH, FW, tp, TH, TW, dt,
+                                            n._heads_arena(pts.device).data_ptr(), n._cam6, out[0].data_ptr(), out[1].data_ptr(),
+                                            out[2].data_ptr(), out[3].data_ptr(), inside.data_ptr(), staging.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        assert rc != 0, hex(dt)
+
+
 @pytest.mark.parametrize("heads_x3,gscale", [(False, 1.0), (True, 1.0), (True, 1e-7), (True, 3e5)])
 def test_training_backward_heads_and_feature_maps(opt, heads_x3, gscale):
     """heads_x3: the GEMM chain of the heads AND their weight gradients on the fp16 matrix cores with split operands
