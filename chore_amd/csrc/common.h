@@ -21,6 +21,7 @@ struct chore_handle {
     // weight gradients of a ConvBlock beside its data-gradient chain (convblock.hip); created on first use
     hipStream_t side = nullptr;
     hipEvent_t side_ev[8] = {};
+    int lds_per_cu = 0;        // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of `device`, read on first use (conv_pc.hip)
 };
 
 // every entry point runs with the handle's device current (a caller whose current device is another GPU -- e.g. the

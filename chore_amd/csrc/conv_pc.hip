@@ -605,18 +605,32 @@ template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT>
 int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     using G = PGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>>;
     size_t smem = G::smem_bytes(a.in.C);
-    if (smem > 160 * 1024) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS", smem);
     // ONE workgroup per CU, always.  The small fp16 tilings (79 KB of LDS, ~120 registers) fit twice; with two workgroups on
     // a CU every SIMD holds two high-priority consumer waves, and when both poll for operands their producers -- priority 0
     // on the same SIMD -- were observed to be starved for SECONDS: conv_pc_kernel<h16_t,9,8,32,3,2> at 256^2 took 25 s for a
     // launch that takes 50 us (scripts/fp16_hang_probe.py; it resolves only when the driver's time slicing reshuffles the
     // waves).  The hand-over by polling was designed and measured with one workgroup per CU (what the fp16 x 3 tilings always
     // get); an LDS request of more than half the CU's 160 KB keeps it that way for every tiling.
-    if (smem < 81 * 1024) smem = 81 * 1024;
+    // The request is derived from the device's LDS per CU (not a constant), and the first launch of every tiling ASKS the
+    // runtime how many of these workgroups a CU would hold: anything but one is refused (a later change that shrinks the
+    // request, or a part with more LDS per CU, would bring the starvation back silently otherwise -- ADVICE round 3).
+    if (h->lds_per_cu <= 0) {
+        CHORE_HIP_CHECK(h, hipDeviceGetAttribute(&h->lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, h->device));
+        if (h->lds_per_cu <= 0) h->lds_per_cu = 160 * 1024;
+    }
+    const int lds_cu = h->lds_per_cu;
+    if (smem > (size_t)lds_cu) CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %zu bytes of LDS, the CU has %d", smem, lds_cu);
+    if (smem < (size_t)lds_cu / 2 + 1024) smem = (size_t)lds_cu / 2 + 1024;
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu));
+        int per_cu = 0;
+        CHORE_HIP_CHECK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,
+                                                                        512, smem));
+        if (per_cu != 1)
+            CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %d workgroups per CU with %zu bytes of LDS -- the hand-over by polling needs exactly one",
+                       per_cu, smem);
         attr = true;
     }
     const int tiles = ((a.W + PTW - 1) / PTW) * ((a.H + TH - 1) / TH);

@@ -94,19 +94,23 @@ class FusedAdam:
             return
         if len(rows) > 16:
             raise ValueError("FusedAdam.step_acc: at most 16 tensors")
-        key = tuple((0 if p is None else p.data_ptr(), a.data_ptr(), 0 if g is None else g.data_ptr()) for p, a, g, _ in rows)
+        # cached on what persists from step to step -- the parameters and their .grad accumulators; this step's fresh gradients
+        # change address every call and are written into the cached pointer array below (a key that contained them never hit,
+        # and keeping them alive for it stopped the allocator from reusing their addresses: ADVICE round 3)
+        key = tuple((0 if p is None else p.data_ptr(), a.data_ptr()) for p, a, _, _ in rows)
         if self._args is None or self._args[0] != key:
             n = len(rows)
             arr = lambda xs: (ctypes.c_void_p * n)(*xs)   # noqa: E731
-            self._keep = [g for _, _, g, _ in rows]
             self._args = (key, arr([None if p is None else p.data_ptr() for p, _, _, _ in rows]), arr([a.data_ptr() for _, a, _, _ in rows]),
-                          arr([None if g is None else g.data_ptr() for _, _, g, _ in rows]),
+                          arr([None] * n),
                           arr([None if mv is None else mv[0].data_ptr() for _, _, _, mv in rows]),
                           arr([None if mv is None else mv[1].data_ptr() for _, _, _, mv in rows]),
                           (ctypes.c_int * n)(*[a.numel() for _, a, _, _ in rows]),
                           (ctypes.c_int * n)(*[(a.numel() if (p is None or p.is_contiguous()) else p.shape[1]) for p, a, _, _ in rows]),
                           (ctypes.c_int * n)(*[(a.numel() if (p is None or p.is_contiguous()) else p.stride(0)) for p, a, _, _ in rows]), n)
         _, pp, aa, gg, mm, vv, nn, cc, ss, n = self._args
+        for i, (_, _, g, _) in enumerate(rows):      # stream-ordered allocation keeps g valid until the launch below has run
+            gg[i] = None if g is None else g.data_ptr()
         dev = self.params[0].device
         h = _lib.handle(dev.index or 0)
         _lib.check(_lib.lib.chore_fit_adam_step_acc(h, pp, aa, gg, mm, vv, nn, cc, ss, n, self.step_t.data_ptr(), self.lr, self.betas[0],
@@ -234,6 +238,9 @@ class EagerStep:
                 # later optimiser of the fit (the caller's contract, see __init__)
                 leaves = [p for p in self.opt.params] + [p for p in self.carry if all(p is not q for q in self.opt.params)]
                 leaves += [p for p in self.params if all(p is not q for q in leaves)]
+                if not getattr(self, "_leaves_checked", False):
+                    self._check_leaves(loss, leaves)
+                    self._leaves_checked = True
                 grads = torch.autograd.grad(loss, leaves, seed, allow_unused=True)
                 self.opt.step_acc(self.stop, leaves, grads)
             lv = loss.detach()
@@ -259,6 +266,29 @@ class EagerStep:
             self.stop.logical_or_(hit & self.armed)
             self.prev.copy_(torch.where(frozen, self.prev, lv))
             self.loss.copy_(lv)
+
+    def _check_leaves(self, loss, leaves):
+        """first step of a stepper: every leaf the loss reaches must be in `leaves`.  The reference's backward() accumulates
+        into EVERY leaf; torch.autograd.grad only returns what it is asked for, so a requires-grad leaf missing from
+        params + carry would silently stop accumulating (and a later phase's Adam would start from other sums than the
+        reference's).  A walk over the graph's AccumulateGrad nodes, no launches.  CHORE_FIT_NO_LEAF_CHECK=1 skips it."""
+        if os.environ.get("CHORE_FIT_NO_LEAF_CHECK") or loss.grad_fn is None:
+            return
+        known = {id(p) for p in leaves}
+        seen, stack, missing = set(), [loss.grad_fn], []
+        while stack:
+            fn = stack.pop()
+            if fn is None or id(fn) in seen:
+                continue
+            seen.add(id(fn))
+            v = getattr(fn, "variable", None)       # AccumulateGrad nodes carry the leaf
+            if v is not None and v.requires_grad and id(v) not in known:
+                missing.append(tuple(v.shape))
+            stack.extend(f for f, _ in fn.next_functions)
+        if missing:
+            raise RuntimeError("fit step: the loss reaches %d requires-grad leaf tensor(s) that are neither stepped nor listed in "
+                               "`carry` (shapes %s): their .grad would not accumulate like the reference's backward() does"
+                               % (len(missing), missing[:4]))
 
     def step(self):
         self._one()

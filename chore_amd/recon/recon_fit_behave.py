@@ -31,7 +31,7 @@ from .recon_fit_base import RECON_PATH, ReconFitterBase  # noqa: F401  (recon_fi
 class ReconFitterBehave(ReconFitterBase):
     use_graphs = False    # True: every inner step is a hipGraph replay (graph_step.py); same update rule
     early_stop = True     # False: never arm the stop rule (benchmarks that time a fixed number of iterations)
-    timer = None          # a list: per outer iteration (start event, end event, number of inner steps) is appended
+    timer = None          # a list: per outer iteration (start event, end event, number of inner steps, phase name) is appended
     adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
 
     def _stepper(self, *a, **k):
@@ -39,7 +39,7 @@ class ReconFitterBehave(ReconFitterBase):
             return GraphedStep(*a, **k)
         return EagerStep(*a, capturable=self.adam_capturable, **k)
 
-    def _inner(self, st, n):
+    def _inner(self, st, n, phase=None):
         """the inner steps of one outer iteration"""
         if self.timer is None:
             for _ in range(n):
@@ -50,7 +50,7 @@ class ReconFitterBehave(ReconFitterBase):
         for _ in range(n):
             st.step()
         e1.record()
-        self.timer.append((e0, e1, n))
+        self.timer.append((e0, e1, n, phase))
 
     @staticmethod
     def release_graphs(split, model):
@@ -207,7 +207,7 @@ class ReconFitterBehave(ReconFitterBase):
                 st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel, carry=carry)
             armed = self.early_stop and it > 0.25 * max_iter + iter_for_betas + iter_for_pose
             st.begin_outer(1 if phase != "kpts" else it / 3, armed=armed, zero=zero)
-            self._inner(st, steps_per_iter)
+            self._inner(st, steps_per_iter, phase)
             if armed and st.stopped():
                 break
         rel()   # graph replays change the parameters without touching their version counters: drop memoised results
@@ -362,7 +362,7 @@ class ReconFitterBehave(ReconFitterBase):
                 decay = (it - obj_iter + 1) / 5
             armed = self.early_stop and phase == "joint" and it > 0.25 * max_iter
             st.begin_outer(decay, armed=armed, zero=False)
-            self._inner(st, steps_per_iter)
+            self._inner(st, steps_per_iter, phase)
             if armed and st.stopped():
                 break
         rel()

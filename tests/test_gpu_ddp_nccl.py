@@ -1,0 +1,105 @@
+"""GPU: the DDP training step over RCCL itself (`backend="nccl"` IS RCCL on ROCm; train_launch.py:30,
+utils/dist_utils.py:28-33 of the reference run NCCL).  The box has one GPU and NCCL allows one rank per device, so the process
+group has world_size 1 -- the collective still runs: DDP's reducer copies every gradient into its buckets, launches
+`ncclAllReduce` per bucket on RCCL's own stream behind an event recorded on the autograd stream when the bucket's last hook
+fires, and copies the result back.  That is exactly the hand-over the two-stream ConvBlock backward has to get right (its
+weight gradients are produced on the handle's SIDE stream, csrc/convblock.hip; the join back to the caller's stream is the last
+thing chore_convblock_bwd does), and gloo -- host-synchronous -- cannot expose an ordering bug there.
+
+A child process (the process group and RCCL's communicator die with it) runs the reference's `Trainer.train_step` sequence
+(trainer/trainer.py:76-85) three times through `DistributedDataParallel(find_unused_parameters=True)` at the full per-GPU size
+of BASELINE configs[3] (4 x 512^2 images, 4 x 20 000 points, 5 stacks, bf16 maps) and, from the same initial weights on the
+same batches, three times without DDP.  With one rank the mean over ranks is the identity, so after every step every `.grad`
+and after the three steps every parameter must be EQUAL BIT FOR BIT."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS = 3
+
+
+def _steps(model, net, batches, record):
+    optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
+    for it in range(STEPS):
+        # ---- Trainer.train_step, line by line ----
+        model.train()
+        torch.autograd.set_detect_anomaly(True)
+        optimizer.zero_grad()
+        loss, _ = model(**batches[it])
+        loss.backward()
+        optimizer.step()
+        value = loss.item()
+        torch.autograd.set_detect_anomaly(False)
+        assert np.isfinite(value)
+        record.append((value, {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    return {n: p.detach().clone() for n, p in net.named_parameters()}
+
+
+def _worker(rank, port, out_path):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import torch.distributed as dist
+    from test_gpu_ddp_trainstep import _make
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    assert dist.get_backend() == "nccl"
+    batches = []
+    for it in range(STEPS):
+        _, b = _make(it)          # three different batches
+        batches.append(b)
+    # a real collective through the communicator before anything else (also what DDP's parameter broadcast does)
+    probe = torch.arange(1024, device="cuda", dtype=torch.float32)
+    dist.all_reduce(probe)
+    assert torch.equal(probe.cpu(), torch.arange(1024, dtype=torch.float32))
+
+    net_ddp, _ = _make(0)
+    model = torch.nn.parallel.DistributedDataParallel(net_ddp, device_ids=[0], find_unused_parameters=True)
+    rec_ddp = []
+    par_ddp = _steps(model, net_ddp, batches, rec_ddp)
+    torch.cuda.synchronize()
+
+    net_ref, _ = _make(0)
+    rec_ref = []
+    par_ref = _steps(net_ref, net_ref, batches, rec_ref)
+    torch.cuda.synchronize()
+
+    worst, differing, checked = 0.0, [], 0
+    for it in range(STEPS):
+        (la, ga), (lb, gb) = rec_ddp[it], rec_ref[it]
+        assert la == lb, (it, la, lb)
+        # DDP materialises zero gradients for the parameters the graph does not reach; the plain run leaves them None
+        for n, g in ga.items():
+            if n not in gb:
+                assert float(g.abs().max()) == 0.0, (it, n)
+                continue
+            checked += 1
+            if not torch.equal(g, gb[n]):
+                d = float((g.float() - gb[n].float()).abs().max() / gb[n].float().abs().max().clamp_min(1e-30))
+                worst = max(worst, d)
+                differing.append((it, n, d))
+    par_diff = [n for n in par_ref if not torch.equal(par_ddp[n], par_ref[n])]
+    np.savez(out_path, worst=np.float64(worst), n_diff=np.int64(len(differing)), n_checked=np.int64(checked),
+             n_par_diff=np.int64(len(par_diff)), first=np.array([str(differing[:5])]), trained=np.int64(len(rec_ref[0][1])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_over_rccl_equals_the_plain_step_bit_for_bit(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "nccl_step.npz")
+    mp.spawn(_worker, args=(29611, out), nprocs=1, join=True)
+    r = np.load(out)
+    print("RCCL DDP vs plain: tensors checked", int(r["n_checked"]), "differing", int(r["n_diff"]), "worst", float(r["worst"]),
+          "parameters differing after", STEPS, "steps:", int(r["n_par_diff"]), str(r["first"][0]))
+    assert int(r["trained"]) >= 475
+    assert int(r["n_checked"]) >= 475 * STEPS
+    assert int(r["n_diff"]) == 0, str(r["first"][0])
+    assert int(r["n_par_diff"]) == 0
