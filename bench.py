@@ -297,7 +297,28 @@ def mode_query(args, ctx):
 
     net, images, points, cc, step = make(args.dtype, rank)
     with torch.no_grad():
-        elapsed = ctx.timed(step, args.steps, args.warmup)
+        # The timed step is ONE hipGraph replay of filter + query (captured once after a warm-up on the capture stream; images and
+        # points live in static device buffers, which is what a serving loop copies its next batch into): the same ~170 launches
+        # without the host in the loop.  --eager-step issues them from Python instead (eager_ms_per_step reports that either way).
+        run, issue = step, "eager launches from Python"
+        if not args.eager_step:
+            try:
+                side = torch.cuda.Stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        step()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize()
+                step_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(step_graph):
+                    step()
+                run, issue = step_graph.replay, "one hipGraph replay per step (filter + query captured once; static input buffers)"
+            except Exception as e:
+                torch.cuda.synchronize()
+                issue = "eager launches from Python (graph capture failed: %s)" % repr(e)[:120]
+        elapsed = ctx.timed(run, args.steps, args.warmup)
+        eager_elapsed = ctx.timed(step, args.steps, 2)
 
         # ---- component timings + live roofline measurement (outside the timed region) ----
         def timed(fn, n):
@@ -443,7 +464,7 @@ def mode_query(args, ctx):
                                        "fp16": "IEEE half feature maps (BASELINE configs[4]'s 'fp16 fields'); convolutions as two fp16 MFMAs per "
                                                "product (activation x weight hi, lo), fp32 accumulation (a 1e-3 mode); heads fp32-grade",
                                        "fp32": "fp32 tensors, native fp32 MFMA"}[args.dtype],
-                         "images_per_gpu": B, "points_per_image": N, "image": "512x512x5",
+                         "images_per_gpu": B, "points_per_image": N, "image": "512x512x5", "step_issue": issue,
                          "heads_dtype": "fp32 results on the fp16 matrix cores, hi/lo split operands" if args.dtype != "fp32"
                                         else "fp32 (native fp32 MFMA)", "sharding": "images across ranks, no collective",
                          "field_err": field_err,
@@ -453,6 +474,7 @@ def mode_query(args, ctx):
                                            "19 232 per image are compared with this repo's own fp32 mode in "
                                            "tests/test_gpu_config2.py); stated tolerances: chore_amd/utils/field_check.py"})
         out.update({"roofline": roof, "other_modes": other_modes, "encode_ms": enc_ms, "query_ms": qry_ms,
+                    "eager_ms_per_step": eager_elapsed / args.steps * 1e3,
                     "query_only_points_per_s": B * N / qry_ms * 1e3,
                     "query_fwd_bwd_points_per_s": B * N / fb_ms * 1e3, "query_fwd_bwd_ms": fb_ms,
                     "encode_tflops": B * ENCODER_FLOP_PER_IMAGE_EVAL / enc_ms / 1e9,
@@ -708,9 +730,15 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="fit mode: frames fitted as one batch per GPU (default 1, or 8 when N > 1)")
     ap.add_argument("--eager", action="store_true", help="fit mode: issue the inner iterations from Python instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager-step", action="store_true", help="query mode: time eager steps instead of hipGraph replays of the step")
     ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without the one-rank DDP wrap (A/B)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()
+    # ONE JSON line on stdout, nothing else: C libraries (RCCL prints a version banner) write to file descriptor 1 behind Python's
+    # back, so fd 1 is pointed at stderr for the whole run and the line goes to a duplicate of the original stdout
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     defaults = {"all": (20, 5), "query": (20, 5), "fit": (5, 1), "train": (10, 3)}[args.mode]
     if args.dtype is None:
         args.dtype = "bf16" if args.mode == "train" else "fp16x3"
@@ -734,15 +762,15 @@ def main():
                              "train": dict(sub), "query_fwd_bwd_points_per_s": 0.0})
                 if ctx.world > 1:
                     line["train"]["allreduce"] = {"ms_per_step_synced": 0.0, "ms_per_step_no_sync": 0.0, "share_of_step": 0.0}
-            print(json.dumps(line), flush=True)
+            print(json.dumps(line), file=real_stdout, flush=True)
         ctx.close()
         return
     if not ctx.cuda:
         raise SystemExit("bench.py needs a GPU (there is no CPU path); --dry-run exercises the launch skeleton only")
     out = {"all": mode_all, "query": mode_query, "fit": mode_fit, "train": mode_train}[args.mode](args, ctx)
-    if ctx.rank == 0:
-        print(json.dumps(out), flush=True)
     ctx.close()
+    if ctx.rank == 0:
+        print(json.dumps(out), file=real_stdout, flush=True)
 
 
 if __name__ == "__main__":

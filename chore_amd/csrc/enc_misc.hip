@@ -143,9 +143,11 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
 // (enc_common.h) -> order-independent totals.
 // ------------------------------------------------------------------------------------------------
 int gn_splits(int HW) {
-    int s = HW / 64;  // >= 64 pixels per slice
+    // >= 64 pixels per slice, at most 256 slices per image (round 4; 64 before): the 256^2 x 64-channel stem output of 4 images
+    // was read by 256 workgroups with one load per thread in flight -- 2.4 TB/s
+    int s = HW / 64;
     if (s < 1) s = 1;
-    if (s > GN_SPLITS_MAX) s = GN_SPLITS_MAX;
+    if (s > 256) s = 256;
     return s;
 }
 
@@ -159,10 +161,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ x, 
     const int p0 = (int)((long long)HW * s / S), p1 = (int)((long long)HW * (s + 1) / S);
     const T* base = x + (size_t)b * HW * cs + co + cv * 4;
     f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
-    for (int p = p0 + pl; p < p1; p += P) {
-        const f32x4 v = Vec4<T>::ld(base + (size_t)p * cs);
-        sum += v;
-        sq += v * v;
+    constexpr int U = 4;          // loads in flight per thread (rows past the slice re-read its last row and add nothing)
+    for (int p = p0 + pl; p < p1; p += U * P) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int q = p + u * P;
+            v[u] = Vec4<T>::ld(base + (size_t)(q < p1 ? q : p1 - 1) * cs);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (p + u * P < p1) {
+                sum += v[u];
+                sq += v[u] * v[u];
+            }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -260,14 +273,15 @@ constexpr int MAP_T = 8;   // tile edge
 template <typename T, int C> struct PoolOp {
     const T* x; int xcs, xco, H, W;   // input view and size
     static constexpr size_t SMEM = 0;
-    __device__ __forceinline__ void stage(char*, int, int, int, int, int) const {}
+    static constexpr int CT = C, TW = MAP_T;      // channels and tile columns per workgroup
+    __device__ __forceinline__ void stage(char*, int, int, int, int, int, int) const {}
     // the MAP_T outputs of tile column ox, rows oy0.. (rows beyond OH repeat the last row; the caller skips them)
-    __device__ __forceinline__ void column(const char*, int b, int oy0, int ox, int cv, int OH,
+    __device__ __forceinline__ void column(const char*, int b, int oy0, int ox, int, int c0, int cv, int OH,
                                            f32x4 (&out)[MAP_T]) const {
 #pragma unroll
         for (int r = 0; r < MAP_T; ++r) {
             const int oy = oy0 + r < OH ? oy0 + r : OH - 1;
-            const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + cv * 4;
+            const T* src = x + (((size_t)b * H + 2 * oy) * W + 2 * ox) * xcs + xco + c0 + cv * 4;
             const f32x4 a = Vec4<T>::ld(src), bb = Vec4<T>::ld(src + xcs);
             const f32x4 c = Vec4<T>::ld(src + (size_t)W * xcs), d = Vec4<T>::ld(src + (size_t)W * xcs + xcs);
             out[r] = (((a + bb) + c) + d) * 0.25f;
@@ -290,40 +304,44 @@ __device__ __forceinline__ void cubic_coeffs(float t, float (&c)[4]) {
 // the tile's working set does not fit.  One thread then produces a whole tile column: the horizontal
 // interpolation of the 8 patch rows is done once (8 x 4 taps) and every output row combines 4 of those
 // (same two-pass order as ATen's upsample_bicubic2d: x first, then y).
+// Round 4: a workgroup owns 8 x 16 output pixels x 64 CHANNELS (was 8 x 8 pixels x all C channels): the staged patch is
+// 8 x 12 source pixels x 64 channels = 24 KB instead of 64 KB, so four workgroups share a CU instead of two and the grid
+// is 4 x larger (2 048 workgroups at 128^2); the source over-read drops from 1.0 to 0.75 staged values per output.
 template <typename T, int C> struct UpAddOp {
-    static constexpr int PS = 8;   // patch edge
-    static constexpr int TPR = C / 4, P = 256 / TPR;
-    static constexpr size_t SMEM = (size_t)PS * PS * C * sizeof(T);
+    static constexpr int CT = 64, TW = 16;            // channels and tile columns per workgroup
+    static constexpr int PS = 8, PSX = TW / 2 + 4;    // patch rows / columns (8 output rows span <= 5 source rows, 16 columns <= 9; + 3 taps)
+    static constexpr int TPR = CT / 4, P = 256 / TPR;
+    static constexpr size_t SMEM = (size_t)PS * PSX * CT * sizeof(T);
+    static_assert(C % CT == 0 && (PS * PSX) % P == 0 && TW % P == 0, "upadd tile geometry");
     const T* a; int acs, aco;
     const T* low; int lcs, lco, H, W;   // low-resolution view and size (output is 2H x 2W)
     __device__ __forceinline__ float scale_y() const { return (float)(H - 1) / (float)(2 * H - 1); }
     __device__ __forceinline__ float scale_x() const { return (float)(W - 1) / (float)(2 * W - 1); }
-    __device__ __forceinline__ void stage(char* sm, int b, int oy0, int ox0, int cv, int pl) const {
+    __device__ __forceinline__ void stage(char* sm, int b, int oy0, int ox0, int c0, int cv, int pl) const {
         const int iy0 = (int)floorf(scale_y() * (float)oy0) - 1, ix0 = (int)floorf(scale_x() * (float)ox0) - 1;
-        constexpr int N = PS * PS / P;
+        constexpr int N = PS * PSX / P;
         typedef typename std::conditional<sizeof(T) == 2, unsigned long long, f32x4>::type Raw;
         Raw v[N];
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int q = pl + i * P;
-            int yy = iy0 + q / PS, xx = ix0 + q % PS;
+            int yy = iy0 + q / PSX, xx = ix0 + q % PSX;
             yy = yy < 0 ? 0 : (yy > H - 1 ? H - 1 : yy);
             xx = xx < 0 ? 0 : (xx > W - 1 ? W - 1 : xx);
-            v[i] = *(const Raw*)(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + cv * 4);
+            v[i] = *(const Raw*)(low + (((size_t)b * H + yy) * W + xx) * lcs + lco + c0 + cv * 4);
         }
 #pragma unroll
-        for (int i = 0; i < N; ++i) *(Raw*)((T*)sm + (size_t)(pl + i * P) * C + cv * 4) = v[i];
+        for (int i = 0; i < N; ++i) *(Raw*)((T*)sm + (size_t)(pl + i * P) * CT + cv * 4) = v[i];
     }
-    __device__ __forceinline__ void column(const char* sm, int b, int oy0, int ox, int cv, int OH,
+    __device__ __forceinline__ void column(const char* sm, int b, int oy0, int ox, int ox0, int c0, int cv, int OH,
                                            f32x4 (&out)[MAP_T]) const {
         const int OW = 2 * W;
-        const int ox0 = ox & ~(MAP_T - 1);
         const int iy0 = (int)floorf(scale_y() * (float)oy0) - 1, ix0 = (int)floorf(scale_x() * (float)ox0) - 1;
         f32x4 av[MAP_T];
 #pragma unroll
         for (int r = 0; r < MAP_T; ++r) {   // issued first: they land while the interpolation runs
             const int oy = oy0 + r < OH ? oy0 + r : OH - 1;
-            av[r] = Vec4<T>::ld(a + (((size_t)b * 2 * H + oy) * OW + ox) * acs + aco + cv * 4);
+            av[r] = Vec4<T>::ld(a + (((size_t)b * 2 * H + oy) * OW + ox) * acs + aco + c0 + cv * 4);
         }
         const float rx = scale_x() * (float)ox, fx = floorf(rx);
         const int kx = (int)fx - 1 - ix0;
@@ -332,11 +350,11 @@ template <typename T, int C> struct UpAddOp {
         f32x4 rows[PS];
 #pragma unroll
         for (int k = 0; k < PS; ++k) {
-            const T* pr = (const T*)sm + (size_t)(k * PS + kx) * C + cv * 4;
+            const T* pr = (const T*)sm + (size_t)(k * PSX + kx) * CT + cv * 4;
             f32x4 acc = Vec4<T>::ld(pr) * cx[0];
 #pragma unroll
             for (int q = 1; q < 4; ++q) {
-                const f32x4 v = Vec4<T>::ld(pr + (size_t)q * C);
+                const f32x4 v = Vec4<T>::ld(pr + (size_t)q * CT);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[e] = fmaf(v[e], cx[q], acc[e]);
             }
@@ -372,25 +390,27 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
                                                         GroupStat* __restrict__ st) {
     extern __shared__ __attribute__((aligned(16))) char map_sm[];
     __shared__ float red[2][1024];
-    constexpr int TPR = C / 4, P = 256 / TPR;
-    const int b = blockIdx.y, tid = threadIdx.x;
+    constexpr int CT = Op::CT, TW = Op::TW;        // channels / tile columns of a workgroup (grid.z = C / CT channel slices)
+    constexpr int TPR = CT / 4, P = 256 / TPR;
+    static_assert(P * CT <= 1024, "partial-sum scratch");
+    const int b = blockIdx.y, tid = threadIdx.x, c0 = blockIdx.z * CT;
     const int cv = tid % TPR, pl = tid / TPR;
-    const int tiles_x = (OW + MAP_T - 1) / MAP_T;
-    const int oy0 = (blockIdx.x / tiles_x) * MAP_T, ox0 = (blockIdx.x % tiles_x) * MAP_T;
-    op.stage(map_sm, b, oy0, ox0, cv, pl);
+    const int tiles_x = (OW + TW - 1) / TW;
+    const int oy0 = (blockIdx.x / tiles_x) * MAP_T, ox0 = (blockIdx.x % tiles_x) * TW;
+    op.stage(map_sm, b, oy0, ox0, c0, cv, pl);
     __syncthreads();
     f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int col = pl; col < MAP_T; col += P) {
+    for (int col = pl; col < TW; col += P) {
         const int ox = ox0 + col;
         if (ox < OW) {
             f32x4 out[MAP_T];
-            op.column(map_sm, b, oy0, ox, cv, OH, out);
+            op.column(map_sm, b, oy0, ox, ox0, c0, cv, OH, out);
 #pragma unroll
             for (int r = 0; r < MAP_T; ++r) {
                 const int oy = oy0 + r;
                 if (oy < OH) {
-                    const f32x4 v = Vec4<T>::st_round(y + (((size_t)b * OH + oy) * OW + ox) * ycs + yco + cv * 4, out[r]);
+                    const f32x4 v = Vec4<T>::st_round(y + (((size_t)b * OH + oy) * OW + ox) * ycs + yco + c0 + cv * 4, out[r]);
                     sum += v;
                     sq += v * v;
                 }
@@ -400,18 +420,19 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
     if (!st) return;   // uniform
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        red[0][pl * C + cv * 4 + j] = sum[j];
-        red[1][pl * C + cv * 4 + j] = sq[j];
+        red[0][pl * CT + cv * 4 + j] = sum[j];
+        red[1][pl * CT + cv * 4 + j] = sq[j];
     }
     __syncthreads();
-    if (tid < C) {
+    if (tid < CT) {
         float a = 0.f, q = 0.f;
 #pragma unroll
-        for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
-        const int gs = C / GN_GROUPS;
+        for (int i = 0; i < P; ++i) { a += red[0][i * CT + tid]; q += red[1][i * CT + tid]; }
+        constexpr int gs = C / GN_GROUPS;
+        static_assert(CT % gs == 0, "a channel slice holds whole GroupNorm groups");
         a = group_lane_sum(a, gs);
         q = group_lane_sum(q, gs);
-        GroupStat* o = st + (size_t)b * GN_GROUPS + tid / gs;      // two lanes of the group, concurrently
+        GroupStat* o = st + (size_t)b * GN_GROUPS + (c0 + tid) / gs;      // two lanes of the group, concurrently
         if (tid % gs == 0) stat_add(&o->sum, act_hi_cells((int)gridDim.y), a);
         if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells((int)gridDim.y), q);
     }
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(256) void map_stats_kernel(Op op, T* y, int ycs, in
 template <typename T, int C, typename Op>
 static int launch_map_c(chore_handle* h, const Op& op, const View& y, int B, int OH, int OW, GroupStat* st,
                         hipStream_t s) {
-    dim3 grid(((OH + MAP_T - 1) / MAP_T) * ((OW + MAP_T - 1) / MAP_T), B);
+    dim3 grid(((OH + MAP_T - 1) / MAP_T) * ((OW + Op::TW - 1) / Op::TW), B, C / Op::CT);
     bool& attr = CHORE_ONCE_FLAG(h);   // per instantiation
     if (!attr && Op::SMEM > 32 * 1024) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)map_stats_kernel<T, C, Op>,

@@ -1,1 +1,2 @@
 from .frame_shard import frames_of_rank, gather_fitted, init_distributed  # noqa: F401
+from .grad_arena import FlatGradReducer  # noqa: F401
