@@ -418,7 +418,10 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                 if (ks + 1 < NKS) load_frag((ks + 1) & 1, s, slot, ks + 1);
                 else if (!last) {
                     // K-step s + 1 needs producer steps 0 .. s - NSLOT + 2 (its weights) and, when it opens a chunk, the steps
-                    // that staged the chunk's patch (the last of them: LASTK of the previous chunk)
+                    // that staged the chunk's patch (the last of them: LASTK of the previous chunk).  (Reading the counts one
+                    // k-step EARLIER, so that the read's LDS round trip runs under MFMAs, was measured in round 4 and is 2 - 8 %
+                    // SLOWER on every layer: the producers finish just in time, an early read sees the old count and the
+                    // consumer polls anyway -- profiles/r04_conv_pp.txt.)
                     const int sn = s + 1;
                     int need = sn - NSLOT + 2;
                     if (sn % KROWS == 0) { const int np = sn - KROWS + LASTK + 1; need = need > np ? need : np; }

@@ -170,6 +170,11 @@ struct PcPlan { int th, nt, tps, nslot; };
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
+// persistent specialised-wave convolution (conv_pp.hip): workgroups loop over tpw tiles, the producers drain a tile's epilogue
+// while the consumers run the next tile; th = 0: not covered (fewer than two tiles per CU, or no tiling whose image fits)
+struct PpPlan { int th, nt, tps, nslot, tpw; };
+PpPlan conv_pp_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
+int launch_conv_pp(chore_handle* h, int dtype, int taps, const PpPlan& p, const ConvArgs& a, hipStream_t s);
 
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);

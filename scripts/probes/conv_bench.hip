@@ -119,22 +119,37 @@ int main(int argc, char** argv) {
         CK(hipEventCreate(&e1));
         const double gflop = 2.0 * sh.taps * sh.Cin * sh.Cout * (double)px * 1e-9;
         // variant 0 = conv_lds_kernel (or conv_small), then the forced tilings of conv_pc_kernel: th * 1000 + nt
-        const int forces9[] = {0, 1, 8128, 8064, 8032, 4064, 4032};   // 1 = the tiling conv_pc_plan picks
-        const int forces1[] = {0, 1, 8128, 8064};
+        // 1 = the tiling conv_pc_plan picks; negative = the persistent kernel (conv_pp.hip): -1 = the tiling conv_pp_plan picks
+        const int forces9[] = {0, 1, 8128, 8064, 8032, 4064, 4032, -1, -4128, -4064, -8032, -4032};
+        const int forces1[] = {0, 1, 8128, 8064, -1, -4128};
         const int* forces = sh.taps == 9 ? forces9 : forces1;
-        const int nforce = sh.taps == 9 ? 7 : 4;
+        const int nforce = getenv("CONV_BENCH_PP_ONLY") ? 0 : (sh.taps == 9 ? 12 : 6);
+        const bool pp_only = getenv("CONV_BENCH_PP_ONLY") != nullptr;
         std::vector<float> ref_out(nout), ref_raw(px * sh.Cout), got(nout);
-        for (int fi = 0; fi < nforce; ++fi) {
-            const int force = forces[fi];
+        (void)pp_only;
+        const int ppf9[] = {0, 1, 8128, 8064, 8032, -1, -4128, -4064, -8032, -4032}, ppf1[] = {0, 1, -1, -4128};
+        const int* fl = pp_only ? (sh.taps == 9 ? ppf9 : ppf1) : forces;
+        const int nfl = pp_only ? (sh.taps == 9 ? 10 : 4) : nforce;
+        for (int fi = 0; fi < nfl; ++fi) {
+            const int force = fl[fi];
             PcPlan pp{0, 0, 0, 0};
+            PpPlan qq{0, 0, 0, 0, 0};
             int vw = wgs;
-            if (force) {
+            if (force > 0) {
                 pp = conv_pc_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force == 1 ? 0 : force);
                 if (!pp.th || sh.Cout % pp.nt || sh.H % pp.th) continue;
                 vw = B * (sh.H / pp.th) * (sh.W / 32) * (sh.Cout / pp.nt);
+            } else if (force < 0) {
+                qq = conv_pp_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force == -1 ? 0 : -force);
+                if (!qq.th || sh.Cout % qq.nt || sh.H % qq.th) continue;
+                if (sh.taps == 1 && qq.nt != 128) continue;
+                if (sh.taps == 9 && !((qq.th == 4 && (qq.nt == 128 || qq.nt == 64 || qq.nt == 32)) || (qq.th == 8 && qq.nt == 32))) continue;
+                vw = (B * (sh.H / qq.th) * (sh.W / 32) * (sh.Cout / qq.nt) + qq.tpw - 1) / qq.tpw;
+                pp.th = qq.th; pp.nt = qq.nt; pp.tps = qq.tps; pp.nslot = qq.tpw;      // (for the label: the last field shows tiles per workgroup)
             }
             auto run = [&](int dbg) -> int {
                 a.dbg = dbg | (1 << 30);
+                if (force < 0) return launch_conv_pp(h, dtype, sh.taps, qq, a, s);
                 return force ? launch_conv_pc(h, dtype, sh.taps, pp, a, s) : launch_conv(h, dtype, sh.taps, a, s);
             };
             // correctness against variant 0 (same arithmetic, another summation order over the chunks)
@@ -154,10 +169,11 @@ int main(int argc, char** argv) {
                     for (size_t i = 0; i < px * sh.Cout; ++i) err_raw = fmax(err_raw, fabs((double)got[i] - ref_raw[i]));
                 }
             }
-            printf("%-20s %-13s %5d", sh.name, force ? (std::string(force == 1 ? "auto" : "pc") + std::to_string(pp.th * 1000 + pp.nt) + "/" + std::to_string(pp.tps) + "/" + std::to_string(pp.nslot)).c_str() : "lds", vw);
+            printf("%-20s %-13s %5d", sh.name, force ? (std::string(force == 1 ? "auto" : (force == -1 ? "ppauto" : (force < 0 ? "pp" : "pc"))) + std::to_string(pp.th * 1000 + pp.nt) + "/" + std::to_string(pp.tps) + "/" + std::to_string(pp.nslot)).c_str() : "lds", vw);
             for (int i = 0; i < 400; ++i) run(0);   // clocks up before the first timed variant (it read 5 us high without)
             double full_us = 0;
             for (size_t di = 0; di < sizeof(dbgs) / sizeof(dbgs[0]); ++di) {
+                if (force < 0 && (dbgs[di] & (16 | 4096 | 8192))) { printf(" %13s", "-"); continue; }   // switches conv_pp does not have
                 for (int i = 0; i < 5; ++i)
                     if (run(dbgs[di])) { fprintf(stderr, "%s\n", h->err.c_str()); return 1; }
                 CK(hipEventRecord(e0, s));
@@ -171,7 +187,18 @@ int main(int argc, char** argv) {
                 printf(" %13.2f", us);
             }
             printf("  %6.2f  %7.1f", gflop, gflop / full_us * 1e-3);
-            if (force) {   // phase stamps of the last full launch (workgroup in the middle of the grid)
+            if (force < 0) {   // persistent kernel: stamps 0 start, 1 main loop, 2 loop done, 3 last tile drained
+                CK(hipMemset(dticks, 0, 32 * 8));
+                run(0);
+                CK(hipStreamSynchronize(s));
+                unsigned long long tk[32];
+                CK(hipMemcpy(tk, dticks, sizeof(tk), hipMemcpyDeviceToHost));
+                for (int w = 0; w < 2; ++w) {
+                    const unsigned long long* q = tk + 16 * w;
+                    printf("  [%s us: pro %.2f loop %.2f final %.2f]", w ? "prod" : "cons", (double)(q[3] - q[1]) * 0.01, (double)(q[5] - q[3]) * 0.01,
+                           (double)(q[7] - q[5]) * 0.01);
+                }
+            } else if (force) {   // phase stamps of the last full launch (workgroup in the middle of the grid)
                 run(getenv("STAMP_DBG") ? atoi(getenv("STAMP_DBG")) : 0);
                 CK(hipStreamSynchronize(s));
                 unsigned long long tk[32];
