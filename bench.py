@@ -630,12 +630,14 @@ def mode_train(args, ctx):
     synth.load_synth_weights(net, seed=0)
     net.train(True)
     net.losses_on_host = False     # the six separate losses stay on the device: no host synchronisation inside the step
-    model = net
-    ddp = ctx.world > 1 or ctx.group1 is not None
-    if ddp:
-        model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], find_unused_parameters=True)
-    # the reference's optimiser (trainer/trainer.py: optim.Adam, lr 1e-4) in torch's single-kernel implementation of the same
-    # update (fused=True: 29.4 ms per step against 29.8 with the default multi-tensor one); CHORE_ADAM_DEFAULT=1 = the default
+    # Gradient reduction.  Default: chore_amd.parallel.FlatGradReducer -- one flat fp32 gradient arena, all-reduced
+    # over RCCL in a few large chunks after the backward, mean over the ranks (the arithmetic of the reference's DDP wrap).  The
+    # stock wrap (train_launch.py:30: DistributedDataParallel(find_unused_parameters=True)) is timed beside it: its per-parameter
+    # hooks and bucket copies sit inside the launch-bound backward chain (profiles/r04_ddp_overhead.txt).  --reducer ddp makes it
+    # the primary number.  With one GPU both run on a ONE-rank RCCL group: the collectives execute, nothing crosses xGMI.
+    from chore_amd.parallel import FlatGradReducer
+    have_group = ctx.world > 1 or ctx.group1 is not None
+    reducer_kind = args.reducer if have_group else "none"
     optim = torch.optim.Adam(net.parameters(), lr=1e-4, **({} if os.environ.get("CHORE_ADAM_DEFAULT") else {"fused": True}))
     B, N = args.batch, args.points
     rs = np.random.RandomState(50 + rank)
@@ -648,21 +650,48 @@ def mode_train(args, ctx):
                  crop_center=torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev))
     last = {}
 
-    def step():
-        optim.zero_grad(set_to_none=True)
-        error, _ = model(**batch)
-        error.backward()
-        optim.step()
-        last["err"] = error
+    def make_step(model, reducer):
+        def step():
+            if reducer is not None:
+                reducer.zero_grad()
+            else:
+                optim.zero_grad(set_to_none=True)
+            error, _ = model(**batch)
+            error.backward()
+            if reducer is not None:
+                reducer.reduce()
+            optim.step()
+            last["err"] = error
+        return step
 
-    elapsed = ctx.timed(step, args.steps, args.warmup)
-    nosync = None
-    if ddp:
-        # the same steps without the gradient all-reduce: what the collective (and its overlap with the backward) costs
+    arena = FlatGradReducer(net) if have_group else None
+    step_plain = make_step(net, None)
+    step_arena = make_step(net, arena) if have_group else None
+    ddp_model = None
+
+    def step_ddp_factory():
+        m = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], find_unused_parameters=True)
+        return m, make_step(m, None)
+
+    if reducer_kind == "ddp":
+        ddp_model, primary = step_ddp_factory()
+    elif reducer_kind == "arena":
+        primary = step_arena
+    else:
+        primary = step_plain
+    elapsed = ctx.timed(primary, args.steps, args.warmup)
+    nosync = other = None
+    if have_group and reducer_kind == "arena":
+        # the same steps without any gradient reduction, and with the reference's wrap: what the collective costs either way
+        # (the DDP wrap last: its hooks stay on the parameters)
+        nosync = ctx.timed(step_plain, args.steps, 2)
+        ddp_model, sd = step_ddp_factory()
+        other = ("torch DistributedDataParallel(find_unused_parameters=True)", ctx.timed(sd, args.steps, 3))
+    elif have_group:
         def step_nosync():
-            with model.no_sync():
-                step()
-        nosync = ctx.timed(step_nosync, args.steps, 1)
+            with ddp_model.no_sync():
+                primary()
+        nosync = ctx.timed(step_nosync, args.steps, 2)
     out = None
     if rank == 0:
         flops = 3.0 * (B * ENCODER_FLOP_PER_IMAGE + 5 * B * N * HEADS_FLOP_PER_POINT)     # 3.82 TFLOP at B=4
@@ -671,17 +700,22 @@ def mode_train(args, ctx):
                         args.steps / elapsed, "steps/s", elapsed, True, args.dtype,
                         {"workload": "BASELINE configs[3]: DDP training, batch %d/GPU, %d points/image, 5 stacks" % (B, N),
                          "images_per_gpu": B, "points_per_image": N, "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
-                         "grad_allreduce": ("torch DDP over RCCL (backend nccl), find_unused_parameters=True" if ctx.world > 1 else
-                                            "torch DDP over RCCL (backend nccl), find_unused_parameters=True, ONE-rank group: the "
-                                            "bucket copies and ncclAllReduce launches run on RCCL's stream, nothing crosses xGMI")
-                                           if ddp else "none (1 GPU, no process group%s)" % (
+                         "grad_allreduce": ({"arena": "chore_amd.parallel.FlatGradReducer: flat fp32 gradient arena (%.1f MB), all-reduced "
+                                                      "over RCCL (backend nccl) in %d chunks after the backward, mean over ranks"
+                                                      % (arena.bytes / 1e6, len(arena.chunks)) if arena is not None else "",
+                                             "ddp": "torch DDP over RCCL (backend nccl), find_unused_parameters=True (the reference's wrap)"}
+                                            [reducer_kind] + ("" if ctx.world > 1 else "; ONE-rank group: the collectives execute on "
+                                                              "RCCL's stream, nothing crosses xGMI"))
+                                           if have_group else "none (1 GPU, no process group%s)" % (
                                                ": " + ctx.group1_error if ctx.group1_error else "")})
         if nosync is not None:
             out["allreduce"] = {"ms_per_step_synced": ms, "ms_per_step_no_sync": nosync / args.steps * 1e3,
                                 "share_of_step": max(0.0, 1.0 - nosync / elapsed), "bytes_per_step": 4 * sum(p.numel() for p in net.parameters()),
+                                "reducer": reducer_kind,
+                                "other_reducer": {"what": other[0], "ms_per_step": other[1] / args.steps * 1e3,
+                                                  "steps_per_s": args.steps / other[1]} if other else None,
                                 "world_size": ctx.world,
-                                "how": "K steps under DistributedDataParallel.no_sync() against K synced steps (bucketed all-reduce "
-                                       "overlapped with the backward by torch DDP, RCCL over xGMI)"}
+                                "how": "K steps without any gradient reduction against K steps with it, same model and batch"}
         out.update({"images_per_s": ctx.world * B * args.steps / elapsed, "final_loss": float(last["err"].detach()),
                     "parameters": sum(p.numel() for p in net.parameters()),
                     "roofline": {"kernel": "whole training step (all kernels)", "bound": "mfma", "achieved": flops / ms / 1e9,
@@ -731,7 +765,9 @@ def main():
     ap.add_argument("--eager", action="store_true", help="fit mode: issue the inner iterations from Python instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager-step", action="store_true", help="query mode: time eager steps instead of hipGraph replays of the step")
-    ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without the one-rank DDP wrap (A/B)")
+    ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without a process group / gradient reduction (A/B)")
+    ap.add_argument("--reducer", default="arena", choices=["arena", "ddp"],
+                    help="training: gradient reduction of the primary number (arena = FlatGradReducer, ddp = torch's DistributedDataParallel)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()
     # ONE JSON line on stdout, nothing else: C libraries (RCCL prints a version banner) write to file descriptor 1 behind Python's

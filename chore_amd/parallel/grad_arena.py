@@ -52,6 +52,13 @@ class FlatGradReducer:
         if mode == "inplace":
             self._attach()
 
+    @torch.no_grad()
+    def sync_parameters(self, src=0):
+        """every rank starts from rank `src`'s parameters (what DistributedDataParallel does when it wraps a module)"""
+        if self.world > 1:
+            for p in self.params:
+                dist.broadcast(p.data, src, group=self.group)
+
     def _attach(self):
         for p, v in zip(self.params, self.views):
             p.grad = v

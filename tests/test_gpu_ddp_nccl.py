@@ -9,8 +9,9 @@ thing chore_convblock_bwd does), and gloo -- host-synchronous -- cannot expose a
 A child process (the process group and RCCL's communicator die with it) runs the reference's `Trainer.train_step` sequence
 (trainer/trainer.py:76-85) three times through `DistributedDataParallel(find_unused_parameters=True)` at the full per-GPU size
 of BASELINE configs[3] (4 x 512^2 images, 4 x 20 000 points, 5 stacks, bf16 maps) and, from the same initial weights on the
-same batches, three times without DDP.  With one rank the mean over ranks is the identity, so after every step every `.grad`
-and after the three steps every parameter must be EQUAL BIT FOR BIT."""
+same batches, three times without DDP, and three times with chore_amd.parallel.FlatGradReducer (the flat gradient arena that
+replaces the wrap, all-reduced over RCCL after the backward).  With one rank the mean over ranks is the identity, so after
+every step every `.grad` and after the three steps every parameter must be EQUAL BIT FOR BIT in all three runs."""
 import os
 import sys
 
@@ -24,15 +25,20 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 3
 
 
-def _steps(model, net, batches, record):
+def _steps(model, net, batches, record, reducer=None):
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
     for it in range(STEPS):
-        # ---- Trainer.train_step, line by line ----
+        # ---- Trainer.train_step, line by line (with a FlatGradReducer: its zero_grad() / reduce() around the backward) ----
         model.train()
         torch.autograd.set_detect_anomaly(True)
-        optimizer.zero_grad()
+        if reducer is not None:
+            reducer.zero_grad()
+        else:
+            optimizer.zero_grad()
         loss, _ = model(**batches[it])
         loss.backward()
+        if reducer is not None:
+            reducer.reduce()
         optimizer.step()
         value = loss.item()
         torch.autograd.set_detect_anomaly(False)
@@ -71,6 +77,24 @@ def _worker(rank, port, out_path):
     par_ref = _steps(net_ref, net_ref, batches, rec_ref)
     torch.cuda.synchronize()
 
+    # chore_amd.parallel.FlatGradReducer (flat gradient arena, chunked all-reduce over RCCL after the backward): same contract
+    from chore_amd.parallel import FlatGradReducer
+    net_ar, _ = _make(0)
+    red = FlatGradReducer(net_ar, chunks=4)
+    red.sync_parameters()
+    rec_ar = []
+    par_ar = _steps(net_ar, net_ar, batches, rec_ar, reducer=red)
+    torch.cuda.synchronize()
+    ar_diff = 0
+    for it in range(STEPS):
+        assert rec_ar[it][0] == rec_ref[it][0], (it, rec_ar[it][0], rec_ref[it][0])
+        for n, g in rec_ar[it][1].items():
+            if n in rec_ref[it][1]:
+                ar_diff += int(not torch.equal(g, rec_ref[it][1][n]))
+            else:
+                assert float(g.abs().max()) == 0.0, (it, n)
+    ar_par_diff = sum(int(not torch.equal(par_ar[n], par_ref[n])) for n in par_ref)
+
     worst, differing, checked = 0.0, [], 0
     for it in range(STEPS):
         (la, ga), (lb, gb) = rec_ddp[it], rec_ref[it]
@@ -87,7 +111,8 @@ def _worker(rank, port, out_path):
                 differing.append((it, n, d))
     par_diff = [n for n in par_ref if not torch.equal(par_ddp[n], par_ref[n])]
     np.savez(out_path, worst=np.float64(worst), n_diff=np.int64(len(differing)), n_checked=np.int64(checked),
-             n_par_diff=np.int64(len(par_diff)), first=np.array([str(differing[:5])]), trained=np.int64(len(rec_ref[0][1])))
+             n_par_diff=np.int64(len(par_diff)), first=np.array([str(differing[:5])]), trained=np.int64(len(rec_ref[0][1])),
+             ar_diff=np.int64(ar_diff), ar_par_diff=np.int64(ar_par_diff))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -103,3 +128,4 @@ def test_ddp_over_rccl_equals_the_plain_step_bit_for_bit(tmp_path):
     assert int(r["n_checked"]) >= 475 * STEPS
     assert int(r["n_diff"]) == 0, str(r["first"][0])
     assert int(r["n_par_diff"]) == 0
+    assert int(r["ar_diff"]) == 0 and int(r["ar_par_diff"]) == 0, (int(r["ar_diff"]), int(r["ar_par_diff"]))
