@@ -518,6 +518,8 @@ def mode_fit(args, ctx):
     synth.load_synth_weights(net, seed=0)
     fitter = ReconFitterBehave(None, device=dev, obj_name="synthetic", outpath=None, args=opt, assets=SyntheticAssets(0))
     fitter.use_graphs = not args.eager
+    fitter.reuse_graphs = not args.eager and not os.environ.get("CHORE_FIT_NO_REUSE")    # recorded steps kept across chains (same shapes)
+    net.image_filter.static_outputs = fitter.reuse_graphs
     fitter.early_stop = False      # time exactly 300 iterations (with random weights the rule fires at once)
     fitter.timer = []
     # random weights have no thin zero level set: a loose filter collects the 5 000 points in the first rounds
@@ -588,7 +590,8 @@ def mode_fit(args, ctx):
                                           "the per-GPU share of BASELINE configs[4] (8 frames per GPU)" if B == 8 else "frame-sharded fit"),
                                          B, SMPL_ITERS, OBJECT_ITERS),
                          "frames_per_gpu": B, "frames": B * ctx.world, "adam_iterations_per_step": iters // max(args.steps, 1),
-                         "inner_iteration": "eager" if args.eager else "hipGraph replay (chore_amd/recon/graph_step.py)",
+                         "inner_iteration": "eager" if args.eager else "hipGraph replay (chore_amd/recon/graph_step.py); the recorded steps "
+                                            "are kept across chains of the same shapes (recon_fit_behave._FitSlot)",
                          "early_stop": "off (a fixed 300 iterations are timed)",
                          "terms": "df_h, part, pose/hand priors, smplz, pinit, j2d | object, scale, ocent | silhouette (HIP "
                                   "rasteriser), trans | contact, collision",

@@ -307,8 +307,17 @@ class CHORE(nn.Module):
         return (("df", self.df), ("part_predictor", self.part_predictor), ("pca_predictor", self.pca_predictor),
                 ("center_predictor", self.center_predictor))
 
+    def _head_params(self):
+        """the parameters of the four heads, listed once (walking four nn.Sequential per query call cost ~90 us of host time, and a
+        fitting step or a surface step is a handful of query calls); Parameter objects are replaced by .to() / load_state_dict
+        (which drop the list) -- not by optimiser steps, which change data in place"""
+        ps = getattr(self, "_head_param_list", None)
+        if ps is None:
+            ps = self._head_param_list = [p for _, m in self._head_modules() for p in m.parameters()]
+        return ps
+
     def _heads_arena(self, device):
-        params = [p for _, m in self._head_modules() for p in m.parameters()]
+        params = self._head_params()
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
         if self._heads_packed is not None and self._heads_packed[0] == key:
             return self._heads_packed[1]
@@ -330,6 +339,7 @@ class CHORE(nn.Module):
         return arena
 
     def invalidate_packed(self):
+        self._head_param_list = None
         """drop the packed copies of the head and encoder weights.  The caches are keyed on (address, version) of every
         parameter, which sees optimiser steps, load_state_dict and .to(); a write through `p.data` is invisible to the
         version counters -- call this after one."""
@@ -339,6 +349,7 @@ class CHORE(nn.Module):
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
         self._heads_packed = None
+        self._head_param_list = None
         return out
 
     def load_state_dict(self, *a, **k):
@@ -383,7 +394,7 @@ class CHORE(nn.Module):
             raise ValueError("points must be (B,N,3) and crop_center (B,2)")
         arena = self._heads_arena(points.device)
         dtype = _QDT[self.compute_dtype]
-        head_params = [p for _, m in self._head_modules() for p in m.parameters()]
+        head_params = self._head_params()
         train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))
         if train and self.compute_dtype == "fp16":

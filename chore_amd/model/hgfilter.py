@@ -101,6 +101,8 @@ class HGFilter(_Params):
                 self.add_module(f"al{i}", _conv(hd, 256, 1, True))
         self._packed = {}  # dtype -> (version key, arena tensor)
         self._work = {}    # (B,H,W,dtype) -> workspace tensor
+        self._static_out = {}      # static_outputs: (shape key) -> the output tensors every call of that shape writes
+        self.static_outputs = False
 
     # ---------------------------------------------------------------------------------------
     def cfg(self):
@@ -182,9 +184,17 @@ class HGFilter(_Params):
             work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self._work = {k: v for k, v in self._work.items() if k[:5] == wkey[:5]}
             self._work[wkey] = work
-        feats = [torch.empty(B, H // 4, W // 4, 256, dtype=tdt, device=dev) for _ in range(n_out)]
-        tmpx = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
-        normx = torch.empty(B, H // 4, W // 4, 128, dtype=tdt, device=dev)
+        # static_outputs: the same output tensors for every call of a shape (each call overwrites the previous call's maps) --
+        # recorded hipGraphs of the fit loop read the maps through fixed addresses and are kept across loader batches
+        outs = self._static_out.get(wkey + (n_out,)) if getattr(self, "static_outputs", False) else None
+        if outs is None:
+            feats = [torch.empty(B, H // 4, W // 4, 256, dtype=tdt, device=dev) for _ in range(n_out)]
+            tmpx = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
+            normx = torch.empty(B, H // 4, W // 4, 128, dtype=tdt, device=dev)
+            if getattr(self, "static_outputs", False):
+                self._static_out = {wkey + (n_out,): (feats, tmpx, normx)}
+        else:
+            feats, tmpx, normx = outs
         fptrs = (ctypes.c_void_p * n_out)(*[f.data_ptr() for f in feats])
         stream = torch.cuda.current_stream(dev).cuda_stream
         _lib.check(_lib.lib.chore_encode_fwd(h, ctypes.byref(cfg), images.data_ptr(), B, H, W, dtype,

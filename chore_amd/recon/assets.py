@@ -221,11 +221,13 @@ class FileAssets(FitAssets):
         return BodyPrior.from_assets(self.assets_root, device), HandPrior.from_assets(self.assets_root, device)
 
     def regressors(self):
-        out = []
-        for n in ("body25", "face", "hand"):
-            r = pkl.load(open(os.path.join(self.assets_root, n + "_regressor.pkl"), "rb"), encoding="latin1").T
-            out.append(np.asarray(r.todense(), np.float32))
-        return out
+        if getattr(self, "_regs", None) is None:      # read once per fitter (every loader batch builds a new SMPL wrapper)
+            out = []
+            for n in ("body25", "face", "hand"):
+                r = pkl.load(open(os.path.join(self.assets_root, n + "_regressor.pkl"), "rb"), encoding="latin1").T
+                out.append(np.asarray(r.todense(), np.float32))
+            self._regs = out
+        return self._regs
 
     def mean_hand_pose(self):
         lh = pkl.load(open(os.path.join(self.assets_root, "priors", "lh_prior.pkl"), "rb"))
@@ -290,8 +292,10 @@ class SyntheticAssets(FitAssets):
         return synth.synth_smplh_surface_model(self.seed)
 
     def regressors(self):
-        from ..lib_smpl.wrapper_pytorch import synthetic_regressors
-        return synthetic_regressors(6890, self.seed)
+        if getattr(self, "_regs", None) is None:      # once per fitter (7 ms of host time per loader batch otherwise)
+            from ..lib_smpl.wrapper_pytorch import synthetic_regressors
+            self._regs = synthetic_regressors(6890, self.seed)
+        return self._regs
 
     def mean_hand_pose(self):
         if self._mhp is not None:

@@ -46,6 +46,13 @@ class FusedAdam:
     def state_tensors(self):
         return [self.step_t] + self.m + self.v
 
+    @torch.no_grad()
+    def reset(self):
+        """a fresh optimiser on the same parameters (a recorded step keeps reading THESE state tensors)"""
+        self.step_t.zero_()
+        for t in self.m + self.v:
+            t.zero_()
+
     def step(self, stop):
         """stop: device bool scalar; the step counter is advanced by the stop-rule launch that follows (EagerStep._one)"""
         live = [(p, p.grad, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
@@ -185,6 +192,7 @@ class EagerStep:
         self.carry = [p for p in carry if all(p is not q for q in self.params)]
         self.opt = opt if opt is not None else self._make_opt(lr, betas, capturable)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
+        self.release = release
         self._init_flags(self.params[0].device)
 
     def _make_opt(self, lr, betas, capturable):
@@ -204,6 +212,19 @@ class EagerStep:
         self.stop = torch.zeros((), dtype=torch.bool, device=dev)    # latched: the reference has returned
         self.loss = torch.zeros((), device=dev)
         self.seed = torch.ones((), device=dev)            # d loss / d loss: handed to backward() (it fills a fresh one per call otherwise)
+
+    @torch.no_grad()
+    def reset(self, reset_opt=True):
+        """make a kept stepper (recon_fit_behave._FitSlot) equal to a newly built one: flags cleared, the optimiser's state zeroed
+        unless it continues another stepper's (reset_opt=False).  Only steppers on a FusedAdam are kept."""
+        self.stop.fill_(False)
+        self.armed.fill_(False)
+        self.loss.zero_()
+        self.denom.fill_(1.0)
+        if reset_opt:
+            self.opt.reset()
+        if self.release is not None:
+            self.release()
 
     def zero_grads(self):
         """what optimizer.zero_grad() did in the reference's torch (zero in place; the tensors stay: a recorded graph

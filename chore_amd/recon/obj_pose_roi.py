@@ -238,6 +238,20 @@ class SilLossROI(nn.Module):
         self.register_buffer("adj_off", torch.from_numpy(off).to(dev), persistent=False)
         self.register_buffer("adj", torch.from_numpy(ent).to(dev), persistent=False)
 
+    @torch.no_grad()
+    def load_from(self, other):
+        """take over another instance's per-image data IN PLACE (reference and keep masks, ROI cameras, edge distance
+        transform): a recorded fitting step keeps reading this object's buffers across loader batches
+        (recon_fit_behave._FitSlot); the template (vertices, faces, corner lists) does not change"""
+        for name in ("image_ref", "keep_mask", "K", "edt_ref_edge"):
+            mine, theirs = getattr(self, name), getattr(other, name)
+            if mine.shape != theirs.shape:
+                raise ValueError("SilLossROI.load_from: %s has another shape" % name)
+            mine.copy_(theirs)
+        if self.vertices.shape != other.vertices.shape or not torch.equal(self.vertices, other.vertices):
+            raise ValueError("SilLossROI.load_from: another template")
+        return self
+
     def prepare_dist_trans(self, image_refs, power=0.25):
         """distance transform of the reference edges (obj_pose_roi.py:92-103); debugging output of forward()"""
         from scipy.ndimage import distance_transform_edt

@@ -24,12 +24,44 @@ import torch.nn.functional as F
 
 from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
 from . import fit_terms
-from .graph_step import EagerStep, GraphedStep
+from .graph_step import EagerStep, FusedAdam, GraphedStep
 from .recon_fit_base import RECON_PATH, ReconFitterBase  # noqa: F401  (recon_fit_coco.py:15 imports RECON_PATH from here)
+
+
+class _FitSlot:
+    """What the recorded inner steps of one driver call read and write, kept for the next call of the same shapes
+    (ReconFitterBehave.reuse_graphs): recording a step costs ~6.6 ms of host time and a frame's chain records six of them
+    (40 of its 135 ms, profiles/r04_fit_chain.txt).  A hipGraph bakes in the ADDRESSES of everything a step touches, so the
+    slot owns private, persistent tensors -- the parameters being fitted, their gradients and optimiser state, the flags, and
+    every input the loss terms read -- and a later call copies its values INTO them (`bind`) instead of recording again;
+    the fitted values are copied back out into the caller's tensors at the end."""
+
+    def __init__(self):
+        self.tensors, self.steppers, self.objects = {}, {}, {}
+
+    def bind(self, name, value, leaf=False):
+        t = self.tensors.get(name)
+        if t is None:
+            t = value.detach().clone()
+            if leaf:
+                t.requires_grad_(True)
+            self.tensors[name] = t
+        else:
+            if t.shape != value.shape or t.dtype != value.dtype or t.device != value.device:
+                raise ValueError("fit slot: '%s' changed shape / type between calls" % name)
+            with torch.no_grad():
+                t.copy_(value)
+        return t
+
+    def obj(self, name, factory):
+        if name not in self.objects:
+            self.objects[name] = factory()
+        return self.objects[name]
 
 
 class ReconFitterBehave(ReconFitterBase):
     use_graphs = False    # True: every inner step is a hipGraph replay (graph_step.py); same update rule
+    reuse_graphs = False  # with use_graphs: keep the recorded steps across calls of the same shapes (_FitSlot)
     early_stop = True     # False: never arm the stop rule (benchmarks that time a fixed number of iterations)
     timer = None          # a list: per outer iteration (start event, end event, number of inner steps, phase name) is appended
     adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
@@ -38,6 +70,39 @@ class ReconFitterBehave(ReconFitterBase):
         if self.use_graphs:
             return GraphedStep(*a, **k)
         return EagerStep(*a, capturable=self.adam_capturable, **k)
+
+    def _slot(self, *key):
+        """the kept state of a driver call with these shapes / schedule, or None when steps are not kept"""
+        if not (self.use_graphs and self.reuse_graphs):
+            return None
+        slots = self.__dict__.setdefault("_slots", {})
+        if key not in slots:
+            if len(slots) >= 8:          # shapes keep changing: do not hoard graphs
+                slots.clear()
+            slots[key] = _FitSlot()
+        return slots[key]
+
+    @staticmethod
+    def _maps_key(model):
+        """identity of the field the kept steps were recorded on: the network object AND the addresses of its feature maps (a
+        recorded query reads the maps through the pointers it was recorded with; HGFilter.static_outputs keeps them fixed
+        across filter() calls -- without it every batch gets new maps, hence a new slot, and nothing stale is ever replayed)"""
+        feats = getattr(model, "im_feat_list", None)
+        tm = getattr(model, "tmpx", None)
+        return (id(model), feats[-1].data_ptr() if feats else 0, tm.data_ptr() if torch.is_tensor(tm) else 0)
+
+    def _kept(self, slot, name, factory, reset_opt=True):
+        """the stepper of phase `name`: built by `factory`, or the one kept from an earlier call, reset"""
+        if slot is None:
+            return factory()
+        st = slot.steppers.get(name)
+        if st is not None:
+            st.reset(reset_opt)
+            return st
+        st = factory()
+        if isinstance(st, GraphedStep) and isinstance(st.opt, FusedAdam):
+            slot.steppers[name] = st
+        return st
 
     def _inner(self, st, n, phase=None):
         """the inner steps of one outer iteration"""
@@ -107,6 +172,8 @@ class ReconFitterBehave(ReconFitterBase):
     def fit_batch(self, data, generator, smpl_iters=None, object_iters=None):
         """one batch through the chain of fit_recon (:46-74); the iteration counts are the reference's"""
         batch_size = data["images"].shape[0]
+        if self.use_graphs and self.reuse_graphs and hasattr(generator.model, "image_filter"):
+            generator.model.image_filter.static_outputs = True      # the kept steps read the maps through fixed addresses
         pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True)
         (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
          smpl) = self.prep_smplfit(data, generator, pc_generated)
@@ -177,15 +244,56 @@ class ReconFitterBehave(ReconFitterBase):
 
     def optimize_smpl(self, smpl, data_dict, iter_for_betas=10, iter_for_pose=10, iter_for_kpts=5, steps_per_iter=10,
                       max_iter=150):
+        """the reference's driver (see _optimize_smpl).  With reuse_graphs the fit runs on the slot's private copy of the body and
+        of the inputs (whose addresses the kept hipGraphs read); the fitted parameters are copied into `smpl`, which is
+        returned like the reference returns it."""
+        slot = None
+        if smpl.pose.is_cuda:
+            slot = self._slot("smpl", tuple(smpl.pose.shape), str(smpl.pose.device), self._maps_key(data_dict["net"]), iter_for_betas,
+                              iter_for_pose, iter_for_kpts, steps_per_iter, max_iter)
+        if slot is None:
+            return self._optimize_smpl(smpl, data_dict, None, iter_for_betas, iter_for_pose, iter_for_kpts, steps_per_iter, max_iter)
+        from ..lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
+        B = smpl.pose.shape[0]
+        priv = slot.obj("smpl", lambda: SMPLPyTorchWrapperBatch(
+            smpl.smpl, B, betas=smpl.betas.detach().clone(), pose=smpl.pose.detach().clone(), trans=smpl.trans.detach().clone(),
+            offsets=smpl.offsets.detach().clone(), faces=smpl.faces, gender=smpl.gender, hands=smpl.hands,
+            num_betas=smpl.betas.shape[1], regressors=(smpl.body25_reg, smpl.face_reg, smpl.hand_reg)).to(smpl.pose.device))
+        with torch.no_grad():
+            for name in ("pose", "betas", "trans", "offsets"):
+                getattr(priv, name).copy_(getattr(smpl, name))
+        priv.forget()
+        dd = slot.obj("data", dict)
+        dd["net"] = data_dict["net"]
+        dd["query_dict"] = {"crop_center": slot.bind("crop_center", data_dict["query_dict"]["crop_center"])}
+        for k in ("part_labels", "pose_init", "body_kpts"):
+            dd[k] = slot.bind(k, data_dict[k])
+        _, scale = self._optimize_smpl(priv, dd, slot, iter_for_betas, iter_for_pose, iter_for_kpts, steps_per_iter, max_iter)
+        with torch.no_grad():
+            for name in ("pose", "betas", "trans"):
+                getattr(smpl, name).copy_(getattr(priv, name))
+        smpl.forget()
+        return smpl, scale.clone()
+
+    def _optimize_smpl(self, smpl, data_dict, slot, iter_for_betas=10, iter_for_pose=10, iter_for_kpts=5, steps_per_iter=10,
+                       max_iter=150):
         """[recon_fit_behave.py:224-291] global (betas 0-1 + translation, lr 0.02) -> all pose (new Adam, lr 0.006) ->
         + keypoints (same Adam), until the stop rule fires.  Reference details that change the result and are kept:
         the split parameters alias `smpl`'s storage; at the switch to 'smpl all pose' the OLD optimiser is zeroed, so
         global_pose / body_pose / other_betas enter the new Adam with the gradients summed over the whole 'global' phase
         (:243-259); the stop rule is tested after every inner step."""
-        split = self.split_smpl(smpl)
+        if slot is None:
+            split = self.split_smpl(smpl)
+            prev = torch.tensor(300.0, device=self.device)
+        else:       # the kept steps read THIS split wrapper (views of the private body's storage) and THIS previous-loss cell
+            split = slot.obj("split", lambda: self.split_smpl(smpl))
+            prev = slot.bind("prev", torch.tensor(300.0, device=self.device))
+            for p in split.parameters():      # a new call starts without accumulated gradients (the reference: fresh parameters)
+                if p.grad is not None:
+                    p.grad.zero_()
+            split.forget()
         height_init = self.get_smpl_height(smpl)
         wd = self.get_loss_weights()
-        prev = torch.tensor(300.0, device=self.device)
 
         def loss_of(phase):
             return lambda decay: self.sum_dict(self.forward_smpl(split, data_dict, phase), wd, decay)
@@ -193,18 +301,22 @@ class ReconFitterBehave(ReconFitterBase):
         phase = "global"
         rel = self.release_graphs(split, data_dict["net"])
         carry = [split.global_pose, split.body_pose, split.other_betas, split.hand_pose]
-        st = self._stepper([split.top_betas, split.trans], 0.02, loss_of(phase), 0.001, prev, release=rel, carry=carry)
+        st = self._kept(slot, phase, lambda: self._stepper([split.top_betas, split.trans], 0.02, loss_of("global"), 0.001, prev,
+                                                           release=rel, carry=carry))
         for it in range(iter_for_betas + iter_for_kpts + iter_for_pose + max_iter):
             zero = True
             if it == iter_for_betas:
                 phase = "smpl all pose"
                 st.zero_grads()            # the reference's zero_grad() of this iteration still goes through the old Adam
-                st = self._stepper([split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas],
-                                   0.006, loss_of(phase), 0.001, prev, release=rel, carry=carry)
+                st = self._kept(slot, phase, lambda: self._stepper(
+                    [split.trans, split.global_pose, split.body_pose, split.top_betas, split.other_betas], 0.006,
+                    loss_of("smpl all pose"), 0.001, prev, release=rel, carry=carry))
                 zero = False
             elif it == iter_for_betas + iter_for_pose:
                 phase = "kpts"            # same Adam, the loss gains the keypoint term
-                st = self._stepper(st.params, 0.006, loss_of(phase), 0.001, prev, opt=st.opt, release=rel, carry=carry)
+                prev_st = st
+                st = self._kept(slot, phase, lambda: self._stepper(prev_st.params, 0.006, loss_of("kpts"), 0.001, prev,
+                                                                   opt=prev_st.opt, release=rel, carry=carry), reset_opt=False)
             armed = self.early_stop and it > 0.25 * max_iter + iter_for_betas + iter_for_pose
             st.begin_outer(1 if phase != "kpts" else it / 3, armed=armed, zero=zero)
             self._inner(st, steps_per_iter, phase)
@@ -289,12 +401,12 @@ class ReconFitterBehave(ReconFitterBase):
         parameters) -> joint (new Adam on t, s, lr 0.002) until the stop rule fires; the SMPL parameters are never
         stepped.  `sil_iter` / `max_iter` are the reference's hard-coded 50 / 100.  The silhouette term is built from
         the two masks of data_dict['images'] like the reference does (:94-96) unless the caller put one into
-        data_dict['silhouette']; without masks and template the phase is skipped."""
+        data_dict['silhouette']; without masks and template the phase is skipped.
+        With reuse_graphs the recorded steps of the three phases are kept for the next call of the same shapes: they run on
+        the slot's private object parameters and inputs (_FitSlot); the fitted values are copied into the caller's tensors."""
         smpl = data_dict["smpl"]
         split = self.split_smpl(smpl)
         data_dict["smpl"] = split
-        obj_R, obj_t, obj_s = data_dict["obj_R"], data_dict["obj_t"], data_dict["obj_s"]
-        wd = self.get_loss_weights()
         if "silhouette" not in data_dict and self.scan is not None and "images" in data_dict:
             from .obj_pose_roi import SilLossROI
             images = data_dict["images"]
@@ -317,7 +429,51 @@ class ReconFitterBehave(ReconFitterBase):
             model.query(body, **data_dict["query_dict"])
             data_dict["smpl_const"] = {"verts": body, "df_hum_o": model.get_preds()[0][:, 1, :].detach().clone()}
         split.forget()
+        obj_R, obj_t, obj_s = data_dict["obj_R"], data_dict["obj_t"], data_dict["obj_s"]
+        sil = data_dict.get("silhouette")
+        slot = None
+        if obj_R.is_cuda and (sil is None or hasattr(sil, "load_from")):
+            slot = self._slot("object", tuple(obj_R.shape), tuple(data_dict["objects"].shape), tuple(body.shape), str(obj_R.device),
+                              self._maps_key(model), obj_iter, joint_iter, steps_per_iter, sil_iter, max_iter,
+                              None if sil is None else (type(sil).__name__, tuple(getattr(sil, "image_ref", torch.empty(0)).shape)))
+        if slot is None:
+            self._optimize_object(model, split, data_dict, None, obj_R, obj_t, obj_s, obj_iter, joint_iter, steps_per_iter,
+                                  sil_iter, max_iter)
+        else:
+            # the steps' view of the call: private parameters, persistent copies of everything the loss terms read
+            dd = slot.obj("data", dict)
+            dd["query_dict"] = {"crop_center": slot.bind("crop_center", data_dict["query_dict"]["crop_center"])}
+            dd["objects"] = slot.bind("objects", data_dict["objects"])
+            dd["smpl_center"] = slot.bind("smpl_center", data_dict["smpl_center"])
+            dd["smpl_const"] = {"verts": slot.bind("verts", body), "df_hum_o": slot.bind("df_hum_o", data_dict["smpl_const"]["df_hum_o"])}
+            dd["smpl"] = slot.obj("split", lambda: split)      # (only its faces are read: the body enters through smpl_const)
+            if sil is not None:
+                kept = slot.obj("silhouette", lambda: sil)
+                if kept is not sil:
+                    kept.load_from(sil)
+                dd["silhouette"] = kept
+            pR, pt, ps = slot.bind("obj_R", obj_R, leaf=True), slot.bind("obj_t", obj_t, leaf=True), slot.bind("obj_s", obj_s, leaf=True)
+            for p_ in (pR, pt, ps):
+                if p_.grad is not None:
+                    p_.grad.zero_()
+            self._optimize_object(model, dd["smpl"], dd, slot, pR, pt, ps, obj_iter, joint_iter, steps_per_iter, sil_iter, max_iter)
+            with torch.no_grad():
+                obj_R.copy_(pR)
+                obj_t.copy_(pt)
+                obj_s.copy_(ps)
+            for k in ("rot_init", "trans_init"):       # what the reference leaves in the caller's dict (:127-128)
+                if k in dd:
+                    data_dict[k] = dd[k].detach().clone()
+        data_dict.pop("smpl_const", None)
+        return smpl, data_dict["obj_R"], data_dict["obj_t"]
+
+    def _optimize_object(self, model, split, data_dict, slot, obj_R, obj_t, obj_s, obj_iter, joint_iter, steps_per_iter, sil_iter,
+                         max_iter):
+        """the three phases on the given parameter tensors (the caller's, or a slot's private ones)"""
+        wd = self.get_loss_weights()
         prev = torch.tensor(300.0, device=self.device)
+        if slot is not None:
+            prev = slot.bind("prev", prev)
         n_outer = joint_iter + obj_iter + max_iter + sil_iter
         # The SO(3) perturbation (recon_fit_base.py:384) comes from the CPU generator in the order the reference
         # consumes it -- one (B,3,3) draw per step, and between the last 'object only' step and the first silhouette
@@ -329,6 +485,8 @@ class ReconFitterBehave(ReconFitterBase):
         noise_rot = torch.rand(B, 3, 3) if sil_iter > 0 else None
         noise = torch.cat([noise_obj, torch.rand((n_outer - obj_iter) * steps_per_iter, B, 3, 3)]).to(self.device)
         k = torch.zeros(1, dtype=torch.long, device=self.device)
+        if slot is not None:
+            noise, k = slot.bind("noise", noise), slot.bind("k", k)
 
         def loss_of(phase):
             def f(decay):
@@ -342,19 +500,25 @@ class ReconFitterBehave(ReconFitterBase):
 
         phase = "object only"
         rel = self.release_graphs(split, model)
-        st = self._stepper([obj_t, obj_R, obj_s], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
+        st = self._kept(slot, phase, lambda: self._stepper([obj_t, obj_R, obj_s], 0.006, loss_of("object only"), 0.0001, prev,
+                                                           state=[k], release=rel))
         for it in range(n_outer):
             # zero_grad() of the reference runs at the top of the iteration through the optimiser of the PREVIOUS
             # phase (:118): identical here, every new Adam owns a subset of the previous one's parameters
             st.zero_grads()
             if it == obj_iter and sil_iter > 0:
                 phase = "sil"
-                data_dict["rot_init"] = self.decopose_axis(obj_R, noise=noise_rot).detach().clone()
-                data_dict["trans_init"] = obj_t.detach().clone()
-                st = self._stepper([obj_R, obj_s, obj_t], 0.006, loss_of(phase), 0.0001, prev, state=[k], release=rel)
+                rot_init = self.decopose_axis(obj_R, noise=noise_rot).detach().clone()
+                trans_init = obj_t.detach().clone()
+                # (a kept step reads these two through fixed addresses: written in place from the second call on)
+                data_dict["rot_init"] = rot_init if slot is None else slot.bind("rot_init", rot_init)
+                data_dict["trans_init"] = trans_init if slot is None else slot.bind("trans_init", trans_init)
+                st = self._kept(slot, phase, lambda: self._stepper([obj_R, obj_s, obj_t], 0.006, loss_of("sil"), 0.0001, prev,
+                                                                   state=[k], release=rel))
             if it == obj_iter + sil_iter:
                 phase = "joint"
-                st = self._stepper([obj_t, obj_s], 0.002, loss_of(phase), 0.0001, prev, state=[k], release=rel, carry=[obj_R])
+                st = self._kept(slot, phase, lambda: self._stepper([obj_t, obj_s], 0.002, loss_of("joint"), 0.0001, prev, state=[k],
+                                                                   release=rel, carry=[obj_R]))
             decay = 1 if phase == "object only" else it
             if phase == "sil":
                 decay = it - obj_iter + 1
@@ -366,8 +530,6 @@ class ReconFitterBehave(ReconFitterBase):
             if armed and st.stopped():
                 break
         rel()
-        data_dict.pop("smpl_const", None)
-        return smpl, data_dict["obj_R"], data_dict["obj_t"]
 
 
 def recon_fit(args):

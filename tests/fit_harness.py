@@ -65,6 +65,13 @@ class SilStub(torch.nn.Module):
         self.register_buffer("P", torch.tensor((rs.standard_normal((B, 40, 3)) * 0.3).astype(np.float32)))
         self.register_buffer("T", torch.tensor((rs.standard_normal((B, 40, 3)) * 0.3 + [0.25, 0.35, 2.25]).astype(np.float32)))
 
+    @torch.no_grad()
+    def load_from(self, other):
+        """(the in-place update recon_fit_behave._FitSlot asks of a silhouette term it keeps across calls)"""
+        self.P.copy_(other.P)
+        self.T.copy_(other.T)
+        return self
+
     def forward(self, R, t, s):
         x = (torch.bmm(self.P, R) + t.unsqueeze(1)) * s.view(-1, 1, 1)
         return {"mask": 2e5 * ((x - self.T) ** 2).mean()}, None, None, None, None

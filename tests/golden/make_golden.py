@@ -662,6 +662,64 @@ def gen_fit_schedule(net):
     np.savez_compressed(os.path.join(HERE, "fit_schedule.npz"), keys_a=np.array(keys_a), keys_b=np.array(keys_b), **out)
 
 
+def gen_fit_anchor(net):
+    """THE REFERENCE's optimize_smpl and optimize_smpl_object (recon/recon_fit_behave.py:224-291, 90-163) on the REAL
+    random-weight network (not the closed-form field of gen_fit_schedule): the same inputs, phase lengths, seeds and stand-ins
+    for the two CUDA-only pieces (SilStub, no collision) as fit_schedule.npz, recorded per step (every loss term) and at the
+    end (fitted parameters).  Two fp32 implementations of the piecewise-linear heads fall on different sides of a few ReLU kinks
+    per step, so the trajectories drift apart slowly (see gen_fit_schedule); this fixture bounds HOW FAR the HIP chain's
+    36 + 161 steps end from the reference's on the product's own field (tests/test_gpu_fit_chain.py states the measured
+    bound)."""
+    from fit_harness import SilStub
+    B = 2
+    fitter, smpl, c, rfb, rfbh = _ref_fit_setup(net, B)
+    labels = torch.from_numpy(c["labels"])
+    cc = torch.from_numpy(c["crop_center"])
+    data = dict(net=net, query_dict={"crop_center": cc}, part_labels=labels.unsqueeze(0).repeat(B, 1),
+                pose_init=torch.from_numpy(c["pose"][:, 3:72].copy()), body_kpts=torch.from_numpy(c["kpts"]))
+    log = []
+
+    def spy(name):
+        orig = getattr(fitter, name)
+
+        def f(*a, **k):
+            ld = orig(*a, **k)
+            log.append({k_: float(v) for k_, v in ld.items()})
+            return ld
+        setattr(fitter, name, f)
+    spy("forward_smpl")
+    out = {}
+    for k in ("pose", "betas", "trans"):
+        out["smpl0_" + k] = getattr(smpl, k).detach().numpy().copy()
+    torch.manual_seed(11)
+    smpl, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5,
+                                       max_iter=8)
+    keys_a = ["df_h", "pose", "hand", "part", "smplz", "pinit", "j2d"]
+    out["smpl_losses"] = np.array([[ld.get(k, np.nan) for k in keys_a] for ld in log], np.float64)
+    out["smpl_scale"] = scale.detach().numpy()
+    for k in ("pose", "betas", "trans"):
+        out["smpl_" + k] = getattr(smpl, k).detach().numpy().copy()
+    with torch.no_grad():
+        out["smpl_verts"] = smpl()[0].numpy().copy()
+    print("optimize_smpl (real network): steps", len(log))
+    log.clear()
+    spy("forward_step")
+    fitter.compute_collision_loss = lambda *a, **k: torch.zeros(())
+    rfbh.SilLossROI = lambda *a, **k: SilStub(B)
+    data2 = dict(obj_R=torch.from_numpy(c["obj_R"].copy()).requires_grad_(True),
+                 obj_t=torch.from_numpy(c["obj_t"].copy()).requires_grad_(True),
+                 obj_s=torch.from_numpy(c["obj_s"].copy()).requires_grad_(True), objects=torch.from_numpy(c["obj"]),
+                 smpl=smpl, images=torch.from_numpy(c["images"]), query_dict={"crop_center": cc})
+    torch.manual_seed(12)
+    _, obj_R, obj_t = fitter.optimize_smpl_object(net, data2, obj_iter=3, joint_iter=2, steps_per_iter=3)
+    keys_b = ["object", "scale", "ocent", "mask", "trans", "contact", "collide"]
+    out["obj_losses"] = np.array([[ld.get(k, np.nan) for k in keys_b] for ld in log], np.float64)
+    out["obj_R"], out["obj_t"], out["obj_s"] = obj_R.detach().numpy(), obj_t.detach().numpy(), data2["obj_s"].detach().numpy()
+    out["smpl_center"] = data2["smpl_center"].numpy()
+    print("optimize_smpl_object (real network): steps", len(log))
+    np.savez_compressed(os.path.join(HERE, "fit_anchor.npz"), keys_a=np.array(keys_a), keys_b=np.array(keys_b), **out)
+
+
 def gen_fit_init(net):
     """THE REFERENCE's glue between the stages of fit_recon (recon/recon_fit_behave.py:29-76):
     prep_smplfit (recon_fit_base.py:398-440: SMPL-H initialisation from the mocap json with the mean hand pose,

@@ -85,9 +85,10 @@ def test_generator_device_loop_matches_reference():
 
 
 # ---- fitting schedules ------------------------------------------------------------------------------------------------
-def _fit_objects(opt, use_graphs=False, analytic=False):
+def _fit_objects(opt, use_graphs=False, analytic=False, net=None, shift=0.0):
     """analytic: the closed-form field instead of the network (what fit_schedule.npz was recorded with, see
-    make_golden.gen_fit_schedule for why)"""
+    make_golden.gen_fit_schedule for why); net: use this field object instead of building one; shift: another problem (the
+    body's and the object's initial translation moved by it)"""
     import copy
     from chore_amd.lib_smpl.priors import synthetic_priors
     from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
@@ -99,7 +100,12 @@ def _fit_objects(opt, use_graphs=False, analytic=False):
     o.compute_dtype = "fp32"
     B = 2
     c = fit_case(B)
-    if analytic:
+    if shift:
+        c["trans"] = c["trans"] + np.float32(shift)
+        c["obj_t"] = c["obj_t"] + np.float32(shift)
+    if net is not None:
+        pass
+    elif analytic:
         net = AnalyticField().cuda()
     else:
         net = CHORE(o).cuda().eval()
@@ -213,6 +219,49 @@ def test_graph_replay_follows_the_same_schedule(opt):
     for name, a, b in zip(("pose", "betas", "trans", "scale", "t", "s", "R"), *out):
         assert np.isfinite(b).all(), name
         assert np.abs(a - b).max() < 2e-4, (name, np.abs(a - b).max())
+
+
+def test_kept_graphs_reproduce_fresh_recordings(opt):
+    """reuse_graphs (recon_fit_behave._FitSlot): the recorded steps of a call are kept and REPLAYED by later calls of the same
+    shapes, on private persistent tensors the new inputs are copied into.  On the real network: call 1 (records) equals a
+    fitter that records afresh, bit for bit; call 2 on new tensors with the same values replays and equals call 1; call 3 on
+    ANOTHER problem (translations moved) replays and equals a fresh fitter on that problem -- parameters, the caller's
+    objects (`smpl2 is smpl`, obj_R / obj_t / obj_s written in place), rot_init."""
+    def run(fitter, net, smpl, data, data2):
+        fitter.adam_capturable = True
+        torch.manual_seed(11)
+        smpl2, scale = fitter.optimize_smpl(smpl, data, iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5, max_iter=8)
+        assert smpl2 is smpl
+        data2["smpl"] = smpl2
+        torch.manual_seed(12)
+        _, obj_R, obj_t = fitter.optimize_smpl_object(net, data2, obj_iter=3, joint_iter=2, steps_per_iter=3, sil_iter=6)
+        assert obj_R is data2["obj_R"] and obj_t is data2["obj_t"]
+        return [x.detach().clone() for x in (smpl2.pose, smpl2.betas, smpl2.trans, scale, obj_t, data2["obj_s"], obj_R,
+                                             data2["rot_init"], data2["smpl_center"])]
+
+    fresh = {}
+    for shift in (0.0, 0.05):
+        fitter, net, smpl, data, data2 = _fit_objects(opt, True, shift=shift)
+        fresh[shift] = run(fitter, net, smpl, data, data2)
+    keeper, net, smpl, data, data2 = _fit_objects(opt, True)
+    keeper.reuse_graphs = True
+    got = [run(keeper, net, smpl, data, data2)]
+    n_slots = len(keeper._slots)
+    kept = {k: dict(v.steppers) for k, v in keeper._slots.items()}
+    assert n_slots == 2 and all(len(v) == 3 for v in kept.values())       # one slot per driver, three recorded phases each
+    for shift in (0.0, 0.05):
+        _, _, smpl, data, data2 = _fit_objects(opt, True, net=net, shift=shift)
+        data["net"] = net
+        got.append(run(keeper, net, smpl, data, data2))
+    assert len(keeper._slots) == n_slots                                   # nothing was recorded again
+    for k, v in keeper._slots.items():
+        assert all(v.steppers[ph] is kept[k][ph] for ph in kept[k])
+    names = ("pose", "betas", "trans", "scale", "obj_t", "obj_s", "obj_R", "rot_init", "smpl_center")
+    for name, a, b, c_, d, e in zip(names, fresh[0.0], got[0], got[1], fresh[0.05], got[2]):
+        assert torch.equal(a, b), ("first call vs fresh recording", name, float((a - b).abs().max()))
+        assert torch.equal(b, c_), ("replay of the same problem", name, float((b - c_).abs().max()))
+        assert torch.equal(d, e), ("replay on another problem vs fresh recording", name, float((d - e).abs().max()))
+        assert not torch.equal(a, d) or name in ("betas",), name           # the two problems do differ
 
 
 # ---- glue of fit_recon ------------------------------------------------------------------------------------------------
