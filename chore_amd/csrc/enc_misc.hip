@@ -539,17 +539,25 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
     constexpr int NC = 12;
     const int oy0 = max(0, 2 * ly - 5), ox0 = max(0, 2 * lx - 5);
     float wy[NC], wx[NC];
-    if (tpr >= 2 * NC) {
-        // the tpr threads of a pixel need the same 24 weights (each a cubic in a floor-ed coordinate): one lane each,
-        // then broadcasts, instead of 24 evaluations per thread
-        const int lane = threadIdx.x & 63, base = lane - (lane % tpr), j = lane % tpr;
+    if (tpr == 64 || tpr == 32) {
+        // the tpr threads of a pixel need the same 24 weights (each a cubic in a floor-ed coordinate): one lane each, then
+        // handed to the others -- through SCALAR registers (v_readlane), not through the LDS crossbar (__shfl = ds_bpermute).
+        // Round 4: with the ds_bpermute broadcast this kernel gave run-to-run different results in 1 - 3 waves of a call when a
+        // SECOND process kept the same GPU busy (32 of 108 training passes; never alone, never in isolation, the same kernel
+        // without the broadcast 0 of 108: scripts/train_determinism3.py, profiles/r04_determinism.txt).  The cause below the
+        // instruction is not known; v_readlane with a constant lane is plain VALU.
+        const int lane = threadIdx.x & 63, j = lane % tpr;
         float mine = 0.f;
         if (j < NC) mine = (oy0 + j < 2 * H) ? up2_weight(oy0 + j, ly, H) : 0.f;
         else if (j < 2 * NC) mine = (ox0 + j - NC < 2 * W) ? up2_weight(ox0 + j - NC, lx, W) : 0.f;
+        const int bits = __float_as_int(mine);
+        const bool upper = tpr == 32 && lane >= 32;      // two pixels per wave: the second one's weights sit in lanes 32 .. 55
 #pragma unroll
         for (int k = 0; k < NC; ++k) {
-            wy[k] = __shfl(mine, base + k, 64);
-            wx[k] = __shfl(mine, base + NC + k, 64);
+            const int y0 = __builtin_amdgcn_readlane(bits, k), x0 = __builtin_amdgcn_readlane(bits, NC + k);
+            const int y1 = __builtin_amdgcn_readlane(bits, 32 + k), x1 = __builtin_amdgcn_readlane(bits, 32 + NC + k);
+            wy[k] = __int_as_float(upper ? y1 : y0);
+            wx[k] = __int_as_float(upper ? x1 : x0);
         }
     } else {
 #pragma unroll
