@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
                                                       size_t total4) {
     const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i0 < total4;
-    const size_t i = live ? i0 : total4 - 1;      // every lane takes part in the weight broadcast below
+    const size_t i = live ? i0 : total4 - 1;
     const int tpr = C / 4;
     const int cv = (int)(i % tpr);
     size_t p = i / tpr;
@@ -539,32 +539,15 @@ __global__ __launch_bounds__(256) void up2_bwd_kernel(const T* __restrict__ dy, 
     constexpr int NC = 12;
     const int oy0 = max(0, 2 * ly - 5), ox0 = max(0, 2 * lx - 5);
     float wy[NC], wx[NC];
-    if (tpr == 64 || tpr == 32) {
-        // the tpr threads of a pixel need the same 24 weights (each a cubic in a floor-ed coordinate): one lane each, then
-        // handed to the others -- through SCALAR registers (v_readlane), not through the LDS crossbar (__shfl = ds_bpermute).
-        // Round 4: with the ds_bpermute broadcast this kernel gave run-to-run different results in 1 - 3 waves of a call when a
-        // SECOND process kept the same GPU busy (32 of 108 training passes; never alone, never in isolation, the same kernel
-        // without the broadcast 0 of 108: scripts/train_determinism3.py, profiles/r04_determinism.txt).  The cause below the
-        // instruction is not known; v_readlane with a constant lane is plain VALU.
-        const int lane = threadIdx.x & 63, j = lane % tpr;
-        float mine = 0.f;
-        if (j < NC) mine = (oy0 + j < 2 * H) ? up2_weight(oy0 + j, ly, H) : 0.f;
-        else if (j < 2 * NC) mine = (ox0 + j - NC < 2 * W) ? up2_weight(ox0 + j - NC, lx, W) : 0.f;
-        const int bits = __float_as_int(mine);
-        const bool upper = tpr == 32 && lane >= 32;      // two pixels per wave: the second one's weights sit in lanes 32 .. 55
+    // Every thread evaluates its pixel's 24 weights itself.  Until round 4 one lane of the pixel's tpr threads evaluated each
+    // weight and the others fetched it with a cross-lane read (`__shfl` = ds_bpermute): with a SECOND process keeping the same GPU
+    // busy that version produced different results in 1 - 3 waves of a call in 32 of 108 training passes (never alone on the
+    // GPU, never when called in isolation; v_readlane instead of ds_bpermute: 8 of 72; this version: 0 of 108 --
+    // scripts/train_determinism3.py, profiles/r04_determinism.txt).  What goes wrong below the instruction level is not known.
 #pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            const int y0 = __builtin_amdgcn_readlane(bits, k), x0 = __builtin_amdgcn_readlane(bits, NC + k);
-            const int y1 = __builtin_amdgcn_readlane(bits, 32 + k), x1 = __builtin_amdgcn_readlane(bits, 32 + NC + k);
-            wy[k] = __int_as_float(upper ? y1 : y0);
-            wx[k] = __int_as_float(upper ? x1 : x0);
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            wy[k] = (oy0 + k < 2 * H) ? up2_weight(oy0 + k, ly, H) : 0.f;
-            wx[k] = (ox0 + k < 2 * W) ? up2_weight(ox0 + k, lx, W) : 0.f;
-        }
+    for (int k = 0; k < NC; ++k) {
+        wy[k] = (oy0 + k < 2 * H) ? up2_weight(oy0 + k, ly, H) : 0.f;
+        wx[k] = (ox0 + k < 2 * W) ? up2_weight(ox0 + k, lx, W) : 0.f;
     }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
