@@ -527,8 +527,7 @@ template <typename T, bool TRAIN, bool X3 = false>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     if constexpr (!TRAIN) {
         static const bool x3_small = getenv("CHORE_QUERY_X3_BWD_SMALL") != nullptr;
-        static const bool x3_w8_forced = getenv("CHORE_QUERY_X3_BWD_W8") != nullptr;
-        if (!(X3 && x3_w8_forced) && (query_small_tiles(a.B, a.N) || (X3 && (x3_small || x3_bwd_prefers_small(a.B, a.N)))))
+        if (query_small_tiles(a.B, a.N) || (X3 && (x3_small || x3_bwd_prefers_small(a.B, a.N))))
             return launch_query_bwd_n<T, false, 1, X3>(h, a, s);
     }
     // the training variants are bound by their staging stores: measured slower with eight waves (39.4 vs 38.6 ms per step)
@@ -537,13 +536,8 @@ static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s
     if constexpr (!TRAIN && !X3) {
         if (!query_w4()) return launch_query_bwd_w8<T, false, false, X3>(h, a, s);
     }
-    // CHORE_QUERY_X3_BWD_W8=1: the eight-wave fp16 x 3 recompute kernel.  Never the default (slower, see above); kept
-    // instantiated behind this switch because in round 2 it produced a non-finite gradient once in ~6 runs of the 8-frame
-    // graph-replay fit test and the stress test (tests/test_gpu_fit_stress.py) runs BOTH variants.
-    if constexpr (!TRAIN && X3) {
-        static const bool x3_w8 = getenv("CHORE_QUERY_X3_BWD_W8") != nullptr;
-        if (x3_w8) return launch_query_bwd_w8<T, false, false, true>(h, a, s);
-    }
+    // (an eight-wave fp16 x 3 RECOMPUTE kernel existed behind a switch through round 3: slower, and in round 2 it produced a
+    // non-finite gradient about once in six runs of the graph-replayed fit that was never reproduced afterwards; removed in round 4)
     return launch_query_bwd_n<T, TRAIN, 2, X3>(h, a, s);
 }
 

@@ -6,11 +6,13 @@ ConvBlock backward on its two streams (the default).
 
 Checked: anomaly mode (it inspects the output of every backward node, ours included) raises nothing; the loss is finite;
 and what DDP's bucketed reducer leaves in `.grad` of ALL 475 trained tensors is the mean of the two ranks' own gradients,
-each recomputed in this process without DDP on that rank's batch.  Bound: 1e-2 of the tensor's largest entry.  When
-nothing else holds a context on the GPU the two agree EXACTLY (deviation 0.0: the kernels' reductions are order-fixed); with
-three processes on one GPU -- the two ranks plus a parent that already used it, as in a full test run -- single passes of
-the bf16 training step differ by up to 2e-3 between runs (seen with and without DDP, in round 2's code as well; not
-reproduced by one process next to busy neighbours).  The 82 bn4 affines of blocks without a downsample
+each recomputed in this process without DDP on that rank's batch.  Bound: 1e-2 of the tensor's largest entry.  A process
+that has the GPU to itself reproduces its gradients bit for bit (tests/test_gpu_ddp_nccl.py asserts exactly that, through
+RCCL); THIS test runs two ranks on ONE GPU, and under that sharing single passes of the bf16 backward differ by up to 2e-3:
+round 4 bisected it (profiles/r04_determinism.txt) to two kernels that, with identical inputs, transiently wrote the work of 1-3
+waves wrong -- the bicubic-upsample backward (cross-lane weight broadcast; fixed: every thread evaluates its own weights) and
+the query's map-gradient scatter (about 1 call in 700 per process, cause not found) -- so the bound stays where it was.
+The 82 bn4 affines of blocks without a downsample
 branch never receive a gradient, like in the reference."""
 import os
 import sys
