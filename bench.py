@@ -641,7 +641,8 @@ def mode_train(args, ctx):
     from chore_amd.parallel import FlatGradReducer
     have_group = ctx.world > 1 or ctx.group1 is not None
     reducer_kind = args.reducer if have_group else "none"
-    optim = torch.optim.Adam(net.parameters(), lr=1e-4, **({} if os.environ.get("CHORE_ADAM_DEFAULT") else {"fused": True}))
+    # capturable: the step counter lives on the device, so optimizer.step() can be recorded into the step's hipGraph
+    optim = torch.optim.Adam(net.parameters(), lr=1e-4, **({} if os.environ.get("CHORE_ADAM_DEFAULT") else {"fused": True, "capturable": True}))
     B, N = args.batch, args.points
     rs = np.random.RandomState(50 + rank)
     t = lambda a: torch.from_numpy(a).to(dev)   # noqa: E731
@@ -676,18 +677,36 @@ def mode_train(args, ctx):
         m = torch.nn.parallel.DistributedDataParallel(net, device_ids=[local], find_unused_parameters=True)
         return m, make_step(m, None)
 
+    # The step is issued as hipGraph replays (chore_amd.parallel.GraphedTrainStep: forward + backward + gradient gather recorded
+    # once, the RCCL all-reduce between two replays, the optimiser recorded too): ~1 600 short dependent launches per step leave
+    # the device idle a quarter of the time when Python issues them.  --eager-step times the eager sequence as the primary number
+    # instead; `eager_ms_per_step` reports it either way.  (Stock DDP cannot be recorded: its reducer lives in the autograd hooks.)
+    from chore_amd.parallel import GraphedTrainStep
+    graphed = (not args.eager_step) and reducer_kind != "ddp"
+
+    def make_graphed(reducer):
+        g = GraphedTrainStep(net, optim, reducer=reducer, warmup=2)
+
+        def step():
+            last["err"], _ = g(**batch)
+        return step
+
+    eager_primary = None
     if reducer_kind == "ddp":
         ddp_model, primary = step_ddp_factory()
     elif reducer_kind == "arena":
-        primary = step_arena
+        primary, eager_primary = (make_graphed(arena), step_arena) if graphed else (step_arena, None)
     else:
-        primary = step_plain
+        primary, eager_primary = (make_graphed(None), step_plain) if graphed else (step_plain, None)
+    if graphed:
+        args.warmup = max(args.warmup, 4)      # two eager calls, the recording, one replay: all before the timed region
     elapsed = ctx.timed(primary, args.steps, args.warmup)
+    eager_elapsed = ctx.timed(eager_primary, args.steps, 2) if eager_primary is not None else None
     nosync = other = None
     if have_group and reducer_kind == "arena":
         # the same steps without any gradient reduction, and with the reference's wrap: what the collective costs either way
         # (the DDP wrap last: its hooks stay on the parameters)
-        nosync = ctx.timed(step_plain, args.steps, 2)
+        nosync = ctx.timed(make_graphed(None) if graphed else step_plain, args.steps, 4 if graphed else 2)
         ddp_model, sd = step_ddp_factory()
         other = ("torch DistributedDataParallel(find_unused_parameters=True)", ctx.timed(sd, args.steps, 3))
     elif have_group:
@@ -702,7 +721,10 @@ def mode_train(args, ctx):
         out = base_line(args, ctx, "training steps/s (CHORE.forward + backward + Adam, B=4 x 512x512 images, 20k points/image per GPU)",
                         args.steps / elapsed, "steps/s", elapsed, True, args.dtype,
                         {"workload": "BASELINE configs[3]: DDP training, batch %d/GPU, %d points/image, 5 stacks" % (B, N),
-                         "images_per_gpu": B, "points_per_image": N, "optimizer": "torch.optim.Adam(lr=1e-4, fused=True)",
+                         "images_per_gpu": B, "points_per_image": N, "optimizer": "torch.optim.Adam(lr=1e-4, fused=True, capturable=True)",
+                         "step_issue": ("hipGraph replays (chore_amd.parallel.GraphedTrainStep: zero_grad + forward + backward + gradient "
+                                        "gather in one recording, optimizer.step() in another, the all-reduce between them)"
+                                        if graphed else "eager (Python issues every launch)"),
                          "grad_allreduce": ({"arena": "chore_amd.parallel.FlatGradReducer: flat fp32 gradient arena (%.1f MB), all-reduced "
                                                       "over RCCL (backend nccl) in %d chunks after the backward, mean over ranks"
                                                       % (arena.bytes / 1e6, len(arena.chunks)) if arena is not None else "",
@@ -719,6 +741,8 @@ def mode_train(args, ctx):
                                                   "steps_per_s": args.steps / other[1]} if other else None,
                                 "world_size": ctx.world,
                                 "how": "K steps without any gradient reduction against K steps with it, same model and batch"}
+        if eager_elapsed is not None:
+            out["eager_ms_per_step"] = eager_elapsed / args.steps * 1e3
         out.update({"images_per_s": ctx.world * B * args.steps / elapsed, "final_loss": float(last["err"].detach()),
                     "parameters": sum(p.numel() for p in net.parameters()),
                     "roofline": {"kernel": "whole training step (all kernels)", "bound": "mfma", "achieved": flops / ms / 1e9,
@@ -767,7 +791,7 @@ def main():
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="fit mode: frames fitted as one batch per GPU (default 1, or 8 when N > 1)")
     ap.add_argument("--eager", action="store_true", help="fit mode: issue the inner iterations from Python instead of replaying hipGraphs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager-step", action="store_true", help="query mode: time eager steps instead of hipGraph replays of the step")
+    ap.add_argument("--eager-step", action="store_true", help="query / train mode: time eager steps instead of hipGraph replays of the step")
     ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without a process group / gradient reduction (A/B)")
     ap.add_argument("--reducer", default="arena", choices=["arena", "ddp"],
                     help="training: gradient reduction of the primary number (arena = FlatGradReducer, ddp = torch's DistributedDataParallel)")

@@ -339,12 +339,19 @@ class CHORE(nn.Module):
         return arena
 
     def invalidate_packed(self):
-        self._head_param_list = None
         """drop the packed copies of the head and encoder weights.  The caches are keyed on (address, version) of every
-        parameter, which sees optimiser steps, load_state_dict and .to(); a write through `p.data` is invisible to the
-        version counters -- call this after one."""
+        parameter, which sees in-place tensor operations, load_state_dict and .to(); a write through `p.data`, the fused
+        optimiser kernels (torch.optim.Adam(fused=True) does not advance the version counters) and a replayed hipGraph are
+        invisible to it -- call this after one.  train() / eval() do it when the mode changes, and a query with trainable heads
+        never uses the cache."""
+        self._head_param_list = None
         self._heads_packed = None
         self.image_filter.invalidate_packed()
+
+    def train(self, mode=True):
+        if bool(mode) != self.training:
+            self.invalidate_packed()          # e.g. validation after training steps whose optimiser the version counters missed
+        return super().train(mode)
 
     def _apply(self, fn, *a, **k):
         out = super()._apply(fn, *a, **k)
@@ -392,11 +399,16 @@ class CHORE(nn.Module):
         cc = crop_center.to(device=points.device, dtype=torch.float32).contiguous()
         if pts.dim() != 3 or pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
             raise ValueError("points must be (B,N,3) and crop_center (B,2)")
-        arena = self._heads_arena(points.device)
         dtype = _QDT[self.compute_dtype]
         head_params = self._head_params()
-        train = torch.is_grad_enabled() and (any(p.requires_grad for p in head_params) or self.tmpx.requires_grad or
+        heads_trainable = any(p.requires_grad for p in head_params)
+        train = torch.is_grad_enabled() and (heads_trainable or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))
+        if train and heads_trainable:
+            # heads that are being trained are packed afresh for every query: the cache key (address, version counter) does not
+            # see every optimiser -- torch's fused Adam / AdamW / SGD kernels update the parameters without advancing `_version`
+            self._heads_packed = None
+        arena = self._heads_arena(points.device)
         if train and self.compute_dtype == "fp16":
             # the training kernels read fp32 / bf16 maps; half maps would be read as fp32 (wrong values, reads past the buffer)
             raise NotImplementedError("compute_dtype 'fp16' is an inference mode: query() with trainable heads or maps that "

@@ -73,8 +73,9 @@ class FlatGradReducer:
                 p.grad = None
 
     @torch.no_grad()
-    def reduce(self):
-        """after backward(): gather, all-reduce, average; leaves every p.grad a view into the arena"""
+    def gather(self):
+        """after backward(): the step's gradient tensors -> the arena; leaves every p.grad a view into it.  No collective --
+        this half can live inside a captured hipGraph (chore_amd.parallel.GraphedTrainStep)"""
         if self.mode == "copy":
             have = [(v, p.grad) for p, v in zip(self.params, self.views) if p.grad is not None]
             missing = [v for p, v in zip(self.params, self.views) if p.grad is None]
@@ -85,9 +86,18 @@ class FlatGradReducer:
             if missing:
                 torch._foreach_zero_(missing)
             self._attach()
+
+    @torch.no_grad()
+    def all_reduce(self):
+        """the collective half: the arena summed over the ranks in `chunks` pieces, then scaled to the mean"""
         if self.world > 1 or dist.is_initialized():
             works = [dist.all_reduce(c, group=self.group, async_op=True) for c in self.chunks]
             for w in works:
                 w.wait()
             if self.average and self.world > 1:
                 self.arena.mul_(1.0 / self.world)
+
+    def reduce(self):
+        """after backward(): gather, all-reduce, average; leaves every p.grad a view into the arena"""
+        self.gather()
+        self.all_reduce()
