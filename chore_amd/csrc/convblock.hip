@@ -253,24 +253,26 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
         return CHORE_OK;
     };
     const int off2 = C1, off3 = C1 + C2;
+    // Launch order inside a stage: the data-gradient kernels (caller's stream) BEFORE the weight-gradient kernels (side stream)
+    // that the same event releases.  Eagerly it makes no difference; recorded into a hipGraph it does: the runtime lays the
+    // graph out on queues by following every node's FIRST-recorded successor, so with the side kernel recorded first the
+    // data-gradient chain changed queue at each of the three releases, ~10 us per change (profiles/r04_train_graph.txt).
     if ((rc = release(0))) return rc;        // dy, the workspace clear
     // ---- conv3: its output gradient is the last slice of dy ----
+    if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da))) return rc;
+    if ((rc = gn_relu_bwd_impl(h, dtype, sv.o2, sv.s2, gb[4], gb[5], da, B, HW, C2, do2, dg3, db3, acc3, 1,
+                               dyb + (size_t)off2 * d.es, Cout, s))) return rc;          // + the concat's gradient of o2
     if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o2, B, H, W, C2, sv.s2, gb[4], gb[5], dyb + (size_t)off3 * d.es, Cout, C2, dw3,
                                      nullptr, wpart3, s2, &fin))) return rc;
     if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpartd, s2, &fin)))
         return rc;
-    if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da))) return rc;
-    if ((rc = gn_relu_bwd_impl(h, dtype, sv.o2, sv.s2, gb[4], gb[5], da, B, HW, C2, do2, dg3, db3, acc3, 1,
-                               dyb + (size_t)off2 * d.es, Cout, s))) return rc;          // + the concat's gradient of o2
     // ---- conv2 ----
     if ((rc = release(1))) return rc;        // d(o2)
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart2, s2, &fin))) return rc;
     if ((rc = dgrad(9, mkview(do2, C2, 0, C2), w2, pk.w2, C1, C2, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o1, sv.s1, gb[2], gb[3], da, B, HW, C1, do1, dg2, db2, acc2, 1, dyb, Cout, s))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart2, s2, &fin))) return rc;
     // ---- conv1 (and the downsample branch): both normalise x ----
     if ((rc = release(2))) return rc;        // d(o1)
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart1, s2, &fin))) return rc;
-    if ((rc = launch_wgrad_finish_multi(h, fin, s2))) return rc;
     const void* skip = dy;          // identity residual: dy itself flows to x
     int skip_cs = Cout;
     if (d.down) {
@@ -280,6 +282,8 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     }
     if ((rc = dgrad(9, mkview(do1, C1, 0, C1), w1, pk.w1, Cin, C1, da))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, x, sx, gb[0], gb[1], da, B, HW, Cin, dx, dg1, db1, acc1, 1, skip, skip_cs, s))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart1, s2, &fin))) return rc;
+    if ((rc = launch_wgrad_finish_multi(h, fin, s2))) return rc;
     if (!serial) {                    // join: the caller's stream continues after the weight gradients too
         CHORE_HIP_CHECK(h, hipEventRecord(h->side_ev[3], s2));
         CHORE_HIP_CHECK(h, hipStreamWaitEvent(s, h->side_ev[3], 0));

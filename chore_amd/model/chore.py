@@ -533,6 +533,9 @@ class CHORE(nn.Module):
 
     def forward(self, images, points, df_h, df_o, parts_gt, pca_gt, body_center=None, max_dist=5.0,
                 obj_center=None, crop_center=None, **kwargs):
+        if self._interleaved_ok(images, points, df_h, crop_center):
+            return self._forward_interleaved(images, points, df_h, df_o, parts_gt, pca_gt, body_center, max_dist, obj_center,
+                                             crop_center)
         self.filter(images)
         self._share_head_grads = True          # the loss below reaches every stack (see query)
         try:
@@ -540,6 +543,76 @@ class CHORE(nn.Module):
         finally:
             self._share_head_grads = False
         return self.get_errors(df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs)
+
+    # ---- training forward with the field queries beside the encoder ---------------------------------------------------------
+    def _interleaved_ok(self, images, points, df_h, crop_center):
+        return (self.training and torch.is_grad_enabled() and images.is_cuda and points.is_cuda and df_h.is_cuda
+                and crop_center is not None and self.compute_dtype in ("fp32", "bf16") and points.dim() == 3
+                and points.shape[1] > 0 and not os.environ.get("CHORE_TRAIN_NO_INTERLEAVE")
+                and not os.environ.get("CHORE_TORCH_LOSS")
+                and any(p.requires_grad for p in self.image_filter.parameters()))
+
+    def _forward_interleaved(self, images, points, df_h, df_o, parts_gt, pca_gt, body_center, max_dist, obj_center, crop_center):
+        """CHORE.forward of a training step (model/chore.py:175-190 of the reference: filter -> query -> get_errors) with the
+        per-stack work reordered: stack i's field query and loss are launched on a second stream the moment the encoder has
+        produced that stack's feature map, so they run beside stacks i+1 .. of the encoder -- and, because autograd replays
+        nodes on the stream of their forward, the query backward of stacks 1 .. i runs beside the encoder backward of the later
+        stacks.  The query kernels are bound by their staging traffic (2.4 GB per stack), the encoder chain by launch latency:
+        they share the chip well.  Same nodes, same arithmetic, same results as the sequential form (CHORE_TRAIN_NO_INTERLEAVE=1)."""
+        from .hgfilter_train import forward_train
+        dev = images.device
+        main = torch.cuda.current_stream(dev)
+        side = self._query_stream(dev)
+        self.points, self.crop_center = points, crop_center
+        pts = points if (points.dtype == torch.float32 and points.is_contiguous()) else points.float().contiguous()
+        cc = crop_center.to(device=dev, dtype=torch.float32).contiguous()
+        if pts.shape[2] != 3 or cc.shape != (pts.shape[0], 2):
+            raise ValueError("points must be (B,N,3) and crop_center (B,2)")
+        head_params = self._head_params()
+        if any(p.requires_grad for p in head_params):
+            self._heads_packed = None           # see query(): fused optimisers do not advance the version counters
+        arena = self._heads_arena(dev)
+        dtype = _QDT[self.compute_dtype]
+        x3 = getattr(self, "heads_x3", None)
+        if x3 is None:
+            x3 = self.compute_dtype != "fp32" and not os.environ.get("CHORE_HEADS_FP32")
+        qdt = dtype | (_lib.HEADS_X3 if x3 else 0)
+        n = self.image_filter.num_modules
+        f32 = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.float().contiguous()   # noqa: E731
+        tgt = dict(df_h=f32(df_h), df_o=f32(df_o), parts_gt=parts_gt.long().contiguous(), pca_gt=f32(pca_gt),
+                   body_center=f32(body_center), obj_center=f32(obj_center), max_dist=max_dist, scale=1.0 / n,
+                   weights=(ctypes.c_float * 6)(*[float(v) for v in self.loss_weights]))
+        share = None
+        if n > 1 and not os.environ.get("CHORE_HEADS_NO_SHARE"):
+            share = {"n": n, "done": 0, "arena": None}
+        preds, outs = [], []
+
+        def on_stack(i, feat, tmpx):
+            side.wait_stream(main)              # stack i's feature map (and, the first time, the targets / the packed heads)
+            with torch.cuda.stream(side):
+                df, pca, parts, centers = _QueryTrainFn.apply(pts, cc, feat, tmpx, arena, self._cam6, qdt, share, *head_params)
+                outs.append(_StackLossFn.apply(df, pca, parts, centers, tgt))
+            B, _, N = df.shape
+            preds.append((df, pca.view(B, 3, 3, N), parts, centers))
+
+        tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
+        feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt, on_stack=on_stack)
+        main.wait_stream(side)
+        self.im_feat_list = feats
+        self.intermediate_preds_list = preds
+        self.preds = preds[-1]
+        tot = outs[0] if n == 1 else torch.stack(outs).sum(0)
+        error, losses_all = tot[6], tot[:6].detach()
+        if self.losses_on_host:
+            losses_all = losses_all.cpu()
+        self.error_buffer = losses_all
+        return error, losses_all
+
+    def _query_stream(self, dev):
+        s = getattr(self, "_qstream", None)
+        if s is None or s.device != dev:
+            s = self._qstream = torch.cuda.Stream(dev)
+        return s
 
     def get_errors(self, df_h, df_o, parts_gt, pca_gt, max_dist, body_center, obj_center, **kwargs):
         """training loss of /root/reference/model/chore.py:192-237, averaged over the stacks"""

@@ -50,14 +50,16 @@ def hourglass(m, level, x, xs=None):
     return ops.upadd(up1, low3, True)
 
 
-def forward_train(enc, images, tdt):
+def forward_train(enc, images, tdt, on_stack=None):
     """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype.
-    Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad."""
+    Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad.
+    on_stack(i, output_i, tmpx): called as soon as stack i's output exists (CHORE.forward launches that stack's field query and
+    loss on a second stream from it, so they run beside the next stack's encoder -- forward and backward)."""
     with ops.zero_arena(images.device):
-        return _forward_train(enc, images, tdt)
+        return _forward_train(enc, images, tdt, on_stack)
 
 
-def _forward_train(enc, images, tdt):
+def _forward_train(enc, images, tdt, on_stack=None):
     x = ops.stem(images, enc.conv1.weight, enc.conv1.bias, tdt)
     x = ops.gn_relu(x, enc.bn1.weight, enc.bn1.bias)
     tmpx = x
@@ -77,6 +79,8 @@ def _forward_train(enc, images, tdt):
         li = getattr(enc, f"l{i}")
         tmp_out = ops.conv_gn(ll, li.weight, li.bias)
         outputs.append(tmp_out)
+        if on_stack is not None:
+            on_stack(i, _nchw(tmp_out), _nchw(tmpx.detach()))
         if i < n - 1:
             bl, al = getattr(enc, f"bl{i}"), getattr(enc, f"al{i}")
             previous = previous + ops.conv_gn(ll, bl.weight, bl.bias) + ops.conv_gn(tmp_out, al.weight, al.bias)

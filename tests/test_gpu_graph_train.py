@@ -113,3 +113,41 @@ def test_fused_optimizer_steps_reach_the_packed_heads():
     assert losses["foreach"][0] == losses["fused"][0]
     for a, b in zip(losses["foreach"][1:], losses["fused"][1:]):
         assert abs(a - b) <= 2e-4 * abs(a), losses
+
+
+def test_queries_beside_the_encoder_equal_the_sequential_forward(monkeypatch):
+    """CHORE.forward in training launches every stack's field query + loss on a second stream as soon as that stack's feature map
+    exists (model/chore.py `_forward_interleaved`); CHORE_TRAIN_NO_INTERLEAVE=1 is the reference's order filter -> query ->
+    get_errors (model/chore.py:175-190).  Same nodes either way: loss, separate losses and all gradients equal bit for bit,
+    over two steps (the second one sees the first one's update)."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_ddp_trainstep import _make
+    batches = [_make(it)[1] for it in range(2)]
+    res = {}
+    for kind in ("sequential", "interleaved"):
+        if kind == "sequential":
+            monkeypatch.setenv("CHORE_TRAIN_NO_INTERLEAVE", "1")
+        else:
+            monkeypatch.delenv("CHORE_TRAIN_NO_INTERLEAVE", raising=False)
+        net, _ = _make(0)
+        opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+        rec = []
+        for it in range(2):
+            net.train()
+            opt.zero_grad(set_to_none=True)
+            loss, sep = net(**batches[it])
+            assert len(net.intermediate_preds_list) == 5 and net.preds is net.intermediate_preds_list[-1]
+            loss.backward()
+            opt.step()
+            rec.append((float(loss.detach()), sep.detach().cpu(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}))
+        torch.cuda.synchronize()
+        res[kind] = rec
+        del net, opt
+        torch.cuda.empty_cache()
+    for (la, sa, ga), (lb, sb, gb) in zip(res["sequential"], res["interleaved"]):
+        assert la == lb, (la, lb)
+        assert torch.equal(sa, sb)
+        assert set(ga) == set(gb) and len(ga) >= 475
+        bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
+        assert not bad, bad[:5]
