@@ -244,7 +244,8 @@ int chore_gen_surface_step_fused(chore_handle* h, const float* points, const flo
 
 size_t chore_query_train_bytes(int B, int N) {
     if (B <= 0 || N <= 0) return 0;
-    return (size_t)B * N * ((2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float) + 3 * HEAD_NUM * 2 * sizeof(unsigned long long));
+    return (size_t)B * N * ((2 * QF_KPAD + 2 * 3 * HEAD_NUM * HEAD_HID) * sizeof(float) + 3 * HEAD_NUM * 2 * sizeof(unsigned long long)) +
+           2 * (size_t)B * scatter_sort_ints(N) * sizeof(int);
 }
 
 static void train_staging(QueryArgs& a, void* staging) {
@@ -255,6 +256,7 @@ static void train_staging(QueryArgs& a, void* staging) {
     a.tdZ = a.tH + P * 3 * HEAD_NUM * HEAD_HID;
     a.tdX = a.tdZ + P * 3 * HEAD_NUM * HEAD_HID;
     a.tM = (unsigned long long*)(a.tdX + P * QF_KPAD);
+    a.tSort = (int*)(a.tM + P * 3 * HEAD_NUM * 2);
 }
 
 // the query forward of a training step: as chore_query_fwd, and the 323-vectors and ReLU outputs of the hidden layers go

@@ -185,10 +185,16 @@ struct QueryArgs {
     float* tdZ = nullptr;   // [3][HEAD_NUM][B*N][128]  gradients w.r.t. the pre-activations of layers 1..3
     float* tdX = nullptr;   // [B*N][QF_KPAD]           gradient w.r.t. the 323-vector (summed over the heads)
     unsigned long long* tM = nullptr;   // [3][HEAD_NUM][B*N][2]  ReLU sign bits of the hidden layers (heads_f32.h, store_masks)
+    int* tSort = nullptr;   // [2][B][scatter_sort_ints(N)]  per-tile point lists of chore_scatter_features (query_scatter.hip)
     // surface step only (chore_gen_surface_step_fused): distance channel and clamp of generator.py:50-79; dpoints = the moved points
     int surf_k = 0;
     float surf_thr = 0.f;
 };
+
+// ints per image and map of the scatter's binned point lists: up to 64 chunks of CH points (CH = ceil(N / 64) rounded up to a
+// multiple of 64), each with room for 4 insertions per point, and 64 offset tables of SCATTER_OFF_STRIDE entries
+constexpr int SCATTER_OFF_STRIDE = 260;     // 256 tiles + the total, padded
+__host__ __device__ static inline size_t scatter_sort_ints(int N) { return 4 * ((size_t)N + 64 * 64) + 64 * (size_t)SCATTER_OFF_STRIDE; }
 
 // launchers implemented in the .hip files
 int launch_heads_pack_f32(chore_handle* h, const HeadsRaw& raw, float* arena, hipStream_t s);

@@ -7,6 +7,13 @@
 // 16x16 x 64 = 64 KB); the workgroup of a tile scans the points of its image in index order, keeps those with a tap
 // inside the tile (ballot-ordered compaction, so the list is sorted) and accumulates them one after the other with
 // one thread per channel: no atomics anywhere, the result is bit-reproducible, and each tile is written once.
+//
+// Round 4: for large queries the 256 tiles of an image no longer scan all its points each (20 000 points x 256 tiles = 5 M
+// projections per image, 79 rounds of loads and barriers per tile: 258 us).  scatter_bin_kernel first cuts the image's points
+// into <= 64 contiguous chunks and sorts every chunk's points by the tile(s) their taps fall into -- a STABLE counting sort, one
+// wave per chunk, a point entered once per tile it touches (1, 2 or 4) -- into the staging buffer's sort region; a tile's
+// workgroup then walks the chunks' segments of its tile in chunk order.  That is the same hit list in the same (point index)
+// order as the scan produces, so the sums are the same bit for bit (tests/test_gpu_query.py), from ~100 candidates instead of 20 000.
 #include "query_common.h"
 
 namespace {
@@ -78,31 +85,255 @@ __global__ __launch_bounds__(256) void scatter_kernel(QueryArgs a, const float* 
         __syncthreads();
         // one channel per thread (C <= 256); the next hit's gradient value is requested while this one is added (the hits are
         // processed in order -- a load per tap inside the loop made every hit a global round trip)
+        // one channel per thread; the hits are added in order, their gradient values fetched SC_BATCH hits ahead (a row per hit:
+        // with two loads in flight the walk was a chain of global round trips, 0.7 us per hit)
         const int c = tid;
+        constexpr int SC_BATCH = 32;
         auto gload = [&](int i) -> float {
             return (i < total && c < C) ? dX[((size_t)b * a.N + hits[i].pt) * QF_KPAD + xoff + c] : 0.f;
         };
-        float gnext = gload(0), gnext2 = gload(1);
-        for (int i = 0; i < total; ++i) {
-            const Hit hh = hits[i];
-            const float gv = gnext;
-            gnext = gnext2;
-            gnext2 = gload(i + 2);
-            if (c < C) {
+        float cur[SC_BATCH], nxt[SC_BATCH];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int x = hh.x0 + (k & 1), y = hh.y0 + (k >> 1);
-                    if (x < tx0 || x >= tx0 + TS || y < ty0 || y >= ty0 + TS || x >= W || y >= H || x < 0 || y < 0) continue;
-                    float* cell = acc + ((y - ty0) * TS + (x - tx0)) * C;
-                    cell[c] = fmaf(hh.w[k], gv, cell[c]);
+        for (int u = 0; u < SC_BATCH; ++u) cur[u] = gload(u);
+        for (int i0 = 0; i0 < total; i0 += SC_BATCH) {
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) nxt[u] = gload(i0 + SC_BATCH + u);
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) {
+                if (i0 + u >= total) break;
+                const Hit hh = hits[i0 + u];
+                const float gv = cur[u];
+                if (c < C) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int x = hh.x0 + (k & 1), y = hh.y0 + (k >> 1);
+                        if (x < tx0 || x >= tx0 + TS || y < ty0 || y >= ty0 + TS || x >= W || y >= H || x < 0 || y < 0) continue;
+                        float* cell = acc + ((y - ty0) * TS + (x - tx0)) * C;
+                        cell[c] = fmaf(hh.w[k], gv, cell[c]);
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) cur[u] = nxt[u];
         }
         __syncthreads();
     }
     for (int i = tid; i < TS * TS * (C / 4); i += 256) {
         const int cell = i / (C / 4), q = i % (C / 4);
         const int x = tx0 + cell % TS, y = ty0 + cell / TS;
+        if (x >= W || y >= H) continue;
+        float* o = dmap + (((size_t)b * H + y) * W + x) * C + 4 * q;
+        f32x4 v = *(const f32x4*)(acc + cell * C + 4 * q);
+        if (accumulate) { const f32x4 old = *(const f32x4*)o; v += old; }
+        *(f32x4*)o = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// binned scatter
+// ---------------------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int scatter_chunk(int N) { const int c = (N + 63) / 64; return (c + 63) / 64 * 64; }
+
+// tap geometry of one point in an (H,W) map: the arithmetic of make_taps (query_common.h); false = no tap anywhere near the map
+__device__ __forceinline__ bool scatter_hit(const QueryArgs& a, const Cam& cam, int b, int n, int H, int W, Hit& h) {
+    const float* p = a.points + ((size_t)b * a.N + n) * 3;
+    float nx, ny;
+    project_point(p[0], p[1], p[2], a.crop_center[b * 2 + 0], a.crop_center[b * 2 + 1], cam, nx, ny);
+    const float ix = __fmul_rn(__fadd_rn(nx, 1.0f), (float)(W - 1) / 2);
+    const float iy = __fmul_rn(__fadd_rn(ny, 1.0f), (float)(H - 1) / 2);
+    const bool sane = (ix > -2.0f) && (ix < (float)W + 1.0f) && (iy > -2.0f) && (iy < (float)H + 1.0f);
+    if (!sane) return false;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float w = __fsub_rn(ix, x0f), e = __fsub_rn(1.0f, w);
+    const float nn = __fsub_rn(iy, y0f), s = __fsub_rn(1.0f, nn);
+    h.pt = n; h.x0 = (int)x0f; h.y0 = (int)y0f;
+    h.w[0] = __fmul_rn(e, s); h.w[1] = __fmul_rn(w, s); h.w[2] = __fmul_rn(e, nn); h.w[3] = __fmul_rn(w, nn);
+    return true;
+}
+
+// the (at most four, distinct) tiles a point's taps fall into; -1 = unused slot
+template <int TS>
+__device__ __forceinline__ void scatter_bins(const QueryArgs& a, const Cam& cam, int b, int n, bool live, int H, int W, int txn, int kb[4]) {
+    kb[0] = kb[1] = kb[2] = kb[3] = -1;
+    Hit h;
+    if (!live || !scatter_hit(a, cam, b, n, H, W, h)) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int x = h.x0 + (k & 1), y = h.y0 + (k >> 1);
+        if (x < 0 || x >= W || y < 0 || y >= H) continue;
+        const int bin = (y / TS) * txn + (x / TS);
+        bool dup = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dup = dup || (j < k && kb[j] == bin);
+        if (!dup) kb[k] = bin;
+    }
+}
+
+// one wave per (chunk, image): stable counting sort of the chunk's points by tile.  Lane l owns the l-th contiguous run of the
+// chunk's points, so "stable" = by lane, then by position in the lane's run: a table of per-(tile, lane) counts (no atomics, no
+// cross-lane ranking), its prefix over the lanes, the prefix over the tiles, and a second walk that places the entries.
+// sort region of the image:  lists [G][4 * CH] point indices, then offsets [G][SCATTER_OFF_STRIDE] (entry nb = the chunk's total)
+constexpr int SB_ROW = 66;      // ushort counters per tile row: 64 lanes + 2 of padding (rows 33 words apart: the per-tile walk
+                                // of lane j over its 5 rows touches 32 different banks across a half-wave)
+template <int TS>
+__global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int W, int* __restrict__ sort) {
+    __shared__ unsigned short cnt[(SCATTER_OFF_STRIDE + 60) * SB_ROW];     // [320 tiles][lane]
+    __shared__ int tot[64];
+    const int lane = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+    const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH, S = CH / 64;
+    const int txn = (W + TS - 1) / TS, nb = txn * ((H + TS - 1) / TS);
+    int* img = sort + (size_t)b * scatter_sort_ints(a.N);
+    int* list = img + (size_t)g * 4 * CH;
+    int* off = img + (size_t)G * 4 * CH + (size_t)g * SCATTER_OFF_STRIDE;
+    const int n0 = g * CH + lane * S, n1 = min(a.N, n0 + S);
+    for (int i = lane; i < 320 * SB_ROW / 2; i += 64) ((unsigned*)cnt)[i] = 0u;
+    __syncthreads();
+    // ---- counts: this lane's column ----
+    for (int n = n0; n < n1; ++n) {
+        int kb[4];
+        scatter_bins<TS>(a, cam, b, n, true, H, W, txn, kb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (kb[k] >= 0) cnt[kb[k] * SB_ROW + lane] += 1;
+    }
+    __syncthreads();
+    // ---- lane j owns tiles 5 j .. 5 j + 4: prefix over the 64 lane counters of each, then the prefix over the tiles ----
+    int t5[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        unsigned short* row = cnt + (lane * 5 + j) * SB_ROW;
+        int run = 0;
+        for (int i = 0; i < 64; ++i) { const int v = row[i]; row[i] = (unsigned short)run; run += v; }
+        t5[j] = run;
+    }
+    tot[lane] = t5[0] + t5[1] + t5[2] + t5[3] + t5[4];
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < 64; ++i) base += i < lane ? tot[i] : 0;
+    __syncthreads();
+    int tb[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k = lane * 5 + j;
+        tb[j] = base;
+        if (k <= nb) off[k] = base;                    // entry nb = the total (tiles >= nb are empty)
+        base += t5[j];
+    }
+    // the tiles' bases go where every lane can read them: the two padding counters of the tile's row (low / high half)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        unsigned short* row = cnt + (lane * 5 + j) * SB_ROW;
+        row[64] = (unsigned short)(tb[j] & 0xffff);
+        row[65] = (unsigned short)(tb[j] >> 16);
+    }
+    __syncthreads();
+    // ---- placement: the lane walks its run again ----
+    for (int n = n0; n < n1; ++n) {
+        int kb[4];
+        scatter_bins<TS>(a, cam, b, n, true, H, W, txn, kb);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (kb[k] < 0) continue;
+            unsigned short* row = cnt + kb[k] * SB_ROW;
+            const int r = row[lane];
+            row[lane] = (unsigned short)(r + 1);
+            list[((int)row[64] | ((int)row[65] << 16)) + r] = n;
+        }
+    }
+}
+
+// A workgroup owns a SUB x SUB block of texels inside a TS x TS tile: it walks the tile's whole list and adds the hits that touch
+// its block.  SUB = TS for the feature map; SUB < TS (more, smaller workgroups walking the same list) measured slower for it
+// (197 against 134 us inside the training step: every workgroup pays the list set-up) -- profiles/r04_scatter.txt.
+template <int C, int TS /*tile edge in texels*/, int SUB /*texels per workgroup edge*/>
+__global__ __launch_bounds__(256) void scatter_csr_kernel(QueryArgs a, const float* __restrict__ dX, int xoff, int H, int W,
+                                                          float* __restrict__ dmap, int accumulate, const int* __restrict__ sort) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];   // [SUB*SUB][C]
+    __shared__ Hit hits[SC_LIST];
+    __shared__ int seg_start[65], seg_src[64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.z, tx0 = blockIdx.x * SUB, ty0 = blockIdx.y * SUB;
+    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
+    const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH;
+    const int bin = (ty0 / TS) * ((W + TS - 1) / TS) + tx0 / TS;
+    const int* img = sort + (size_t)b * scatter_sort_ints(a.N);
+    const int* offs = img + (size_t)G * 4 * CH;
+    for (int i = tid; i < SUB * SUB * C; i += 256) acc[i] = 0.f;
+    if (tid < 64) {      // the tile's segment of every chunk, in chunk order
+        int o0 = 0, len = 0;
+        if (lane < G) { o0 = offs[(size_t)lane * SCATTER_OFF_STRIDE + bin]; len = offs[(size_t)lane * SCATTER_OFF_STRIDE + bin + 1] - o0; }
+        int incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        seg_start[lane] = incl - len;
+        seg_src[lane] = lane * 4 * CH + o0;
+        if (lane == 63) seg_start[64] = incl;
+    }
+    __syncthreads();
+    const int total_all = seg_start[64];
+    for (int base = 0; base < total_all; base += SC_LIST) {
+        const int total = min(SC_LIST, total_all - base);
+#pragma unroll
+        for (int j = 0; j < SC_SUB; ++j) {
+            const int i = j * 256 + tid;
+            if (i < total) {
+                const int gi = base + i;
+                int lo = 0;                          // the last chunk whose segment starts at or before gi
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) if (lo + step < 64 && seg_start[lo + step] <= gi) lo += step;
+                const int n = img[seg_src[lo] + (gi - seg_start[lo])];
+                Hit h;
+                scatter_hit(a, cam, b, n, H, W, h);  // was sane when it was binned
+                hits[i] = h;
+            }
+        }
+        __syncthreads();
+        // one channel per thread; the hits are added in order, their gradient values fetched SC_BATCH hits ahead (a row per hit:
+        // with two loads in flight the walk was a chain of global round trips, 0.7 us per hit)
+        const int c = tid;
+        constexpr int SC_BATCH = 32;
+        // (unconditional loads at a clamped index: a guard per load made every address a separate LDS round trip)
+        const float* dXc = dX + (size_t)b * a.N * QF_KPAD + xoff + (c < C ? c : 0);
+        auto gload = [&](int i) -> float { return dXc[(size_t)hits[min(i, total - 1)].pt * QF_KPAD]; };
+        float cur[SC_BATCH], nxt[SC_BATCH];
+#pragma unroll
+        for (int u = 0; u < SC_BATCH; ++u) cur[u] = gload(u);
+        for (int i0 = 0; i0 < total; i0 += SC_BATCH) {
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) nxt[u] = gload(i0 + SC_BATCH + u);
+            Hit hn = hits[i0];                 // the next hit's record is read while this one's cells make their round trip
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) {
+                if (i0 + u >= total) break;
+                // the hit is the same for every thread: its geometry goes to scalar registers (uniform branches, scalar cell
+                // addresses); the four taps are four different cells, so their reads are issued together and the writes after --
+                // one LDS round trip per hit instead of four dependent ones
+                const Hit hv = hn;
+                hn = hits[min(i0 + u + 1, total - 1)];
+                const int hx = __builtin_amdgcn_readfirstlane(hv.x0) - tx0, hy = __builtin_amdgcn_readfirstlane(hv.y0) - ty0;
+                const float gv = cur[u];
+                float* cell[4];
+                bool ok[4];
+                float old[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int x = hx + (k & 1), y = hy + (k >> 1);
+                    ok[k] = c < C && x >= 0 && x < SUB && y >= 0 && y < SUB && x + tx0 < W && y + ty0 < H;
+                    cell[k] = acc + (y * SUB + x) * C + c;
+                    old[k] = ok[k] ? *cell[k] : 0.f;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (ok[k]) *cell[k] = fmaf(hv.w[k], gv, old[k]);
+            }
+#pragma unroll
+            for (int u = 0; u < SC_BATCH; ++u) cur[u] = nxt[u];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < SUB * SUB * (C / 4); i += 256) {
+        const int cell = i / (C / 4), q = i % (C / 4);
+        const int x = tx0 + cell % SUB, y = ty0 + cell / SUB;
         if (x >= W || y >= H) continue;
         float* o = dmap + (((size_t)b * H + y) * W + x) * C + 4 * q;
         f32x4 v = *(const f32x4*)(acc + cell * C + 4 * q);
@@ -121,17 +352,38 @@ int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_kernel<TMPX_C, 16>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * TMPX_C * 4));
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_csr_kernel<FEAT_C, 8, 8>,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));
         attr = true;
     }
+    // binned path: needs the sort region of the staging buffer, <= 256 tiles per image and enough points to pay for the extra
+    // launch (CHORE_SCATTER_SCAN=1: every tile scans all points, the round 1 - 3 kernel)
+    const bool scan_only = getenv("CHORE_SCATTER_SCAN") != nullptr;      // read per call: the test flips it
+    const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH;
+    const bool binned = a.tSort && !scan_only && a.N >= 2048;
     if (dfeat) {
         dim3 grid((a.FW + 7) / 8, (a.FH + 7) / 8, a.B);
-        hipLaunchKernelGGL((scatter_kernel<FEAT_C, 8>), grid, dim3(256), 8 * 8 * FEAT_C * 4, s, a, dX, 0, a.FH, a.FW, dfeat,
-                           accumulate);
+        if (binned && grid.x * grid.y <= 256) {
+            int* sort = a.tSort;
+            hipLaunchKernelGGL((scatter_bin_kernel<8>), dim3(G, a.B), dim3(64), 0, s, a, a.FH, a.FW, sort);
+            hipLaunchKernelGGL((scatter_csr_kernel<FEAT_C, 8, 8>), dim3((a.FW + 7) / 8, (a.FH + 7) / 8, a.B), dim3(256), 8 * 8 * FEAT_C * 4,
+                               s, a, dX, 0, a.FH, a.FW, dfeat, accumulate, (const int*)sort);
+        } else {
+            hipLaunchKernelGGL((scatter_kernel<FEAT_C, 8>), grid, dim3(256), 8 * 8 * FEAT_C * 4, s, a, dX, 0, a.FH, a.FW, dfeat,
+                               accumulate);
+        }
     }
     if (dtmpx) {
         dim3 grid((a.TW + 15) / 16, (a.TH + 15) / 16, a.B);
-        hipLaunchKernelGGL((scatter_kernel<TMPX_C, 16>), grid, dim3(256), 16 * 16 * TMPX_C * 4, s, a, dX, FEAT_C + 3, a.TH,
-                           a.TW, dtmpx, accumulate);
+        if (binned && grid.x * grid.y <= 256) {
+            int* sort = a.tSort + (size_t)a.B * scatter_sort_ints(a.N);
+            hipLaunchKernelGGL((scatter_bin_kernel<16>), dim3(G, a.B), dim3(64), 0, s, a, a.TH, a.TW, sort);
+            hipLaunchKernelGGL((scatter_csr_kernel<TMPX_C, 16, 8>), dim3((a.TW + 7) / 8, (a.TH + 7) / 8, a.B), dim3(256), 8 * 8 * TMPX_C * 4,
+                               s, a, dX, FEAT_C + 3, a.TH, a.TW, dtmpx, accumulate, (const int*)sort);
+        } else {
+            hipLaunchKernelGGL((scatter_kernel<TMPX_C, 16>), grid, dim3(256), 16 * 16 * TMPX_C * 4, s, a, dX, FEAT_C + 3, a.TH,
+                               a.TW, dtmpx, accumulate);
+        }
     }
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;

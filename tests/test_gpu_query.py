@@ -479,3 +479,51 @@ def test_fp16x3_heads_stay_finite_beyond_the_half_range(opt):
         res[x3] = preds
     for a, b in zip(res[True], res[False]):
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,N,maps,spread", [(4, 20000, (128, 128, 256, 256), "uniform"), (2, 5000, (128, 128, 256, 256), "clustered"),
+                                               (3, 2500, (16, 24, 32, 48), "uniform"), (1, 70001, (128, 128, 256, 256), "uniform")])
+def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypatch):
+    """chore_scatter_features (the transpose of `index`, model/geometry.py:4-14, for the training query): round 4's binned path
+    (a stable per-chunk counting sort of the points by map tile, then every tile walks only its own points) against the
+    round 1 - 3 kernel in which every tile scans all points (CHORE_SCATTER_SCAN=1).  Both add a tile's hits in point-index order:
+    equal BIT FOR BIT, for random gradient rows, also when thousands of points share one tile (several rounds of the 512-entry
+    hit list), on small maps with partial tiles, and for a point count that is not a multiple of anything."""
+    import ctypes
+    from chore_amd import _lib
+    from chore_amd.utils import synth
+    from chore_amd.model.camera import KinectColorCamera
+    dev = torch.device("cuda", 0)
+    FH, FW, TH, TW = maps
+    rs = np.random.RandomState(B * 1000 + N)
+    pts = synth.synth_points(B, N, seed=3)
+    if spread == "clustered":                      # 80 % of the points inside a few centimetres: one or two tiles get thousands
+        k = int(0.8 * N)
+        pts[:, :k] = pts[:, :1] + rs.standard_normal((B, k, 3)).astype(np.float32) * 0.02
+    pts[:, -3:] = [[50.0, 50.0, 2.0]]              # far outside the image: no tap anywhere
+    points = torch.from_numpy(pts).to(dev)
+    cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev)
+    nbytes = _lib.lib.chore_query_train_bytes(B, N)
+    P, KPAD = B * N, 328
+    staging = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    f = staging[:(nbytes // 4) * 4].view(torch.float32)
+    o = P * (KPAD + 2 * 3 * 4 * 128)              # X, H, dZ come first (csrc/capi.hip train_staging)
+    f[o:o + P * KPAD] = torch.from_numpy(rs.standard_normal(P * KPAD).astype(np.float32)).to(dev)
+    cam6 = (ctypes.c_float * 6)(*KinectColorCamera(512).kernel_constants())
+    h = _lib.handle(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    for kind in ("scan", "binned"):
+        if kind == "scan":
+            monkeypatch.setenv("CHORE_SCATTER_SCAN", "1")
+        else:
+            monkeypatch.delenv("CHORE_SCATTER_SCAN", raising=False)
+        dfe = torch.full((B, FH, FW, 256), float("nan"), device=dev)
+        dtm = torch.full((B, TH, TW, 64), float("nan"), device=dev)
+        _lib.check(_lib.lib.chore_scatter_features(h, points.data_ptr(), cc.data_ptr(), B, N, FH, FW, TH, TW, cam6, staging.data_ptr(),
+                                                   dfe.data_ptr(), dtm.data_ptr(), 0, stream), h, "chore_scatter_features")
+        torch.cuda.synchronize()
+        out[kind] = (dfe, dtm)
+    for a, b, name in zip(out["scan"], out["binned"], ("dfeat", "dtmpx")):
+        assert torch.isfinite(a).all() and float(a.abs().max()) > 0, name
+        assert torch.equal(a, b), (name, int((a != b).sum()))
