@@ -797,6 +797,8 @@ def main():
                     help="training: gradient reduction of the primary number (arena = FlatGradReducer, ddp = torch's DistributedDataParallel)")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args.gpus)            # (before fd 1 is redirected: the launched ranks inherit the real stdout)
     # ONE JSON line on stdout, nothing else: C libraries (RCCL prints a version banner) write to file descriptor 1 behind Python's
     # back, so fd 1 is pointed at stderr for the whole run and the line goes to a duplicate of the original stdout
     sys.stdout.flush()
@@ -807,8 +809,6 @@ def main():
         args.dtype = "bf16" if args.mode == "train" else "fp16x3"
     args.steps = defaults[0] if args.steps is None else args.steps
     args.warmup = defaults[1] if args.warmup is None else args.warmup
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        self_launch(args.gpus)
     ctx = Ctx(args.gpus, one_rank_group=(args.mode in ("all", "train") and not args.dry_run and not args.no_ddp))
     if args.dry_run:
         # the distributed skeleton without the device work: used by the CPU test of the N > 1 launch path
