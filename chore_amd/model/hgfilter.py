@@ -182,7 +182,8 @@ class HGFilter(_Params):
         if work is None:
             nbytes = _lib.lib.chore_encoder_workspace_bytes(ctypes.byref(cfg), B, H, W, dtype)
             work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self._work = {k: v for k, v in self._work.items() if k[:5] == wkey[:5]}
+            same = [k for k in self._work if k[:5] == wkey[:5]]
+            self._work = {k: self._work[k] for k in same[-3:]}       # at most four live workspaces of a shape (streams come and go)
             self._work[wkey] = work
         # static_outputs: the same output tensors for every call of a shape (each call overwrites the previous call's maps) --
         # recorded hipGraphs of the fit loop read the maps through fixed addresses and are kept across loader batches
