@@ -356,11 +356,11 @@ int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));
         attr = true;
     }
-    // binned path: needs the sort region of the staging buffer, <= 256 tiles per image and enough points to pay for the extra
-    // launch (CHORE_SCATTER_SCAN=1: every tile scans all points, the round 1 - 3 kernel)
+    // binned path: needs the sort region of the staging buffer and <= 256 tiles per image
+    // (CHORE_SCATTER_SCAN=1: every tile scans all points, the round 1 - 3 kernel -- which was seen to mis-execute under GPU sharing)
     const bool scan_only = getenv("CHORE_SCATTER_SCAN") != nullptr;      // read per call: the test flips it
     const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH;
-    const bool binned = a.tSort && !scan_only && a.N >= 2048;
+    const bool binned = a.tSort && !scan_only && a.N >= 64;
     if (dfeat) {
         dim3 grid((a.FW + 7) / 8, (a.FH + 7) / 8, a.B);
         if (binned && grid.x * grid.y <= 256) {

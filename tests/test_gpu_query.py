@@ -482,7 +482,7 @@ def test_fp16x3_heads_stay_finite_beyond_the_half_range(opt):
 
 
 @pytest.mark.parametrize("B,N,maps,spread", [(4, 20000, (128, 128, 256, 256), "uniform"), (2, 5000, (128, 128, 256, 256), "clustered"),
-                                               (3, 2500, (16, 24, 32, 48), "uniform"), (1, 70001, (128, 128, 256, 256), "uniform")])
+                                               (3, 2500, (16, 24, 32, 48), "uniform"), (2, 100, (16, 24, 32, 48), "uniform"), (1, 70001, (128, 128, 256, 256), "uniform")])
 def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypatch):
     """chore_scatter_features (the transpose of `index`, model/geometry.py:4-14, for the training query): round 4's binned path
     (a stable per-chunk counting sort of the points by map tile, then every tile walks only its own points) against the
