@@ -7,8 +7,8 @@ channel stacking.  All pixel work runs in libchore_hip.so (csrc/image_prep.hip: 
 _crop_compose / _crop_compose_mean); the host does the few scalar steps in numpy with the reference's expressions.
 use_mean_center=True (the COCO loader, recon/recon_fit_coco.py:28): the patch is moved to the mean crop centre of the
 BEHAVE training set (pad_image :133-160 -- a float64 canvas in the reference, a translated clipped lookup here) and cv2's
-generic float resize applies.  JPEG decoding and the keypoint / mocap based `fullbody_crop` scale (:167-200) stay with the
-reference's host code.
+generic float resize applies.  `fullbody_crop` (:174-210, the crop scale from the openpose keypoints and the mocap mesh) runs on the
+device since round 4; JPEG / PLY decoding stays with the reference's host code.
 
     prep = ImagePrep(image_size=(512, 512), crop_size=1200)
     images, crop_center, resize_scale, old_center = prep.prepare(rgb_u8, person_u8, obj_u8, scale)
@@ -30,6 +30,32 @@ class ImagePrep:
             raise ValueError("the crop is square: image_size must be (S, S)")
         self.img_size, self.crop_size = tuple(image_size), float(crop_size)
         self.device = torch.device(device)
+
+    def fullbody_crop(self, kpts, mocap_verts, body25_regressor, z0=2.2, camera=None):
+        """the scale of the crop that makes the person look as if standing at depth z0   [data/test_data.py:174-210]
+        kpts: (25,3) openpose keypoints (x, y, confidence) in the 2048-px image; mocap_verts: (V,3) vertices of the frame's
+        FrankMocap mesh (what `load_mocap_mesh` reads); body25_regressor: dense (25,V) landmark regressor
+        (`FitAssets.regressors()[0]`, the matrix of lib_smpl/body_landmark.py:62-66).  Returns a python float (one host read);
+        (None, 1.0) when no keypoint has confidence, like the reference.  float64 on the device: the reference computes in numpy
+        doubles."""
+        from ..model.camera import KinectColorCamera
+        dev = self.device
+        pts = torch.as_tensor(np.asarray(kpts), dtype=torch.float64, device=dev)
+        if float(pts[:, 2].sum()) == 0:
+            return None, 1.0
+        v = torch.as_tensor(np.asarray(mocap_verts), dtype=torch.float64, device=dev)
+        reg = torch.as_tensor(np.asarray(body25_regressor), dtype=torch.float64, device=dev)
+        cam = camera if camera is not None else KinectColorCamera(self.crop_size)
+        v = v - v.mean(0) + torch.tensor([0.0, 0.0, float(z0)], dtype=torch.float64, device=dev)     # move to depth z0
+        j3d = reg @ v                                                                                # (25,3) body keypoints
+        px, py = cam.project_screen(j3d)
+        valid = pts[:, 2] > 0.3
+        j2d, j2d_mocap = pts[valid, :2], torch.cat([px, py], 1)[valid]
+
+        def width(j, exp=1.1):                     # get_bbox :224-228
+            return (j.max(0).values - j.min(0).values) * exp
+        (w, h), (wm, hm) = width(j2d).tolist(), width(j2d_mocap).tolist()
+        return w / wm if (w >= h and wm >= hm) else h / hm
 
     def _u8(self, a, ndim):
         t = torch.as_tensor(a)

@@ -843,6 +843,55 @@ def gen_coco():
         os.chdir(cwd)
 
 
+def gen_fullbody_crop():
+    """TestData.fullbody_crop (data/test_data.py:174-210) -- the crop scale from openpose keypoints and the frame's mocap mesh -- run
+    from the reference's own class (created with __new__: its constructor reads dataset folders and SMPL assets; `load_mocap_mesh`
+    and the landmark regressor, whose files are not redistributable, are fed from synthetic arrays)"""
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        _install_stub_finder()
+        from data.test_data import TestData
+        from model.camera import KinectColorCamera
+    finally:
+        os.chdir(cwd)
+    from chore_amd.lib_smpl.wrapper_pytorch import synthetic_regressors
+    reg = np.asarray(synthetic_regressors(6890, seed=0)[0], np.float64)             # (25, 6890) body-25 regressor
+    rs = np.random.RandomState(77)
+
+    class Mesh:
+        pass
+
+    class Landmark:
+        def get_body_kpts(self, mesh):
+            return reg @ mesh.v
+
+    td = TestData.__new__(TestData)
+    td.depth, td.landmark, td.camera = 2.2, Landmark(), KinectColorCamera(1200)
+    cases = []
+    for i, (stretch, conf) in enumerate([((0.5, 0.9, 0.2), "mixed"), ((0.9, 0.4, 0.2), "mixed"), ((0.3, 0.3, 0.3), "high"),
+                                         ((0.6, 0.8, 0.1), "low"), ((0.5, 0.9, 0.2), "zero")]):
+        verts = rs.standard_normal((6890, 3)) * np.array(stretch) + rs.uniform(-1, 1, 3) * [1.0, 1.0, 0.5] + [0, 0, 2.5]
+        verts = verts.astype(np.float32).astype(np.float64)        # what the fixture stores
+        kpts = np.concatenate([rs.uniform(300, 1700, (25, 1)) if stretch[0] > stretch[1] else rs.uniform(800, 1100, (25, 1)),
+                               rs.uniform(200, 1300, (25, 1)), rs.uniform(0, 1, (25, 1))], 1)
+        if conf == "high":
+            kpts[:, 2] = rs.uniform(0.5, 1, 25)
+        elif conf == "low":
+            kpts[:, 2] = rs.uniform(0.0, 0.45, 25)
+            kpts[:3, 2] = 0.9
+        elif conf == "zero":
+            kpts[:, 2] = 0.0
+        m = Mesh()
+        m.v = verts.copy()
+        td.load_mocap_mesh = lambda f, m=m: m
+        out = td.fullbody_crop(kpts.copy(), "frame.color.jpg")
+        cases.append((verts, kpts, np.float64(1.0 if isinstance(out, tuple) else out), isinstance(out, tuple)))
+    np.savez_compressed(os.path.join(HERE, "fullbody_crop.npz"), verts=np.stack([c[0] for c in cases]).astype(np.float32),
+                        kpts=np.stack([c[1] for c in cases]), scale=np.array([c[2] for c in cases]),
+                        no_keypoints=np.array([c[3] for c in cases]), regressor_seed=np.int64(0))
+
+
 def main():
     """no arguments: everything; otherwise the named generators (e.g. `make_golden.py config2 fit`)"""
     torch.manual_seed(0)
@@ -852,6 +901,8 @@ def main():
         return gen_eval()
     if todo == ["coco"]:
         return gen_coco()
+    if todo == ["fullbody_crop"]:
+        return gen_fullbody_crop()
     net = ref_model(seed=0)
     if todo:
         for name in todo:
@@ -875,6 +926,7 @@ def main():
     gen_train_grads(net)
     gen_eval()
     gen_coco()
+    gen_fullbody_crop()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

@@ -102,3 +102,24 @@ def test_prepare_image_crop_with_mean_center_matches_restatement(case):
     assert got.shape == (5, 512, 512) and got.dtype == np.float32
     assert np.array_equal(got, ref), (case, np.abs(got - ref).max())
     assert got[3].max() > 0.9 and (got[:3][:, (got[3] <= 0.5) & (got[4] <= 0.5)] == 0).all()
+
+
+def test_fullbody_crop_matches_the_reference():
+    """ImagePrep.fullbody_crop against TestData.fullbody_crop itself (data/test_data.py:174-210), run by
+    tests/golden/make_golden.py::gen_fullbody_crop on synthetic mocap meshes / keypoints: width-driven and height-driven scales,
+    keypoints below the 0.3 confidence cut, and the no-keypoint case -- pinned (fixture written by the reference's own code)."""
+    import os
+    from chore_amd.data import ImagePrep
+    from chore_amd.lib_smpl.wrapper_pytorch import synthetic_regressors
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "fullbody_crop.npz"))
+    reg = synthetic_regressors(6890, seed=int(g["regressor_seed"]))[0]
+    prep = ImagePrep(image_size=(512, 512), crop_size=1200)
+    branches = set()
+    for verts, kpts, want, none in zip(g["verts"], g["kpts"], g["scale"], g["no_keypoints"]):
+        got = prep.fullbody_crop(kpts, verts, reg)
+        if none:
+            assert got == (None, 1.0)
+            continue
+        assert abs(got - want) <= 1e-9 * abs(want), (got, want)
+        branches.add(got > 2.5)
+    assert len(branches) == 2
