@@ -206,7 +206,11 @@ class Ctx:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             if self.cuda:
-                dist.init_process_group(backend=backend or "nccl", init_method="env://", device_id=self.dev)
+                # RCCL for device tensors (the gradient all-reduce, the fitted-parameter gather), gloo for the timing's barrier and
+                # MAX on host scalars -- and NO device_id: the RCCL communicator is then created by the first device collective,
+                # i.e. by the training record.  A live communicator costs the query record most of what two batches in flight buy
+                # (4.74 -> 5.09 ms per step with a communicator merely initialised: scripts/inflight_rccl_probe.py).
+                dist.init_process_group(backend=backend or "cpu:gloo,cuda:nccl", init_method="env://")
             else:
                 dist.init_process_group(backend=backend or "gloo", init_method="env://")
             self.dist = dist
@@ -224,14 +228,17 @@ class Ctx:
                         s.bind(("127.0.0.1", 0))
                         os.environ["MASTER_PORT"] = str(s.getsockname()[1])
                         s.close()
-                    dist.init_process_group(backend=backend or "nccl", init_method="env://", rank=0, world_size=1, device_id=self.dev)
+                    dist.init_process_group(backend=backend or "cpu:gloo,cuda:nccl", init_method="env://", rank=0, world_size=1)   # lazy, see above
                 self.group1 = dist
             except Exception as e:      # the record then says so ("grad_allreduce": "none ..."); the bench line itself must not die here
                 self.group1_error = repr(e)
 
     def barrier(self):
         if self.dist is not None:
-            self.dist.barrier()
+            if self.cuda:       # on a host tensor: gloo (a device barrier would instantiate the RCCL communicator)
+                self.dist.all_reduce(torch.zeros(1))
+            else:
+                self.dist.barrier()
 
     def sync(self):
         if self.cuda:
@@ -240,7 +247,7 @@ class Ctx:
     def max_over_ranks(self, seconds):
         if self.dist is None:
             return seconds
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.dev)
+        t = torch.tensor([seconds], dtype=torch.float64)          # host tensor: gloo
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
         return float(t.item())
 
