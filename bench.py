@@ -205,6 +205,7 @@ class Ctx:
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: gloo must not try to resolve the container's hostname
             if self.cuda:
                 # RCCL for device tensors (the gradient all-reduce, the fitted-parameter gather), gloo for the timing's barrier and
                 # MAX on host scalars -- and NO device_id: the RCCL communicator is then created by the first device collective,
@@ -223,6 +224,7 @@ class Ctx:
             try:
                 if not dist.is_initialized():
                     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
                     if "MASTER_PORT" not in os.environ:
                         s = socket.socket()
                         s.bind(("127.0.0.1", 0))
