@@ -41,6 +41,11 @@ SIGNATURES = {
                                 c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                 c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_void_p]),
+    "chore_query_fwd_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "chore_query_fwd_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                   c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
+                                   c_void_p, POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p,
+                                   c_void_p, c_void_p, c_void_p]),
     "chore_sample_features": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
                                       c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int,
                                       POINTER(c_float), c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -151,10 +151,23 @@ static int fill_query_args(chore_handle* h, QueryArgs& a, const float* points, c
     return CHORE_OK;
 }
 
+size_t chore_query_fwd_workspace_bytes(int B, int N) {
+    if (B <= 0 || N <= 0) return 0;
+    return (size_t)B * query_sort_ints(N) * sizeof(int);
+}
+
 int chore_query_fwd(chore_handle* h, const float* points, const float* crop_center, int B, int N,
                     const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
                     const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
                     float* centers, uint8_t* in_img, chore_stream_t stream) {
+    return chore_query_fwd_ws(h, points, crop_center, B, N, feat, FH, FW, tmpx, TH, TW, dtype, heads_arena, cam6_host, df, pca, parts,
+                              centers, in_img, nullptr, stream);
+}
+
+int chore_query_fwd_ws(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                       const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                       const void* heads_arena, const float* cam6_host, float* df, float* pca, float* parts,
+                       float* centers, uint8_t* in_img, void* workspace, chore_stream_t stream) {
     CHORE_ENTER(h);
     if (!df && !pca && !parts && !centers) CHORE_FAIL(h, CHORE_EINVAL, "chore_query_fwd: no output asked for");
     QueryArgs a;
@@ -167,6 +180,11 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
     if (nan_check_on()) {
         nan_scan(points, (size_t)B * N * 3, 0, (hipStream_t)stream);
         if (dtype == CHORE_F32) { nan_scan((const float*)feat, (size_t)B * FH * FW * 256, 5, (hipStream_t)stream); nan_scan((const float*)tmpx, (size_t)B * TH * TW * 64, 6, (hipStream_t)stream); }
+    }
+    // sorted order: asked for by passing a workspace; large queries on the fp16 x 3 split kernel (the only one that reads QueryArgs::perm)
+    if (workspace && x3 && N >= 8192 && !getenv("CHORE_QUERY_X3_NOSPLIT") && query_sort_covers(a)) {
+        if ((rc = launch_query_sort(h, a, (int*)workspace, (hipStream_t)stream))) return rc;
+        a.perm = (const int*)workspace;
     }
     rc = x3 ? launch_query_fwd_x3(h, dtype, a, (hipStream_t)stream)
             : (dtype == CHORE_F32 ? launch_query_fwd_f32(h, a, (hipStream_t)stream) : launch_query_fwd_f32_bf16maps(h, a, (hipStream_t)stream));

@@ -176,6 +176,7 @@ struct QueryArgs {
     float fx, fy, cx, cy, half_crop, crop;
     float* out[HEAD_NUM];  // df, parts, pca, centers
     uint8_t* in_img;
+    const int* perm = nullptr;   // [B][N] forward in sorted order (chore_query_fwd_ws): tile slot i of image b holds point perm[b][i]
     // backward only
     const float* g[HEAD_NUM];
     float* dpoints;
@@ -205,3 +206,8 @@ int launch_query_bwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipSt
 int launch_query_fwd_train(chore_handle* h, int dtype, const QueryArgs& a, hipStream_t s, int x3 = 0);
 int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX, float* dfeat, float* dtmpx,
                             int accumulate, hipStream_t s);
+// the points of every image ordered by the 8 x 8-texel tile of the feature map their sample falls into: perm [B][N] at the
+// start of `work` (B x query_sort_ints(N) ints in all: the permutations, then the images' sort regions); false = shape not covered
+__host__ __device__ static inline size_t query_sort_ints(int N) { return (size_t)N + scatter_sort_ints(N); }
+bool query_sort_covers(const QueryArgs& a);
+int launch_query_sort(chore_handle* h, const QueryArgs& a, int* work, hipStream_t s);

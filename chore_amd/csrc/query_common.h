@@ -139,6 +139,7 @@ struct PtTableT {
     float tw[4][PTS];
     int in_img[PTS];
     int valid[PTS];
+    int pidx[PTS];       // index of the point inside its image (= tile slot unless the query runs in sorted order, QueryArgs::perm)
     // backward only: fractional tap coordinates (w, n) of both maps and the raw depth
     float ffrac[2][PTS];
     float tfrac[2][PTS];
@@ -147,13 +148,16 @@ struct PtTableT {
 using PtTable = PtTableT<QT_PTS>;
 
 // thread `t` (< PTS) fills entry t of the table
+// slot n of the tile order holds point `perm[n]` of the image when a permutation is given (queries in sorted order)
 template <typename Tab>
 __device__ __forceinline__ void fill_pt_table(Tab& tab, int t, const float* points,
                                               const float* crop_center, int b, int n, int N,
                                               const Cam& cam, int FH, int FW, int TH, int TW,
-                                              float* nxy_out /* optional [2] */) {
+                                              float* nxy_out /* optional [2] */, const int* perm = nullptr) {
     const bool valid = n < N;
-    const int nn = valid ? n : (N - 1);
+    const int slot = valid ? n : (N - 1);
+    const int nn = perm ? perm[(size_t)b * N + slot] : slot;
+    tab.pidx[t] = nn;
     const float* p = points + ((size_t)b * N + nn) * 3;
     const float x = p[0], y = p[1], z = p[2];
     float nx, ny;

@@ -316,8 +316,8 @@ __global__ __launch_bounds__(512, 1) void query_fwd_x3_split_kernel(QueryArgs a)
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
     QSTAMP(0);
     if (tid < PTS) {
-        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW, nullptr);
-        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + n0 + tid] = (uint8_t)sm.tab.in_img[tid];
+        fill_pt_table(sm.tab, tid, a.points, a.crop_center, b, n0 + tid, a.N, cam, a.FH, a.FW, a.TH, a.TW, nullptr, a.perm);
+        if (a.in_img && n0 + tid < a.N) a.in_img[(size_t)b * a.N + sm.tab.pidx[tid]] = (uint8_t)sm.tab.in_img[tid];
     }
     __syncthreads();
     QSTAMP(1);
@@ -465,12 +465,12 @@ __global__ __launch_bounds__(512, 1) void query_fwd_x3_split_kernel(QueryArgs a)
     }
     const int odim = head_out_dim(head);
     float* outp = a.out[head] + (size_t)b * odim * a.N;
-    const int pt = cb_o * 32 + col, n = n0 + pt;
+    const int pt = cb_o * 32 + col, n = sm.tab.pidx[pt];        // (sorted order: the outputs go back to the point's own column)
     const bool inside = sm.tab.in_img[pt] != 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int chn = mfma32_row(r, half);
-        if (chn < odim && n < a.N) {
+        if (chn < odim && n0 + pt < a.N) {
             float v = o[r] * QX_INV;
             if (head == 0 && !inside) v = 5.0f;
             outp[(size_t)chn * a.N + n] = v;

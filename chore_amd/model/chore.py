@@ -60,10 +60,14 @@ class _QueryFn(torch.autograd.Function):
         parts = torch.empty(B, 14, N, device=dev, dtype=torch.float32)
         centers = torch.empty(B, 6, N, device=dev, dtype=torch.float32)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        _lib.check(_lib.lib.chore_query_fwd(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
-                                            tp, TH, TW, fwd_dtype, arena.data_ptr(), cam6, df.data_ptr(),
-                                            pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), None,
-                                            stream), h, "chore_query_fwd")
+        # CHORE_QUERY_SORTED=1: a workspace for the sorted-order gather of large queries (chore_query_fwd_ws; same results bit for
+        # bit, a third of the gather's bytes, but 25 - 45 us of sorting for 15 - 20 us of gather on one MI355X: off by default)
+        ws = (torch.empty(_lib.lib.chore_query_fwd_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+              if N >= 8192 and os.environ.get("CHORE_QUERY_SORTED") else None)
+        _lib.check(_lib.lib.chore_query_fwd_ws(h, points.data_ptr(), crop_center.data_ptr(), B, N, fp, FH, FW,
+                                               tp, TH, TW, fwd_dtype, arena.data_ptr(), cam6, df.data_ptr(),
+                                               pca.data_ptr(), parts.data_ptr(), centers.data_ptr(), None,
+                                               None if ws is None else ws.data_ptr(), stream), h, "chore_query_fwd_ws")
         ctx.save_for_backward(points, crop_center, feat, tmpx, arena)
         ctx.cam6, ctx.dtype = cam6, fwd_dtype
         ctx.set_materialize_grads(False)      # heads without an upstream gradient arrive as None = NULL for the kernel

@@ -100,6 +100,20 @@ int chore_query_fwd(chore_handle* h, const float* points, const float* crop_cent
                     const void* heads_arena, const float* cam6_host, float* df, float* pca,
                     float* parts, float* centers, uint8_t* in_img, chore_stream_t stream);
 
+/* chore_query_fwd in SORTED ORDER: with a workspace of chore_query_fwd_workspace_bytes(B, N) bytes (NULL = chore_query_fwd) the points of
+ * a large query with the fp16 x 3 heads are first ordered by the 8 x 8-texel tile of the feature map their sample falls into (two
+ * small launches writing a permutation into the workspace) and the tiles of 64 points are formed in that order, so that a tile's
+ * gather (BasePIFuNet.index, model/geometry.py:4-14, called from model/chore.py:134-143) reads a texel row once instead of once per
+ * point: a third of the fetched bytes.  Every point's arithmetic is unchanged and its outputs go to its own column: results are
+ * bit-identical to chore_query_fwd's.  The two extra launches cost more time than the gather saves on one MI355X (DESIGN.md section
+ * 4): the host code passes a workspace only with CHORE_QUERY_SORTED=1.  Shapes the ordering does not cover (fewer than 8 192 points,
+ * feature maps of more than 256 tiles, the native-fp32 heads) run exactly as chore_query_fwd. */
+size_t chore_query_fwd_workspace_bytes(int B, int N);
+int chore_query_fwd_ws(chore_handle* h, const float* points, const float* crop_center, int B, int N,
+                       const void* feat, int FH, int FW, const void* tmpx, int TH, int TW, int dtype,
+                       const void* heads_arena, const float* cam6_host, float* df, float* pca,
+                       float* parts, float* centers, uint8_t* in_img, void* workspace, chore_stream_t stream);
+
 /* Pixel-aligned feature sample without the heads: BasePIFuNet.index (model/BasePIFuNet.py:23 ->
  * model/geometry.py:4-14) on both maps plus z_feat, concatenated as in model/chore.py:139-143.
  *   features (B,N,323) fp32 point-major [feat 0..255 | x y z-2.2 | tmpx 0..63]

@@ -527,3 +527,47 @@ def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypa
     for a, b, name in zip(out["scan"], out["binned"], ("dfeat", "dtmpx")):
         assert torch.isfinite(a).all() and float(a.abs().max()) > 0, name
         assert torch.equal(a, b), (name, int((a != b).sum()))
+
+
+@pytest.mark.parametrize("B,N,spread", [(4, 20000, "uniform"), (2, 9001, "clustered"), (1, 70001, "uniform")])
+def test_sorted_order_forward_equals_the_unsorted_one_bit_for_bit(B, N, spread, opt, monkeypatch):
+    """chore_query_fwd_ws (round 4): the points are ordered by the map tile their sample falls into before the tiles of 64 points
+    are formed (CHORE.query for >= 8 192 points, model/chore.py:107-154).  Every point's arithmetic is untouched and its outputs go
+    to its own column: all four predictions and in_img equal the unsorted forward's (no workspace) BIT FOR BIT -- random
+    points, points piled into one tile, points far outside the image, a point count that is no multiple of anything."""
+    import ctypes
+    from chore_amd import _lib
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    dev = torch.device("cuda", 0)
+    opt.compute_dtype = "fp16x3"
+    net = CHORE(opt).to(dev).eval()
+    synth.load_synth_weights(net, seed=0)
+    rs = np.random.RandomState(N)
+    pts = synth.synth_points(B, N, seed=5)
+    if spread == "clustered":
+        k = int(0.7 * N)
+        pts[:, :k] = pts[:, :1] + rs.standard_normal((B, k, 3)).astype(np.float32) * 0.01
+    pts[:, -5:] = [[40.0, -40.0, 2.0]]
+    points = torch.from_numpy(pts).to(dev)
+    cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev)
+    feat = torch.from_numpy(rs.standard_normal((B, 128, 128, 256)).astype(np.float32)).to(dev)
+    tmpx = torch.from_numpy(rs.standard_normal((B, 256, 256, 64)).astype(np.float32)).to(dev)
+    arena = net._heads_arena(dev)
+    h = _lib.handle(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    ws = torch.empty(_lib.lib.chore_query_fwd_workspace_bytes(B, N), dtype=torch.uint8, device=dev)
+    out = {}
+    for kind in ("unsorted", "sorted"):
+        t = [torch.full((B, c, N), float("nan"), device=dev) for c in (2, 9, 14, 6)]
+        inimg = torch.full((B, N), 7, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.lib.chore_query_fwd_ws(h, points.data_ptr(), cc.data_ptr(), B, N, feat.data_ptr(), 128, 128, tmpx.data_ptr(), 256,
+                                               256, _lib.F16X3, arena.data_ptr(), net._cam6, t[0].data_ptr(), t[1].data_ptr(),
+                                               t[2].data_ptr(), t[3].data_ptr(), inimg.data_ptr(), ws.data_ptr() if kind == "sorted" else None, stream), h, "fwd_ws")
+        torch.cuda.synchronize()
+        out[kind] = t + [inimg]
+    perm = ws.view(torch.int32)[:N].long().cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(N))
+    for a, b, name in zip(out["unsorted"], out["sorted"], ("df", "pca", "parts", "centers", "in_img")):
+        assert torch.isfinite(a.float()).all(), name
+        assert torch.equal(a, b), (name, int((a != b).sum()))
