@@ -39,3 +39,23 @@ def field_errors(preds, golden=None):
         num += (d ** 2).sum(); den += (ref ** 2).sum(); worst = max(worst, d.max()); tot += d.sum(); cnt += d.size
     out["all"] = {"max_abs": float(worst), "mean_abs": float(tot / cnt), "rel_l2": float(np.sqrt(num / den))}
     return out
+
+
+BLOCKS = os.path.join(os.path.dirname(GOLDEN), "config2_blocksums.npz")
+
+
+def block_errors(preds, golden=None):
+    """ALL 4 x 20 000 benchmark points against the reference through block sums: tests/golden/config2_blocksums.npz holds the
+    reference's four predictions summed over consecutive blocks of 32 points (make_golden.py::gen_config2_blocks).  The deviation of a
+    block's MEAN bounds the mean error of its 32 points from below-by-cancellation only -- a systematic error, or a single point
+    off by 32 x the bound, shows.  -> {"max_block_mean_dev", "mean_block_mean_dev", "blocks", "points_covered"}"""
+    g = np.load(golden or BLOCKS)
+    blk, ref = int(g["block"]), g["sums"]
+    B, C, nblk = ref.shape
+    df, pca, parts, centers = [p.detach().float().cpu().numpy().astype(np.float64) for p in preds]
+    N = df.shape[-1]
+    allv = np.concatenate([df, pca.reshape(B, 9, N), parts, centers], 1)
+    got = allv[..., :nblk * blk].reshape(B, C, nblk, blk).sum(-1)
+    d = np.abs(got - ref) / blk
+    return {"max_block_mean_dev": float(d.max()), "mean_block_mean_dev": float(d.mean()), "blocks": int(d.size),
+            "points_covered": int(B * nblk * blk)}

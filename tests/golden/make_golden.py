@@ -206,6 +206,26 @@ def gen_config2(net):
                         centers=centers)
 
 
+def gen_config2_blocks(net):
+    """BASELINE configs[1] on the reference, ALL 4 x 20 000 benchmark points: the four predictions summed over consecutive blocks
+    of 32 points (float64 sums of the reference's float32 values), per image and channel -- 310 KB instead of the 10 MB the values
+    themselves would take.  A block sum bounds the mean error of its 32 points; config2_fields.npz keeps full values for 768 points
+    per image."""
+    B, N, BLK = 4, 20000, 32
+    img = synth.synth_images(B, 512, 512, seed=0)
+    pts = synth.synth_points(B, N, seed=1)
+    cc = np.array([synth.CROP_CENTER] * B, np.float32)
+    with torch.no_grad():
+        net.train(False)
+        net.filter(torch.from_numpy(img))
+        net.query(torch.from_numpy(pts), crop_center=torch.from_numpy(cc))
+        df, pca, parts, centers = [t.numpy() for t in net.get_preds()]
+    allv = np.concatenate([df, pca.reshape(B, 9, N), parts, centers], 1).astype(np.float64)          # (B, 31, N)
+    sums = allv.reshape(B, 31, N // BLK, BLK).sum(-1)
+    np.savez_compressed(os.path.join(HERE, "config2_blocksums.npz"), block=np.int64(BLK), sums=sums.astype(np.float64),
+                        absmax=np.abs(allv).max(-1))
+
+
 def train_batch(seed=21, B=2, N=512):
     """synthetic training batch with the tensor contract of data/ (SURVEY 3.5); shared with the tests"""
     rs = np.random.RandomState(seed)
@@ -918,6 +938,7 @@ def main():
     gen_query(net)
     gen_encoder(net)
     gen_config2(net)
+    gen_config2_blocks(net)
     gen_surface(net)
     gen_smpl()
     gen_fit(net)
