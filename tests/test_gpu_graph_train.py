@@ -151,3 +151,66 @@ def test_queries_beside_the_encoder_equal_the_sequential_forward(monkeypatch):
         assert set(ga) == set(gb) and len(ga) >= 475
         bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
         assert not bad, bad[:5]
+
+
+def test_eval_after_fused_training_sees_the_trained_weights():
+    """The packed encoder / heads caches are keyed on parameter version counters, which a fused optimiser does not advance:
+    CHORE.train() / eval() drop the packs on a mode change (round 4).  After three fused-Adam steps, an eval-mode filter + query of
+    the trained model must equal that of a FRESH model loaded with the trained state_dict, bit for bit."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_ddp_trainstep import _make
+    net, batch = _make(0)
+    net.eval()
+    with torch.no_grad():                       # packs built from the initial weights
+        net.filter(batch["images"])
+        net.query(batch["points"], crop_center=batch["crop_center"])
+        before = [t.clone() for t in net.get_preds()]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True)
+    for _ in range(3):
+        net.train()
+        opt.zero_grad(set_to_none=True)
+        loss, _ = net(**batch)
+        loss.backward()
+        opt.step()
+    net.eval()
+    with torch.no_grad():
+        net.filter(batch["images"])
+        net.query(batch["points"], crop_center=batch["crop_center"])
+        after = [t.clone() for t in net.get_preds()]
+    fresh, _ = _make(0)
+    fresh.load_state_dict(net.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        fresh.filter(batch["images"])
+        fresh.query(batch["points"], crop_center=batch["crop_center"])
+        want = fresh.get_preds()
+    assert not torch.equal(before[0], after[0])
+    for a, b in zip(after, want):
+        assert torch.equal(a, b)
+
+
+def test_flat_grad_reducer_inplace_mode_equals_copy_mode():
+    """FlatGradReducer(mode="inplace") keeps p.grad attached to the arena through the backward (autograd accumulates in place),
+    mode="copy" gathers afterwards: same gradients, bit for bit, also for the parameters the loss does not reach (zeros)."""
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from test_gpu_ddp_trainstep import _make
+    from chore_amd.parallel import FlatGradReducer
+    out = {}
+    for mode in ("copy", "inplace"):
+        net, batch = _make(0)
+        red = FlatGradReducer(net, mode=mode)
+        net.train()
+        red.zero_grad()
+        loss, _ = net(**batch)
+        loss.backward()
+        red.reduce()
+        out[mode] = {n: p.grad.clone() for n, p in net.named_parameters()}
+        assert all(p.grad is not None and p.grad.data_ptr() >= red.arena.data_ptr() for p in net.parameters())
+        del net, red
+        torch.cuda.empty_cache()
+    assert set(out["copy"]) == set(out["inplace"])
+    bad = [n for n in out["copy"] if not torch.equal(out["copy"][n], out["inplace"][n])]
+    assert not bad, bad[:5]
+    assert sum(int(float(g.abs().max()) == 0.0) for g in out["copy"].values()) >= 82      # the bn4 affines without a downsample branch
