@@ -343,22 +343,21 @@ def mode_query(args, ctx):
                     # a queue shared with the first recording's work the two steps run one after the other (5.1 - 5.6 ms per step
                     # over ten candidate streams in one process, scripts/half_batch_probe.py).  Warm-up calibration: a few pairs
                     # per candidate stream, the fastest one is kept.
-                    def pair_ms(s1, n=4):
+                    def round_ms(k, sk, n=4):          # recordings 0 .. k round robin, recording k on candidate stream sk
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
                         for _ in range(n):
-                            graphs[0][0].replay()
-                            with torch.cuda.stream(s1):
-                                graphs[1][0].replay()
+                            for j in range(k + 1):
+                                with torch.cuda.stream(sk if j == k else graphs[j][1]):
+                                    graphs[j][0].replay()
                         torch.cuda.synchronize()
-                        return (time.perf_counter() - t0) / (2 * n)
+                        return (time.perf_counter() - t0) / ((k + 1) * n)
                     for k in range(1, len(graphs)):
                         cands = [graphs[k][1]] + [torch.cuda.Stream(dev) for _ in range(7)]
-                        if k == 1:
-                            for c in cands:
-                                pair_ms(c, 1)
-                            best = min(cands, key=pair_ms)
-                            graphs[k] = (graphs[k][0], best, graphs[k][2])
+                        for c in cands:
+                            round_ms(k, c, 1)
+                        best = min(cands, key=lambda c: round_ms(k, c))
+                        graphs[k] = (graphs[k][0], best, graphs[k][2])
                     run = run_pipelined
                     issue = ("%d recordings of the step (filter + query, own workspace and outputs each) replayed round robin on %d streams: "
                              "%d batches in flight; static input buffers" % (len(graphs), len(graphs), len(graphs)))
