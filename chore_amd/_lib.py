@@ -91,11 +91,13 @@ SIGNATURES = {
                                   c_void_p]),
     "chore_conv2d_fwd": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "chore_amax_bytes": (c_size_t, []),
+    "chore_absmax_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "chore_conv2d_bwd_data": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
-                                      c_void_p, c_void_p, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "chore_conv2d_bwd_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
-                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                        c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_convblock_saved_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "chore_convblock_out_stats_offset": (c_size_t, [c_int]),
     "chore_convblock_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int, c_int]),

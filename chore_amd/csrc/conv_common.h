@@ -41,8 +41,10 @@ __device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* 
 }
 
 // fp16 x 3 staging: 8 fp32 channels (two vectors) -> GroupNorm + ReLU -> fp16 hi and lo vectors
+// `mul` (a power of two; 1 leaves every value as it is): the operand scale of a gradient input (ConvArgs::in_amax), applied when
+// no GroupNorm is fused
 __device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
-                                         u32x4& lo) {
+                                         u32x4& lo, float mul = 1.f) {
     float t[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { t[j] = __uint_as_float(r0[j]); t[4 + j] = __uint_as_float(r1[j]); }
@@ -52,6 +54,9 @@ __device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const
             const float y = fmaf(t[j], sc[j], sh[j]);
             t[j] = y > 0.f ? y : 0.f;
         }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] *= mul;
     }
     f16x8_t h, l;
 #pragma unroll

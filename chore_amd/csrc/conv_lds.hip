@@ -93,6 +93,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid % WAVES_N, wm = wid / WAVES_N;
     const int tiles_x = (a.W + TW - 1) / TW;
+    float in_mul = 1.f, in_inv = 1.f;                    // operand scale of a gradient input (ConvArgs::in_amax)
+    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
     // XCD-aware placement: the dispatcher puts workgroup id on XCD id % 8 (each XCD has its own L2).  The logical order is
     // (image, pixel tile, channel tile) with the channel tile fastest, and every XCD takes a CONTIGUOUS range of it: the
     // channel tiles of one pixel tile -- which read the same halo patch -- and neighbouring pixel tiles share an L2
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 u32x4 val = {0u, 0u, 0u, 0u};
                 if constexpr (X3) {
                     u32x4 lo = {0u, 0u, 0u, 0u};
-                    if (row_off[j] >= 0) xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo);
+                    if (row_off[j] >= 0) xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo, in_mul);
                     *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + v * 16) = val;
                     *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + 64 + v * 16) = lo;
                 } else {
@@ -319,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     if (DBG(a) & 8) return;
 
     // ---- epilogue (the loop ended with a barrier: patch and ring are dead, reuse them) ----
-    constexpr float ASCALE = X3 ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;   // undoes the weight scaling of the fp16 x 3 packing
+    const float ASCALE = X3 ? in_inv / (float)(1 << X3_WSHIFT) : 1.0f;     // undoes the weight scaling of the fp16 x 3 packing (and the operand scale)
     float* scr = (float*)smem + wid * (32 * SCR_LD);          // wave-private [32 pixels][SCR_LD]
     float* red = (float*)smem + 4 * 32 * SCR_LD;              // [4][WAVES_M][NT]
     constexpr int CW = NBW * 32;                              // channels of this wave
@@ -567,7 +569,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     // CHORE_CONV_PP=1: the persistent variant (conv_pp.hip) where a layer has at least two tiles per CU.  Measured slower than
     // conv_pc_kernel on every layer of the encoder (profiles/r04_conv_pp.txt): opt-in, for A/B runs and tests.
     static const bool use_pp = getenv("CHORE_CONV_PP") != nullptr;
-    if (use_pp && (dtype == CHORE_F16X3 || dtype == CHORE_F16) && !a_in.res2.p && conv_use_pc()) {
+    if (use_pp && (dtype == CHORE_F16X3 || dtype == CHORE_F16) && !a_in.res2.p && !a_in.in_amax && conv_use_pc()) {
         const PpPlan qq = conv_pp_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
         if (qq.th) return launch_conv_pp(h, dtype, taps, qq, a_in, s);
     }
@@ -668,6 +670,11 @@ __global__ void pack_conv_multi_kernel(PackJobs j) {
         }
         blk -= j.job[k].blocks;
     }
+    const unsigned zb = (unsigned)((j.zero_vecs + 255) / 256);
+    if (blk >= zb) {                                        // the last AMAX_CELLS workgroups: max |x| of j.amax_x
+        absmax_block(j.amax_x, j.amax_n4, j.amax_cells, blk - zb);
+        return;
+    }
     const size_t i = (size_t)blk * 256 + threadIdx.x;      // the clear region, 16 bytes per thread
     const u32x4 z = {0u, 0u, 0u, 0u};
     if (i < j.zero_vecs) ((u32x4*)j.zero)[i] = z;
@@ -681,6 +688,7 @@ int launch_pack_conv_multi(chore_handle* h, int dtype, PackJobs& j, hipStream_t 
         blocks += j.job[k].blocks;
     }
     blocks += (unsigned)((j.zero_vecs + 255) / 256);
+    if (j.amax_x) blocks += AMAX_CELLS;
     if (!blocks) return CHORE_OK;
     if (dtype == CHORE_F16X3 || dtype == CHORE_F16) hipLaunchKernelGGL(pack_conv_multi_kernel<x3_t>, dim3(blocks), dim3(256), 0, s, j);
     else if (dtype == CHORE_F32) hipLaunchKernelGGL(pack_conv_multi_kernel<float>, dim3(blocks), dim3(256), 0, s, j);

@@ -128,6 +128,8 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float in_mul = 1.f, in_inv = 1.f;                    // operand scale of a gradient input (training's data-gradient convolutions)
+    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
 #if CHORE_CONV_ABLATE
     // phase stamps of one consumer and one producer wave of the workgroup in the middle of the grid: shader clock and 100 MHz wall clock
     auto stamp = [&](int i) {
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
         char* d = patch + pbuf * PATCHB + row * RB + v * 16;
         if constexpr (X3) {
-            if (off >= 0) xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo);
+            if (off >= 0) xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo, in_mul);
             *(u32x4*)d = hi;
             *(u32x4*)(d + 64) = lo;
         } else {
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     }
 
     // epilogue coordinates (needed early: the residual rows are requested before the main loop ends)
-    constexpr float ASCALE = 1.0f / (float)(1 << X3_WSHIFT);   // undoes the weight scaling of the fp16 x 3 packing
+    const float ASCALE = in_inv / (float)(1 << X3_WSHIFT);      // undoes the weight scaling of the fp16 x 3 packing (and the operand scale)
     const int g8 = tid % G8;
     const int nv = n_tile * NT + g8 * 8;                        // this thread's 8 channels
     const size_t img = (size_t)b * a.H * a.W;

@@ -87,6 +87,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     const int y = (t % rgs) * ROWS, b = t / rgs;            // first row of this workgroup
     const int x0 = seg * 32;
     const bool use_gn = a.in_st != nullptr;
+    float in_mul = 1.f, in_inv = 1.f;                       // operand scale of a gradient input (ConvArgs::in_amax)
+    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
 
     // ---- stage the patch: all loads first, the affine while they fly ----
     const ST* in_b = (const ST*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
@@ -139,6 +141,10 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
                 }
             }
             if constexpr (X3) {
+                if (!use_gn) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] *= in_mul;
+                }
                 f16x8_t h, l;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) { h[k] = (_Float16)f[k]; l[k] = (_Float16)(f[k] - (float)h[k]); }
@@ -220,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wid * 32 + mfma32_row(r, half)) * RED_LD + px] = acc[r];
     __syncthreads();
-    constexpr float ASCALE = WLO ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f;
+    const float ASCALE = WLO ? in_inv / (float)(1 << X3_WSHIFT) : 1.0f;
     const int p = tid >> 3, g4 = (tid & 7) * 4;              // this thread: pixel p, channels g4 .. g4+3 of the tile
     const int cg = n_tile * 32 + g4;
     const bool want_stats = a.st_raw || a.st_out;

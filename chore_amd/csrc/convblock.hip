@@ -24,10 +24,10 @@ struct Dims {
 };
 
 bool make_dims(Dims& d, int dtype, int B, int H, int W, int Cin, int Cout) {
-    if ((dtype != CHORE_F32 && dtype != CHORE_BF16) || B <= 0 || H <= 0 || W <= 0) return false;
+    if ((dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) || B <= 0 || H <= 0 || W <= 0) return false;
     if (Cout % 128 || Cin % 32 || Cin > 256 || Cout > 256) return false;      // slices of Cout/4 channels, whole groups
     d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.Cout = Cout; d.C1 = Cout / 2; d.C2 = Cout / 4;
-    d.px = (size_t)B * H * W; d.es = dtype == CHORE_F32 ? 4 : 2; d.nb = act_stats_bytes(B);
+    d.px = (size_t)B * H * W; d.es = dtype == CHORE_BF16 ? 2 : 4; d.nb = act_stats_bytes(B);
     d.down = Cin != Cout;
     return true;
 }
@@ -72,6 +72,7 @@ int side_stream(chore_handle* h) {
 View mkview(const void* p, int cs, int co, int C) { View v; v.p = const_cast<void*>(p); v.cs = cs; v.co = co; v.C = C; return v; }
 
 size_t gn_acc_bytes(int B, int C) { return chore_gn_relu_bwd_workspace_bytes(B, C); }   // two tables of cells (enc_common.h)
+constexpr size_t AMAX_BYTES = AMAX_CELLS * sizeof(unsigned);      // range cells of one gradient tensor (fp16 x 3 mode)
 
 }  // namespace
 
@@ -89,7 +90,7 @@ size_t chore_convblock_workspace_bytes(int dtype, int B, int H, int W, int Cin, 
     Dims d;
     if (!make_dims(d, dtype, B, H, W, Cin, Cout)) return 0;
     const size_t fwd = pack_layout(d, dtype, 0, false).end;
-    size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, d.C1) + gn_acc_bytes(B, d.C2));
+    size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, d.C1) + gn_acc_bytes(B, d.C2) + 2 * AMAX_BYTES) + AMAX_BYTES;
     o = pack_layout(d, dtype, o, true).end;
     // the four weight gradients keep their shares' partials until ONE launch sums all of them: a region each
     o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, d.C1)) + al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, d.C1, d.C2)) +
@@ -134,7 +135,7 @@ int chore_convblock_fwd(chore_handle* h, int dtype, const void* x, const void* x
     }
     const GroupStat* sx = (const GroupStat*)x_stats;
     if (!sx) {
-        if ((rc = launch_gn_stats(h, dtype, mkview(x, Cin, 0, Cin), B, H * W, (GroupStat*)sv.sx, s))) return rc;
+        if ((rc = launch_gn_stats(h, dtype == CHORE_F16X3 ? CHORE_F32 : dtype, mkview(x, Cin, 0, Cin), B, H * W, (GroupStat*)sv.sx, s))) return rc;
         sx = (const GroupStat*)sv.sx;
     }
     const void* res = x;
@@ -195,10 +196,17 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     const void* sx = x_stats ? x_stats : (const void*)sv.sx;
     const int C1 = d.C1, C2 = d.C2, HW = H * W;
     char* ws = (char*)workspace;
-    // workspace: GroupNorm-backward accumulators (zeroed) | transposed packed weights | wgrad partials | da | d(o2) | d(o1) | dx4
+    // workspace: GroupNorm-backward accumulators, range cells of d(o2), d(o1) (zeroed) | range cells of dy | transposed packed
+    // weights | wgrad partials | da | d(o2) | d(o1) | dx4
     char* acc1 = ws; char* acc4 = acc1 + gn_acc_bytes(B, Cin); char* acc2 = acc4 + gn_acc_bytes(B, Cin); char* acc3 = acc2 + gn_acc_bytes(B, C1);
-    size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, C1) + gn_acc_bytes(B, C2));
+    const bool x3 = dtype == CHORE_F16X3;
+    // fp16 x 3: every gradient tensor that feeds a GEMM carries max |g| (enc_common.h, AMAX_CELLS): of dy from a reduction
+    // that rides in the pack launch below, of d(o2) / d(o1) from the GroupNorm backward that writes them
+    unsigned* amax_o2 = (unsigned*)(acc3 + gn_acc_bytes(B, C2));
+    unsigned* amax_o1 = amax_o2 + AMAX_CELLS;
+    size_t o = al(gn_acc_bytes(B, Cin) * 2 + gn_acc_bytes(B, C1) + gn_acc_bytes(B, C2) + 2 * AMAX_BYTES);
     const size_t zero_bytes = o;
+    unsigned* amax_dy = (unsigned*)(ws + o); o += AMAX_BYTES;      // plain stores: outside the cleared region
     const PackOff pk = pack_layout(d, dtype, o, true);
     o = pk.end;
     char* wpart1 = ws + o; o += al(chore_conv2d_wgrad_workspace_bytes(9, B, H, W, Cin, C1));
@@ -224,9 +232,12 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
         pj.add(w3, ws + pk.w3, 9, C2, C2, 1);
         if (d.down) pj.add(wd, ws + pk.wd, 1, Cout, Cin, 1);
         pj.zero = ws; pj.zero_vecs = zero_bytes / 16;
+        if (x3) { pj.amax_x = (const float*)dy; pj.amax_n4 = d.px * (size_t)Cout / 4; pj.amax_cells = amax_dy; }
         if ((rc = launch_pack_conv_multi(h, dtype, pj, s))) return rc;
     }
-    auto dgrad = [&](int taps, const View& in, const float* w, size_t wpk_off, int cin_fwd, int cout_fwd, void* out) -> int {
+    const int adt = x3 ? CHORE_F32 : dtype;          // the element type of the tensors (what the non-GEMM kernels see)
+    (void)adt;
+    auto dgrad = [&](int taps, const View& in, const float* w, size_t wpk_off, int cin_fwd, int cout_fwd, void* out, const unsigned* amax) -> int {
         // data gradient of a layer Cin_fwd -> Cout_fwd: the forward kernel on the transposed, flipped weights
         (void)w; (void)cout_fwd;
         ConvArgs a{};
@@ -234,6 +245,7 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
         a.wpk = ws + wpk_off;
         a.out = mkview(out, cin_fwd, 0, cin_fwd);
         a.B = B; a.H = H; a.W = W; a.Cout = cin_fwd;
+        a.in_amax = x3 ? amax : nullptr;
         return launch_conv(h, dtype, taps, a, s);
     };
     // Two chains: the data-gradient chain  dgrad3 -> gn3 -> dgrad2 -> gn2 -> [downsample] -> dgrad1 -> gn1  on the
@@ -259,30 +271,34 @@ int chore_convblock_bwd(chore_handle* h, int dtype, const void* x, const void* x
     // data-gradient chain changed queue at each of the three releases, ~10 us per change (profiles/r04_train_graph.txt).
     if ((rc = release(0))) return rc;        // dy, the workspace clear
     // ---- conv3: its output gradient is the last slice of dy ----
-    if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da))) return rc;
+    if ((rc = dgrad(9, mkview(dy, Cout, off3, C2), w3, pk.w3, C2, C2, da, amax_dy))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, sv.o2, sv.s2, gb[4], gb[5], da, B, HW, C2, do2, dg3, db3, acc3, 1,
-                               dyb + (size_t)off2 * d.es, Cout, s))) return rc;          // + the concat's gradient of o2
+                               dyb + (size_t)off2 * d.es, Cout, s, x3 ? amax_o2 : nullptr))) return rc;          // + the concat's gradient of o2
     if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o2, B, H, W, C2, sv.s2, gb[4], gb[5], dyb + (size_t)off3 * d.es, Cout, C2, dw3,
-                                     nullptr, wpart3, s2, &fin))) return rc;
-    if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpartd, s2, &fin)))
+                                     nullptr, wpart3, s2, &fin, x3 ? amax_dy : nullptr))) return rc;
+    if (d.down && (rc = conv2d_bwd_weight_impl(h, dtype, 1, x, B, H, W, Cin, sx, gb[6], gb[7], dy, Cout, Cout, dwd, nullptr, wpartd, s2, &fin,
+                                               x3 ? amax_dy : nullptr)))
         return rc;
     // ---- conv2 ----
     if ((rc = release(1))) return rc;        // d(o2)
-    if ((rc = dgrad(9, mkview(do2, C2, 0, C2), w2, pk.w2, C1, C2, da))) return rc;
-    if ((rc = gn_relu_bwd_impl(h, dtype, sv.o1, sv.s1, gb[2], gb[3], da, B, HW, C1, do1, dg2, db2, acc2, 1, dyb, Cout, s))) return rc;
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart2, s2, &fin))) return rc;
+    if ((rc = dgrad(9, mkview(do2, C2, 0, C2), w2, pk.w2, C1, C2, da, amax_o2))) return rc;
+    if ((rc = gn_relu_bwd_impl(h, dtype, sv.o1, sv.s1, gb[2], gb[3], da, B, HW, C1, do1, dg2, db2, acc2, 1, dyb, Cout, s,
+                               x3 ? amax_o1 : nullptr))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, sv.o1, B, H, W, C1, sv.s1, gb[2], gb[3], do2, C2, C2, dw2, nullptr, wpart2, s2, &fin,
+                                     x3 ? amax_o2 : nullptr))) return rc;
     // ---- conv1 (and the downsample branch): both normalise x ----
     if ((rc = release(2))) return rc;        // d(o1)
     const void* skip = dy;          // identity residual: dy itself flows to x
     int skip_cs = Cout;
     if (d.down) {
-        if ((rc = dgrad(1, mkview(dy, Cout, 0, Cout), wd, pk.wd, Cin, Cout, da))) return rc;
+        if ((rc = dgrad(1, mkview(dy, Cout, 0, Cout), wd, pk.wd, Cin, Cout, da, amax_dy))) return rc;
         if ((rc = gn_relu_bwd_impl(h, dtype, x, sx, gb[6], gb[7], da, B, HW, Cin, dx4, dg4, db4, acc4, 1, nullptr, 0, s))) return rc;
         skip = dx4; skip_cs = Cin;
     }
-    if ((rc = dgrad(9, mkview(do1, C1, 0, C1), w1, pk.w1, Cin, C1, da))) return rc;
+    if ((rc = dgrad(9, mkview(do1, C1, 0, C1), w1, pk.w1, Cin, C1, da, amax_o1))) return rc;
     if ((rc = gn_relu_bwd_impl(h, dtype, x, sx, gb[0], gb[1], da, B, HW, Cin, dx, dg1, db1, acc1, 1, skip, skip_cs, s))) return rc;
-    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart1, s2, &fin))) return rc;
+    if ((rc = conv2d_bwd_weight_impl(h, dtype, 9, x, B, H, W, Cin, sx, gb[0], gb[1], do1, C1, C1, dw1, nullptr, wpart1, s2, &fin,
+                                     x3 ? amax_o1 : nullptr))) return rc;
     if ((rc = launch_wgrad_finish_multi(h, fin, s2))) return rc;
     if (!serial) {                    // join: the caller's stream continues after the weight gradients too
         CHORE_HIP_CHECK(h, hipEventRecord(h->side_ev[3], s2));

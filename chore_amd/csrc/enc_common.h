@@ -91,6 +91,76 @@ __device__ __forceinline__ void gn_scale_shift(const GroupStat* st, int B, int b
     shift = beta[c] - (float)mean * scale;
 }
 
+// ---- range of a gradient tensor (fp16 x 3 training) ------------------------------------------------------------------
+// AMAX_CELLS words, each the float bits of max |x| over a part of the tensor (0 = untouched).  Written either with plain stores
+// (a reduction launch with exactly AMAX_CELLS workgroups) or with integer atomic max into zeroed cells (a producer's epilogue);
+// a reader wave takes the maximum of all cells (4 loads per lane + 6 cross-lane steps, no LDS, no barrier).
+constexpr int AMAX_CELLS = 256;
+#ifdef __HIPCC__
+__device__ __forceinline__ unsigned amax_read(const unsigned* cells) {
+    const int lane = threadIdx.x & 63;
+    unsigned a = cells[lane], b = cells[lane + 64], c = cells[lane + 128], d = cells[lane + 192];
+    a = a > b ? a : b; c = c > d ? c : d;
+    unsigned v = a > c ? a : c;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    return v;
+}
+// power-of-two operand scale `mul` (max |x| * mul in [2^13, 2^14)) and its inverse from the cells; 1, 1 without cells or when the
+// maximum is zero / tiny / not finite
+__device__ __forceinline__ void x3_in_scale(const unsigned* cells, float& mul, float& inv) {
+    mul = 1.f; inv = 1.f;
+    if (!cells) return;
+    const unsigned e = (amax_read(cells) >> 23) & 0xffu;       // biased exponent of max |x|
+    if (e >= 14u && e <= 240u) { mul = __uint_as_float((267u - e) << 23); inv = __uint_as_float((e - 13u) << 23); }
+}
+// block-wide max of the float bits `v` (non-negative floats compare like their bits) -> one atomic max into cells[cell]
+__device__ __forceinline__ void amax_block_atomic(unsigned v, unsigned* cells, int cell, unsigned* lds4 /*[nwaves]*/) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)v, o, 64); v = v > w ? v : w; }
+    const int wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) lds4[wid] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) v = v > lds4[i] ? v : lds4[i];
+        if (v) (void)__hip_atomic_fetch_max(&cells[cell], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the work of workgroup `blk` (of AMAX_CELLS, 256 threads) of a max-|x| reduction over n4 16-byte vectors: eight loads in flight
+// per thread, the workgroup's maximum stored (plain store) into cells[blk]
+__device__ __forceinline__ void absmax_block(const float* __restrict__ x, size_t n4, unsigned* __restrict__ cells, unsigned blk) {
+    __shared__ unsigned amax_red[4];
+    const u32x4* p = (const u32x4*)x;
+    unsigned m = 0u;
+    const size_t stride = (size_t)AMAX_CELLS * 256;
+    size_t i = (size_t)blk * 256 + threadIdx.x;
+    for (; i + 7 * stride < n4; i += 8 * stride) {
+        u32x4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[i + j * stride];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { const unsigned b = v[j][k] & 0x7fffffffu; m = b > m ? b : m; }
+    }
+    for (; i < n4; i += stride) {
+        const u32x4 v = p[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const unsigned b = v[k] & 0x7fffffffu; m = b > m ? b : m; }
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { const unsigned w = (unsigned)__shfl_xor((int)m, o, 64); m = m > w ? m : w; }
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < 4; ++k) m = m > amax_red[k] ? m : amax_red[k];
+        cells[blk] = m;
+    }
+}
+#endif
+// max |x| of n fp32 values (n a multiple of 4, 16-byte aligned) -> AMAX_CELLS cells, plain stores, one launch (enc_misc.hip)
+int launch_absmax_f32(chore_handle* h, const float* x, size_t n, unsigned* cells, hipStream_t s);
+
 struct ConvArgs {
     View in;                 // input activations (a whole tensor when GroupNorm is fused: co = 0, C = cs)
     const GroupStat* in_st;  // [B][32] statistics of the input, or null: no GroupNorm+ReLU prologue
@@ -106,6 +176,11 @@ struct ConvArgs {
     // the tensor `raw` / `out` belong to; *_C = channels of that tensor (group size = C/32), *_co = offset of this slice
     GroupStat* st_raw = nullptr; int st_raw_C = 0, st_raw_co = 0;
     GroupStat* st_out = nullptr; int st_out_C = 0, st_out_co = 0;
+    // fp16 x 3 only: range of the INPUT when it is a gradient (the data-gradient convolutions of training, whose operand has no
+    // GroupNorm in front and any magnitude): AMAX_CELLS partial maxima of |x| as float bits (absmax_* in enc_common.h).  The
+    // kernel multiplies the operand by the power of two that brings the maximum to 2^13 .. 2^14 before the hi / lo split (fp16
+    // keeps 22 bits of a pair only above 2^-3) and the accumulators by its inverse.  NULL: operand taken as is.
+    const unsigned* in_amax = nullptr;
     unsigned long long* dbg_ticks = nullptr;   // CHORE_CONV_ABLATE builds: phase time stamps of workgroup 0 (conv_pc.hip)
     int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
@@ -184,6 +259,7 @@ struct PackJobs {
     struct Job { const float* w; void* dst; int taps, Cin, Cout, transposed; size_t nvec; unsigned blocks; } job[MAXJ];
     int n = 0;
     void* zero = nullptr; size_t zero_vecs = 0;
+    const float* amax_x = nullptr; size_t amax_n4 = 0; unsigned* amax_cells = nullptr;   // optional: max |x| of a tensor (AMAX_CELLS more workgroups)
     void add(const float* w, void* dst, int taps, int Cin, int Cout, int transposed) {
         job[n].w = w; job[n].dst = dst; job[n].taps = taps; job[n].Cin = Cin; job[n].Cout = Cout; job[n].transposed = transposed;
         ++n;
@@ -202,7 +278,8 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Gr
 // train_bwd.hip: the layer backward pieces with channel-strided gradients (what a ConvBlock's concat hands its convs)
 int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                      const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
-                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s);
+                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s, unsigned* amax_out = nullptr);
+// (amax_out: AMAX_CELLS zeroed cells that receive max |dx| -- fp16 x 3 training, the operand range of the GEMMs that read dx)
 // the ordered sums over the shares' partials of up to four weight gradients, deferred into one launch (a ConvBlock's)
 struct WgradFinishJobs {
     int n = 0;
@@ -212,7 +289,8 @@ struct WgradFinishJobs {
 // needs its own workspace then)
 int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                            const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
-                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer = nullptr);
+                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer = nullptr,
+                           const unsigned* dy_amax = nullptr);
 int launch_wgrad_finish_multi(chore_handle* h, const WgradFinishJobs& jobs, hipStream_t s);
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,

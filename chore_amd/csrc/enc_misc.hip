@@ -501,6 +501,21 @@ int launch_copy_f32(chore_handle* h, const float* src, float* dst, size_t n, hip
 }
 
 // ------------------------------------------------------------------------------------------------
+// max |x| of a gradient tensor (fp16 x 3 training: the operand scale of the data- and weight-gradient GEMMs, enc_common.h).
+// Exactly AMAX_CELLS workgroups, each strides over the tensor with eight 16-byte loads in flight per thread and stores ITS
+// maximum: plain stores, no zero-initialised cells, order-independent (a maximum is).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absmax_f32_kernel(const float* __restrict__ x, size_t n4, unsigned* __restrict__ cells) {
+    absmax_block(x, n4, cells, blockIdx.x);
+}
+int launch_absmax_f32(chore_handle* h, const float* x, size_t n, unsigned* cells, hipStream_t s) {
+    if (!x || !cells || (n & 3) || ((size_t)x & 15)) CHORE_FAIL(h, CHORE_EINVAL, "absmax: needs a 16-byte aligned tensor of a multiple of 4 floats");
+    hipLaunchKernelGGL(absmax_f32_kernel, dim3(AMAX_CELLS), dim3(256), 0, s, x, n / 4, cells);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward of the bicubic x2 upsampling (align_corners=True, A=-0.75; HGFilters.py:47): d_low = U^T dy.
 // Gather form -- every low-resolution pixel sums the high-resolution pixels whose 4x4 support contains it, with
 // the separable weights recomputed on the fly (border clamping folds several taps onto the edge pixels) -- so there

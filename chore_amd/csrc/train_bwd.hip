@@ -46,6 +46,7 @@ struct WgradArgs {
     float* part;              // [S][Cout/32][Cin/32][TAPS][32][32] partial sums
     float* part_bias;         // [S][Cout] or null
     int S;                    // shares of the pixel tiles
+    const unsigned* dy_amax;  // fp16 x 3 kernels: AMAX_CELLS partial maxima of |dy| (enc_common.h), or null
 };
 
 template <typename T, int TAPS>
@@ -329,6 +330,174 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
     if (a.part_bias && pair % nbc == 0 && tid < 64) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp16 x 3 weight gradient (CHORE_F16X3 training: fp32 tensors, fp32-grade result on the fp16 matrix cores).
+// The structure of wgrad64_kernel -- 64 output x 64 input channels x all taps per workgroup, wave (coh, cih) owns a 32 x 32
+// block over the whole pixel tile, transposing LDS reads -- with BOTH operands split into an fp16 hi and lo plane while they
+// are staged:   dW += dYhi^T Ahi + dYlo^T Ahi + dYhi^T Alo   (three v_mfma_f32_32x32x16_f16 per product, fp32 accumulation;
+// the dropped lo x lo term is 2^-22 relative).  Four planes of [pixel][64 ch] fp16 images: the pixel tile is 4 x 32 instead of
+// 8 x 32 (204 + 128 rows x 2 planes x 160 B = 106 KB).
+// Range: A = relu(groupnorm(x)) is O(1) like in the forward convolution; dY is a gradient of any magnitude and is multiplied by
+// the power of two that puts max |dY| (WgradArgs::dy_amax, from the kernel that produced dY) at 2^13 .. 2^14 before the split --
+// an fp16 pair keeps 22 bits only above 2^-3 -- and the accumulators by its inverse at the end.
+// ------------------------------------------------------------------------------------------------
+constexpr int WX_TH = 4;
+typedef _Float16 tb_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
+    f16_saturate_mode();
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int AW = TW + 2 * PAD, AH = WX_TH + 2 * PAD, AROWS = AH * AW, YROWS = WX_TH * TW;
+    constexpr int NVX = (AROWS * 8 + 255) / 256, NVY = YROWS * 8 / 256;        // 8-channel slots (two 16-byte loads) per thread
+    constexpr int PLA = AROWS * W64_PITCH, PLY = YROWS * W64_PITCH;            // bytes of one plane
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* imgA = smem;                                     // [2 planes][AROWS] x 160 B
+    char* imgY = smem + 2 * PLA;                           // [2 planes][YROWS] x 160 B
+    float* ss = (float*)(imgY + 2 * PLY);                  // [64][2]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, cih = wid & 1, coh = wid >> 1;
+    const int nbo = a.Cout / 64, nbc = a.Cin / 64, npairs = nbo * nbc;
+    int share, pair;
+    {
+        const int L = blockIdx.x;
+        if (a.S % 8 == 0) { const int xcd = L & 7, j = L >> 3; share = (j / npairs) * 8 + xcd; pair = j % npairs; }
+        else { share = L / npairs; pair = L % npairs; }
+    }
+    const int co0 = (pair / nbc) * 64, ci0 = (pair % nbc) * 64;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + WX_TH - 1) / WX_TH;
+    const int tiles = a.B * tiles_x * tiles_y;
+    const bool use_gn = a.st != nullptr;
+    const float* X = (const float*)a.x;
+    const float* DY = (const float*)a.dy;
+    float ymul, yinv;
+    x3_in_scale(a.dy_amax, ymul, yinv);
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    float bias_acc = 0.f;
+    int cur_b = -1;
+    const int h = lane >> 5, g = (lane >> 4) & 1, i16 = lane & 15;
+    const int lane_off = (8 * h + (i16 >> 2)) * W64_PITCH + (g * 16 + (i16 & 3) * 4) * 2;
+    auto frag = [&](const char* p) -> tb_f16x8 {           // p: plane + pixel * pitch + channel * 2 (+ lane_off)
+        const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+        const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(tb_f16x8, v);
+    };
+    // 8 fp32 values -> fp16 hi / lo vectors
+    auto split8 = [](const float (&f)[8], u32x4& hi, u32x4& lo) {
+        tb_f16x8 hh, ll;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { hh[j] = (_Float16)f[j]; ll[j] = (_Float16)(f[j] - (float)hh[j]); }
+        hi = __builtin_bit_cast(u32x4, hh);
+        lo = __builtin_bit_cast(u32x4, ll);
+    };
+
+    for (int tile = share; tile < tiles; tile += a.S) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        const int ty0 = (tt / tiles_x) * WX_TH, tx0 = (tt % tiles_x) * TW;
+        __syncthreads();                                   // previous tile fully consumed
+        if (use_gn && b != cur_b) {
+            if (tid < 64) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            __syncthreads();
+        }
+        cur_b = b;
+        // ---- all loads of both tiles in flight, then the splits and the LDS stores ----
+        u32x4 vy[NVY][2], vx[NVX][2];
+#pragma unroll
+        for (int q = 0; q < NVY; ++q) {
+            const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+            const int y = min(ty0 + row / TW, a.H - 1), x = min(tx0 + row % TW, a.W - 1);
+            const u32x4* p = (const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.ys + co0 + v * 8);
+            vy[q][0] = p[0]; vy[q][1] = p[1];
+        }
+#pragma unroll
+        for (int q = 0; q < NVX; ++q) {
+            const int i = min(tid + 256 * q, AROWS * 8 - 1), row = i >> 3, v = i & 7;
+            const int y = min(max(ty0 + row / AW - PAD, 0), a.H - 1), x = min(max(tx0 + row % AW - PAD, 0), a.W - 1);
+            const u32x4* p = (const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.xs + ci0 + v * 8);
+            vx[q][0] = p[0]; vx[q][1] = p[1];
+        }
+#pragma unroll
+        for (int q = 0; q < NVY; ++q) {
+            const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vy[q][0][j]) * ymul; f[4 + j] = __uint_as_float(vy[q][1][j]) * ymul; }
+            u32x4 hi, lo;
+            split8(f, hi, lo);
+            if (ty0 + row / TW >= a.H || tx0 + row % TW >= a.W) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
+            *(u32x4*)(imgY + row * W64_PITCH + v * 16) = hi;
+            *(u32x4*)(imgY + PLY + row * W64_PITCH + v * 16) = lo;
+        }
+#pragma unroll
+        for (int q = 0; q < NVX; ++q) {
+            const int i = tid + 256 * q, row = i >> 3, v = i & 7;
+            const int y = ty0 + row / AW - PAD, x = tx0 + row % AW - PAD;
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vx[q][0][j]); f[4 + j] = __uint_as_float(vx[q][1][j]); }
+            if (use_gn) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], ss[2 * (v * 8 + j)], ss[2 * (v * 8 + j) + 1]); f[j] = t > 0.f ? t : 0.f; }
+            }
+            u32x4 hi, lo;
+            split8(f, hi, lo);
+            if (y < 0 || y >= a.H || x < 0 || x >= a.W) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
+            if (i < AROWS * 8) {
+                *(u32x4*)(imgA + row * W64_PITCH + v * 16) = hi;
+                *(u32x4*)(imgA + PLA + row * W64_PITCH + v * 16) = lo;
+            }
+        }
+        __syncthreads();
+        if (a.part_bias && pair % nbc == 0 && tid < 64) {
+            for (int p = 0; p < YROWS; ++p)
+                bias_acc += (float)*(const _Float16*)(imgY + p * W64_PITCH + tid * 2) + (float)*(const _Float16*)(imgY + PLY + p * W64_PITCH + tid * 2);
+        }
+        // ---- MFMAs: small terms first, all three into the same accumulator ----
+        const char* baseY = imgY + lane_off + coh * 64;
+        const char* baseA = imgA + lane_off + cih * 64;
+#pragma unroll 1
+        for (int y = 0; y < WX_TH; ++y) {
+#pragma unroll
+            for (int xb = 0; xb < TW; xb += 16) {
+                const tb_f16x8 fyh = frag(baseY + (y * TW + xb) * W64_PITCH), fyl = frag(baseY + PLY + (y * TW + xb) * W64_PITCH);
+#pragma unroll
+                for (int t = 0; t < TAPS; ++t) {
+                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                    const char* pa = baseA + ((y + ky) * AW + xb + kx) * W64_PITCH;
+                    const tb_f16x8 fxh = frag(pa), fxl = frag(pa + PLA);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl, fxh, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxl, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    // ---- this share's partial: [tap][64 co][64 ci] ----
+    const int col = lane & 31;
+    float* out = a.part + ((size_t)share * npairs + pair) * TAPS * 4096;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            out[(size_t)t * 4096 + (coh * 32 + mfma32_row(r, h)) * 64 + cih * 32 + col] = acc[t][r] * yinv;
+    if (a.part_bias && pair % nbc == 0 && tid < 64) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc * yinv;
+}
+
+static int wgrad64_x3_shares(int B, int H, int W, int Cin, int Cout) {
+    const int tiles = B * ((W + TW - 1) / TW) * ((H + WX_TH - 1) / WX_TH);
+    const int pairs = (Cout / 64) * (Cin / 64);
+    int S = ((256 + pairs - 1) / pairs + 7) / 8 * 8;
+    if (S > tiles) S = tiles;
+    return S;
+}
+
 static int wgrad64_shares(int B, int H, int W, int Cin, int Cout) {
     const int tiles = B * ((W + TW - 1) / TW) * ((H + TH - 1) / TH);
     const int pairs = (Cout / 64) * (Cin / 64);
@@ -337,7 +506,7 @@ static int wgrad64_shares(int B, int H, int W, int Cin, int Cout) {
     return S;
 }
 static bool wgrad_use64(int dtype, int taps, int Cin, int Cout) {
-    return dtype == CHORE_BF16 && (taps == 9 || taps == 1) && Cin % 64 == 0 && Cout % 64 == 0;
+    return (dtype == CHORE_BF16 || dtype == CHORE_F16X3) && (taps == 9 || taps == 1) && Cin % 64 == 0 && Cout % 64 == 0;
 }
 
 // dW (O,C,kh,kw) = sum over the shares, in order
@@ -569,8 +738,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const GroupStat* __restrict__ st, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, int C, int HW, GnBwdAcc acc,
                                                            T* __restrict__ dx, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, const T* __restrict__ extra, int ecs) {
+                                                           float* __restrict__ dbeta, const T* __restrict__ extra, int ecs,
+                                                           unsigned* __restrict__ amax_out) {
     __shared__ float pc[1792];         // [C][7] mean, rstd, gamma, S1/n, S2/n, scale, shift
+    __shared__ unsigned amax_red[4];
+    unsigned amax = 0u;                // max |dx| of this thread (fp16 x 3 training: the next GEMMs' operand scale)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int gs = C / GN_GROUPS;
     if (tid < C) {
@@ -618,7 +790,11 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             for (int j = 0; j < 4; ++j) r[j] += e4[j];
         }
         Vec4<T>::st(dx + o, r);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const unsigned bts = __float_as_uint(r[j]) & 0x7fffffffu; amax = bts > amax ? bts : amax; }
     }
+    if (amax_out)      // uniform.  One atomic max per workgroup into one of AMAX_CELLS zeroed cells
+        amax_block_atomic(amax, amax_out, (int)((blockIdx.y * gridDim.x + blockIdx.x) % AMAX_CELLS), amax_red);
 }
 
 }  // namespace
@@ -640,7 +816,8 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
     const int S = wgrad_shares(B, H, W, Cin, Cout);
     size_t n = (size_t)S * (Cout / 32) * (Cin / 32) * taps * 1024 + (size_t)S * Cout;
     if (wgrad_use64(CHORE_BF16, taps, Cin, Cout)) {       // the bf16 path of these shapes uses 64-channel tiles
-        const int S64 = wgrad64_shares(B, H, W, Cin, Cout);
+        const int Sb = wgrad64_shares(B, H, W, Cin, Cout), Sx = wgrad64_x3_shares(B, H, W, Cin, Cout);
+        const int S64 = Sb > Sx ? Sb : Sx;
         const size_t n64 = (size_t)S64 * (Cout / 64) * (Cin / 64) * taps * 4096 + (size_t)S64 * Cout;
         if (n64 > n) n = n64;
     }
@@ -652,7 +829,8 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
 // extra (or null): (B,HW,*) with channel stride extra_cs, already offset to its first channel -- added to dx
 int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma, const float* beta,
                      const void* da, int B, int HW, int C, void* dx, float* dgamma, float* dbeta, void* workspace,
-                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s) {
+                     int workspace_zeroed, const void* extra, int extra_cs, hipStream_t s, unsigned* amax_out) {
+    if (dtype == CHORE_F16X3) dtype = CHORE_F32;        // fp32 tensors; only the convolutions differ
     if (!x || !stats || !gamma || !beta || !da || !dx || !dgamma || !dbeta || !workspace)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: null argument");
     if (C % GN_GROUPS || C > 256 || C < 32 || 256 % (C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "chore_gn_relu_bwd: unsupported C=%d", C);
@@ -672,13 +850,13 @@ int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stat
                            (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(blocks, B), dim3(256), 0, s, (const float*)x, (const float*)da,
                            (const GroupStat*)stats, gamma, beta, C, HW, acc, (float*)dx, dgamma, dbeta, (const float*)extra,
-                           extra_cs);
+                           extra_cs, amax_out);
     } else {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(S, B), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)da,
                            (const GroupStat*)stats, gamma, beta, C, HW, S, acc);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(blocks, B), dim3(256), 0, s, (const bf16_t*)x,
                            (const bf16_t*)da, (const GroupStat*)stats, gamma, beta, C, HW, acc, (bf16_t*)dx, dgamma, dbeta,
-                           (const bf16_t*)extra, extra_cs);
+                           (const bf16_t*)extra, extra_cs, amax_out);
     }
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
@@ -687,13 +865,15 @@ int gn_relu_bwd_impl(chore_handle* h, int dtype, const void* x, const void* stat
 // the weight gradient with a channel-strided dy (dy_stride = channels of the tensor dy is a slice of; dy already offset)
 int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                            const void* stats, const float* gamma, const float* beta, const void* dy, int dy_stride, int Cout,
-                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer) {
+                           float* dw, float* dbias, void* workspace, hipStream_t s, WgradFinishJobs* defer, const unsigned* dy_amax) {
     if (!x || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: null argument");
+    if (dtype == CHORE_F16X3 && !dy_amax) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: the fp16 x 3 mode needs the range of dy (dy_amax)");
     if (defer && defer->n >= 4) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: more than four deferred sums");
     if ((taps != 1 && taps != 9) || Cin % 32 || Cout % 32 || Cin > 256)
         CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: unsupported taps=%d Cin=%d Cout=%d", taps, Cin, Cout);
-    if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
+    if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
     WgradArgs a;
+    a.dy_amax = dy_amax;
     a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.xs = Cin; a.ys = dy_stride; a.npix = (long long)B * H * W;
@@ -701,9 +881,30 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
     int ct = 32;
     if (wgrad_use64(dtype, taps, Cin, Cout)) {
         ct = 64;
-        a.S = wgrad64_shares(B, H, W, Cin, Cout);
+        const bool x3 = dtype == CHORE_F16X3;
+        a.S = x3 ? wgrad64_x3_shares(B, H, W, Cin, Cout) : wgrad64_shares(B, H, W, Cin, Cout);
         const int npairs = (Cout / 64) * (Cin / 64);
         a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
+        if (x3) {
+            const size_t smx = (size_t)2 * ((taps == 9 ? (WX_TH + 2) * PW : WX_TH * TW) + WX_TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
+            bool& attrx = CHORE_ONCE_FLAG(h);
+            if (!attrx) {
+                CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_x3_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((size_t)2 * ((WX_TH + 2) * PW + WX_TH * TW) * W64_PITCH + 512)));
+                CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((size_t)2 * (2 * WX_TH * TW) * W64_PITCH + 512)));
+                attrx = true;
+            }
+            if (taps == 9) hipLaunchKernelGGL(wgrad64_x3_kernel<9>, dim3(a.S * npairs), dim3(256), smx, s, a);
+            else hipLaunchKernelGGL(wgrad64_x3_kernel<1>, dim3(a.S * npairs), dim3(256), smx, s, a);
+            CHORE_LAUNCH_CHECK(h, s);
+            if (defer) { defer->j[defer->n++] = {a.part, a.part_bias, dw, dbias, a.S, Cout, Cin, taps, ct}; return CHORE_OK; }
+            const size_t n = (size_t)Cout * Cin * taps;
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
+                               Cin, taps, dw, dbias, ct);
+            CHORE_LAUNCH_CHECK(h, s);
+            return CHORE_OK;
+        }
         const size_t smem64 = (size_t)((taps == 9 ? PH * PW : TH * TW) + TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
         bool& attr64 = CHORE_ONCE_FLAG(h);
         if (!attr64) {
@@ -723,6 +924,7 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
         CHORE_LAUNCH_CHECK(h, s);
         return CHORE_OK;
     }
+    if (dtype == CHORE_F16X3) dtype = CHORE_F32;      // channel counts below 64 (the 256^2 block): the exact fp32 matrix-core kernel
     a.S = wgrad_shares(B, H, W, Cin, Cout);
     a.part_bias = dbias ? a.part + (size_t)a.S * (Cout / 32) * (Cin / 32) * taps * 1024 : nullptr;
     const size_t es = dtype == CHORE_F32 ? 4 : 2;
@@ -768,10 +970,10 @@ extern "C" {
 // dw (Cout,Cin,k,k) fp32 and dbias (Cout, or NULL) of y = conv(a) + bias, a = relu(groupnorm(x)) if stats else x
 int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                             const void* stats, const float* gamma, const float* beta, const void* dy, int Cout, float* dw,
-                            float* dbias, void* workspace, chore_stream_t stream) {
+                            float* dbias, void* workspace, const void* dy_amax, chore_stream_t stream) {
     CHORE_ENTER(h);
     return conv2d_bwd_weight_impl(h, dtype, taps, x, B, H, W, Cin, stats, gamma, beta, dy, Cout, Cout, dw, dbias, workspace,
-                                  (hipStream_t)stream);
+                                  (hipStream_t)stream, nullptr, (const unsigned*)dy_amax);
 }
 
 // C (M x N, fp32, row-major) = A^T B for row-major A (P x M, row stride lda) and B (P x N, row stride ldb), fp32, exact
@@ -830,6 +1032,7 @@ int chore_stem_bwd_weight(chore_handle* h, int dtype, const float* images, int B
     if (!images || !dy || !dw || !workspace) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: null argument");
     if (B <= 0 || Cin <= 0 || Cin > SW_MAXC || H <= 0 || W <= 0 || (H & 1) || (W & 1))
         CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: Cin <= %d and even H, W (Cin=%d H=%d W=%d)", SW_MAXC, Cin, H, W);
+    if (dtype == CHORE_F16X3) dtype = CHORE_F32;        // fp32 tensors; the stem is plain fp32 arithmetic in every mode
     if (dtype != CHORE_F32 && dtype != CHORE_BF16) CHORE_FAIL(h, CHORE_EINVAL, "chore_stem_bwd_weight: dtype");
     hipStream_t s = (hipStream_t)stream;
     const int S = stem_wgrad_shares(B, H, W);
@@ -854,7 +1057,7 @@ int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* sta
                       int workspace_zeroed, chore_stream_t stream) {
     CHORE_ENTER(h);
     return gn_relu_bwd_impl(h, dtype, x, stats, gamma, beta, da, B, HW, C, dx, dgamma, dbeta, workspace, workspace_zeroed,
-                            nullptr, 0, (hipStream_t)stream);
+                            nullptr, 0, (hipStream_t)stream, nullptr);
 }
 
 }  // extern "C"

@@ -323,7 +323,8 @@ class CHORE(nn.Module):
     def _heads_arena(self, device):
         params = self._head_params()
         key = (str(device),) + tuple((p.data_ptr(), p._version) for p in params)
-        if self._heads_packed is not None and self._heads_packed[0] == key:
+        # heads with requires_grad=True never hit the cache (any entry point, any grad mode): see query()
+        if self._heads_packed is not None and self._heads_packed[0] == key and not any(p.requires_grad for p in params):
             return self._heads_packed[1]
         dtype = _QDT[self.compute_dtype]
         h = _lib.handle(device.index or 0)
@@ -346,8 +347,8 @@ class CHORE(nn.Module):
         """drop the packed copies of the head and encoder weights.  The caches are keyed on (address, version) of every
         parameter, which sees in-place tensor operations, load_state_dict and .to(); a write through `p.data`, the fused
         optimiser kernels (torch.optim.Adam(fused=True) does not advance the version counters) and a replayed hipGraph are
-        invisible to it -- call this after one.  train() / eval() do it when the mode changes, and a query with trainable heads
-        never uses the cache."""
+        invisible to it -- call this after one.  train() / eval() do it when the mode changes, and a query whose heads have
+        requires_grad=True never uses the cache, whatever the grad mode (frozen heads -- inference, fitting -- do)."""
         self._head_param_list = None
         self._heads_packed = None
         self.image_filter.invalidate_packed()
@@ -376,10 +377,10 @@ class CHORE(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.image_filter.parameters()):
             # training: the layer-by-layer differentiable forward (model/hgfilter_train.py)
             from .hgfilter_train import forward_train
-            if self.compute_dtype in ("fp16x3", "fp16"):
-                raise NotImplementedError("compute_dtype '%s' is an inference mode (train in 'fp32' or 'bf16')" % self.compute_dtype)
-            tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
-            feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt)
+            if self.compute_dtype == "fp16":
+                raise NotImplementedError("compute_dtype 'fp16' is an inference mode (train in 'fp32', 'fp16x3' or 'bf16')")
+            tdt = torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+            feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt, x3=self.compute_dtype == "fp16x3")
             feats = feats[-n_out:]
         else:
             feats, self.tmpx, self.normx = self.image_filter(images, _DT[self.compute_dtype], n_out)
@@ -408,9 +409,10 @@ class CHORE(nn.Module):
         heads_trainable = any(p.requires_grad for p in head_params)
         train = torch.is_grad_enabled() and (heads_trainable or self.tmpx.requires_grad or
                                              any(f.requires_grad for f in self.im_feat_list))
-        if train and heads_trainable:
-            # heads that are being trained are packed afresh for every query: the cache key (address, version counter) does not
-            # see every optimiser -- torch's fused Adam / AdamW / SGD kernels update the parameters without advancing `_version`
+        if heads_trainable:
+            # heads that are being trained are packed afresh for every query -- under torch.no_grad() too (a validation pass
+            # between training steps that never called eval()): the cache key (address, version counter) does not see every
+            # optimiser -- torch's fused Adam / AdamW / SGD kernels update the parameters without advancing `_version`
             self._heads_packed = None
         arena = self._heads_arena(points.device)
         if train and self.compute_dtype == "fp16":
@@ -551,7 +553,7 @@ class CHORE(nn.Module):
     # ---- training forward with the field queries beside the encoder ---------------------------------------------------------
     def _interleaved_ok(self, images, points, df_h, crop_center):
         return (self.training and torch.is_grad_enabled() and images.is_cuda and points.is_cuda and df_h.is_cuda
-                and crop_center is not None and self.compute_dtype in ("fp32", "bf16") and points.dim() == 3
+                and crop_center is not None and self.compute_dtype in ("fp32", "bf16", "fp16x3") and points.dim() == 3
                 and points.shape[1] > 0 and not os.environ.get("CHORE_TRAIN_NO_INTERLEAVE")
                 and not os.environ.get("CHORE_TORCH_LOSS")
                 and any(p.requires_grad for p in self.image_filter.parameters()))
@@ -599,8 +601,9 @@ class CHORE(nn.Module):
             B, _, N = df.shape
             preds.append((df, pca.view(B, 3, 3, N), parts, centers))
 
-        tdt = torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
-        feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt, on_stack=on_stack)
+        tdt = torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+        feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt, on_stack=on_stack,
+                                                     x3=self.compute_dtype == "fp16x3")
         main.wait_stream(side)
         self.im_feat_list = feats
         self.intermediate_preds_list = preds

@@ -50,12 +50,13 @@ def hourglass(m, level, x, xs=None):
     return ops.upadd(up1, low3, True)
 
 
-def forward_train(enc, images, tdt, on_stack=None):
-    """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype.
+def forward_train(enc, images, tdt, on_stack=None, x3=False):
+    """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype; x3 (with fp32
+    activations): the convolutions and their gradients on the fp16 matrix cores with split operands (ops.x3_convs).
     Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad.
     on_stack(i, output_i, tmpx): called as soon as stack i's output exists (CHORE.forward launches that stack's field query and
     loss on a second stream from it, so they run beside the next stack's encoder -- forward and backward)."""
-    with ops.zero_arena(images.device):
+    with ops.zero_arena(images.device), ops.x3_convs(x3 and tdt == torch.float32):
         return _forward_train(enc, images, tdt, on_stack)
 
 

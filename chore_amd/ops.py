@@ -16,6 +16,38 @@ import torch
 from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+# fp16 x 3 training ("fp16x3" compute mode): fp32 tensors whose convolutions -- forward, data gradient, weight gradient -- run on
+# the fp16 matrix cores with hi / lo split operands (csrc/conv_pc.hip, train_bwd.hip wgrad64_x3_kernel).  The tensor dtype cannot
+# tell this mode from the exact-fp32 one, so it is a switch the forward pass sets (`with ops.x3_convs():`); every node remembers
+# the dtype word of its forward for its backward, which runs outside the `with`.
+_X3 = False
+
+
+class x3_convs:
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _X3
+        self.prev, _X3 = _X3, self.on
+        return self
+
+    def __exit__(self, *exc):
+        global _X3
+        _X3 = self.prev
+        return False
+
+
+def _conv_dt(dt):
+    """dtype word of the convolution entry points for a tensor of element type dt"""
+    return _lib.F16X3 if (_X3 and dt == _lib.F32) else dt
+
+
+def _absmax(t, dev, h, stream):
+    """the range cells of a gradient tensor (chore_absmax_f32): what the fp16 x 3 data / weight gradient kernels scale it by"""
+    cells = torch.empty(_lib.lib.chore_amax_bytes(), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib.chore_absmax_f32(h, t.data_ptr(), t.numel(), cells.data_ptr(), stream), h, "chore_absmax_f32")
+    return cells
 
 
 def _u8(n, dev):
@@ -151,8 +183,9 @@ class _ConvGN(torch.autograd.Function):
             nb = _lib.lib.chore_gn_stats_bytes(B)
             st_y = _arena.take(nb) if (_arena is not None and _arena.dev == dev) else \
                 torch.zeros(max(nb, 16), dtype=torch.uint8, device=dev)
-        ws = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cin, Cout), dev)
-        _lib.check(_lib.lib.chore_conv2d_fwd(h, dt, taps, x.data_ptr(), B, H, W, Cin, None if st is None else st.data_ptr(),
+        cdt = ctx.cdt = _conv_dt(dt)
+        ws = _u8(_lib.lib.chore_conv2d_workspace_bytes(cdt, taps, Cin, Cout), dev)
+        _lib.check(_lib.lib.chore_conv2d_fwd(h, cdt, taps, x.data_ptr(), B, H, W, Cin, None if st is None else st.data_ptr(),
                                              None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
                                              wf.data_ptr(), None if bf is None else bf.data_ptr(), Cout, y.data_ptr(),
                                              None if st_y is None else st_y.data_ptr(), ws.data_ptr(), stream), h,
@@ -177,18 +210,21 @@ class _ConvGN(torch.autograd.Function):
         dw = torch.empty_like(wf)
         dbias = torch.empty(Cout, device=dev) if ctx.has_bias else None
         ws = _u8(_lib.lib.chore_conv2d_wgrad_workspace_bytes(taps, B, H, W, Cin, Cout), dev)
+        dt = ctx.cdt
+        amax = _absmax(dy, dev, h, stream) if dt == _lib.F16X3 else None
+        ap = None if amax is None else amax.data_ptr()
         _lib.check(_lib.lib.chore_conv2d_bwd_weight(h, dt, taps, x.data_ptr(), B, H, W, Cin,
                                                     None if st is None else st.data_ptr(),
                                                     None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
                                                     dy.data_ptr(), Cout, dw.data_ptr(),
-                                                    None if dbias is None else dbias.data_ptr(), ws.data_ptr(), stream), h,
+                                                    None if dbias is None else dbias.data_ptr(), ws.data_ptr(), ap, stream), h,
                    "chore_conv2d_bwd_weight")
         dx = dg = db = None
         if ctx.needs_input_grad[0] or ctx.has_gn:
             da = torch.empty_like(x)                      # gradient w.r.t. what the convolution saw
             ws2 = _u8(_lib.lib.chore_conv2d_workspace_bytes(dt, taps, Cout, Cin), dev)
             _lib.check(_lib.lib.chore_conv2d_bwd_data(h, dt, taps, dy.data_ptr(), B, H, W, Cout, wf.data_ptr(), Cin,
-                                                      da.data_ptr(), ws2.data_ptr(), stream), h, "chore_conv2d_bwd_data")
+                                                      da.data_ptr(), ws2.data_ptr(), ap, stream), h, "chore_conv2d_bwd_data")
             if ctx.has_gn:
                 dx, dg, db = _gn_relu_bwd(x, st, g, b, da, ctx.acc)
                 ctx.acc = None
@@ -205,6 +241,7 @@ class _ConvBlock(torch.autograd.Function):
     def forward(ctx, x, x_stats, w1, w2, w3, g1, b1, g2, b2, g3, b3, wd, g4, b4):
         import ctypes
         dev, h, dt, stream = _env(x)
+        dt = ctx.cdt = _conv_dt(dt)
         B, H, W, Cin = x.shape
         Cout = w1.shape[0] * 2
         ps = [None if p is None else p.detach().float().contiguous() for p in (w1, w2, w3, wd, g1, b1, g2, b2, g3, b3, g4, b4)]
@@ -236,6 +273,7 @@ class _ConvBlock(torch.autograd.Function):
         else:
             (w1, w2, w3, g1, b1, g2, b2, g3, b3), wd, g4, b4 = ps, None, None, None
         dev, h, dt, stream = _env(x)
+        dt = ctx.cdt
         B, H, W, Cin = x.shape
         Cout = w1.shape[0] * 2
         C1, C2 = Cout // 2, Cout // 4

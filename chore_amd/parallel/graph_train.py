@@ -18,12 +18,29 @@ What differs from the eager sequence: `torch.autograd.set_detect_anomaly(True)` 
 reads every gradient back to the host) and is left out; the loss comes back as a device tensor (`.item()` it when a number is
 needed: the one host synchronisation of the step); the optimiser must be built with `capturable=True`.  The arithmetic is the
 same: tests/test_gpu_graph_train.py compares parameters after replayed steps with eager steps bit for bit.
+
+Hyper-parameters under replay (the reference decays the rate with MultiStepLR(gamma=0.3) and rewrites `g['lr']` when it resumes,
+trainer/trainer.py:56-60,246-257).  A Python-float `lr` would be baked into the recorded Adam launch, so the constructor moves
+every group's `lr` into a one-element fp32 DEVICE tensor, which the capturable Adam kernels read at run time: schedulers fill
+that tensor in place (torch.optim.lr_scheduler does for tensor rates), and a float written over it (`g['lr'] = 3e-5`) is copied
+into the tensor -- and the tensor put back -- at the next call.  The remaining group entries (betas, eps, weight_decay, amsgrad,
+maximize) and the identity of the optimiser's state tensors are compared with what was recorded at every call:
+`optimizer.load_state_dict()` or an edited beta drops the recordings and the step is recorded again.  A rate of 1e-4 held as
+fp32 differs from the Python double by 3e-9 relative.
+
+A recording is made per batch signature (shapes / dtypes / non-tensor arguments): the FIRST call of a new signature runs
+eagerly (per-shape lazy initialisation happens outside any capture), the second one records.  At most `max_recordings` live at
+a time (each holds the step's activations in a private pool: ~10 GB at the configs[3] size); the signatures beyond that -- the
+short last batch of an epoch -- keep running eagerly.
+
+Side effect: `model.losses_on_host` is switched off (the reference returns the six separate losses as a CPU tensor, a host copy
+per step that cannot be recorded); `close()` restores it.
 """
 import torch
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, reducer=None, warmup=3):
+    def __init__(self, model, optimizer, reducer=None, warmup=3, max_recordings=2):
         """model: CHORE (or a wrapper with the same call surface) returning (loss, separate losses); optimizer: a torch
         optimiser over its parameters built with capturable=True; reducer: chore_amd.parallel.FlatGradReducer or None."""
         for g in optimizer.param_groups:
@@ -32,12 +49,47 @@ class GraphedTrainStep:
                                  "the device to be recorded)")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         inner = getattr(model, "module", model)
-        if getattr(inner, "losses_on_host", False):
+        self._losses_on_host_before = getattr(inner, "losses_on_host", None)
+        if self._losses_on_host_before:
             inner.losses_on_host = False      # the reference returns the separate losses as a CPU tensor: a host copy per step
         self.warmup = int(warmup)
+        self.max_recordings = int(max_recordings)
         self.calls = 0
-        self._rec = {}            # shape key -> recording
+        self._rec = {}            # batch signature -> recording
+        self._seen = set()        # signatures that have run eagerly once
         self._side = None
+        # the learning rates as device tensors (see the module docstring)
+        dev = next(model.parameters()).device
+        self._lr = []
+        import os
+        for g in ([] if os.environ.get("CHORE_GRAPH_FLOAT_LR") else optimizer.param_groups):      # (debug switch: keep the float rate)
+            lr = g["lr"]
+            t = lr if (torch.is_tensor(lr) and lr.device == dev) else torch.tensor(float(lr), dtype=torch.float32, device=dev)
+            g["lr"] = t
+            self._lr.append(t)
+        self._hyper = None        # what the live recordings were made with
+
+    def close(self):
+        """drop the recordings (and their memory pools) and give `model.losses_on_host` its old value back"""
+        self._rec.clear()
+        inner = getattr(self.model, "module", self.model)
+        if self._losses_on_host_before is not None:
+            inner.losses_on_host = self._losses_on_host_before
+
+    # ---- optimiser hyper-parameters and state under replay ---------------------------------------------------------------
+    def _sync_lr(self):
+        for g, t in zip(self.optimizer.param_groups, self._lr):
+            lr = g["lr"]
+            if lr is not t:                   # `g['lr'] = value` (the reference's resume path) or a scheduler that assigns
+                t.fill_(float(lr))
+                g["lr"] = t
+
+    def _hyper_key(self):
+        opt = self.optimizer
+        groups = tuple(tuple((k, repr(v)) for k, v in sorted(g.items()) if k not in ("params", "lr")) for g in opt.param_groups)
+        state = tuple((id(p), tuple((k, v.data_ptr()) for k, v in sorted(opt.state[p].items()) if torch.is_tensor(v)))
+                      for g in opt.param_groups for p in g["params"] if p in opt.state)
+        return groups, state
 
     # ---- the step, as the eager sequence --------------------------------------------------------------------------------
     def _zero(self):
@@ -104,13 +156,22 @@ class GraphedTrainStep:
         """one training step on `batch` (keyword arguments of CHORE.forward; tensors on the device).  Returns (loss, separate
         losses) as device tensors that the NEXT call overwrites."""
         self.calls += 1
-        if self.calls <= self.warmup:
+        self._sync_lr()
+        key = self._key(batch)
+        if self.calls <= self.warmup or key not in self._seen:
+            self._seen.add(key)
             self.model.train()
             return self._eager(batch)
-        key = self._key(batch)
+        hyper = self._hyper_key()
+        if self._rec and hyper != self._hyper:
+            self._rec.clear()                 # load_state_dict() / an edited beta: the recorded Adam launch is stale
         rec = self._rec.get(key)
         if rec is None:
+            if len(self._rec) >= self.max_recordings:
+                self.model.train()
+                return self._eager(batch)     # a rare signature beyond the cap stays eager
             rec = self._rec[key] = self._record(batch)
+            self._hyper = self._hyper_key()   # (the first recorded step may have created state tensors)
         for k, v in batch.items():
             if torch.is_tensor(v) and v.data_ptr() != rec["static"][k].data_ptr():
                 rec["static"][k].copy_(v, non_blocking=True)

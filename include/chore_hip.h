@@ -410,7 +410,9 @@ int chore_collision_bwd(chore_handle* h, const float* gverts, const float* gout,
  * F.interpolate(scale 2, bicubic, align_corners=True) + add (HGFilters.py:47-50), and their backward passes.
  * The host (chore_amd/ops.py, model/hgfilter_train.py) wires them into torch.autograd.Function nodes.
  *
- * Activations: NHWC (B,H,W,C), `dtype` = CHORE_F32 or CHORE_BF16.  Parameters and parameter gradients: fp32
+ * Activations: NHWC (B,H,W,C), `dtype` = CHORE_F32, CHORE_BF16 or -- round 5 -- CHORE_F16X3 (fp32 tensors; every convolution,
+ * data gradient and weight gradient on the fp16 matrix cores with hi / lo split operands, fp32-grade: the mode that trains at the
+ * reference's precision, trainer/trainer.py:76-85, at matrix-core speed).  Parameters and parameter gradients: fp32
  * in the reference layouts (weight (Cout,Cin,k,k), bias/gamma/beta (C)).  taps = 1 (1x1) or 9 (3x3, pad 1).
  * C, Cin, Cout multiples of 32.  `stats`: chore_gn_stats_bytes(B) bytes, the exact per-(image, group)
  * sum / sum of squares of x, filled by chore_gn_stats; wherever an operator takes (stats, gamma, beta) != NULL
@@ -421,6 +423,12 @@ int chore_collision_bwd(chore_handle* h, const float* gverts, const float* gout,
  * ------------------------------------------------------------------------------------------- */
 size_t chore_conv2d_workspace_bytes(int dtype, int taps, int Cin, int Cout);
 size_t chore_gn_stats_bytes(int B);
+/* CHORE_F16X3 training: a gradient that feeds a data- or weight-gradient GEMM has any magnitude, while an fp16 hi / lo pair keeps
+ * 22 bits only for |x| in 2^-3 .. 2^16; the kernels therefore scale it by a power of two derived from max |x|, which travels
+ * with the tensor: chore_amax_bytes() bytes of partial maxima (float bits), written by chore_absmax_f32 (n a multiple of 4,
+ * x 16-byte aligned) -- inside chore_convblock_bwd by the kernels that produce the gradients. */
+size_t chore_amax_bytes(void);
+int chore_absmax_f32(chore_handle* h, const float* x, size_t n, void* amax, chore_stream_t stream);
 /* zeroed != 0: `stats` already holds zeros (a slice of an arena cleared once per pass) */
 int chore_gn_stats(chore_handle* h, int dtype, const void* x, int B, int HW, int C, void* stats, int zeroed,
                    chore_stream_t stream);
@@ -432,14 +440,15 @@ int chore_gn_relu_fwd(chore_handle* h, int dtype, const void* x, const void* sta
 int chore_conv2d_fwd(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                      const void* stats, const float* gamma, const float* beta, const float* w, const float* bias,
                      int Cout, void* y, void* out_stats, void* workspace, chore_stream_t stream);
-/* dx (B,H,W,Cin) = gradient w.r.t. the tensor the convolution saw (a) */
+/* dx (B,H,W,Cin) = gradient w.r.t. the tensor the convolution saw (a).  dy_amax: chore_absmax_f32 of dy, required with
+ * CHORE_F16X3 (NULL otherwise); the same for chore_conv2d_bwd_weight */
 int chore_conv2d_bwd_data(chore_handle* h, int dtype, int taps, const void* dy, int B, int H, int W, int Cout,
-                          const float* w, int Cin, void* dx, void* workspace, chore_stream_t stream);
+                          const float* w, int Cin, void* dx, void* workspace, const void* dy_amax, chore_stream_t stream);
 /* dw (Cout,Cin,k,k), dbias (Cout, or NULL) */
 size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin, int Cout);
 int chore_conv2d_bwd_weight(chore_handle* h, int dtype, int taps, const void* x, int B, int H, int W, int Cin,
                             const void* stats, const float* gamma, const float* beta, const void* dy, int Cout,
-                            float* dw, float* dbias, void* workspace, chore_stream_t stream);
+                            float* dw, float* dbias, void* workspace, const void* dy_amax, chore_stream_t stream);
 /* da = gradient w.r.t. relu(groupnorm(x))  ->  dx, dgamma (C), dbeta (C) */
 size_t chore_gn_relu_bwd_workspace_bytes(int B, int C);
 int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* stats, const float* gamma,
@@ -449,7 +458,7 @@ int chore_gn_relu_bwd(chore_handle* h, int dtype, const void* x, const void* sta
  * identity or GroupNorm -> ReLU -> conv1x1 residual) as a training operator, forward and backward in one call each: the
  * convolutions write their slices of y with the residual added in the epilogue and produce the GroupNorm statistics of
  * o1, o2 and y there; the backward reads dy in channel-strided slices and sums the skip gradients inside the GroupNorm
- * backward.  dtype: CHORE_F32 | CHORE_BF16; Cout in {128, 256}, Cin a multiple of 32 (<= 256); conv weights in the
+ * backward.  dtype: CHORE_F32 | CHORE_BF16 | CHORE_F16X3; Cout in {128, 256}, Cin a multiple of 32 (<= 256); conv weights in the
  * reference layout (O,C,kh,kw) fp32, no biases; wd and gb[6], gb[7] only when Cin != Cout.
  *   gb      host array of 8 device pointers: gamma, beta of bn1, bn2, bn3, bn4
  *   x_stats chore_gn_stats_bytes(B) statistics of x (the previous block's: `saved` + chore_convblock_out_stats_offset(B)),

@@ -682,8 +682,76 @@ def gen_fit_schedule(net):
     np.savez_compressed(os.path.join(HERE, "fit_schedule.npz"), keys_a=np.array(keys_a), keys_b=np.array(keys_b), **out)
 
 
+HEAD_MODULES = ("df", "part_predictor", "pca_predictor", "center_predictor")
+
+
+def gen_fit_heads(net):
+    """A field WITH SIGNAL for the real-network fitting fixtures.  On random weights the heads' output
+    is noise as a function of position: Adam's normalised update random-walks and any two fp32 implementations end decimetres
+    apart, so a fixture recorded there bounds nothing.  Here the four heads of the reference's own network (301 983
+    parameters; the random feature maps of fit_harness.fit_case stay as they are, the 3 position inputs carry the signal) are
+    fitted, on the reference's CPU path, to the closed-form field of fit_harness.AnalyticField -- distance shells around a body
+    and an object centre, linear part logits / centres, sinusoidal axes -- with a few hundred Adam steps, and the fitted head
+    weights are stored (tests/golden/fit_heads.npz, 1.2 MB).  The result is a real piecewise-linear network field (ReLU kinks and
+    all) whose gradient points somewhere: what gen_fit_anchor records the reference's schedules on."""
+    from fit_harness import AnalyticField, fit_case
+    B, N = 2, 4096
+    c = fit_case(B)
+    net.im_feat_list = [torch.from_numpy(c["feat"])]
+    net.tmpx = torch.from_numpy(c["tmpx"])
+    cc = torch.from_numpy(c["crop_center"])
+    target = AnalyticField()
+    heads = [p for m in HEAD_MODULES for p in getattr(net, m).parameters()]
+    for p in heads:
+        p.requires_grad_(True)
+    opt = torch.optim.Adam(heads, lr=2e-3)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[400, 650], gamma=0.3)
+    g = torch.Generator().manual_seed(31)
+    centre = target.c[:B, 0:1]                                        # (B,1,3) the body shells' centres
+
+    def batch():
+        half = N // 2
+        wide = centre + (torch.rand(B, half, 3, generator=g) * 2 - 1) * 1.3
+        near = centre + torch.randn(B, N - half, 3, generator=g) * 0.45   # where the body's vertices and the object's points live
+        return torch.cat([wide, near], 1)
+    for it in range(800):
+        pts = batch()
+        net.query(pts, crop_center=cc)
+        df, pca, parts, centers = net.get_preds()
+        with torch.no_grad():
+            target.query(pts)
+            tdf, tpca, tparts, tcent = target.get_preds()
+            inside = (df.detach() != net.OUT_DIST).float()            # outside the image the reference overwrites df with 5.0
+        loss = (((df - tdf) ** 2) * inside).mean() * 30 + ((pca - tpca) ** 2).mean() + ((parts - tparts) ** 2).mean() * 0.3 \
+            + ((centers - tcent) ** 2).mean() * 30
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        sched.step()
+        if it % 100 == 0 or it == 799:
+            print("fit_heads it %d loss %.4f | df mae %.4f parts mae %.3f pca mae %.3f centers mae %.4f" % (
+                it, float(loss), float(((df - tdf).abs() * inside).sum() / inside.sum()), float((parts - tparts).abs().mean()),
+                float((pca - tpca).abs().mean()), float((centers - tcent).abs().mean())))
+    for p in heads:
+        p.requires_grad_(False)
+    out = {"%s.%s" % (m, k): v.detach().numpy().copy() for m in HEAD_MODULES for k, v in getattr(net, m).state_dict().items()}
+    np.savez_compressed(os.path.join(HERE, "fit_heads.npz"), **out)
+    return out
+
+
+def load_fit_heads(net):
+    """the fitted heads of gen_fit_heads into the reference network"""
+    w = np.load(os.path.join(HERE, "fit_heads.npz"))
+    with torch.no_grad():
+        for m in HEAD_MODULES:
+            for k, v in getattr(net, m).state_dict().items():
+                v.copy_(torch.from_numpy(w["%s.%s" % (m, k)]))
+
+
 def gen_fit_anchor(net):
-    """THE REFERENCE's optimize_smpl and optimize_smpl_object (recon/recon_fit_behave.py:224-291, 90-163) on the REAL
+    """(round 5: on the heads of gen_fit_heads -- a field with signal; the first version of this fixture ran on random heads,
+    where the fit is a random walk)
+    THE REFERENCE's optimize_smpl and optimize_smpl_object (recon/recon_fit_behave.py:224-291, 90-163) on the REAL
     random-weight network (not the closed-form field of gen_fit_schedule): the same inputs, phase lengths, seeds and stand-ins
     for the two CUDA-only pieces (SilStub, no collision) as fit_schedule.npz, recorded per step (every loss term) and at the
     end (fitted parameters).  Two fp32 implementations of the piecewise-linear heads fall on different sides of a few ReLU kinks
@@ -692,6 +760,9 @@ def gen_fit_anchor(net):
     bound)."""
     from fit_harness import SilStub
     B = 2
+    if not os.path.exists(os.path.join(HERE, "fit_heads.npz")):
+        gen_fit_heads(net)
+    load_fit_heads(net)
     fitter, smpl, c, rfb, rfbh = _ref_fit_setup(net, B)
     labels = torch.from_numpy(c["labels"])
     cc = torch.from_numpy(c["crop_center"])

@@ -193,8 +193,11 @@ def test_heads_train_on_a_frozen_encoder(opt):
     assert losses[-1] < losses[0]
 
 
-def test_full_training_backward_matches_reference(opt):
-    """CHORE.forward + backward with EVERY parameter trainable (encoder included) against the gradients the reference's
+@pytest.mark.parametrize("mode", ["fp32", "fp16x3"])
+def test_full_training_backward_matches_reference(opt, mode):
+    """(mode "fp16x3", round 5: the same bound with every convolution, data gradient and weight gradient of the encoder on the
+    fp16 matrix cores with hi / lo split operands and the heads on their fp16 x 3 path -- the fp32-grade training mode)
+    CHORE.forward + backward with EVERY parameter trainable (encoder included) against the gradients the reference's
     autograd produced on the same batch (tests/golden/train_grads.npz): loss value, and per parameter the sum, abs-sum
     and L2 norm of the gradient, the complete gradient of every small tensor (GroupNorm affines, biases) and crops of
     three convolution kernels.  fp32 mode.  Tolerance 3e-3 of the tensor's L2 norm: the loss sums 5 x 1024 points, a
@@ -202,7 +205,7 @@ def test_full_training_backward_matches_reference(opt):
     implementation (gradient parity note); everything upstream inherits that."""
     import copy
     g, gg = golden("train_loss.npz"), golden("train_grads.npz")
-    net = make_net(copy.copy(opt), "fp32")
+    net = make_net(copy.copy(opt), mode)
     net.train(True)
     for p in net.parameters():
         p.requires_grad_(True)
@@ -214,6 +217,7 @@ def test_full_training_backward_matches_reference(opt):
     params = dict(net.named_parameters())
     n_grad = n_none = 0
     worst = (0.0, "")
+    rel_l2 = []
     for name in [str(n) for n in gg["names"]]:
         ref = gg["s_" + name]
         p = params[name]
@@ -231,12 +235,14 @@ def test_full_training_backward_matches_reference(opt):
             err = np.sqrt(((a - gg["g_" + name]) ** 2).sum())
             assert err < 3e-3 * l2, (name, err, l2)
             worst = max(worst, (err / l2, name))
+            rel_l2.append(err / l2)
         if "c_" + name in gg.files:
             c = a.reshape(a.shape[0], -1)[:16, :24]
             assert np.abs(c - gg["c_" + name]).max() < 3e-3 * np.abs(gg["c_" + name]).max(), name
         n_grad += 1
     assert n_grad == 475 and n_none == 82, (n_grad, n_none)
-    print("worst small-tensor relative L2 error", worst)
+    print("mode %s: small-tensor relative L2 error of the gradients against the reference: median %.2e worst %.2e (%s)"
+          % (mode, float(np.median(rel_l2)), worst[0], worst[1]))
 
 
 def test_full_training_backward_bf16_mode_within_stated_bound(opt):

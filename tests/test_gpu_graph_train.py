@@ -31,12 +31,22 @@ batches = [_make(it)[1] for it in range(STEPS)]
 
 def run(graphed):
     net, _ = _make(0)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True, fused=True)
+    # the rate as an fp32 device tensor on BOTH sides (GraphedTrainStep moves a float rate into one: the recorded Adam launch
+    # reads it at run time); it changes under replay twice: MultiStepLR's decay after step 3 (trainer/trainer.py:56-60) and a
+    # plain `g['lr'] = value` before step 5 (the reference's resume path, trainer.py:246-257)
+    opt = torch.optim.Adam(net.parameters(), lr=(1e-4 if graphed else torch.tensor(1e-4, device="cuda")), capturable=True, fused=True)
     red = FlatGradReducer(net) if use_reducer else None
     rec = []
     if graphed:
         step = GraphedTrainStep(net, opt, reducer=red, warmup=WARM)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[3], gamma=0.3)
     for it in range(STEPS):
+        if it == 4:
+            for g in opt.param_groups:
+                if graphed:
+                    g["lr"] = 2e-5
+                else:
+                    g["lr"].fill_(2e-5)
         if graphed:
             loss, sep = step(**batches[it])
         else:
@@ -47,8 +57,10 @@ def run(graphed):
             if red is not None:
                 red.reduce()
             opt.step()
+        sched.step()
         rec.append((float(loss), sep.detach().cpu().numpy().copy(),
                     {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    assert abs(float(opt.param_groups[0]["lr"]) - 2e-5) < 1e-11
     torch.cuda.synchronize()
     state = {n: p.detach().clone() for n, p in net.named_parameters()}
     moments = [opt.state[p]["exp_avg_sq"].clone() for p in net.parameters() if p in opt.state]
@@ -70,6 +82,22 @@ assert all(torch.equal(sa[n], sb[n]) for n in sa), "parameters differ"
 assert len(ma) == len(mb) and all(torch.equal(a, b) for a, b in zip(ma, mb)), "Adam moments differ"
 moved = sum(int(not torch.equal(sa[n], _make(0)[0].state_dict()[n])) for n in list(sa)[:20])
 assert moved > 0
+# the decayed rates REACHED the replayed launches: the same six steps at a constant rate end somewhere else
+if not use_reducer:
+    net, _ = _make(0)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, capturable=True, fused=True)
+    step2 = GraphedTrainStep(net, opt, warmup=WARM)
+    for it in range(STEPS):
+        step2(**batches[it])
+    torch.cuda.synchronize()
+    sc = {n: p.detach().clone() for n, p in net.named_parameters()}
+    assert sum(int(not torch.equal(sc[n], sb[n])) for n in sb) > 400
+    # load_state_dict() swaps the optimiser's state tensors: the recording is dropped and made again (not replayed on stale state)
+    import copy
+    opt.load_state_dict(copy.deepcopy(opt.state_dict()))      # (a checkpoint read back: new tensors)
+    n_rec = id(next(iter(step2._rec.values()))["ga"])
+    step2(**batches[0])
+    assert id(next(iter(step2._rec.values()))["ga"]) != n_rec
 print("graphed == eager over", STEPS, "steps (", STEPS - WARM, "replayed ),", len(ra[0][2]), "gradient tensors; losses", [round(r[0], 6) for r in rb])
 print("graph train ok")
 '''

@@ -3,7 +3,9 @@ against torch's fp32 CPU implementation of the same layers with autograd (what t
 nn.Conv2d / nn.GroupNorm(32, C) / ReLU, model/net_util.py:346-396).
 
 Tolerances: fp32 mode 2e-5 of the tensor's largest entry; bf16 mode (bf16 activations and MFMA operands, fp32
-accumulation) 3e-2 of it, relative L2 <= 1.5e-2."""
+accumulation) 3e-2 of it, relative L2 <= 1.5e-2.  "x3" = the fp16x3 training mode (round 5): fp32 tensors, every convolution, data
+gradient and weight gradient on the fp16 matrix cores with hi / lo split operands -- held to the fp32 bounds, with upstream
+gradients scaled from 1e-7 to 3e4 (the operand scale of the gradient GEMMs, csrc/enc_common.h x3_in_scale)."""
 import numpy as np
 import pytest
 import torch
@@ -19,17 +21,21 @@ def ref_layer(x_nchw, w, bias, gamma, beta):
     return F.conv2d(a, w, bias, padding=w.shape[-1] // 2)
 
 
+def _tdt(dtype):
+    return torch.float32 if dtype == "x3" else dtype
+
+
 def check(a, b, dtype, what):
     a, b = a.detach().float().cpu().numpy(), b.detach().float().cpu().numpy()
     scale = np.abs(b).max()
-    if dtype == torch.float32:
+    if _tdt(dtype) == torch.float32:
         assert np.abs(a - b).max() <= 2e-5 * scale, (what, np.abs(a - b).max(), scale)
     else:
         assert np.abs(a - b).max() <= 3e-2 * scale, (what, np.abs(a - b).max(), scale)
         assert np.linalg.norm((a - b).ravel()) <= 1.5e-2 * np.linalg.norm(b.ravel()), what
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "x3"])
 @pytest.mark.parametrize("k,cin,cout,gn,bias,shape", [
     (3, 64, 32, True, False, (2, 24, 40)),     # ragged tiles
     (3, 128, 64, True, False, (2, 16, 32)),
@@ -52,6 +58,9 @@ def test_conv_gn_layer(dtype, k, cin, cout, gn, bias, shape):
     gamma = torch.rand(cin, generator=g) + 0.5 if gn else None
     beta = torch.randn(cin, generator=g) * 0.2 if gn else None
     up = torch.randn(B, cout, H, W, generator=g)
+    if dtype == "x3":      # gradients of any magnitude: a different power of ten per layer shape
+        up = up * float(10.0 ** ((cin // 32 + cout // 32 + k + H) % 12 - 7))
+    x3, dtype = dtype == "x3", _tdt(dtype)
     # reference on CPU; in bf16 mode the reference sees the same bf16-rounded input
     xr = x.to(dtype).float().clone().requires_grad_(True)
     pr = [p.clone().requires_grad_(True) if p is not None else None for p in (w, bs, gamma, beta)]
@@ -59,7 +68,8 @@ def test_conv_gn_layer(dtype, k, cin, cout, gn, bias, shape):
     (yr * up).sum().backward()
     xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
     pd = [p.clone().cuda().requires_grad_(True) if p is not None else None for p in (w, bs, gamma, beta)]
-    yd = ops.conv_gn(xd, *pd)
+    with ops.x3_convs(x3):
+        yd = ops.conv_gn(xd, *pd)
     (yd.float() * up.permute(0, 2, 3, 1).cuda()).sum().backward()
     check(yd.permute(0, 3, 1, 2), yr, dtype, "y")
     check(xd.grad.permute(0, 3, 1, 2), xr.grad, dtype, "dx")
@@ -172,7 +182,7 @@ class _RefConvBlock(torch.nn.Module):
         return torch.cat((o1, o2, o3), 1) + res
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, "x3"])
 @pytest.mark.parametrize("cin,cout,shape", [(64, 128, (2, 24, 40)), (128, 128, (2, 16, 32)), (128, 256, (1, 32, 32)),
                                             (256, 256, (3, 20, 44)), (256, 256, (4, 64, 64))])
 def test_conv_block_operator(dtype, cin, cout, shape):
@@ -189,6 +199,9 @@ def test_conv_block_operator(dtype, cin, cout, shape):
                 p.data = (torch.rand_like(p) + 0.5) if n.endswith("weight") else torch.randn_like(p) * 0.2
     x = torch.randn(B, cin, H, W) * 1.5 + 0.3
     up = torch.randn(B, cout, H, W)
+    x3, dtype = dtype == "x3", _tdt(dtype)
+    if x3:
+        up = up * float(10.0 ** ((cin // 64 + H) % 9 - 6))        # gradients of any magnitude
     xr = x.to(dtype).float().clone().requires_grad_(True)
     yr1 = blocks[0](xr)
     yr = blocks[1](yr1)
@@ -198,8 +211,9 @@ def test_conv_block_operator(dtype, cin, cout, shape):
     for m in dev:
         m.zero_grad()
     xd = x.permute(0, 2, 3, 1).contiguous().to(dtype).cuda().requires_grad_(True)
-    y1, s1 = ops.conv_block(xd, dev[0])
-    y2, _ = ops.conv_block(y1, dev[1], s1)
+    with ops.x3_convs(x3):
+        y1, s1 = ops.conv_block(xd, dev[0])
+        y2, _ = ops.conv_block(y1, dev[1], s1)
     (y2.float() * up.permute(0, 2, 3, 1).cuda()).sum().backward()
 
     def check(a, b, dtype, what):
