@@ -712,6 +712,36 @@ def mode_fit(args, ctx):
 
 
 # ---- mode: train ------------------------------------------------------------------------------------------------------
+def train_grad_error(mode, dev):
+    """gradient error of a training mode against THE REFERENCE's autograd on the golden batch (tests/golden/train_grads.npz: every
+    trained tensor's L2 norm, and the complete gradient of every small tensor -- GroupNorm affines, biases): the deviation of the
+    norms over all 475 tensors and the relative L2 error of the small tensors (what tests/test_gpu_encoder.py bounds per mode)"""
+    from chore_amd.model import CHORE
+    from chore_amd.utils import synth
+    gdir = os.path.join(REPO, "tests", "golden")
+    g, gg = np.load(os.path.join(gdir, "train_loss.npz")), np.load(os.path.join(gdir, "train_grads.npz"))
+    net = CHORE(chore_opt(mode)).to(dev)
+    synth.load_synth_weights(net, seed=0)
+    net.train(True)
+    keys = ("images", "points", "df_h", "df_o", "parts_gt", "pca_gt", "body_center", "obj_center", "crop_center")
+    error, _ = net(**{k: torch.from_numpy(g[k]).to(dev) for k in keys})
+    error.backward()
+    params = dict(net.named_parameters())
+    norm_dev, rel = [], []
+    for name in [str(n) for n in gg["names"]]:
+        ref = gg["s_" + name]
+        if np.isnan(ref).any() or params[name].grad is None:
+            continue
+        a = params[name].grad.detach().float().cpu().numpy().astype(np.float64)
+        norm_dev.append(abs(np.sqrt((a ** 2).sum()) - ref[2]) / ref[2])
+        if "g_" + name in gg.files:
+            rel.append(np.sqrt(((a - gg["g_" + name]) ** 2).sum()) / ref[2])
+    return {"loss_rel_err": abs(float(error.detach()) - float(gg["error"])) / float(gg["error"]), "tensors": len(norm_dev),
+            "l2_norm_rel_dev_max": float(np.max(norm_dev)), "l2_norm_rel_dev_median": float(np.median(norm_dev)),
+            "small_tensor_rel_l2_median": float(np.median(rel)), "small_tensor_rel_l2_max": float(np.max(rel)),
+            "against": "the reference's CPU autograd gradients of the same batch (tests/golden/train_grads.npz)"}
+
+
 def mode_train(args, ctx):
     from chore_amd.model import CHORE
     from chore_amd.utils import synth
@@ -839,6 +869,42 @@ def mode_train(args, ctx):
                                  "traffic": None, "flops_per_step": flops}})
         if ctx.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_train()
+    # ---- the other precision modes of the same step (replayed, no gradient reduction), and every mode's gradient error ----
+    if getattr(args, "train_other_modes", False):
+        del primary, eager_primary, step_plain, step_arena, arena, ddp_model
+        optim.zero_grad(set_to_none=True)
+        others, errs = {}, {}
+        for mode in ("fp16x3", "bf16", "fp32"):
+            torch.cuda.empty_cache()
+            try:
+                errs[mode] = train_grad_error(mode, dev) if rank == 0 else None
+            except Exception as e:
+                errs[mode] = {"error": repr(e)[:200]}
+            if mode == args.dtype:
+                continue
+            o2 = chore_opt(mode)
+            o2.gpu_id = local
+            net2 = CHORE(o2).to(dev)
+            synth.load_synth_weights(net2, seed=0)
+            net2.train(True)
+            opt2 = torch.optim.Adam(net2.parameters(), lr=1e-4, fused=True, capturable=True)
+            g2 = GraphedTrainStep(net2, opt2, reducer=None, warmup=2)
+            n2 = 10
+            t2 = ctx.timed(lambda: g2(**batch), n2, 4)
+            others[mode] = {"ms_per_step": t2 / n2 * 1e3, "steps_per_s": n2 / t2, "step_issue": "hipGraph replay, no gradient reduction"}
+            g2.close()
+            del g2, opt2, net2
+        if rank == 0:
+            for mode, rec in others.items():
+                rec["grad_err"] = errs.get(mode)
+            out["other_modes"] = others
+            out["grad_err"] = errs.get(args.dtype)
+            out["precision"] = {"fp16x3": "fp32 tensors; every convolution, data gradient and weight gradient of the encoder and every GEMM of the "
+                                          "heads on the fp16 matrix cores with hi / lo split operands (three MFMAs per product, fp32 accumulation): "
+                                          "the reference's training precision (fp32, trainer/trainer.py:76-85) -- see grad_err",
+                                "bf16": "bf16 activations and MFMA operands, fp32 accumulation, heads fp32-grade: narrower than the reference "
+                                        "(grad_err: percent-level gradient error)",
+                                "fp32": "fp32 tensors, native fp32 MFMA"}[args.dtype]
     return out
 
 
@@ -850,7 +916,7 @@ def mode_all(args, ctx):
     # training first: after the fit (a dozen capture streams, a few dozen live hipGraphs in the process) the two streams of the
     # ConvBlock backward no longer overlap and the same training step measures 25.0 ms instead of 22.7 (scripts/bench_order_probe.py;
     # the fit measures the same either way) -- an artefact of doing both in one process, which no deployment does
-    for name, fn, over in (("train", mode_train, dict(steps=20, warmup=8, dtype="bf16", mode="train")),
+    for name, fn, over in (("train", mode_train, dict(steps=20, warmup=8, dtype="fp16x3", mode="train", train_other_modes=True)),
                            ("fit", mode_fit, dict(steps=5, warmup=1, dtype="fp16x3", mode="fit")),
                            # configs[4] as BASELINE states it: fp16 fields + hipGraph-captured inner iteration, 8 frames per GPU
                            ("fit_fp16_fields", mode_fit, dict(steps=2, warmup=1, dtype="fp16", mode="fit", frames_per_gpu=8,
@@ -871,7 +937,9 @@ def mode_all(args, ctx):
             out[name] = {k: rec[k] for k in rec if k not in ("n_gpus", "data", "scaling", "vs_baseline")}
         out["records"] = {"fit": "BASELINE metric 2 (ms per fit iteration), configs[2] / configs[4]: same function as --mode fit, 5 chains after "
                                  "1 warm-up chain (medians per phase in fit.per_phase)", "train": "BASELINE metric 3 (training steps/s), configs[3]: same function as --mode train, "
-                                                             "20 steps after 8 warm-up steps",
+                                                             "20 steps after 8 warm-up steps, in the fp16x3 mode = the reference's fp32 training "
+                                                             "precision on the fp16 matrix cores (round 5); train.other_modes: bf16 (faster, percent-level "
+                                                             "gradient error) and fp32 (native fp32 MFMA), each with its measured gradient error",
                           "fit_fp16_fields": "BASELINE configs[4]'s per-GPU share in its stated mode: 8 frames per GPU fitted as one batch on fp16 "
                                              "fields (IEEE half feature maps), every inner iteration a hipGraph replay; 2 chains after 1 warm-up; the "
                                              "mode's field error is other_modes.fp16.field_err"}
@@ -885,7 +953,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--mode", default="all", choices=["all", "query", "fit", "train"])
     ap.add_argument("--dtype", default=None, choices=["bf16", "fp32", "fp16x3", "fp16"],
-                    help="default: fp16x3 for query / fit (meets the 1e-4 field tolerance), bf16 for train")
+                    help="default: fp16x3 (fp32-grade: meets the 1e-4 field tolerance; trains at the reference's fp32 precision)")
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--frames-per-gpu", type=int, default=0, help="fit mode: frames fitted as one batch per GPU (default 1, or 8 when N > 1)")
@@ -896,6 +964,7 @@ def main():
     ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without a process group / gradient reduction (A/B)")
     ap.add_argument("--reducer", default="arena", choices=["arena", "ddp"],
                     help="training: gradient reduction of the primary number (arena = FlatGradReducer, ddp = torch's DistributedDataParallel)")
+    ap.add_argument("--train-other-modes", action="store_true", help="train mode: also time the other precision modes and measure every mode's gradient error")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -907,7 +976,7 @@ def main():
     os.dup2(2, 1)
     defaults = {"all": (20, 5), "query": (20, 5), "fit": (5, 1), "train": (10, 3)}[args.mode]
     if args.dtype is None:
-        args.dtype = "bf16" if args.mode == "train" else "fp16x3"
+        args.dtype = "fp16x3"
     args.steps = defaults[0] if args.steps is None else args.steps
     args.warmup = defaults[1] if args.warmup is None else args.warmup
     ctx = Ctx(args.gpus, one_rank_group=(args.mode in ("all", "train") and not args.dry_run and not args.no_ddp))

@@ -14,7 +14,8 @@ constexpr int KGC = 2;           // k-groups (one MFMA K each) per 32-channel ch
 template <typename T> struct CT;
 template <> struct CT<float> { static constexpr int VE = 4, KGE = 8; };
 template <> struct CT<bf16_t> { static constexpr int VE = 8, KGE = 16; };
-template <> struct CT<x3_t> { static constexpr int VE = 8, KGE = 16; };   // VE: channels per staging slot (two 16-byte loads)
+template <> struct CT<x3_t> { static constexpr int VE = 8, KGE = 16; };
+template <> struct CT<x3s_t> { static constexpr int VE = 8, KGE = 16; };   // VE: channels per staging slot (two 16-byte loads)
 
 
 template <typename T>
@@ -43,8 +44,9 @@ __device__ __forceinline__ u32x4 xform(u32x4 raw, const float* sc, const float* 
 // fp16 x 3 staging: 8 fp32 channels (two vectors) -> GroupNorm + ReLU -> fp16 hi and lo vectors
 // `mul` (a power of two; 1 leaves every value as it is): the operand scale of a gradient input (ConvArgs::in_amax), applied when
 // no GroupNorm is fused
-__device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
-                                         u32x4& lo, float mul = 1.f) {
+template <bool SCALED>
+__device__ __forceinline__ void xform_x3_t(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
+                                           u32x4& lo, float mul) {
     float t[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) { t[j] = __uint_as_float(r0[j]); t[4 + j] = __uint_as_float(r1[j]); }
@@ -54,7 +56,7 @@ __device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const
             const float y = fmaf(t[j], sc[j], sh[j]);
             t[j] = y > 0.f ? y : 0.f;
         }
-    } else {
+    } else if constexpr (SCALED) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) t[j] *= mul;
     }
@@ -66,6 +68,15 @@ __device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const
     }
     hi = __builtin_bit_cast(u32x4, h);
     lo = __builtin_bit_cast(u32x4, l);
+}
+
+__device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
+                                         u32x4& lo) {
+    xform_x3_t<false>(r0, r1, sc, sh, use_gn, hi, lo, 1.f);
+}
+__device__ __forceinline__ void xform_x3(const u32x4& r0, const u32x4& r1, const float* sc, const float* sh, bool use_gn, u32x4& hi,
+                                         u32x4& lo, float mul) {
+    xform_x3_t<true>(r0, r1, sc, sh, use_gn, hi, lo, mul);
 }
 
 __device__ __forceinline__ void mfma_x3(f32x16& acc, const u32x4& ah, const u32x4& al, const u32x4& bh, const u32x4& bl) {

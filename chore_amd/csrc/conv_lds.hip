@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     const int wn = wid % WAVES_N, wm = wid / WAVES_N;
     const int tiles_x = (a.W + TW - 1) / TW;
     float in_mul = 1.f, in_inv = 1.f;                    // operand scale of a gradient input (ConvArgs::in_amax)
-    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
+    if constexpr (IS_X3S<T>) x3_in_scale(a.in_amax, in_mul, in_inv);
     // XCD-aware placement: the dispatcher puts workgroup id on XCD id % 8 (each XCD has its own L2).  The logical order is
     // (image, pixel tile, channel tile) with the channel tile fastest, and every XCD takes a CONTIGUOUS range of it: the
     // channel tiles of one pixel tile -- which read the same halo patch -- and neighbouring pixel tiles share an L2
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
                 u32x4 val = {0u, 0u, 0u, 0u};
                 if constexpr (X3) {
                     u32x4 lo = {0u, 0u, 0u, 0u};
-                    if (row_off[j] >= 0) xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo, in_mul);
+                    if (row_off[j] >= 0) {
+                        if constexpr (IS_X3S<T>) xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo, in_mul);
+                        else xform_x3(pre[j * LV], pre[j * LV + 1], sc, sh, use_gn, val, lo);
+                    }
                     *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + v * 16) = val;
                     *(u32x4*)(patch + pbuf * PATCHB + (idx >> 2) * RB + 64 + v * 16) = lo;
                 } else {
@@ -321,7 +324,8 @@ __global__ __launch_bounds__(256, 2) void conv_lds_kernel(ConvArgs a) {
     if (DBG(a) & 8) return;
 
     // ---- epilogue (the loop ended with a barrier: patch and ring are dead, reuse them) ----
-    const float ASCALE = X3 ? in_inv / (float)(1 << X3_WSHIFT) : 1.0f;     // undoes the weight scaling of the fp16 x 3 packing (and the operand scale)
+    // undoes the weight scaling of the fp16 x 3 packing (and, x3s_t, the operand scale)
+    const float ASCALE = IS_X3S<T> ? in_inv / (float)(1 << X3_WSHIFT) : (X3 ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f);
     float* scr = (float*)smem + wid * (32 * SCR_LD);          // wave-private [32 pixels][SCR_LD]
     float* red = (float*)smem + 4 * 32 * SCR_LD;              // [4][WAVES_M][NT]
     constexpr int CW = NBW * 32;                              // channels of this wave
@@ -578,7 +582,9 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (!pp.th || a_in.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv: layer not covered in the fp16 mode (Cin=%d Cout=%d)", a_in.in.C, a_in.Cout);
         return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }
-    if (dtype == CHORE_F16X3 && !a_in.res2.p && conv_use_pc()) {   // specialised-wave kernel (conv_pc.hip)
+    // specialised-wave kernel (conv_pc.hip): fp16 x 3, and since round 5 bf16 (CHORE_CONV_LDS_BF16=1: the round 1 - 4 kernel)
+    static const bool bf16_lds = getenv("CHORE_CONV_LDS_BF16") != nullptr;
+    if ((dtype == CHORE_F16X3 || (dtype == CHORE_BF16 && !bf16_lds)) && !a_in.res2.p && conv_use_pc()) {
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
         if (pp.th) return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }
@@ -592,7 +598,8 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     if (dtype == CHORE_F32)
         return taps == 9 ? launch_nt<float, 9>(h, nt, small_grid, a, s) : launch_nt<float, 1>(h, nt, small_grid, a, s);
     if (dtype == CHORE_F16X3)
-        return taps == 9 ? launch_nt<x3_t, 9>(h, nt, false, a, s) : launch_nt<x3_t, 1>(h, nt, false, a, s);
+        return a.in_amax ? (taps == 9 ? launch_nt<x3s_t, 9>(h, nt, false, a, s) : launch_nt<x3s_t, 1>(h, nt, false, a, s))
+                         : (taps == 9 ? launch_nt<x3_t, 9>(h, nt, false, a, s) : launch_nt<x3_t, 1>(h, nt, false, a, s));
     return taps == 9 ? launch_nt<bf16_t, 9>(h, nt, small_grid, a, s) : launch_nt<bf16_t, 1>(h, nt, small_grid, a, s);
 }
 

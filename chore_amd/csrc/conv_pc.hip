@@ -34,7 +34,7 @@ namespace {
 constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
 
 // TH rows x 32 pixels x NT channels; K-step = TPS taps of one 32-channel chunk
-template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_ = true> struct PGeo {
+template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_ = true, int WPL_ = 2> struct PGeo {
     static constexpr int TH = TH_, NT = NT_, TPS = TPS_, NSLOT = NSLOT_;   // NSLOT: K-steps of weights resident in the LDS ring
     static constexpr int PAD = (TAPS == 9) ? 1 : 0;
     static constexpr int PW = PTW + 2 * PAD, PH = TH + 2 * PAD, ROWS = PH * PW;
@@ -43,7 +43,7 @@ template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_ = true> str
     static constexpr int KROWS = TAPS / TPS;                        // K-steps per chunk
     static constexpr int NB = NT / 32;
     static constexpr int SB1 = TPS * KGC * NB * 1024;               // bytes of one operand plane of a K-step
-    static constexpr int SBYTES = 2 * SB1;                          // hi plane, then lo plane
+    static constexpr int SBYTES = WPL_ * SB1;                       // hi plane, then lo plane (bf16: one plane)
     static constexpr int NBW = NT >= 64 ? 2 : 1;                    // channel blocks per consumer wave
     static constexpr int WAVES_N = NB / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
     static constexpr int SCR_LD = NT + 4;                           // epilogue image: floats per pixel
@@ -88,16 +88,22 @@ __device__ __forceinline__ void wg_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <typename T, int TAPS, int TH_, int NT_, int TPS_, int NSLOT_>
+// SC (fp16 x 3 only): the input is a gradient whose range comes in ConvArgs::in_amax (training's data-gradient convolutions); a
+// separate instantiation, so that the inference kernels' register allocation is what it was before the operand scale existed
+template <typename T, int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool SC = false>
 __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     if constexpr (IS_X3<T> || IS_H16<T>) f16_saturate_mode();     // the fp16 x 3 / fp16 operand split never produces inf (common.h)
     // T = x3_t: fp32 tensors, activations split into fp16 hi + lo while they are staged, three MFMAs per product;
-    // T = h16_t ("fp16 fields"): fp16 tensors, one activation plane, two MFMAs per product (a * w_lo, a * w_hi)
-    static_assert(IS_X3<T> || IS_H16<T>, "conv_pc_kernel: fp16 x 3 or fp16 operands");
+    // T = h16_t ("fp16 fields"): fp16 tensors, one activation plane, two MFMAs per product (a * w_lo, a * w_hi);
+    // T = bf16_t (round 5: the bf16 inference mode and the bf16 training forward / data gradient): bf16 tensors, one activation
+    //     and one weight plane, one v_mfma_f32_32x32x16_bf16 per product
+    constexpr bool BF = std::is_same<T, bf16_t>::value;
+    static_assert(IS_X3<T> || IS_H16<T> || BF, "conv_pc_kernel: fp16 x 3, fp16 or bf16 operands");
     constexpr bool X3 = IS_X3<T>;
+    constexpr int WPL = BF ? 1 : 2;                     // weight planes
     using ST = typename std::conditional<X3, float, unsigned short>::type;     // element type in memory
     constexpr int LVI = X3 ? 2 : 1;                     // 16-byte loads per 8 channels
-    using G = PGeo<TAPS, TH_, NT_, TPS_, NSLOT_, X3>;
+    using G = PGeo<TAPS, TH_, NT_, TPS_, NSLOT_, X3, WPL>;
     constexpr int NSLOT = G::NSLOT;
     constexpr int TH = G::TH, NT = G::NT, TPS = G::TPS, PAD = G::PAD, PW = G::PW, ROWS = G::ROWS, RB = G::RB;
     constexpr int PATCHB = G::PATCHB, KROWS = G::KROWS, SB1 = G::SB1, SBYTES = G::SBYTES;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     float in_mul = 1.f, in_inv = 1.f;                    // operand scale of a gradient input (training's data-gradient convolutions)
-    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
+    if constexpr (X3 && SC) x3_in_scale(a.in_amax, in_mul, in_inv);
 #if CHORE_CONV_ABLATE
     // phase stamps of one consumer and one producer wave of the workgroup in the middle of the grid: shader clock and 100 MHz wall clock
     auto stamp = [&](int i) {
@@ -189,20 +195,34 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
         u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
         char* d = patch + pbuf * PATCHB + row * RB + v * 16;
         if constexpr (X3) {
-            if (off >= 0) xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo, in_mul);
+            if (off >= 0) {
+                if constexpr (SC) xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo, in_mul);
+                else xform_x3(r[0], r[LVI - 1], sc, sh, use_gn, hi, lo);
+            }
             *(u32x4*)d = hi;
             *(u32x4*)(d + 64) = lo;
         } else {
             if (off >= 0) {
-                if (use_gn) {   // relu(x * scale + shift) in fp32, rounded to fp16 once
-                    const f16x8_t x = __builtin_bit_cast(f16x8_t, r[0]);
-                    f16x8_t y;
+                if (use_gn) {   // relu(x * scale + shift) in fp32, rounded to the 16-bit type once
+                    if constexpr (BF) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = fmaf((float)x[j], sc[j], sh[j]);
-                        y[j] = (_Float16)(t > 0.f ? t : 0.f);
+                        for (int j = 0; j < 4; ++j) {
+                            float x0 = fmaf(__uint_as_float(r[0][j] << 16), sc[2 * j], sh[2 * j]);
+                            float x1 = fmaf(__uint_as_float(r[0][j] & 0xffff0000u), sc[2 * j + 1], sh[2 * j + 1]);
+                            x0 = x0 > 0.f ? x0 : 0.f;
+                            x1 = x1 > 0.f ? x1 : 0.f;
+                            hi[j] = pack2bf(x0, x1);
+                        }
+                    } else {
+                        const f16x8_t x = __builtin_bit_cast(f16x8_t, r[0]);
+                        f16x8_t y;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float t = fmaf((float)x[j], sc[j], sh[j]);
+                            y[j] = (_Float16)(t > 0.f ? t : 0.f);
+                        }
+                        hi = __builtin_bit_cast(u32x4, y);
                     }
-                    hi = __builtin_bit_cast(u32x4, y);
                 } else hi = r[0];
             }
             *(u32x4*)d = hi;
@@ -269,7 +289,8 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     }
 
     // epilogue coordinates (needed early: the residual rows are requested before the main loop ends)
-    const float ASCALE = in_inv / (float)(1 << X3_WSHIFT);      // undoes the weight scaling of the fp16 x 3 packing (and the operand scale)
+    // undoes the weight scaling of the fp16 x 3 packing (and, SC, the operand scale)
+    const float ASCALE = BF ? 1.0f : (SC ? in_inv / (float)(1 << X3_WSHIFT) : 1.0f / (float)(1 << X3_WSHIFT));
     const int g8 = tid % G8;
     const int nv = n_tile * NT + g8 * 8;                        // this thread's 8 channels
     const size_t img = (size_t)b * a.H * a.W;
@@ -404,12 +425,14 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
             }
 #pragma unroll
             for (int m = 0; m < MB; ++m) af[fs][m] = *(const u32x4*)(ar + ((m + ky) * PW + kx) * RB + kg * 32);
+            if constexpr (WPL == 2) {
             if (!(PDBG(a) & 4096)) {
 #pragma unroll
             for (int q = 0; q < NBW; ++q) bfl[fs][q] = *(const u32x4*)(bs + SB1 + ((t * KGC + kg) * (NT / 32) + q) * 1024);
             }
+            }
         };
-        constexpr int NRD = (X3 ? 2 : 1) * MB + 2 * NBW, NMF = (X3 ? 3 : 2) * MB * NBW;     // LDS reads / MFMAs of one k-step
+        constexpr int NRD = (X3 ? 2 : 1) * MB + WPL * NBW, NMF = (X3 ? 3 : WPL) * MB * NBW;     // LDS reads / MFMAs of one k-step
         static_assert(NKS % 2 == 0, "fragment double buffer: even k-steps per K-step");
         int slot = 0;
         auto mfma_step = [&](int s, bool last) {
@@ -445,6 +468,14 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                             acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, afl[ks & 1][m]),
                                                                                __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
                 }
+                if constexpr (BF) {
+#pragma unroll
+                    for (int m = 0; m < MB; ++m)
+#pragma unroll
+                        for (int q = 0; q < NBW; ++q)
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, af[ks & 1][m]),
+                                                                                __builtin_bit_cast(bf16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+                } else {
 #pragma unroll
                 for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -457,6 +488,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
                     for (int q = 0; q < NBW; ++q)
                         acc[m][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, af[ks & 1][m]),
                                                                            __builtin_bit_cast(f16x8_t, bf[ks & 1][q]), acc[m][q], 0, 0, 0);
+                }
                 // issue order: one MFMA, one read of the next k-step's fragments, ... (the reads ride in the matrix pipe's shadow)
                 if (pre) {
 #pragma unroll
@@ -504,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 
     ST* out_p = (ST*)a.out.p + img * a.out.cs + a.out.co + nv;
     ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
-    using ET = typename std::conditional<X3, float, h16_t>::type;       // store8 / load8 element tag
+    using ET = typename std::conditional<X3, float, typename std::conditional<BF, bf16_t, h16_t>::type>::type;       // store8 / load8 element tag
     const bool want_stats = (a.st_raw || a.st_out) && !(PDBG(a) & 256);
     float sr[8], qr[8], so[8], qo[8];
 #pragma unroll
@@ -534,7 +566,9 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if constexpr (X3) { f[k] += __uint_as_float(rq[j][0][k]); f[4 + k] += __uint_as_float(rq[j][LVI - 1][k]); }
-                    else {
+                    else if constexpr (BF) {
+                        f[2 * k] += __uint_as_float(rq[j][0][k] << 16); f[2 * k + 1] += __uint_as_float(rq[j][0][k] & 0xffff0000u);
+                    } else {
                         const f16x8_t rh = __builtin_bit_cast(f16x8_t, rq[j][0]);
                         f[2 * k] += (float)rh[2 * k]; f[2 * k + 1] += (float)rh[2 * k + 1];
                     }
@@ -606,9 +640,9 @@ __global__ __launch_bounds__(512, 2) void conv_pc_kernel(ConvArgs a) {
     }
 }
 
-template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT>
+template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT, bool SC = false>
 int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = PGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>>;
+    using G = PGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>, std::is_same<T, bf16_t>::value ? 1 : 2>;
     size_t smem = G::smem_bytes(a.in.C);
     // ONE workgroup per CU, always.  The small fp16 tilings (79 KB of LDS, ~120 registers) fit twice; with two workgroups on
     // a CU every SIMD holds two high-priority consumer waves, and when both poll for operands their producers -- priority 0
@@ -628,10 +662,10 @@ int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     if (smem < (size_t)lds_cu / 2 + 1024) smem = (size_t)lds_cu / 2 + 1024;
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT, SC>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_cu));
         int per_cu = 0;
-        CHORE_HIP_CHECK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>,
+        CHORE_HIP_CHECK(h, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT, SC>,
                                                                         512, smem));
         if (per_cu != 1)
             CHORE_FAIL(h, CHORE_EINVAL, "conv_pc: %d workgroups per CU with %zu bytes of LDS -- the hand-over by polling needs exactly one",
@@ -640,7 +674,7 @@ int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     }
     const int tiles = ((a.W + PTW - 1) / PTW) * ((a.H + TH - 1) / TH);
     dim3 grid(tiles * (a.Cout / NT) * a.B);
-    hipLaunchKernelGGL((conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT>), grid, dim3(512), smem, s, a);
+    hipLaunchKernelGGL((conv_pc_kernel<T, TAPS, TH, NT, TPS, NSLOT, SC>), grid, dim3(512), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
@@ -650,7 +684,7 @@ int launch_pc_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 // tile configuration of the specialised-wave kernel for a layer: th = 0 -> not covered (the caller uses conv_lds_kernel)
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force) {
     PcPlan p{0, 0, 0, 0};
-    if ((dtype != CHORE_F16X3 && dtype != CHORE_F16) || Cin % 32 || Cout % 32) return p;
+    if ((dtype != CHORE_F16X3 && dtype != CHORE_F16 && dtype != CHORE_BF16) || Cin % 32 || Cout % 32) return p;
     auto ring = [&](PcPlan& q) {   // taps per K-step and ring depth of a tiling (what fits 160 KB of LDS)
         // (measured, profiles/r03_conv_phase_breakdown.txt: rings of single taps with 4 - 6 slots are no faster than two slots of
         // whole kernel rows -- the consumers pay per K-step for the hand-over -- except where only single taps fit: 128 channels)
@@ -688,7 +722,9 @@ int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const 
     const int key = ((taps * 10 + p.th) * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
 #define PC_CASE(TAPS, TH, NT, TPS, NSLOT) \
     case ((TAPS * 10 + TH) * 1000 + NT) * 100 + TPS * 10 + NSLOT:                                              \
-        return dtype == CHORE_F16 ? launch_pc_t<h16_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s) : launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)
+        return dtype == CHORE_F16 ? launch_pc_t<h16_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s) \
+             : dtype == CHORE_BF16 ? launch_pc_t<bf16_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)                     \
+             : a.in_amax ? launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT, true>(h, a, s) : launch_pc_t<x3_t, TAPS, TH, NT, TPS, NSLOT>(h, a, s)
     switch (key) {
         PC_CASE(9, 8, 128, 1, 3);
         PC_CASE(9, 8, 64, 3, 2);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
     const int x0 = seg * 32;
     const bool use_gn = a.in_st != nullptr;
     float in_mul = 1.f, in_inv = 1.f;                       // operand scale of a gradient input (ConvArgs::in_amax)
-    if constexpr (X3) x3_in_scale(a.in_amax, in_mul, in_inv);
+    if constexpr (IS_X3S<T>) x3_in_scale(a.in_amax, in_mul, in_inv);
 
     // ---- stage the patch: all loads first, the affine while they fly ----
     const ST* in_b = (const ST*)a.in.p + (size_t)b * a.H * a.W * a.in.cs + a.in.co;
@@ -141,9 +141,11 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
                 }
             }
             if constexpr (X3) {
-                if (!use_gn) {
+                if constexpr (IS_X3S<T>) {
+                    if (!use_gn) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) f[k] *= in_mul;
+                        for (int k = 0; k < 8; ++k) f[k] *= in_mul;
+                    }
                 }
                 f16x8_t h, l;
 #pragma unroll
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(256) void conv_small_kernel(ConvArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wid * 32 + mfma32_row(r, half)) * RED_LD + px] = acc[r];
     __syncthreads();
-    const float ASCALE = WLO ? in_inv / (float)(1 << X3_WSHIFT) : 1.0f;
+    const float ASCALE = IS_X3S<T> ? in_inv / (float)(1 << X3_WSHIFT) : (WLO ? 1.0f / (float)(1 << X3_WSHIFT) : 1.0f);
     const int p = tid >> 3, g4 = (tid & 7) * 4;              // this thread: pixel p, channels g4 .. g4+3 of the tile
     const int cg = n_tile * 32 + g4;
     const bool want_stats = a.st_raw || a.st_out;
@@ -426,5 +428,6 @@ int launch_conv_small(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t
     if ((size_t)a.B * a.H * (a.W / 32) * (a.Cout / 32) > 0x7fffffffull) CHORE_FAIL(h, CHORE_EINVAL, "conv_small: grid too large");
     const int rows = small_rows(dtype, a.H, a.W, a.in.C);
     if (dtype == CHORE_F16) return launch_small_c<h16_t>(h, rows, a, s);
+    if (dtype == CHORE_F16X3 && a.in_amax) return launch_small_c<x3s_t>(h, rows, a, s);
     return dtype == CHORE_F16X3 ? launch_small_c<x3_t>(h, rows, a, s) : launch_small_c<bf16_t>(h, rows, a, s);
 }

@@ -25,6 +25,14 @@ template <typename T> constexpr bool IS_H16 = IsH16<T>::value;
 template <> struct Store<x3_t> { using type = float; };
 template <typename T> struct IsX3 { static constexpr bool value = false; };
 template <> struct IsX3<x3_t> { static constexpr bool value = true; };
+// x3_t whose INPUT is a gradient that is scaled into fp16's range (ConvArgs::in_amax): the data-gradient convolutions of fp16 x 3
+// training.  A type of its own, so that the kernels of the inference path are compiled exactly as before the scale existed.
+struct x3s_t { float v; };
+template <> struct Store<x3s_t> { using type = float; };
+template <> struct IsX3<x3s_t> { static constexpr bool value = true; };
+template <typename T> struct IsX3S { static constexpr bool value = false; };
+template <> struct IsX3S<x3s_t> { static constexpr bool value = true; };
+template <typename T> constexpr bool IS_X3S = IsX3S<T>::value;
 template <typename T> constexpr bool IS_X3 = IsX3<T>::value;
 
 struct View {
@@ -111,7 +119,8 @@ __device__ __forceinline__ unsigned amax_read(const unsigned* cells) {
 __device__ __forceinline__ void x3_in_scale(const unsigned* cells, float& mul, float& inv) {
     mul = 1.f; inv = 1.f;
     if (!cells) return;
-    const unsigned e = (amax_read(cells) >> 23) & 0xffu;       // biased exponent of max |x|
+    // (readfirstlane: the value is wave-uniform; held in scalar registers it costs the convolutions no vector register)
+    const unsigned e = ((unsigned)__builtin_amdgcn_readfirstlane((int)amax_read(cells)) >> 23) & 0xffu;       // biased exponent of max |x|
     if (e >= 14u && e <= 240u) { mul = __uint_as_float((267u - e) << 23); inv = __uint_as_float((e - 13u) << 23); }
 }
 // block-wide max of the float bits `v` (non-negative floats compare like their bits) -> one atomic max into cells[cell]

@@ -4,130 +4,26 @@
 // runs when CHORE.forward is trained, model/chore.py:107-154): every point adds w_k * d(323-vector)[c] to its four
 // taps of the hourglass feature map (channels 0..255) and of tmpx (channels 259..322).  ATen scatters with float
 // atomics (order-dependent results).  Here the map is cut into tiles that fit LDS (8x8 texels x 256 channels /
-// 16x16 x 64 = 64 KB); the workgroup of a tile scans the points of its image in index order, keeps those with a tap
-// inside the tile (ballot-ordered compaction, so the list is sorted) and accumulates them one after the other with
-// one thread per channel: no atomics anywhere, the result is bit-reproducible, and each tile is written once.
+// 16x16 x 64 = 64 KB); the workgroup of a tile adds the points that have a tap inside the tile one after the other, in point
+// index order, with one thread per channel: no atomics anywhere, the result is bit-reproducible, and each tile is written once.
 //
-// Round 4: for large queries the 256 tiles of an image no longer scan all its points each (20 000 points x 256 tiles = 5 M
-// projections per image, 79 rounds of loads and barriers per tile: 258 us).  scatter_bin_kernel first cuts the image's points
-// into <= 64 contiguous chunks and sorts every chunk's points by the tile(s) their taps fall into -- a STABLE counting sort, one
-// wave per chunk, a point entered once per tile it touches (1, 2 or 4) -- into the staging buffer's sort region; a tile's
-// workgroup then walks the chunks' segments of its tile in chunk order.  That is the same hit list in the same (point index)
-// order as the scan produces, so the sums are the same bit for bit (tests/test_gpu_query.py), from ~100 candidates instead of 20 000.
+// Which points a tile has: scatter_bin_kernel cuts the image's points into <= 64 contiguous chunks and sorts every chunk's
+// points by the tile(s) their taps fall into -- a STABLE counting sort, one wave per chunk, a point entered once per tile it
+// touches (1, 2 or 4) -- into the staging buffer's sort region; a tile's workgroup then walks the chunks' segments of its tile
+// in chunk order = in point-index order.  (Rounds 1 - 3 had every tile scan all points of its image: 20 000 points x 256 tiles =
+// 5 M projections per image, 258 us.  Round 4 kept that kernel for fewer than 64 points and for maps of more than 256 tiles; it
+// had been seen to produce a wrong tile about once in 700 calls when two processes shared the GPU and nothing was ever found
+// wrong in it.  Round 5 REMOVED it: the sort handles any point count, and a map of more than 256 tiles is processed in windows
+// of <= 16 x 16 tiles, one sort + one walk per window -- a tile's list does not depend on the window it is in, so the sums are
+// the same bit for bit whatever the window size: tests/test_gpu_query.py.)
 #include "query_common.h"
 
 namespace {
 
-constexpr int SC_SUB = 2;                  // sub-batches of 256 points per round (4 would need 93 KB of LDS: one workgroup per CU, 416 us against 256)
-constexpr int SC_LIST = 256 * SC_SUB;      // points examined per round (= the capacity of the hit list)
+constexpr int SC_SUB = 2;                  // sub-batches of 256 hits per round
+constexpr int SC_LIST = 256 * SC_SUB;      // the capacity of the hit list
 
 struct Hit { int pt; int x0, y0; float w[4]; };
-
-template <int C, int TS /*tile edge in texels*/>
-__global__ __launch_bounds__(256) void scatter_kernel(QueryArgs a, const float* __restrict__ dX, int xoff, int H, int W,
-                                                      float* __restrict__ dmap, int accumulate) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];   // [TS*TS][C]
-    __shared__ Hit hits[SC_LIST];
-    __shared__ int wave_cnt[4 * SC_SUB];
-    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int b = blockIdx.z, tx0 = blockIdx.x * TS, ty0 = blockIdx.y * TS;
-    const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
-    for (int i = tid; i < TS * TS * C; i += 256) acc[i] = 0.f;
-    __syncthreads();
-    for (int base = 0; base < a.N; base += SC_LIST) {
-        // SC_SUB x 256 points per round, their coordinates requested together: a round costs a global round trip and two
-        // barriers whatever it holds, and 20 000 points in rounds of 256 made that 79 times per tile
-        bool keep[SC_SUB];
-        Hit hme[SC_SUB];
-        float px[SC_SUB], py[SC_SUB], pz[SC_SUB];
-#pragma unroll
-        for (int j = 0; j < SC_SUB; ++j) {
-            const int n = base + j * 256 + tid;
-            const float* p = a.points + ((size_t)b * a.N + (n < a.N ? n : a.N - 1)) * 3;
-            px[j] = p[0]; py[j] = p[1]; pz[j] = p[2];
-        }
-#pragma unroll
-        for (int j = 0; j < SC_SUB; ++j) {
-            const int n = base + j * 256 + tid;
-            keep[j] = false;
-            if (n < a.N) {
-                float nx, ny;
-                project_point(px[j], py[j], pz[j], a.crop_center[b * 2 + 0], a.crop_center[b * 2 + 1], cam, nx, ny);
-                // same tap arithmetic as make_taps (query_common.h); x0/y0 kept instead of flat offsets
-                const float ix = __fmul_rn(__fadd_rn(nx, 1.0f), (float)(W - 1) / 2);
-                const float iy = __fmul_rn(__fadd_rn(ny, 1.0f), (float)(H - 1) / 2);
-                const bool sane = (ix > -2.0f) && (ix < (float)W + 1.0f) && (iy > -2.0f) && (iy < (float)H + 1.0f);
-                if (sane) {
-                    const float x0f = floorf(ix), y0f = floorf(iy);
-                    const float w = __fsub_rn(ix, x0f), e = __fsub_rn(1.0f, w);
-                    const float nn = __fsub_rn(iy, y0f), s = __fsub_rn(1.0f, nn);
-                    hme[j].pt = n; hme[j].x0 = (int)x0f; hme[j].y0 = (int)y0f;
-                    hme[j].w[0] = __fmul_rn(e, s); hme[j].w[1] = __fmul_rn(w, s); hme[j].w[2] = __fmul_rn(e, nn); hme[j].w[3] = __fmul_rn(w, nn);
-                    keep[j] = hme[j].x0 + 1 >= tx0 && hme[j].x0 < tx0 + TS && hme[j].y0 + 1 >= ty0 && hme[j].y0 < ty0 + TS;
-                }
-            }
-        }
-        // ordered compaction: position = number of kept points with a smaller index (sub-batch major, then wave, then lane)
-        unsigned long long m[SC_SUB];
-#pragma unroll
-        for (int j = 0; j < SC_SUB; ++j) {
-            m[j] = __ballot(keep[j]);
-            if (lane == 0) wave_cnt[j * 4 + wid] = __popcll(m[j]);
-        }
-        __syncthreads();
-        int total = 0;
-#pragma unroll
-        for (int j = 0; j < SC_SUB; ++j) {
-            int off = total;
-            for (int w = 0; w < 4; ++w) { if (w < wid) off += wave_cnt[j * 4 + w]; total += wave_cnt[j * 4 + w]; }
-            if (keep[j]) hits[off + __popcll(m[j] & ((1ull << lane) - 1ull))] = hme[j];
-        }
-        __syncthreads();
-        // one channel per thread (C <= 256); the next hit's gradient value is requested while this one is added (the hits are
-        // processed in order -- a load per tap inside the loop made every hit a global round trip)
-        // one channel per thread; the hits are added in order, their gradient values fetched SC_BATCH hits ahead (a row per hit:
-        // with two loads in flight the walk was a chain of global round trips, 0.7 us per hit)
-        const int c = tid;
-        constexpr int SC_BATCH = 32;
-        auto gload = [&](int i) -> float {
-            return (i < total && c < C) ? dX[((size_t)b * a.N + hits[i].pt) * QF_KPAD + xoff + c] : 0.f;
-        };
-        float cur[SC_BATCH], nxt[SC_BATCH];
-#pragma unroll
-        for (int u = 0; u < SC_BATCH; ++u) cur[u] = gload(u);
-        for (int i0 = 0; i0 < total; i0 += SC_BATCH) {
-#pragma unroll
-            for (int u = 0; u < SC_BATCH; ++u) nxt[u] = gload(i0 + SC_BATCH + u);
-#pragma unroll
-            for (int u = 0; u < SC_BATCH; ++u) {
-                if (i0 + u >= total) break;
-                const Hit hh = hits[i0 + u];
-                const float gv = cur[u];
-                if (c < C) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int x = hh.x0 + (k & 1), y = hh.y0 + (k >> 1);
-                        if (x < tx0 || x >= tx0 + TS || y < ty0 || y >= ty0 + TS || x >= W || y >= H || x < 0 || y < 0) continue;
-                        float* cell = acc + ((y - ty0) * TS + (x - tx0)) * C;
-                        cell[c] = fmaf(hh.w[k], gv, cell[c]);
-                    }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < SC_BATCH; ++u) cur[u] = nxt[u];
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < TS * TS * (C / 4); i += 256) {
-        const int cell = i / (C / 4), q = i % (C / 4);
-        const int x = tx0 + cell % TS, y = ty0 + cell / TS;
-        if (x >= W || y >= H) continue;
-        float* o = dmap + (((size_t)b * H + y) * W + x) * C + 4 * q;
-        f32x4 v = *(const f32x4*)(acc + cell * C + 4 * q);
-        if (accumulate) { const f32x4 old = *(const f32x4*)o; v += old; }
-        *(f32x4*)o = v;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // binned scatter
@@ -151,9 +47,12 @@ __device__ __forceinline__ bool scatter_hit(const QueryArgs& a, const Cam& cam, 
     return true;
 }
 
-// the (at most four, distinct) tiles a point's taps fall into; -1 = unused slot
+// a window of the map's tiles: origin (wx, wy) and extent (wtx, wty) in tiles, wtx * wty <= 256
+struct TileWin { int wx, wy, wtx, wty; };
+
+// the (at most four, distinct) tiles OF THE WINDOW a point's taps fall into (numbered inside the window); -1 = unused slot
 template <int TS>
-__device__ __forceinline__ void scatter_bins(const QueryArgs& a, const Cam& cam, int b, int n, bool live, int H, int W, int txn, int kb[4]) {
+__device__ __forceinline__ void scatter_bins(const QueryArgs& a, const Cam& cam, int b, int n, bool live, int H, int W, const TileWin& tw, int kb[4]) {
     kb[0] = kb[1] = kb[2] = kb[3] = -1;
     Hit h;
     if (!live || !scatter_hit(a, cam, b, n, H, W, h)) return;
@@ -161,7 +60,9 @@ __device__ __forceinline__ void scatter_bins(const QueryArgs& a, const Cam& cam,
     for (int k = 0; k < 4; ++k) {
         const int x = h.x0 + (k & 1), y = h.y0 + (k >> 1);
         if (x < 0 || x >= W || y < 0 || y >= H) continue;
-        const int bin = (y / TS) * txn + (x / TS);
+        const int tx = x / TS - tw.wx, ty = y / TS - tw.wy;
+        if (tx < 0 || tx >= tw.wtx || ty < 0 || ty >= tw.wty) continue;
+        const int bin = ty * tw.wtx + tx;
         bool dup = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) dup = dup || (j < k && kb[j] == bin);
@@ -176,13 +77,13 @@ __device__ __forceinline__ void scatter_bins(const QueryArgs& a, const Cam& cam,
 constexpr int SB_ROW = 66;      // ushort counters per tile row: 64 lanes + 2 of padding (rows 33 words apart: the per-tile walk
                                 // of lane j over its 5 rows touches 32 different banks across a half-wave)
 template <int TS>
-__global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int W, int* __restrict__ sort) {
+__global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int W, int* __restrict__ sort, TileWin tw) {
     __shared__ unsigned short cnt[(SCATTER_OFF_STRIDE + 60) * SB_ROW];     // [320 tiles][lane]
     __shared__ int tot[64];
     const int lane = threadIdx.x, g = blockIdx.x, b = blockIdx.y;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
     const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH, S = CH / 64;
-    const int txn = (W + TS - 1) / TS, nb = txn * ((H + TS - 1) / TS);
+    const int nb = tw.wtx * tw.wty;
     int* img = sort + (size_t)b * scatter_sort_ints(a.N);
     int* list = img + (size_t)g * 4 * CH;
     int* off = img + (size_t)G * 4 * CH + (size_t)g * SCATTER_OFF_STRIDE;
@@ -192,7 +93,7 @@ __global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int
     // ---- counts: this lane's column ----
     for (int n = n0; n < n1; ++n) {
         int kb[4];
-        scatter_bins<TS>(a, cam, b, n, true, H, W, txn, kb);
+        scatter_bins<TS>(a, cam, b, n, true, H, W, tw, kb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (kb[k] >= 0) cnt[kb[k] * SB_ROW + lane] += 1;
     }
@@ -230,7 +131,7 @@ __global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int
     // ---- placement: the lane walks its run again ----
     for (int n = n0; n < n1; ++n) {
         int kb[4];
-        scatter_bins<TS>(a, cam, b, n, true, H, W, txn, kb);
+        scatter_bins<TS>(a, cam, b, n, true, H, W, tw, kb);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (kb[k] < 0) continue;
@@ -247,15 +148,16 @@ __global__ __launch_bounds__(64) void scatter_bin_kernel(QueryArgs a, int H, int
 // (197 against 134 us inside the training step: every workgroup pays the list set-up) -- profiles/r04_scatter.txt.
 template <int C, int TS /*tile edge in texels*/, int SUB /*texels per workgroup edge*/>
 __global__ __launch_bounds__(256) void scatter_csr_kernel(QueryArgs a, const float* __restrict__ dX, int xoff, int H, int W,
-                                                          float* __restrict__ dmap, int accumulate, const int* __restrict__ sort) {
+                                                          float* __restrict__ dmap, int accumulate, const int* __restrict__ sort,
+                                                          TileWin tw) {
     extern __shared__ __attribute__((aligned(16))) float acc[];   // [SUB*SUB][C]
     __shared__ Hit hits[SC_LIST];
     __shared__ int seg_start[65], seg_src[64];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int b = blockIdx.z, tx0 = blockIdx.x * SUB, ty0 = blockIdx.y * SUB;
+    const int b = blockIdx.z, tx0 = tw.wx * TS + blockIdx.x * SUB, ty0 = tw.wy * TS + blockIdx.y * SUB;
     const Cam cam{a.fx, a.fy, a.cx, a.cy, a.half_crop, a.crop};
     const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH;
-    const int bin = (ty0 / TS) * ((W + TS - 1) / TS) + tx0 / TS;
+    const int bin = (ty0 / TS - tw.wy) * tw.wtx + (tx0 / TS - tw.wx);
     const int* img = sort + (size_t)b * scatter_sort_ints(a.N);
     const int* offs = img + (size_t)G * 4 * CH;
     for (int i = tid; i < SUB * SUB * C; i += 256) acc[i] = 0.f;
@@ -454,42 +356,41 @@ int launch_scatter_features(chore_handle* h, const QueryArgs& a, const float* dX
                             int accumulate, hipStream_t s) {
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_kernel<FEAT_C, 8>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_kernel<TMPX_C, 16>,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 16 * 16 * TMPX_C * 4));
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)scatter_csr_kernel<FEAT_C, 8, 8>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 8 * FEAT_C * 4));
         attr = true;
     }
-    // binned path: needs the sort region of the staging buffer and <= 256 tiles per image
-    // (CHORE_SCATTER_SCAN=1: every tile scans all points, the round 1 - 3 kernel -- which was seen to mis-execute under GPU sharing)
-    const bool scan_only = getenv("CHORE_SCATTER_SCAN") != nullptr;      // read per call: the test flips it
+    if (!a.tSort) CHORE_FAIL(h, CHORE_EINVAL, "scatter_features: the staging buffer has no sort region");
+    if (a.N <= 0) return CHORE_OK;
+    // windows of the map's tiles: <= 16 x 16 (the sort's count table and offset tables hold 256 tiles); one sort + one walk per
+    // window, in stream order (they share the sort region).  CHORE_SCATTER_WINDOW=k: k x k tiles (tests: same bits for any k)
+    int win = 16;
+    if (const char* e = getenv("CHORE_SCATTER_WINDOW")) { const int v = atoi(e); if (v >= 1 && v <= 16) win = v; }     // read per call: the test changes it
     const int CH = scatter_chunk(a.N), G = (a.N + CH - 1) / CH;
-    const bool binned = a.tSort && !scan_only && a.N >= 64;
     if (dfeat) {
-        dim3 grid((a.FW + 7) / 8, (a.FH + 7) / 8, a.B);
-        if (binned && grid.x * grid.y <= 256) {
-            int* sort = a.tSort;
-            hipLaunchKernelGGL((scatter_bin_kernel<8>), dim3(G, a.B), dim3(64), 0, s, a, a.FH, a.FW, sort);
-            hipLaunchKernelGGL((scatter_csr_kernel<FEAT_C, 8, 8>), dim3((a.FW + 7) / 8, (a.FH + 7) / 8, a.B), dim3(256), 8 * 8 * FEAT_C * 4,
-                               s, a, dX, 0, a.FH, a.FW, dfeat, accumulate, (const int*)sort);
-        } else {
-            hipLaunchKernelGGL((scatter_kernel<FEAT_C, 8>), grid, dim3(256), 8 * 8 * FEAT_C * 4, s, a, dX, 0, a.FH, a.FW, dfeat,
-                               accumulate);
-        }
+        const int txn = (a.FW + 7) / 8, tyn = (a.FH + 7) / 8;
+        int* sort = a.tSort;
+        for (int wy = 0; wy < tyn; wy += win)
+            for (int wx = 0; wx < txn; wx += win) {
+                const TileWin tw{wx, wy, txn - wx < win ? txn - wx : win, tyn - wy < win ? tyn - wy : win};
+                hipLaunchKernelGGL((scatter_bin_kernel<8>), dim3(G, a.B), dim3(64), 0, s, a, a.FH, a.FW, sort, tw);
+                hipLaunchKernelGGL((scatter_csr_kernel<FEAT_C, 8, 8>), dim3(tw.wtx, tw.wty, a.B), dim3(256), 8 * 8 * FEAT_C * 4,
+                                   s, a, dX, 0, a.FH, a.FW, dfeat, accumulate, (const int*)sort, tw);
+            }
     }
     if (dtmpx) {
-        dim3 grid((a.TW + 15) / 16, (a.TH + 15) / 16, a.B);
-        if (binned && grid.x * grid.y <= 256) {
-            int* sort = a.tSort + (size_t)a.B * scatter_sort_ints(a.N);
-            hipLaunchKernelGGL((scatter_bin_kernel<16>), dim3(G, a.B), dim3(64), 0, s, a, a.TH, a.TW, sort);
-            hipLaunchKernelGGL((scatter_csr_kernel<TMPX_C, 16, 8>), dim3((a.TW + 7) / 8, (a.TH + 7) / 8, a.B), dim3(256), 8 * 8 * TMPX_C * 4,
-                               s, a, dX, FEAT_C + 3, a.TH, a.TW, dtmpx, accumulate, (const int*)sort);
-        } else {
-            hipLaunchKernelGGL((scatter_kernel<TMPX_C, 16>), grid, dim3(256), 16 * 16 * TMPX_C * 4, s, a, dX, FEAT_C + 3, a.TH,
-                               a.TW, dtmpx, accumulate);
-        }
+        const int txn = (a.TW + 15) / 16, tyn = (a.TH + 15) / 16;
+        int* sort = a.tSort + (size_t)a.B * scatter_sort_ints(a.N);
+        for (int wy = 0; wy < tyn; wy += win)
+            for (int wx = 0; wx < txn; wx += win) {
+                const TileWin tw{wx, wy, txn - wx < win ? txn - wx : win, tyn - wy < win ? tyn - wy : win};
+                hipLaunchKernelGGL((scatter_bin_kernel<16>), dim3(G, a.B), dim3(64), 0, s, a, a.TH, a.TW, sort, tw);
+                // 8 x 8-texel workgroups inside the 16 x 16 tiles: two per tile edge, clipped to the map
+                const int bx = (a.TW + 7) / 8 - 2 * wx, by = (a.TH + 7) / 8 - 2 * wy;
+                const int gx = 2 * tw.wtx < bx ? 2 * tw.wtx : bx, gy = 2 * tw.wty < by ? 2 * tw.wty : by;
+                hipLaunchKernelGGL((scatter_csr_kernel<TMPX_C, 16, 8>), dim3(gx, gy, a.B), dim3(256), 8 * 8 * TMPX_C * 4,
+                                   s, a, dX, FEAT_C + 3, a.TH, a.TW, dtmpx, accumulate, (const int*)sort, tw);
+            }
     }
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;

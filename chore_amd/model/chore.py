@@ -602,9 +602,18 @@ class CHORE(nn.Module):
             preds.append((df, pca.view(B, 3, 3, N), parts, centers))
 
         tdt = torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+        keep = getattr(self, "keep_train_segments", False)
+        cuts = [] if keep else None
         feats, self.tmpx, self.normx = forward_train(self.image_filter, images, tdt, on_stack=on_stack,
-                                                     x3=self.compute_dtype == "fp16x3")
+                                                     x3=self.compute_dtype == "fp16x3", cuts=cuts)
         main.wait_stream(side)
+        if keep:
+            # what chore_amd.parallel.backward_in_segments needs to run this step's backward one hourglass stack at a time (so
+            # that each stack's gradients can go to the all-reduce while the next stack's backward runs): the tensor entering
+            # every stack and every stack's share of the error
+            if share is None and n > 1:
+                raise RuntimeError("keep_train_segments needs the stacks' shared head-gradient arena (CHORE_HEADS_NO_SHARE is set)")
+            self.train_segments = dict(cuts=cuts, stack_losses=[o[6] for o in outs])
         self.im_feat_list = feats
         self.intermediate_preds_list = preds
         self.preds = preds[-1]

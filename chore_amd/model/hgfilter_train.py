@@ -50,17 +50,19 @@ def hourglass(m, level, x, xs=None):
     return ops.upadd(up1, low3, True)
 
 
-def forward_train(enc, images, tdt, on_stack=None, x3=False):
+def forward_train(enc, images, tdt, on_stack=None, x3=False, cuts=None):
     """enc: chore_amd.model.hgfilter.HGFilter (parameter tree); images (B,C,H,W) fp32; tdt: activation dtype; x3 (with fp32
     activations): the convolutions and their gradients on the fp16 matrix cores with split operands (ops.x3_convs).
     Returns (outputs, tmpx, normx) as (B,C,H,W) channels-last views like HGFilter.forward; outputs carry grad.
     on_stack(i, output_i, tmpx): called as soon as stack i's output exists (CHORE.forward launches that stack's field query and
-    loss on a second stream from it, so they run beside the next stack's encoder -- forward and backward)."""
+    loss on a second stream from it, so they run beside the next stack's encoder -- forward and backward).
+    cuts (a list, filled here): the tensor that enters each stack -- all that stack i and everything before it share; what
+    chore_amd.parallel.backward_in_segments cuts the backward at."""
     with ops.zero_arena(images.device), ops.x3_convs(x3 and tdt == torch.float32):
-        return _forward_train(enc, images, tdt, on_stack)
+        return _forward_train(enc, images, tdt, on_stack, cuts)
 
 
-def _forward_train(enc, images, tdt, on_stack=None):
+def _forward_train(enc, images, tdt, on_stack=None, cuts=None):
     x = ops.stem(images, enc.conv1.weight, enc.conv1.bias, tdt)
     x = ops.gn_relu(x, enc.bn1.weight, enc.bn1.bias)
     tmpx = x
@@ -71,6 +73,8 @@ def _forward_train(enc, images, tdt, on_stack=None):
     outputs = []
     n = enc.num_modules
     for i in range(n):
+        if cuts is not None:
+            cuts.append(previous)
         hg, sh = hourglass(getattr(enc, f"m{i}"), enc.opt.num_hourglass, previous, sp)
         sp = None                  # `previous` is re-formed by torch adds below: its statistics are recomputed
         ll, _ = conv_block(getattr(enc, f"top_m_{i}"), hg, sh)

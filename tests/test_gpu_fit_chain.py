@@ -85,10 +85,12 @@ def test_generator_device_loop_matches_reference():
 
 
 # ---- fitting schedules ------------------------------------------------------------------------------------------------
-def _fit_objects(opt, use_graphs=False, analytic=False, net=None, shift=0.0):
+def _fit_objects(opt, use_graphs=False, analytic=False, net=None, shift=0.0, signal_heads=False):
     """analytic: the closed-form field instead of the network (what fit_schedule.npz was recorded with, see
     make_golden.gen_fit_schedule for why); net: use this field object instead of building one; shift: another problem (the
-    body's and the object's initial translation moved by it)"""
+    body's and the object's initial translation moved by it); signal_heads: the network's four heads are the ones
+    make_golden.gen_fit_heads fitted to the closed-form field on the reference's CPU path (tests/golden/fit_heads.npz) -- a real
+    network field with signal, what fit_anchor.npz was recorded on"""
     import copy
     from chore_amd.lib_smpl.priors import synthetic_priors
     from chore_amd.lib_smpl.wrapper_pytorch import SMPLPyTorchWrapperBatch
@@ -110,6 +112,13 @@ def _fit_objects(opt, use_graphs=False, analytic=False, net=None, shift=0.0):
     else:
         net = CHORE(o).cuda().eval()
         synth.load_synth_weights(net, seed=0)
+        if signal_heads:
+            w = golden("fit_heads.npz")
+            with torch.no_grad():
+                for m in ("df", "part_predictor", "pca_predictor", "center_predictor"):
+                    for k, v in getattr(net, m).state_dict().items():
+                        v.copy_(torch.from_numpy(w["%s.%s" % (m, k)]))
+            net.invalidate_packed()
         for p in net.parameters():
             p.requires_grad_(False)
         net.im_feat_list = [nhwc(c["feat"])]
@@ -222,22 +231,24 @@ def test_graph_replay_follows_the_same_schedule(opt):
 
 
 def test_real_network_schedules_end_near_the_reference(opt):
-    """The COMPLETE schedules of test_optimize_schedules_match_reference on the REAL random-weight network (the product's
-    field, HIP kernels, fp32 mode) against the reference's CPU run on that network (tests/golden/fit_anchor.npz,
-    make_golden.gen_fit_anchor): same inputs, seeds, stand-ins; both stop rules fire at the reference's step.
+    """The COMPLETE schedules of test_optimize_schedules_match_reference on a REAL network field (the product's heads and HIP
+    kernels, fp32 mode) against the reference's CPU run on that network (tests/golden/fit_anchor.npz, make_golden.gen_fit_anchor):
+    same inputs, seeds, stand-ins; both stop rules fire at the reference's step.  Round 5: the four heads are the ones
+    make_golden.gen_fit_heads FITTED to the closed-form field (fit_heads.npz) -- a field with signal, not random weights.
 
-    What "near" can mean here was MEASURED (MI355X, round 4): two fp32 implementations of the piecewise-linear heads put a few
-    of the 13 780 queried points per step on different sides of a ReLU kink, Adam's normalised update turns a gradient
-    component that is noise into a +-lr random walk, and on a random-weight network many components are noise.  After the
-    36 steps of optimize_smpl OUR OWN two fp32-grade head kernels (native fp32 MFMA vs fp16 x 3) end 0.13 rad / 0.12 (betas) /
-    4.9 cm / 0.49 m (largest vertex) apart -- and 0.12 rad / 0.18 / 4.5 cm / 0.54 m from the reference.  So the reference sits
-    inside our own spread: asserted as `<= 2 x spread`, plus the absolute bounds below (about 2.5 x the measured values).
-    The loss terms that carry the fit (df_h, part, j2d) stay within a few percent over all steps.  The object stage, started
-    from the REFERENCE's fitted body, is well conditioned: after its 161 steps translation 0.26 mm, scale 6e-8, rotation 6e-4,
-    every loss term within 0.2 % at every step (bounds below: about 3 x the measured values)."""
+    What "near" can mean for optimize_smpl is a property of the reference, MEASURED there (round 5): its own CPU run repeated with
+    every queried point scaled by (1 + 1e-7) ends 0.13 rad / 0.12 (betas) / 5.5 cm / 0.67 m (largest vertex) from itself after
+    the 36 steps (fit_anchor.npz `smpl_self_dev`): a ReLU network's gradient is piecewise constant, a handful of the 13 780
+    queried vertices change linear region, the clamped df_h term's gradient moves by ~1 %, and Adam's normalised update
+    amplifies that within three steps (4e-9 -> 1e-4 -> 3e-2).  A field with signal does not change this (the random-weight
+    fixture of round 4 measured the same numbers).  So the HIP chain is held to 1.5 x the reference's own self-deviation; the
+    loss terms that carry the fit stay within a few percent over all steps.  The schedule logic itself is pinned to 1e-5 on
+    the smooth closed-form field (test_optimize_schedules_match_reference).
+    The object stage, started from the REFERENCE's fitted body, is well conditioned: after its 161 steps translation
+    0.2 mm, scale 4e-6, rotation 1e-2, every loss term within 0.2 % (contact 1.5 %) at every step (bounds: about 2-3 x measured)."""
     g = golden("fit_anchor.npz")
     sched = dict(iter_for_betas=2, iter_for_pose=2, iter_for_kpts=2, steps_per_iter=5, max_iter=8)
-    fitter, net, smpl, data, data2 = _fit_objects(opt)
+    fitter, net, smpl, data, data2 = _fit_objects(opt, signal_heads=True)
     log = []
     _log_losses(fitter, "forward_smpl", log)
     torch.manual_seed(11)
@@ -248,7 +259,7 @@ def test_real_network_schedules_end_near_the_reference(opt):
     assert np.array_equal(np.isnan(got[:36]), np.isnan(ref))
     per_key = dict(zip(keys, np.nanmax(np.abs(got[:36] - ref), 0) / np.nanmax(np.abs(ref), 0).clip(1e-30)))   # of each term's largest value
     # two fp32-grade implementations of ours on the same problem: native fp32 MFMA heads (above) and fp16 x 3 heads
-    fitter_b, net_b, smpl_b, data_b, _ = _fit_objects(opt)
+    fitter_b, net_b, smpl_b, data_b, _ = _fit_objects(opt, signal_heads=True)
     net_b.compute_dtype = "fp16x3"
     torch.manual_seed(11)
     fitter_b.optimize_smpl(smpl_b, data_b, **sched)
@@ -259,14 +270,15 @@ def test_real_network_schedules_end_near_the_reference(opt):
                    trans=float((smpl.trans - t("smpl_trans")).abs().max()), verts=float((va - t("smpl_verts")).abs().max()))
     spread = dict(pose=float((smpl.pose - smpl_b.pose).abs().max()), betas=float((smpl.betas - smpl_b.betas).abs().max()),
                   trans=float((smpl.trans - smpl_b.trans).abs().max()), verts=float((va - vb).abs().max()))
-    print("optimize_smpl, real network: deviation from the reference", {k: round(v, 4) for k, v in dev_ref.items()},
-          "| spread between our two head kernels", {k: round(v, 4) for k, v in spread.items()},
-          "| loss terms (of the term's largest value)", {k: round(float(v), 4) for k, v in per_key.items()})
-    bound = dict(pose=0.3, betas=0.45, trans=0.12, verts=1.3)
+    print("optimize_smpl, real network: deviation from the reference", {k: "%.2e" % v for k, v in dev_ref.items()},
+          "| spread between our two head kernels", {k: "%.2e" % v for k, v in spread.items()},
+          "| loss terms (of the term's largest value)", {k: "%.2e" % float(v) for k, v in per_key.items()})
+    self_dev = dict(zip(("pose", "betas", "trans", "verts"), g["smpl_self_dev"]))
+    print("the reference against itself under a 1e-7 perturbation of the queried points:", {k: "%.2e" % v for k, v in self_dev.items()})
     for k in dev_ref:
-        assert dev_ref[k] <= 2.0 * spread[k] + 1e-3, (k, dev_ref[k], spread[k])
-        assert dev_ref[k] < bound[k], (k, dev_ref[k])
-    for k, b in (("df_h", 0.08), ("part", 0.005), ("j2d", 0.05), ("pose", 0.12)):
+        assert dev_ref[k] <= 1.5 * self_dev[k] + 1e-3, (k, dev_ref[k], self_dev[k])
+        assert spread[k] <= 1.5 * self_dev[k] + 1e-3, (k, spread[k], self_dev[k])
+    for k, b in (("df_h", 0.03), ("part", 0.015), ("j2d", 0.15), ("pose", 0.12)):
         assert per_key[k] < b, (k, per_key[k])
     # ---- the object stage from the reference's fitted body ----
     with torch.no_grad():
@@ -290,8 +302,8 @@ def test_real_network_schedules_end_near_the_reference(opt):
     d_c = np.abs(data2["smpl_center"].cpu().numpy() - g["smpl_center"]).max()
     print("optimize_smpl_object, real network: obj_t %.2e m, obj_s %.2e, R %.2e, smpl_center %.2e | loss terms" % (d_t, d_s, d_R, d_c),
           {k: round(float(v), 5) for k, v in per_key.items()})
-    assert d_t < 1e-3 and d_s < 1e-5 and d_R < 3e-3 and d_c < 1e-5
-    for k, b in (("object", 5e-4), ("scale", 1e-3), ("ocent", 3e-4), ("mask", 3e-4), ("trans", 6e-3), ("contact", 5e-3)):
+    assert d_t < 6e-4 and d_s < 1.2e-5 and d_R < 2.5e-2 and d_c < 1e-5
+    for k, b in (("object", 1e-3), ("scale", 1e-3), ("ocent", 3e-4), ("mask", 1.5e-3), ("trans", 6e-3), ("contact", 4e-2)):
         assert per_key[k] < b, (k, per_key[k])
 
 
@@ -306,7 +318,7 @@ def test_fp16_fields_fit_against_the_fp32_grade_fields(opt):
     g = golden("fit_anchor.npz")
     out = {}
     for mode in ("fp16x3", "fp16"):
-        fitter, net, smpl, data, data2 = _fit_objects(opt, use_graphs=True)
+        fitter, net, smpl, data, data2 = _fit_objects(opt, use_graphs=True, signal_heads=True)
         fitter.adam_capturable = True
         net.compute_dtype = mode
         if mode == "fp16":

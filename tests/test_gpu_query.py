@@ -481,14 +481,37 @@ def test_fp16x3_heads_stay_finite_beyond_the_half_range(opt):
         assert float((a - b).abs().max()) <= 1e-3 * max(1.0, float(b.abs().max()))
 
 
+def _grid_sample_scatter_reference(points, cc, dX, maps, xoffs):
+    """the transpose of `index` as the reference's autograd computes it: the backward of F.grid_sample(bilinear, zeros,
+    align_corners=True) at the reference's own projection (model/camera.py through chore_amd's bit-exact restatement), fp64 on the
+    CPU -- (B,H,W,C) gradients of both maps"""
+    import torch.nn.functional as F
+    from chore_amd.model.camera import KinectColorCamera
+    cam = KinectColorCamera(1200)
+    xy = cam.project_points(points.cpu(), cc.cpu())[:, :2].double()          # (B,2,N) normalised image coordinates
+    out = []
+    for (H, W, C), xo in zip(maps, xoffs):
+        m = torch.zeros(points.shape[0], C, H, W, dtype=torch.float64, requires_grad=True)
+        samp = F.grid_sample(m, xy.permute(0, 2, 1).unsqueeze(2), mode="bilinear", padding_mode="zeros", align_corners=True)   # (B,C,N,1)
+        g = dX[:, :, xo:xo + C].permute(0, 2, 1).unsqueeze(-1).double().cpu()
+        (samp * g).sum().backward()
+        out.append(m.grad.permute(0, 2, 3, 1))
+    return out
+
+
 @pytest.mark.parametrize("B,N,maps,spread", [(4, 20000, (128, 128, 256, 256), "uniform"), (2, 5000, (128, 128, 256, 256), "clustered"),
-                                               (3, 2500, (16, 24, 32, 48), "uniform"), (2, 100, (16, 24, 32, 48), "uniform"), (1, 70001, (128, 128, 256, 256), "uniform")])
-def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypatch):
-    """chore_scatter_features (the transpose of `index`, model/geometry.py:4-14, for the training query): round 4's binned path
-    (a stable per-chunk counting sort of the points by map tile, then every tile walks only its own points) against the
-    round 1 - 3 kernel in which every tile scans all points (CHORE_SCATTER_SCAN=1).  Both add a tile's hits in point-index order:
-    equal BIT FOR BIT, for random gradient rows, also when thousands of points share one tile (several rounds of the 512-entry
-    hit list), on small maps with partial tiles, and for a point count that is not a multiple of anything."""
+                                               (3, 2500, (16, 24, 32, 48), "uniform"), (2, 100, (16, 24, 32, 48), "uniform"),
+                                               (2, 37, (16, 24, 32, 48), "uniform"), (1, 1, (128, 128, 256, 256), "uniform"),
+                                               (1, 9000, (136, 200, 272, 400), "uniform"), (1, 70001, (128, 128, 256, 256), "uniform")])
+def test_scatter_features_any_size_and_window(B, N, maps, spread, monkeypatch):
+    """chore_scatter_features (the transpose of `index`, model/geometry.py:4-14, for the training query).  Round 5: the binned
+    path -- a stable per-chunk counting sort of the points by map tile, then every tile walks only its own points, in point
+    order -- is the ONLY path: fewer than 64 points (rounds 1 - 4: the old scan kernel), one point, and maps of more than 256
+    tiles (136 x 200 texels = 17 x 25 tiles: windows of 16 x 16 tiles, each its own sort + walk).  Checked (a) against the
+    backward of F.grid_sample in fp64 on the CPU (2e-5 of the largest entry: the order of the fp32 sums is the only difference)
+    and (b) BIT FOR BIT against the same call with 3 x 3-tile windows (CHORE_SCATTER_WINDOW=3: a tile's list does not depend
+    on the window it is sorted in) -- random gradient rows, thousands of points in one tile (several rounds of the 512-entry hit
+    list), partial tiles, points far outside the image, a point count that is no multiple of anything."""
     import ctypes
     from chore_amd import _lib
     from chore_amd.utils import synth
@@ -500,7 +523,8 @@ def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypa
     if spread == "clustered":                      # 80 % of the points inside a few centimetres: one or two tiles get thousands
         k = int(0.8 * N)
         pts[:, :k] = pts[:, :1] + rs.standard_normal((B, k, 3)).astype(np.float32) * 0.02
-    pts[:, -3:] = [[50.0, 50.0, 2.0]]              # far outside the image: no tap anywhere
+    if N > 3:
+        pts[:, -3:] = [[50.0, 50.0, 2.0]]          # far outside the image: no tap anywhere
     points = torch.from_numpy(pts).to(dev)
     cc = torch.tensor([synth.CROP_CENTER] * B, dtype=torch.float32, device=dev)
     nbytes = _lib.lib.chore_query_train_bytes(B, N)
@@ -508,25 +532,32 @@ def test_binned_scatter_equals_the_scan_bit_for_bit(B, N, maps, spread, monkeypa
     staging = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     f = staging[:(nbytes // 4) * 4].view(torch.float32)
     o = P * (KPAD + 2 * 3 * 4 * 128)              # X, H, dZ come first (csrc/capi.hip train_staging)
-    f[o:o + P * KPAD] = torch.from_numpy(rs.standard_normal(P * KPAD).astype(np.float32)).to(dev)
-    cam6 = (ctypes.c_float * 6)(*KinectColorCamera(512).kernel_constants())
+    dX = torch.from_numpy(rs.standard_normal(P * KPAD).astype(np.float32)).to(dev)
+    f[o:o + P * KPAD] = dX
+    cam6 = (ctypes.c_float * 6)(*KinectColorCamera(1200).kernel_constants())
     h = _lib.handle(0)
     stream = torch.cuda.current_stream().cuda_stream
     out = {}
-    for kind in ("scan", "binned"):
-        if kind == "scan":
-            monkeypatch.setenv("CHORE_SCATTER_SCAN", "1")
+    for kind in ("windows of 3", "default"):
+        if kind == "default":
+            monkeypatch.delenv("CHORE_SCATTER_WINDOW", raising=False)
         else:
-            monkeypatch.delenv("CHORE_SCATTER_SCAN", raising=False)
+            monkeypatch.setenv("CHORE_SCATTER_WINDOW", "3")
         dfe = torch.full((B, FH, FW, 256), float("nan"), device=dev)
         dtm = torch.full((B, TH, TW, 64), float("nan"), device=dev)
         _lib.check(_lib.lib.chore_scatter_features(h, points.data_ptr(), cc.data_ptr(), B, N, FH, FW, TH, TW, cam6, staging.data_ptr(),
                                                    dfe.data_ptr(), dtm.data_ptr(), 0, stream), h, "chore_scatter_features")
         torch.cuda.synchronize()
         out[kind] = (dfe, dtm)
-    for a, b, name in zip(out["scan"], out["binned"], ("dfeat", "dtmpx")):
-        assert torch.isfinite(a).all() and float(a.abs().max()) > 0, name
+    for a, b, name in zip(out["windows of 3"], out["default"], ("dfeat", "dtmpx")):
+        assert torch.isfinite(a).all(), name
         assert torch.equal(a, b), (name, int((a != b).sum()))
+    if B * N <= 20000:                             # the fp64 CPU reference (seconds for the small cases)
+        ref = _grid_sample_scatter_reference(points, cc, dX.view(B, N, KPAD), ((FH, FW, 256), (TH, TW, 64)), (0, 259))
+        for got, want, name in zip(out["default"], ref, ("dfeat", "dtmpx")):
+            err = float((got.double().cpu() - want).abs().max())
+            assert float(want.abs().max()) > 0 or N < 4
+            assert err <= 2e-5 * max(1.0, float(want.abs().max())), (name, err)
 
 
 @pytest.mark.parametrize("B,N,spread", [(4, 20000, "uniform"), (2, 9001, "clustered"), (1, 70001, "uniform")])
