@@ -757,7 +757,7 @@ def mode_train(args, ctx):
     # stock wrap (train_launch.py:30: DistributedDataParallel(find_unused_parameters=True)) is timed beside it: its per-parameter
     # hooks and bucket copies sit inside the launch-bound backward chain (profiles/r04_ddp_overhead.txt).  --reducer ddp makes it
     # the primary number.  With one GPU both run on a ONE-rank RCCL group: the collectives execute, nothing crosses xGMI.
-    from chore_amd.parallel import FlatGradReducer
+    from chore_amd.parallel import FlatGradReducer, chore_segments
     have_group = ctx.world > 1 or ctx.group1 is not None
     reducer_kind = args.reducer if have_group else "none"
     # capturable: the step counter lives on the device, so optimizer.step() can be recorded into the step's hipGraph
@@ -787,9 +787,21 @@ def mode_train(args, ctx):
             last["err"] = error
         return step
 
-    arena = FlatGradReducer(net) if have_group else None
+    # round 5: the arena laid out by hourglass stack and each stack's slice all-reduced while the next stack's backward runs
+    # (FlatGradReducer(segments=...) + backward_in_segments inside GraphedTrainStep); --reducer-layout flat = round 4's four
+    # all-reduces after the whole backward
+    # "auto": segmented when there are other ranks to exchange with; with ONE rank nothing travels, the collectives return at once and
+    # the five extra graph boundaries of the segmented recording are pure cost (measured: 33.3 against 32.7 ms per step) -- the
+    # N = 1 record times every layout in allreduce.variants
+    layout = args.reducer_layout if args.reducer_layout != "auto" else ("segmented" if ctx.world > 1 else "flat")
+    if have_group and layout == "flat":
+        arena = FlatGradReducer(net)
+    elif have_group:
+        arena = FlatGradReducer(net, segments=chore_segments(net), collective=args.collective)
+    else:
+        arena = None
     step_plain = make_step(net, None)
-    step_arena = make_step(net, arena) if have_group else None
+    step_arena = make_step(net, FlatGradReducer(net) if (arena is not None and arena.segments is not None) else arena) if have_group else None
     ddp_model = None
 
     def step_ddp_factory():
@@ -822,6 +834,23 @@ def mode_train(args, ctx):
     elapsed = ctx.timed(primary, args.steps, args.warmup)
     eager_elapsed = ctx.timed(eager_primary, args.steps, 2) if eager_primary is not None else None
     nosync = other = None
+    variants = {}
+    if have_group and reducer_kind == "arena" and graphed:
+        # the same replayed step with the other reduction schemes (each its own recording, made and dropped in turn)
+        for name, mk in (("flat: 4 all_reduce after the backward", lambda: FlatGradReducer(net)),
+                         ("segmented all_reduce under the backward", lambda: FlatGradReducer(net, segments=chore_segments(net))),
+                         ("segmented reduce_scatter + all_gather under the backward",
+                          lambda: FlatGradReducer(net, segments=chore_segments(net), collective="rs_ag"))):
+            try:
+                red = mk()
+                gs = GraphedTrainStep(net, optim, reducer=red, warmup=2)
+                tv = ctx.timed(lambda: gs(**batch), args.steps, 4)
+                variants[name] = {"ms_per_step": tv / args.steps * 1e3}
+                gs.close()
+                del gs, red
+            except Exception as e:
+                variants[name] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
     if have_group and reducer_kind == "arena":
         # the same steps without any gradient reduction, and with the reference's wrap: what the collective costs either way
         # (the DDP wrap last: its hooks stay on the parameters)
@@ -844,9 +873,12 @@ def mode_train(args, ctx):
                          "step_issue": ("hipGraph replays (chore_amd.parallel.GraphedTrainStep: zero_grad + forward + backward + gradient "
                                         "gather in one recording, optimizer.step() in another, the all-reduce between them)"
                                         if graphed else "eager (Python issues every launch)"),
-                         "grad_allreduce": ({"arena": "chore_amd.parallel.FlatGradReducer: flat fp32 gradient arena (%.1f MB), all-reduced "
-                                                      "over RCCL (backend nccl) in %d chunks after the backward, mean over ranks"
-                                                      % (arena.bytes / 1e6, len(arena.chunks)) if arena is not None else "",
+                         "grad_allreduce": ({"arena": ("chore_amd.parallel.FlatGradReducer: flat fp32 gradient arena (%.1f MB), all-reduced "
+                                                       "over RCCL (backend nccl) in %d %s, mean over ranks"
+                                                       % (arena.bytes / 1e6, len(arena.chunks),
+                                                          "segments (one per hourglass stack + the stem), each launched on RCCL's stream when its part "
+                                                          "of the backward is done, under the rest of the backward (%s)" % args.collective
+                                                          if arena.segments is not None else "chunks after the backward")) if arena is not None else "",
                                              "ddp": "torch DDP over RCCL (backend nccl), find_unused_parameters=True (the reference's wrap)"}
                                             [reducer_kind] + ("" if ctx.world > 1 else "; ONE-rank group: the collectives execute on "
                                                               "RCCL's stream, nothing crosses xGMI"))
@@ -855,7 +887,8 @@ def mode_train(args, ctx):
         if nosync is not None:
             out["allreduce"] = {"ms_per_step_synced": ms, "ms_per_step_no_sync": nosync / args.steps * 1e3,
                                 "share_of_step": max(0.0, 1.0 - nosync / elapsed), "bytes_per_step": 4 * sum(p.numel() for p in net.parameters()),
-                                "reducer": reducer_kind,
+                                "reducer": reducer_kind, "variants": variants,
+                                "exposed_ms": ms - nosync / args.steps * 1e3,
                                 "other_reducer": {"what": other[0], "ms_per_step": other[1] / args.steps * 1e3,
                                                   "steps_per_s": args.steps / other[1]} if other else None,
                                 "world_size": ctx.world,
@@ -964,6 +997,10 @@ def main():
     ap.add_argument("--no-ddp", action="store_true", help="N = 1 training record without a process group / gradient reduction (A/B)")
     ap.add_argument("--reducer", default="arena", choices=["arena", "ddp"],
                     help="training: gradient reduction of the primary number (arena = FlatGradReducer, ddp = torch's DistributedDataParallel)")
+    ap.add_argument("--reducer-layout", default="auto", choices=["auto", "segmented", "flat"],
+                    help="training, arena reducer: segmented = one slice per hourglass stack, all-reduced under the backward (round 5); flat = 4 chunks after it")
+    ap.add_argument("--collective", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="training, segmented arena: one all_reduce per segment, or reduce_scatter + all_gather")
     ap.add_argument("--train-other-modes", action="store_true", help="train mode: also time the other precision modes and measure every mode's gradient error")
     ap.add_argument("--dry-run", action="store_true", help="launch / rendezvous / timing skeleton only (no GPU needed): CPU + gloo")
     args = ap.parse_args()

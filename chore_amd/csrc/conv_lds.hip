@@ -582,9 +582,15 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (!pp.th || a_in.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv: layer not covered in the fp16 mode (Cin=%d Cout=%d)", a_in.in.C, a_in.Cout);
         return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }
-    // specialised-wave kernel (conv_pc.hip): fp16 x 3, and since round 5 bf16 (CHORE_CONV_LDS_BF16=1: the round 1 - 4 kernel)
-    static const bool bf16_lds = getenv("CHORE_CONV_LDS_BF16") != nullptr;
-    if ((dtype == CHORE_F16X3 || (dtype == CHORE_BF16 && !bf16_lds)) && !a_in.res2.p && conv_use_pc()) {
+    // specialised-wave kernel (conv_pc.hip): fp16 x 3; since round 5 also bf16, where it measured faster layer by layer
+    // (profiles/r05_conv_layer_ab.txt: 3x3 layers of <= 128 input channels on maps up to 128^2 -- 64^2 128->64 15.4 against 20.2 us,
+    // 64->64 13.2 against 15.7; the 1x1 layers, the 256-channel inputs and the 256^2 maps stay on conv_lds_kernel, which wins there:
+    // with one MFMA per product the bf16 K loop is short and the producer / consumer hand-over costs more than it hides).
+    // CHORE_CONV_LDS_BF16=1: conv_lds_kernel everywhere (rounds 1 - 4); CHORE_CONV_PC_BF16=1: conv_pc_kernel wherever it has a tiling
+    static const bool bf16_lds = getenv("CHORE_CONV_LDS_BF16") != nullptr, bf16_pc_all = getenv("CHORE_CONV_PC_BF16") != nullptr;
+    const bool bf16_pc = dtype == CHORE_BF16 && !bf16_lds &&
+                         (bf16_pc_all || (taps == 9 && a_in.in.C <= 128 && (long)a_in.H * a_in.W <= 128 * 128));
+    if ((dtype == CHORE_F16X3 || bf16_pc) && !a_in.res2.p && conv_use_pc()) {
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
         if (pp.th) return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }

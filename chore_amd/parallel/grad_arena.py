@@ -151,7 +151,7 @@ class FlatGradReducer:
         if not (self.world > 1 or dist.is_initialized()):
             return
         c = self.chunks[segment]
-        if self.collective == "rs_ag" and self.world > 1:
+        if self.collective == "rs_ag":
             n = c.numel() // self.world
             shard = self._shards.get(segment)
             if shard is None:

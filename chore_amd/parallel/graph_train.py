@@ -33,6 +33,13 @@ eagerly (per-shape lazy initialisation happens outside any capture), the second 
 a time (each holds the step's activations in a private pool: ~10 GB at the configs[3] size); the signatures beyond that -- the
 short last batch of an epoch -- keep running eagerly.
 
+The all-reduce UNDER the backward (round 5): with a reducer built with `segments=chore_segments(model)` the recording is cut at
+the hourglass stacks -- graph A0 = zero + forward + the backward of the last stack + its gradients' gather, A1 .. A5 = the backward
+of one earlier stack (finally: of what precedes the first stack) + gather -- and each segment's slice of the gradient arena goes
+to RCCL (asynchronously, on RCCL's stream) the moment its graph has been issued, so it travels while the following graphs run;
+only the last, 3.6 MB segment's collective is exposed before graph B (the optimiser).  Same autograd nodes, same order: the
+gradients equal the unsegmented step's bit for bit (tests/test_gpu_ddp_nccl.py).
+
 Side effect: `model.losses_on_host` is switched off (the reference returns the six separate losses as a CPU tensor, a host copy
 per step that cannot be recorded); `close()` restores it.
 """
@@ -58,6 +65,7 @@ class GraphedTrainStep:
         self._rec = {}            # batch signature -> recording
         self._seen = set()        # signatures that have run eagerly once
         self._side = None
+        self._seg_params = None
         # the learning rates as device tensors (see the module docstring)
         dev = next(model.parameters()).device
         self._lr = []
@@ -98,12 +106,36 @@ class GraphedTrainStep:
         else:
             self.optimizer.zero_grad(set_to_none=True)
 
-    def _fwd_bwd(self, batch):
+    def _segmented(self):
+        return self.reducer is not None and getattr(self.reducer, "segments", None) is not None
+
+    def _fwd_bwd(self, batch, on_segment=None):
+        """on_segment (segmented reducer only): called between the segments of the backward -- the eager step launches the
+        segment's collective there, the recording closes one graph and opens the next"""
         self._zero()
-        loss, sep = self.model(**batch)
-        loss.backward()
-        if self.reducer is not None:
-            self.reducer.gather()
+        if not self._segmented():
+            loss, sep = self.model(**batch)
+            loss.backward()
+            if self.reducer is not None:
+                self.reducer.gather()
+            return loss, sep
+        from .grad_arena import backward_in_segments, chore_segments
+        inner = getattr(self.model, "module", self.model)
+        inner.keep_train_segments = True
+        try:
+            loss, sep = self.model(**batch)
+        finally:
+            inner.keep_train_segments = False
+        seg = inner.train_segments
+        inner.train_segments = None
+        if self._seg_params is None:
+            self._seg_params = chore_segments(inner)
+
+        def after(k):
+            self.reducer.gather(k)
+            if on_segment is not None:
+                on_segment(k)
+        backward_in_segments(seg["stack_losses"], seg["cuts"], self._seg_params, after)
         return loss, sep
 
     def _invalidate(self):
@@ -119,9 +151,13 @@ class GraphedTrainStep:
             self._side = torch.cuda.Stream(dev)
         self._side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self._side):
-            loss, sep = self._fwd_bwd(batch)
-            if self.reducer is not None:
-                self.reducer.all_reduce()
+            if self._segmented():
+                loss, sep = self._fwd_bwd(batch, on_segment=self.reducer.all_reduce_async)
+                self.reducer.finish()
+            else:
+                loss, sep = self._fwd_bwd(batch)
+                if self.reducer is not None:
+                    self.reducer.all_reduce()
             self.optimizer.step()
         torch.cuda.current_stream(dev).wait_stream(self._side)
         self._invalidate()
@@ -141,6 +177,31 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         # a process group's watchdog thread polls events while we record: only THIS thread's calls belong to the recording
         mode = dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}
+        if split and self._segmented():
+            # one graph per segment of the backward: a capture is closed where the segment's collective will be launched and the
+            # next one opened on the same stream and memory pool (the autograd graph and its saved tensors carry over)
+            graphs = [ga]
+            state = {"cm": torch.cuda.graph(ga, **mode)}
+            state["cm"].__enter__()
+            nseg = len(self.reducer.segments)
+
+            def cut(k):
+                state["cm"].__exit__(None, None, None)
+                state["cm"] = None
+                if k + 1 < nseg:
+                    g = torch.cuda.CUDAGraph()
+                    graphs.append(g)
+                    state["cm"] = torch.cuda.graph(g, pool=ga.pool(), **mode)
+                    state["cm"].__enter__()
+            try:
+                loss, sep = self._fwd_bwd(static, on_segment=cut)
+            finally:
+                if state["cm"] is not None:
+                    state["cm"].__exit__(None, None, None)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool(), **mode):
+                self.optimizer.step()
+            return dict(static=static, ga=ga, gb=gb, segs=graphs, loss=loss.detach(), sep=sep)
         with torch.cuda.graph(ga, **mode):
             loss, sep = self._fwd_bwd(static)
             if not split:
@@ -150,7 +211,7 @@ class GraphedTrainStep:
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb, pool=ga.pool(), **mode):
                 self.optimizer.step()
-        return dict(static=static, ga=ga, gb=gb, loss=loss.detach(), sep=sep)
+        return dict(static=static, ga=ga, gb=gb, segs=None, loss=loss.detach(), sep=sep)
 
     def __call__(self, **batch):
         """one training step on `batch` (keyword arguments of CHORE.forward; tensors on the device).  Returns (loss, separate
@@ -175,9 +236,16 @@ class GraphedTrainStep:
         for k, v in batch.items():
             if torch.is_tensor(v) and v.data_ptr() != rec["static"][k].data_ptr():
                 rec["static"][k].copy_(v, non_blocking=True)
-        rec["ga"].replay()
-        if rec["gb"] is not None:
-            self.reducer.all_reduce()
+        if rec.get("segs"):
+            for k, g in enumerate(rec["segs"]):      # segment k's graph, then its slice of the arena to RCCL while the next one runs
+                g.replay()
+                self.reducer.all_reduce_async(k)
+            self.reducer.finish()
             rec["gb"].replay()
+        else:
+            rec["ga"].replay()
+            if rec["gb"] is not None:
+                self.reducer.all_reduce()
+                rec["gb"].replay()
         self._invalidate()
         return rec["loss"], rec["sep"]

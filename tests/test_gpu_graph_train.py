@@ -20,8 +20,9 @@ import numpy as np
 import torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
 from test_gpu_ddp_trainstep import _make
-from chore_amd.parallel import FlatGradReducer, GraphedTrainStep
-use_reducer = sys.argv[2] == "arena"
+from chore_amd.parallel import FlatGradReducer, GraphedTrainStep, chore_segments
+use_reducer = sys.argv[2] in ("arena", "segmented", "segmented_rs_ag")
+segmented = sys.argv[2].startswith("segmented")
 if use_reducer:
     import os, torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29631")
@@ -36,6 +37,11 @@ def run(graphed):
     # plain `g['lr'] = value` before step 5 (the reference's resume path, trainer.py:246-257)
     opt = torch.optim.Adam(net.parameters(), lr=(1e-4 if graphed else torch.tensor(1e-4, device="cuda")), capturable=True, fused=True)
     red = FlatGradReducer(net) if use_reducer else None
+    if graphed and segmented:
+        # round 5: the recording cut at the hourglass stacks, every stack's slice of the gradient arena all-reduced (RCCL, its own
+        # stream) while the graph of the next stack's backward runs -- against the EAGER, UNSEGMENTED step with the flat reducer
+        red = FlatGradReducer(net, segments=chore_segments(net), collective="rs_ag" if sys.argv[2].endswith("rs_ag") else "all_reduce")
+        assert len(red.segments) == 6 and len(red.chunks) == 6
     rec = []
     if graphed:
         step = GraphedTrainStep(net, opt, reducer=red, warmup=WARM)
@@ -69,6 +75,8 @@ def run(graphed):
 ra, sa, ma, _ = run(False)
 rb, sb, mb, step = run(True)
 assert step.calls == STEPS and len(step._rec) == 1, (step.calls, len(step._rec))
+if segmented:
+    assert len(next(iter(step._rec.values()))["segs"]) == 6
 bad = 0
 for it in range(STEPS):
     assert ra[it][0] == rb[it][0], ("loss", it, ra[it][0], rb[it][0])
@@ -103,7 +111,7 @@ print("graph train ok")
 '''
 
 
-@pytest.mark.parametrize("reducer", ["none", "arena"])
+@pytest.mark.parametrize("reducer", ["none", "arena", "segmented", "segmented_rs_ag"])
 def test_replayed_training_steps_equal_eager_steps_bit_for_bit(tmp_path, reducer):
     script = tmp_path / "graph_train.py"
     script.write_text(CHILD)
