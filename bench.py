@@ -660,6 +660,35 @@ def mode_fit(args, ctx):
                       "samples": len(v), "iterations": len(v) * SMPL_ITERS["steps_per_iter"]} for ph, v in by_phase.items()}
     chain_wall = [sum(c.values()) for c in chains]
     fitted = gather_fitted(result, B * ctx.world, rank, ctx.world, device=dev)
+    # ---- the loop over loader batches (recon_fit_behave.py:41-76), serial and pipelined (round 5): 6 consecutive batches through
+    # fit_recon; per-frame wall time of batches 2 .. 5 (the first two record the inner steps of the two map sets) ----
+    loop = {}
+    if fitter.reuse_graphs and not args.eager:
+        fitter.smpl_iters, fitter.object_iters, fitter.batch_seed = SMPL_ITERS, OBJECT_ITERS, 1234
+        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(6)]
+        for name, pipe in (("serial", False), ("pipelined", True)):
+            marks = []
+
+            class Loader(list):
+                pass
+            try:
+                for rep in range(3):               # first pass: recordings; second: allocator warm-up of the concurrent pattern; third: timed
+                    fitter.batch_ends = []
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fitter.fit_recon(opt, loader=Loader(batches), generator=gen, save=False, pipeline=pipe)
+                    torch.cuda.synchronize()
+                    marks.append((time.perf_counter() - t0) * 1e3)
+                ends = fitter.batch_ends
+                gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)]     # device time between consecutive batches' ends
+                fitter.batch_ends = None
+                loop[name] = {"ms_per_batch": marks[2] / len(batches), "ms_per_frame": marks[2] / (len(batches) * B),
+                              "steady_state_ms_per_batch_median": float(np.median(gaps)), "steady_state_ms_per_frame": float(np.median(gaps)) / B,
+                              "gaps_ms": [round(g, 1) for g in gaps],
+                              "first_pass_ms_per_batch": marks[0] / len(batches), "batches": len(batches)}
+            except Exception as e:
+                loop[name] = {"error": repr(e)[:300]}
+                torch.cuda.synchronize()
     out = None
     if rank == 0:
         per_step = {k: v / args.steps for k, v in stages.items()}
@@ -691,6 +720,10 @@ def mode_fit(args, ctx):
                     "chain_ms_median": float(np.median(chain_wall)), "chain_ms_all": [round(c, 2) for c in chain_wall],
                     "chain_stage_ms_median": {k: float(np.median([c.get(k, 0.0) for c in chains])) for k in per_step},
                     "per_phase": per_phase,
+                    "loader_loop": dict(loop, note="fit_recon over 6 consecutive loader batches of the same shapes (recordings kept), wall time "
+                                                   "per batch of the second pass; pipelined = batch k+1's encoder + point clouds + SMPL-H "
+                                                   "initialisation on a second stream / host thread while batch k is optimised, results equal to "
+                                                   "the serial loop bit for bit (tests/test_gpu_fit_chain.py)"),
                     "per_phase_note": "SURVEY 8(d) metric 2: median device ms per Adam iteration per phase over all outer iterations "
                                       "of all timed chains ('global' / 'smpl all pose' / 'kpts' = optimize_smpl; 'object only' / "
                                       "'sil' / 'joint' = optimize_smpl_object, joint incl. contact + collision terms)",

@@ -214,11 +214,16 @@ _handles = {}
 
 
 def handle(device_index: int) -> c_void_p:
-    """one chore_handle per (process, device)"""
+    """one chore_handle per (process, device) -- and per host THREAD: a handle carries an error string, lazily set kernel
+    attributes and (training) a side stream with its events, none of which two threads should share; the pipelined fit
+    (recon_fit_behave.fit_recon(pipeline=True)) drives a second stream from a second thread"""
+    import threading
+    if threading.current_thread() is not threading.main_thread():
+        device_index = (device_index, threading.get_ident())
     h = _handles.get(device_index)
     if h is None:
         h = c_void_p()
-        rc = lib.chore_create(ctypes.byref(h), device_index)
+        rc = lib.chore_create(ctypes.byref(h), device_index if isinstance(device_index, int) else device_index[0])
         if rc != 0:
             raise ChoreError(f"chore_create(device={device_index}) failed with {rc}: "
                              f"{lib.chore_last_error(None).decode()}")

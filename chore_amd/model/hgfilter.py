@@ -193,7 +193,11 @@ class HGFilter(_Params):
             tmpx = torch.empty(B, H // 2, W // 2, 64, dtype=tdt, device=dev)
             normx = torch.empty(B, H // 4, W // 4, 128, dtype=tdt, device=dev)
             if getattr(self, "static_outputs", False):
-                self._static_out = {wkey + (n_out,): (feats, tmpx, normx)}
+                # one set per (shape, stream): the pipelined fit encodes batch k+1 on a second stream while batch k's recorded
+                # steps still read batch k's maps; at most four sets live (streams come and go)
+                keep = list(self._static_out.items())[-3:]
+                self._static_out = dict(keep)
+                self._static_out[wkey + (n_out,)] = (feats, tmpx, normx)
         else:
             feats, tmpx, normx = outs
         fptrs = (ctypes.c_void_p * n_out)(*[f.data_ptr() for f in feats])

@@ -141,11 +141,21 @@ class Generator:
         s[0, :, 2] = (s[0, :, 2] - 0.5) * 0.5 + 2.2
         return s
 
-    def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=False):
+    def generate_pclouds_batch(self, data, num_steps=10, num_points=50000, mute=False, generators=None):
+        """generators: None = the process-wide random streams (the reference draws from torch's global CPU generator); or
+        (cpu torch.Generator, device torch.Generator) -- every random number of this call comes from them, so the result does
+        not depend on what else draws random numbers meanwhile (the pipelined fit prepares batch k+1 in a second thread)"""
         self.filter(data)
         bs = data.get("images").shape[0]
-        samples = self.get_grid_samples(30000, batch_size=bs)
-        return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute)
+        if generators is None:
+            samples = self.get_grid_samples(30000, batch_size=bs)
+            rng = None
+        else:
+            cpu_g, dev_g = generators
+            samples = self.init_samples(30000, bs, generator=cpu_g)
+            dev = self.device
+            rng = (lambda shape: torch.rand(shape, device=dev, generator=dev_g), lambda shape: torch.randn(shape, device=dev, generator=dev_g))
+        return {t: self.gen_pc_batch(self.model, t, samples, num_points, data, num_steps, mute=mute, rng=rng)
                 for t in ("human", "object")}
 
     def gen_pc_batch(self, model, df_type, samples_init, num_points, batch, num_steps, max_iter=100, mute=False,

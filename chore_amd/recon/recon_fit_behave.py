@@ -135,12 +135,18 @@ class ReconFitterBehave(ReconFitterBase):
         return {k: (lambda cst, it, c=c: c * cst / (1 + it)) for k, c in w.items()}
 
     # ---- the whole chain ------------------------------------------------------------------------------
-    def fit_recon(self, args, loader=None, model=None, generator=None, save=True):
+    def fit_recon(self, args, loader=None, model=None, generator=None, save=True, pipeline=None):
         """[recon_fit_behave.py:29-76] for every batch of the loader: dense point clouds from the two UDFs -> SMPL-H
         initialisation -> optimize_smpl -> object initialisation -> optimize_smpl_object -> results on disk.
         `loader` / `model` / `generator` default to what the reference builds from `args` (TestData loader of the
         sequence, CHORE(args), Generator with the experiment's checkpoint).  Under torch.distributed every rank takes the
-        batches rank::world_size (frames are independent: BASELINE configs[4]); returns this rank's fitted parameters."""
+        batches rank::world_size (frames are independent: BASELINE configs[4]); returns this rank's fitted parameters.
+
+        pipeline (default: the fitter's `pipeline` attribute; round 5): the reference's loop is strictly serial per batch, and a
+        batch's chain starts with the encoder + the point clouds (a quarter of its time) before the first Adam step.  Pipelined,
+        batch k+1's encode + point clouds + SMPL-H initialisation run on a second stream, issued by a second host thread, while
+        batch k is being optimised (`_fit_pipelined`) -- same results bit for bit as the serial loop with the same `batch_seed`
+        (tests/test_gpu_fit_chain.py), since every batch then draws its point-cloud random numbers from its own generators."""
         from ..model import CHORE
         from ..parallel.frame_shard import shard_indices
         from .generator import Generator
@@ -153,7 +159,7 @@ class ReconFitterBehave(ReconFitterBase):
                                   checkpoint=getattr(args, "checkpoint", None))
         batches = list(loader) if not hasattr(loader, "__len__") else loader
         mine = set(shard_indices(len(batches)))
-        results = []
+        todo = []
         for i, data in enumerate(batches):
             if i not in mine:
                 continue
@@ -161,31 +167,174 @@ class ReconFitterBehave(ReconFitterBase):
                     self.is_done(data["path"], args.save_name, args.test_kid):
                 print(data["path"], args.save_name, "already done, skipped")
                 continue
-            smpl, obj_R, obj_t, obj_s = self.fit_batch(data, generator)
+            todo.append((i, data))
+        results = []
+
+        def finish(i, data, fitted):
+            smpl, obj_R, obj_t, obj_s = fitted
             if save and self.outpath is not None:
                 self.save_outputs(smpl, obj_R, obj_t, data["path"], args.save_name, args.test_kid, obj_s)
             results.append(dict(index=i, pose=smpl.pose.detach(), betas=smpl.betas.detach(), trans=smpl.trans.detach(),
                                 obj_R=self.decopose_axis(obj_R, no_rand=True).detach(), obj_t=obj_t.detach(),
                                 obj_s=obj_s.detach()))
+        use_pipe = self.pipeline if pipeline is None else pipeline
+        if use_pipe and len(todo) > 1 and torch.device(self.device).type == "cuda":
+            self._fit_pipelined(todo, generator, finish)
+        else:
+            for i, data in todo:
+                fitted = self.fit_batch(data, generator, index=i)
+                if self.batch_ends is not None and torch.device(self.device).type == "cuda":
+                    self._mark_read([None], 0, torch.cuda.current_stream(torch.device(self.device)))
+                finish(i, data, fitted)
         return results
 
-    def fit_batch(self, data, generator, smpl_iters=None, object_iters=None):
-        """one batch through the chain of fit_recon (:46-74); the iteration counts are the reference's"""
-        batch_size = data["images"].shape[0]
+    # Every batch's point-cloud random numbers from generators of its own (seed = batch_seed + the batch's index in the loader):
+    # None = the process-wide streams, like the reference (serial loop only -- two threads drawing from one stream have no order).
+    batch_seed = None
+    pipeline = False      # fit_recon: prepare batch k+1 on a second stream / host thread while batch k is optimised
+    smpl_iters = None     # fit_recon / fit_batch: keyword arguments of optimize_smpl / optimize_smpl_object other than the
+    object_iters = None   # reference's (benchmarks and tests with shorter schedules)
+
+    def _batch_generators(self, index):
+        if self.batch_seed is None or index is None:
+            return None
+        dev = torch.device(self.device)
+        cpu_g, dev_g = torch.Generator(), torch.Generator(device=dev)
+        cpu_g.manual_seed(int(self.batch_seed) + 2 * int(index))
+        dev_g.manual_seed(int(self.batch_seed) + 2 * int(index) + 1)
+        return cpu_g, dev_g
+
+    def prepare_batch(self, data, generator, index=None):
+        """the first half of a batch's chain (fit_recon :46-57): encoder, dense point clouds, SMPL-H initialisation -- everything
+        before the first optimiser step"""
         if self.use_graphs and self.reuse_graphs and hasattr(generator.model, "image_filter"):
             generator.model.image_filter.static_outputs = True      # the kept steps read the maps through fixed addresses
-        pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True)
+        pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True,
+                                                        generators=self._batch_generators(index))
+        return dict(data=data, pc=pc_generated, model=generator.model, smplfit=self.prep_smplfit(data, generator, pc_generated))
+
+    def optimise_batch(self, prep, smpl_iters=None, object_iters=None):
+        """the second half (:58-74): optimize_smpl -> object initialisation -> optimize_smpl_object"""
+        data, pc_generated = prep["data"], prep["pc"]
+        batch_size = data["images"].shape[0]
         (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
-         smpl) = self.prep_smplfit(data, generator, pc_generated)
-        smpl, scale = self.optimize_smpl(smpl, betas_dict, **(smpl_iters or dict(iter_for_kpts=1, iter_for_pose=1,
-                                                                                 iter_for_betas=1)))
+         smpl) = prep["smplfit"]
+        smpl, scale = self.optimize_smpl(smpl, betas_dict, **(smpl_iters or self.smpl_iters or dict(iter_for_kpts=1, iter_for_pose=1,
+                                                                                                    iter_for_betas=1)))
         obj_R, obj_s, obj_t, object_init = self.init_obj_fit_data(batch_size, human_t, pc_generated, scale)
         data_dict = {"obj_R": obj_R, "obj_t": obj_t, "obj_s": obj_s, "objects": object_init, "smpl": smpl,
                      "images": data.get("images").to(self.device), "human_init": human_points, "obj_init": obj_points,
                      "human_parts": human_parts, "part_labels": part_labels, "part_colors": part_colors,
                      "body_kpts": body_kpts, "query_dict": query_dict, "obj_t_init": obj_t.clone().detach().to(self.device)}
-        smpl, obj_R, obj_t = self.optimize_smpl_object(generator.model, data_dict, **(object_iters or {}))
+        smpl, obj_R, obj_t = self.optimize_smpl_object(prep["model"], data_dict, **(object_iters or self.object_iters or {}))
         return smpl, obj_R, obj_t, obj_s
+
+    def fit_batch(self, data, generator, smpl_iters=None, object_iters=None, index=None):
+        """one batch through the chain of fit_recon (:46-74); the iteration counts are the reference's"""
+        return self.optimise_batch(self.prepare_batch(data, generator, index), smpl_iters, object_iters)
+
+    def _fit_pipelined(self, todo, generator, finish, smpl_iters=None, object_iters=None):
+        """Batch k+1 is PREPARED (encoder + point clouds + SMPL-H initialisation) while batch k is OPTIMISED.
+        Two slots, alternating: each has its own stream, its own view of the field network (a shallow copy of the CHORE object:
+        the same parameters and packed weights, its own `im_feat_list / tmpx / preds`) and therefore its own feature maps
+        (HGFilter.static_outputs is keyed by stream) and its own kept recordings (_FitSlot is keyed by the maps' addresses).
+        The preparation is issued by a worker thread (it waits for the device several times per point-cloud round; ctypes and
+        torch release the GIL while they wait or launch), the optimisation by the calling thread on its current stream.
+        Ordering on the device: a slot's preparation waits for the optimisation that last read the slot's maps; an optimisation
+        waits for its batch's preparation.  While a slot's inner steps are being RECORDED (its first batch) nothing else is
+        issued: a capture does not tolerate another thread's allocations."""
+        import copy
+        from concurrent.futures import ThreadPoolExecutor
+        if self.batch_seed is None:
+            self.batch_seed = 0
+        dev = torch.device(self.device)
+        main = torch.cuda.current_stream(dev)
+        state = self.__dict__.get("_pipe_state")
+        if state is None or state[0] is not generator or state[1][0] is not generator.model:
+            # kept across calls: the second view's identity is part of the kept recordings' key (_maps_key)
+            nets = [generator.model, copy.copy(generator.model)]
+            gens = [generator, copy.copy(generator)]
+            gens[1].model = nets[1]
+            prio = int(os.environ.get("CHORE_PIPE_PRIO", "0"))
+            state = self._pipe_state = (generator, nets, gens, [torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev, priority=prio)],
+                                        [False, False])
+        _, nets, gens, streams, warm = state            # warm[s]: slot s's inner steps are recorded (kept across calls with the slots)
+        if not self.reuse_graphs:
+            warm[0] = warm[1] = False
+        last_read = [None, None]        # event: the optimisation that last used the slot has been issued AND executed up to here
+
+        import time
+        dbg = [] if os.environ.get("CHORE_PIPE_DEBUG") else None
+        t_base = time.perf_counter()
+
+        def prepare(k, ready):
+            i, data = todo[k]
+            s = k % 2
+            torch.cuda.set_device(dev)
+            th0 = time.perf_counter()
+            with torch.cuda.stream(streams[s]):
+                streams[s].wait_event(ready)                       # the loader's tensors, issued on the caller's stream
+                if last_read[s] is not None:
+                    streams[s].wait_event(last_read[s])
+                e0 = torch.cuda.Event(enable_timing=True) if dbg is not None else None
+                if e0 is not None:
+                    e0.record(streams[s])
+                prep = self.prepare_batch(data, gens[s], index=i)
+                done = torch.cuda.Event(enable_timing=dbg is not None)
+                done.record(streams[s])
+            if dbg is not None:
+                dbg.append(("prep", k, th0 - t_base, time.perf_counter() - t_base, e0, done))
+            return prep, done
+
+        def submit(pool, k):
+            ready = torch.cuda.Event()
+            ready.record(main)
+            return pool.submit(prepare, k, ready)
+
+        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-prep") as pool:
+            fut = submit(pool, 0)
+            for k, (i, data) in enumerate(todo):
+                prep, done = fut.result()
+                s = k % 2
+                fut = None
+                if k + 1 < len(todo):
+                    if not warm[s] and self.use_graphs:            # this optimisation records: nothing beside it
+                        main.wait_event(done)
+                        fitted = self.optimise_batch(prep, smpl_iters, object_iters)
+                        self._mark_read(last_read, s, main)
+                        warm[s] = True
+                        fut = submit(pool, k + 1)
+                        finish(i, data, fitted)
+                        continue
+                    fut = submit(pool, k + 1)
+                th0 = time.perf_counter()
+                main.wait_event(done)
+                if dbg is not None:
+                    o0 = torch.cuda.Event(enable_timing=True)
+                    o0.record(main)
+                fitted = self.optimise_batch(prep, smpl_iters, object_iters)
+                self._mark_read(last_read, s, main)
+                if dbg is not None:
+                    o1 = torch.cuda.Event(enable_timing=True)
+                    o1.record(main)
+                    dbg.append(("opt", k, th0 - t_base, time.perf_counter() - t_base, o0, o1))
+                warm[s] = True
+                finish(i, data, fitted)
+        if dbg:
+            torch.cuda.synchronize()
+            ref = [d for d in dbg if d[0] == "opt"][0][4]
+            for kind, k, h0, h1, e0, e1 in sorted(dbg, key=lambda d: d[2]):
+                print("[pipe] %-4s batch %d  host %7.1f .. %7.1f ms   device %7.1f .. %7.1f ms (relative to the first timed optimisation's start)"
+                      % (kind, k, h0 * 1e3, h1 * 1e3, ref.elapsed_time(e0), ref.elapsed_time(e1)), file=__import__("sys").stderr)
+
+    batch_ends = None     # a list: one timing event per finished batch of fit_recon (serial or pipelined) is appended
+
+    def _mark_read(self, last_read, s, stream):
+        ev = torch.cuda.Event(enable_timing=self.batch_ends is not None)
+        ev.record(stream)
+        last_read[s] = ev
+        if self.batch_ends is not None:
+            self.batch_ends.append(ev)
 
     def init_dataloader(self, args):
         """[recon_fit_behave.py:78-88] the image loader is the reference's own host-side code (data/test_data.py, cv2

@@ -485,3 +485,45 @@ def test_fit_recon_chain_end_to_end(opt, tmp_path):
     assert v.shape == (fitter.scan.v.shape[0], 3) and f.shape == fitter.scan.f.shape
     res2 = fitter.fit_recon(args, loader=loader, generator=gen)      # is_done: nothing to do
     assert res2 == [] and len(calls) == 2
+
+
+def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
+    """fit_recon(pipeline=True) (round 5): batch k+1's encoder + point clouds + SMPL-H initialisation on a second stream, issued by
+    a second host thread, while batch k is optimised (recon/recon_fit_behave.py:41-76 loops the batches strictly one after the
+    other).  Five different loader batches through the whole chain (silhouette, contact and collision terms, hipGraph-replayed
+    inner iterations kept across batches), pipelined and serial with the same `batch_seed`: every fitted parameter of every batch
+    EQUAL -- the pipelined batches read the right maps (two alternating map sets), wait for the right events, and draw the
+    same random numbers."""
+    import copy
+    import bench
+    from chore_amd.model import CHORE
+    from chore_amd.recon.assets import SyntheticAssets
+    from chore_amd.recon.generator import Generator
+    from chore_amd.recon.recon_fit_behave import ReconFitterBehave
+    from chore_amd.utils import synth
+    dev = torch.device("cuda", 0)
+    o = copy.copy(opt)
+    o.compute_dtype = "fp16x3"
+    res = {}
+    for pipe in (False, True):
+        net = CHORE(o).to(dev).eval()
+        synth.load_synth_weights(net, seed=0)
+        fitter = ReconFitterBehave(None, device=dev, obj_name="synthetic", outpath=None, args=o, assets=SyntheticAssets(0))
+        fitter.use_graphs, fitter.reuse_graphs, fitter.early_stop, fitter.adam_capturable = True, True, False, True
+        fitter.batch_seed = 7
+        fitter.smpl_iters = dict(iter_for_betas=1, iter_for_pose=1, iter_for_kpts=1, steps_per_iter=5, max_iter=1)
+        fitter.object_iters = dict(obj_iter=2, sil_iter=2, joint_iter=2, max_iter=1, steps_per_iter=5)
+        gen = Generator(net, None, threshold=2.0, sparse_thres=0.03, filter_val=1.0, device=dev)
+        loader = [bench.fit_batch_inputs(1, 10 + k, dev) for k in range(5)]
+        torch.manual_seed(3)                       # the optimisation's own draws (CPU stream, calling thread only)
+        out = fitter.fit_recon(o, loader=loader, generator=gen, save=False, pipeline=pipe)
+        torch.cuda.synchronize()
+        assert [r["index"] for r in out] == list(range(5))
+        res[pipe] = [{k: v.detach().cpu().clone() for k, v in r.items() if torch.is_tensor(v)} for r in out]
+        if pipe:
+            assert len(fitter._slots) == 4         # (smpl, object) x two map sets, each recorded once
+    for k, (a, b) in enumerate(zip(res[False], res[True])):
+        for name in a:
+            assert torch.isfinite(b[name]).all(), (k, name)
+            assert torch.equal(a[name], b[name]), (k, name, float((a[name] - b[name]).abs().max()))
+    assert not torch.equal(res[True][0]["obj_t"], res[True][1]["obj_t"])      # different batches, different fits
