@@ -47,6 +47,8 @@ struct WgradArgs {
     float* part_bias;         // [S][Cout] or null
     int S;                    // shares of the pixel tiles
     const unsigned* dy_amax;  // fp16 x 3 kernels: AMAX_CELLS partial maxima of |dy| (enc_common.h), or null
+    int dbg;                  // CHORE_WGRAD_DBG ablation bits (measurements only; results are wrong when set): 1 no MFMAs, 2 no split / LDS
+                              // stores, 4 no global loads
 };
 
 template <typename T, int TAPS>
@@ -398,17 +400,14 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
         lo = __builtin_bit_cast(u32x4, ll);
     };
 
-    for (int tile = share; tile < tiles; tile += a.S) {
+    // The global loads of tile i + 1 are issued BEFORE the MFMAs of tile i and consumed after them (registers vy / vx live across
+    // the MFMA loop): with one wave per SIMD nothing else hides a load's round trip, and the first version -- load, wait, split,
+    // store, MFMAs, one after the other -- spent 21 us per tile on 3 us of MFMAs (profiles/r05_wgrad_x3.txt).  Loads are
+    // unconditional at clamped addresses (a branch around a load makes the compiler wait for everything in flight).
+    u32x4 vy[NVY][2], vx[NVX][2];
+    auto issue_loads = [&](int tile) {
         const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
         const int ty0 = (tt / tiles_x) * WX_TH, tx0 = (tt % tiles_x) * TW;
-        __syncthreads();                                   // previous tile fully consumed
-        if (use_gn && b != cur_b) {
-            if (tid < 64) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
-            __syncthreads();
-        }
-        cur_b = b;
-        // ---- all loads of both tiles in flight, then the splits and the LDS stores ----
-        u32x4 vy[NVY][2], vx[NVX][2];
 #pragma unroll
         for (int q = 0; q < NVY; ++q) {
             const int i = tid + 256 * q, row = i >> 3, v = i & 7;
@@ -423,6 +422,18 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
             const u32x4* p = (const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.xs + ci0 + v * 8);
             vx[q][0] = p[0]; vx[q][1] = p[1];
         }
+    };
+    if (share < tiles && !(a.dbg & 4)) issue_loads(share);
+    for (int tile = share; tile < tiles; tile += a.S) {
+        const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+        const int ty0 = (tt / tiles_x) * WX_TH, tx0 = (tt % tiles_x) * TW;
+        __syncthreads();                                   // previous tile fully consumed
+        if (use_gn && b != cur_b) {
+            if (tid < 64) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + tid, a.H * a.W, a.gamma, a.beta, ss[2 * tid], ss[2 * tid + 1]);
+            __syncthreads();
+        }
+        cur_b = b;
+        if (!(a.dbg & 2)) {
 #pragma unroll
         for (int q = 0; q < NVY; ++q) {
             const int i = tid + 256 * q, row = i >> 3, v = i & 7;
@@ -454,7 +465,9 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
                 *(u32x4*)(imgA + PLA + row * W64_PITCH + v * 16) = lo;
             }
         }
+        }
         __syncthreads();
+        if (!(a.dbg & 4)) issue_loads(tile + a.S < tiles ? tile + a.S : tile);      // the next tile's operands travel under this tile's MFMAs
         if (a.part_bias && pair % nbc == 0 && tid < 64) {
             for (int p = 0; p < YROWS; ++p)
                 bias_acc += (float)*(const _Float16*)(imgY + p * W64_PITCH + tid * 2) + (float)*(const _Float16*)(imgY + PLY + p * W64_PITCH + tid * 2);
@@ -462,6 +475,7 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
         // ---- MFMAs: small terms first, all three into the same accumulator ----
         const char* baseY = imgY + lane_off + coh * 64;
         const char* baseA = imgA + lane_off + cih * 64;
+        if (!(a.dbg & 1)) {
 #pragma unroll 1
         for (int y = 0; y < WX_TH; ++y) {
 #pragma unroll
@@ -477,6 +491,7 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, acc[t], 0, 0, 0);
                 }
             }
+        }
         }
     }
     // ---- this share's partial: [tap][64 co][64 ci] ----
@@ -874,6 +889,8 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
     if (dtype != CHORE_F32 && dtype != CHORE_BF16 && dtype != CHORE_F16X3) CHORE_FAIL(h, CHORE_EINVAL, "chore_conv2d_bwd_weight: bad dtype");
     WgradArgs a;
     a.dy_amax = dy_amax;
+    static const int wdbg = getenv("CHORE_WGRAD_DBG") ? atoi(getenv("CHORE_WGRAD_DBG")) : 0;
+    a.dbg = wdbg;
     a.x = x; a.st = (const GroupStat*)stats; a.gamma = gamma; a.beta = beta; a.dy = dy;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
     a.xs = Cin; a.ys = dy_stride; a.npix = (long long)B * H * W;
@@ -995,6 +1012,7 @@ int chore_gemm_tn_f32(chore_handle* h, const float* A, int lda, const float* B, 
         CHORE_FAIL(h, CHORE_EINVAL, "chore_gemm_tn_f32: M, N must be multiples of 32 (P=%d M=%d N=%d)", P, M, N);
     hipStream_t s = (hipStream_t)stream;
     WgradArgs a;
+    a.dy_amax = nullptr; a.dbg = 0;
     a.x = B; a.st = nullptr; a.gamma = nullptr; a.beta = nullptr; a.dy = A;
     a.B = 1; a.H = (P + 31) / 32; a.W = 32; a.Cin = N; a.Cout = M; a.xs = ldb; a.ys = lda; a.npix = P;
     a.S = wgrad_shares(1, a.H, a.W, N, M);

@@ -11,11 +11,23 @@ Backward of conv_gn: data gradient = the forward convolution kernel on transpose
 (chore_conv2d_bwd_data); weight gradient = pixel-contraction MFMA GEMM (chore_conv2d_bwd_weight, recomputes
 relu(gn(x)) while staging); GroupNorm+ReLU backward from the exact group statistics (chore_gn_relu_bwd).
 """
+import os
+
 import torch
 
 from . import _lib
 
 _DT = {torch.float32: _lib.F32, torch.bfloat16: _lib.BF16}
+_SIDE = {}
+
+
+def _side_stream(dev):
+    """the stream the stand-alone layers' weight gradients run on (one per device)"""
+    s = _SIDE.get(dev)
+    if s is None:
+        s = _SIDE[dev] = torch.cuda.Stream(dev)
+    return s
+
 # fp16 x 3 training ("fp16x3" compute mode): fp32 tensors whose convolutions -- forward, data gradient, weight gradient -- run on
 # the fp16 matrix cores with hi / lo split operands (csrc/conv_pc.hip, train_bwd.hip wgrad64_x3_kernel).  The tensor dtype cannot
 # tell this mode from the exact-fp32 one, so it is a switch the forward pass sets (`with ops.x3_convs():`); every node remembers
@@ -213,12 +225,16 @@ class _ConvGN(torch.autograd.Function):
         dt = ctx.cdt
         amax = _absmax(dy, dev, h, stream) if dt == _lib.F16X3 else None
         ap = None if amax is None else amax.data_ptr()
-        _lib.check(_lib.lib.chore_conv2d_bwd_weight(h, dt, taps, x.data_ptr(), B, H, W, Cin,
-                                                    None if st is None else st.data_ptr(),
-                                                    None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
-                                                    dy.data_ptr(), Cout, dw.data_ptr(),
-                                                    None if dbias is None else dbias.data_ptr(), ws.data_ptr(), ap, stream), h,
-                   "chore_conv2d_bwd_weight")
+        # CHORE_CONVGN_SIDE=1: the weight gradient of a stand-alone layer on a side stream beside its data-gradient chain (fork after
+        # dy's range is known, join before this node returns; the caller's-stream kernels issued first, see convblock.hip).
+        # Built and measured in round 5 -- and OFF by default: the 1x1 layers' data and weight gradients are both bound by the same
+        # HBM traffic, side by side each takes as long as the two in turn (77 + 174 us in turn, 227 and 224 us together), the
+        # step is 31.6 ms either way (profiles/r05_train_kernel_stats.txt).
+        cur = torch.cuda.current_stream(dev)
+        side = _side_stream(dev) if os.environ.get("CHORE_CONVGN_SIDE") else None
+        if side is not None:
+            fork = torch.cuda.Event()
+            fork.record(cur)
         dx = dg = db = None
         if ctx.needs_input_grad[0] or ctx.has_gn:
             da = torch.empty_like(x)                      # gradient w.r.t. what the convolution saw
@@ -230,6 +246,17 @@ class _ConvGN(torch.autograd.Function):
                 ctx.acc = None
             else:
                 dx = da
+        if side is not None:
+            side.wait_event(fork)
+        _lib.check(_lib.lib.chore_conv2d_bwd_weight(h, dt, taps, x.data_ptr(), B, H, W, Cin,
+                                                    None if st is None else st.data_ptr(),
+                                                    None if g is None else g.data_ptr(), None if b is None else b.data_ptr(),
+                                                    dy.data_ptr(), Cout, dw.data_ptr(),
+                                                    None if dbias is None else dbias.data_ptr(), ws.data_ptr(), ap,
+                                                    stream if side is None else side.cuda_stream), h,
+                   "chore_conv2d_bwd_weight")
+        if side is not None:
+            cur.wait_stream(side)
         return dx, dw, dbias, dg, db, None, None
 
 

@@ -1,4 +1,5 @@
-cd $GRAFT_REPO_ROOT
-timeout 900 python bench.py --mode fit --no-cpu-baseline > gpurun_out/r05_i_fit.json 2> gpurun_out/r05_i_fit.err; echo rc=$?
-timeout 900 python bench.py --mode fit --frames-per-gpu 8 --steps 2 --no-cpu-baseline > gpurun_out/r05_i_fit8.json 2> gpurun_out/r05_i_fit8.err; echo rc=$?
-timeout 900 python -m pytest tests/test_gpu_fit_chain.py -q -x -k "pipelined or kept_graphs" 2>&1 | tail -3
+cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/proft
+timeout 600 rocprofv3 --kernel-trace -d /tmp/proft -o train -- python $GRAFT_REPO_ROOT/scripts/train_graph_trace.py 6 fp16x3 > /dev/null 2> $GRAFT_REPO_ROOT/gpurun_out/tr.err
+f=$(find /tmp/proft -name "*results.db" | head -1)
+python $GRAFT_REPO_ROOT/scripts/train_step_trace.py $f $GRAFT_REPO_ROOT/gpurun_out/r05b_train_step_listing.txt > $GRAFT_REPO_ROOT/gpurun_out/r05b_train_kernel_stats.txt
+head -30 $GRAFT_REPO_ROOT/gpurun_out/r05b_train_kernel_stats.txt | cut -c1-150

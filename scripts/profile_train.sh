@@ -7,13 +7,12 @@
 tag=${1:-r02}
 repo=$(pwd); out=$repo/gpurun_out; mkdir -p $out
 export TMPDIR=/tmp
-timeout 900 python bench.py --mode train --steps 20 --warmup 5 > $out/${tag}_bench_train.json 2> $out/${tag}_bench_train.err
-timeout 900 python bench.py --mode train --steps 10 --warmup 3 --dtype fp32 --no-cpu-baseline > $out/${tag}_bench_train_fp32.json 2>> $out/${tag}_bench_train.err
+timeout 900 python bench.py --mode train --train-other-modes --steps 20 --warmup 5 > $out/${tag}_bench_train.json 2> $out/${tag}_bench_train.err
 timeout 900 python bench.py --mode fit > $out/${tag}_bench_fit.json 2> $out/${tag}_bench_fit.err
 # one REPLAYED training step (chore_amd.parallel.GraphedTrainStep): per-class kernel time, busy / idle, launch listing
 cd /tmp; rm -rf /tmp/proft_$tag
 timeout 600 rocprofv3 --kernel-trace -d /tmp/proft_$tag -o train -- \
-    python $repo/scripts/train_graph_trace.py 6 > /dev/null 2> $out/${tag}_train_rocprof.err
+    python $repo/scripts/train_graph_trace.py 6 fp16x3 > /dev/null 2> $out/${tag}_train_rocprof.err
 f=$(find /tmp/proft_$tag -name "*results.db" | head -1)
 if [ -n "$f" ]; then
     python $repo/scripts/train_step_trace.py $f $out/${tag}_train_step_listing.txt > $out/${tag}_train_kernel_stats.txt

@@ -27,12 +27,12 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B, N = 4, 20000
 
 
-def _make(rank):
+def _make(rank, dtype="bf16"):
     sys.path.insert(0, REPO)
     import bench
     from chore_amd.model import CHORE
     from chore_amd.utils import synth
-    net = CHORE(bench.chore_opt("bf16")).cuda()
+    net = CHORE(bench.chore_opt(dtype)).cuda()
     synth.load_synth_weights(net, seed=0)
     net.losses_on_host = False
     rs = np.random.RandomState(50 + rank)
