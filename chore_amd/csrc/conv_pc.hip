@@ -17,6 +17,8 @@
 //   * epilogue: the accumulators go through an LDS image of the whole tile, then ALL 512 threads add the residuals
 //     (fetched during the last chunk), store 16-byte vectors and reduce the GroupNorm statistics in a fixed order.
 #include "conv_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 #ifndef CHORE_CONV_ABLATE
 #define CHORE_CONV_ABLATE 0
@@ -693,6 +695,18 @@ PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout,
         else if (q.th == 4 && q.nt == 32) { q.tps = 9; q.nslot = 2; }
         else { q.tps = 3; q.nslot = 2; }
     };
+    if (!force) {   // CHORE_PC_FORCE="taps,Cin,Cout,H:th*1000+nt[;...]" -- tiling experiments (scripts/conv_layer_ab.py)
+        static const char* env = getenv("CHORE_PC_FORCE");
+        if (env) {
+            const char* q = env;
+            while (*q) {
+                int t, ci, co, hh, f, n = 0;
+                if (sscanf(q, "%d,%d,%d,%d:%d%n", &t, &ci, &co, &hh, &f, &n) == 5 && t == taps && ci == Cin && co == Cout && hh == H) { force = f; break; }
+                while (*q && *q != ';') ++q;
+                if (*q == ';') ++q;
+            }
+        }
+    }
     if (force) {   // development: th * 1000 + nt (e.g. 8064)
         p.th = force / 1000; p.nt = force % 1000;
         ring(p);
