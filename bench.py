@@ -430,7 +430,21 @@ def mode_query(args, ctx):
                     step2()
                 t2 = timed(step2, 5)
                 other_modes[mode] = {"ms_per_step": t2, "value": B * N / t2 * 1e3, "unit": "points/s",
+                                     "step_issue": "eager launches from Python, one step at a time",
                                      "field_err": field_errors(net2.get_preds())["all"]}
+                try:        # the same step as ONE hipGraph replay (what `single_in_flight_ms_per_step` is for the headline mode)
+                    torch.cuda.synchronize()
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        step2()
+                    for _ in range(3):
+                        g2.replay()
+                    t3 = timed(g2.replay, 20)
+                    other_modes[mode].update(replayed_ms_per_step=t3, replayed_points_per_s=B * N / t3 * 1e3)
+                    del g2
+                except Exception as e:
+                    torch.cuda.synchronize()
+                    other_modes[mode]["replayed_error"] = repr(e)[:120]
                 del net2
     # metric 1(ii): forward + backward to the points (the generator's projection step, recon/generator.py:50-79)
     pg = points.clone().requires_grad_(True)

@@ -290,6 +290,46 @@ def gen_train_grads(net):
     np.savez_compressed(os.path.join(HERE, "train_grads.npz"), error=np.float32(error.detach()), names=np.array(names), **out)
 
 
+def gen_train_steps(net):
+    """FOUR optimiser steps of the reference's Trainer.train_step sequence (trainer/trainer.py:76-85: zero_grad, model(**batch) ->
+    loss, backward, Adam step; optim.Adam(model.parameters(), lr) as in :35) on two alternating synthetic batches: the loss of
+    every step (steps 2-4 see parameters the earlier steps moved), per parameter tensor the L2 norm of its total displacement, and the
+    final values of the small tensors.  What a training MODE (fp32, fp16x3, bf16) must reproduce beyond one step's gradients."""
+    batches = [train_batch(seed=21), train_batch(seed=22)]
+    net.train(True)
+    net.print_errors = lambda *a, **k: None
+    for p in net.parameters():
+        p.requires_grad_(True)
+        p.grad = None
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    errors, sep = [], []
+    for it in range(4):
+        b = batches[it % 2]
+        opt.zero_grad()
+        error, losses_all = net.forward(**{k: torch.from_numpy(v) for k, v in b.items()})
+        error.backward()
+        opt.step()
+        errors.append(float(error.detach()))
+        sep.append(losses_all.numpy().copy())
+    out, names = {}, []
+    for n, p in net.named_parameters():
+        names.append(n)
+        d = (p.detach() - before[n]).double()
+        out["d_" + n] = np.array([float(d.norm()), float(d.abs().max())])
+        if p.numel() <= 512:
+            out["v_" + n] = p.detach().numpy().copy()
+    with torch.no_grad():          # the parameters back to where they were (the other generators share `net`)
+        for n, p in net.named_parameters():
+            p.copy_(before[n])
+            p.requires_grad_(False)
+            p.grad = None
+    net.train(False)
+    print("train_steps: errors", errors)
+    np.savez_compressed(os.path.join(HERE, "train_steps.npz"), errors=np.array(errors, np.float64), losses_all=np.array(sep),
+                        names=np.array(names), seeds=np.array([21, 22]), lr=np.float64(1e-4), **out)
+
+
 def gen_surface(net):
     """reference Generator.approx_surface (recon/generator.py:50-79) for 3 projection steps on the
     query_full inputs; the constructor (checkpoint folders) is bypassed"""
@@ -1035,6 +1075,7 @@ def main():
     gen_train_loss(net)
     gen_query_train(net)
     gen_train_grads(net)
+    gen_train_steps(net)
     gen_eval()
     gen_coco()
     gen_fullbody_crop()

@@ -245,6 +245,48 @@ def test_full_training_backward_matches_reference(opt, mode):
           % (mode, float(np.median(rel_l2)), worst[0], worst[1]))
 
 
+@pytest.mark.parametrize("mode", ["fp32", "fp16x3", "bf16"])
+def test_four_training_steps_follow_the_reference(opt, mode):
+    """FOUR steps of the reference's Trainer.train_step sequence (trainer/trainer.py:76-85; Adam, lr 1e-4) on two alternating batches,
+    against the reference's own CPU run (tests/golden/train_steps.npz, make_golden.gen_train_steps): the loss of every step -- steps
+    2-4 are evaluated at parameters the earlier steps moved -- and how far every parameter tensor travelled.  Bounds: fp32 and
+    fp16x3 (the fp32-grade training mode of round 5) losses 2e-4 relative, displacement norms 2 % (Adam's first steps move every
+    entry by ~lr whatever its gradient's size, so an entry whose gradient is round-off noise goes either way: the NORM of a
+    tensor's displacement is stable, its entries are not); bf16 losses 2e-2, norms 10 %."""
+    import copy
+    from make_train_batch import train_batch
+    g = golden("train_steps.npz")
+    net = make_net(copy.copy(opt), mode)
+    net.train(True)
+    for p in net.parameters():
+        p.requires_grad_(True)
+    before = {n: p.detach().clone() for n, p in net.named_parameters()}
+    batches = [{k: torch.from_numpy(v).cuda() for k, v in train_batch(seed=int(sd)).items()} for sd in g["seeds"]]
+    optim = torch.optim.Adam(net.parameters(), lr=float(g["lr"]))
+    errors = []
+    for it in range(4):
+        optim.zero_grad()
+        error, _ = net.forward(**batches[it % 2])
+        error.backward()
+        optim.step()
+        errors.append(float(error.detach()))
+    ltol, ntol = (5e-3, 0.10) if mode == "bf16" else (2e-4, 0.02)      # measured: bf16 1.5e-3 / 4.4e-2, fp16x3 8.7e-5 / 3.4e-3, fp32 6.2e-5 / 3.4e-3
+    rel = [abs(a - b) / b for a, b in zip(errors, g["errors"])]
+    print("mode %s: losses %s | relative deviation from the reference's %s" % (mode, ["%.3f" % e for e in errors], ["%.1e" % r for r in rel]))
+    assert max(rel) < ltol, (errors, list(g["errors"]))
+    assert errors[-1] < 0.5 * errors[0]
+    worst = (0.0, "")
+    for n, p in net.named_parameters():
+        ref = g["d_" + n]
+        d = float((p.detach() - before[n]).double().norm())
+        if ref[0] == 0.0:
+            assert d == 0.0, n                      # the never-used bn4 affines stay where they are
+            continue
+        worst = max(worst, (abs(d - ref[0]) / ref[0], n))
+    print("largest deviation of a tensor's displacement norm: %.2e (%s)" % worst)
+    assert worst[0] < ntol, worst
+
+
 def test_full_training_backward_bf16_mode_within_stated_bound(opt):
     """the same backward in the mode bench.py --mode train runs (bf16 activations and MFMA operands, fp32 heads and
     accumulation) against the reference's fp32 autograd gradients (tests/golden/train_grads.npz).  Stated bound: loss
