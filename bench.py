@@ -353,7 +353,10 @@ def mode_query(args, ctx):
                         torch.cuda.synchronize()
                         return (time.perf_counter() - t0) / ((k + 1) * n)
                     for k in range(1, len(graphs)):
-                        cands = [graphs[k][1]] + [torch.cuda.Stream(dev) for _ in range(7)]
+                        # Round 5: NO calibration by default -- over 5 process starts the two-in-flight step read 4.518 .. 4.543 ms with the
+                        # calibration and 4.523 .. 4.528 ms without (profiles/r05_headline_variance.txt): the unlucky stream pairs of
+                        # round 4 did not occur on this runtime.  CHORE_BENCH_CALIBRATE=1 brings the eight-candidate search back.
+                        cands = [graphs[k][1]] + [torch.cuda.Stream(dev) for _ in range(7 if os.environ.get("CHORE_BENCH_CALIBRATE") else 0)]
                         for c in cands:
                             round_ms(k, c, 1)
                         best = min(cands, key=lambda c: round_ms(k, c))
