@@ -182,7 +182,8 @@ class ReconFitterBehave(ReconFitterBase):
             self._fit_pipelined(todo, generator, finish)
         else:
             for i, data in todo:
-                fitted = self.fit_batch(data, generator, index=i)
+                # (index only when per-batch generators are on: a subclass's fit_batch(data, generator) keeps working)
+                fitted = self.fit_batch(data, generator) if self.batch_seed is None else self.fit_batch(data, generator, index=i)
                 if self.batch_ends is not None and torch.device(self.device).type == "cuda":
                     self._mark_read([None], 0, torch.cuda.current_stream(torch.device(self.device)))
                 finish(i, data, fitted)
@@ -209,8 +210,9 @@ class ReconFitterBehave(ReconFitterBase):
         before the first optimiser step"""
         if self.use_graphs and self.reuse_graphs and hasattr(generator.model, "image_filter"):
             generator.model.image_filter.static_outputs = True      # the kept steps read the maps through fixed addresses
-        pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True,
-                                                        generators=self._batch_generators(index))
+        gens = self._batch_generators(index)
+        kw = {} if gens is None else {"generators": gens}      # (the reference's signature when the global streams are used)
+        pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True, **kw)
         return dict(data=data, pc=pc_generated, model=generator.model, smplfit=self.prep_smplfit(data, generator, pc_generated))
 
     def optimise_batch(self, prep, smpl_iters=None, object_iters=None):
