@@ -42,7 +42,7 @@ def _wrap(cls):
 
 def child(tag, passes):
     from test_gpu_ddp_trainstep import _make
-    net, batch = _make(0)
+    net, batch = _make(0, os.environ.get("CHORE_TRAIN_DTYPE", "bf16"))
     net.train(True)
     names = [n for n, _ in net.named_parameters()][::-1]
     if os.environ.get("TRACE_OPS"):
