@@ -945,6 +945,11 @@ def mode_train(args, ctx):
                                 "how": "K steps without any gradient reduction against K steps with it, same model and batch"}
         if eager_elapsed is not None:
             out["eager_ms_per_step"] = eager_elapsed / args.steps * 1e3
+        if other:
+            # what the reference's UNCHANGED train_launch.py gets from this package: its own DistributedDataParallel wrap around the
+            # eager step.  `value` needs the three-line edit of Trainer documented in INTEGRATION.md (GraphedTrainStep + FlatGradReducer).
+            out["unchanged_train_launch"] = {"ms_per_step": other[1] / args.steps * 1e3, "steps_per_s": args.steps / other[1],
+                                             "what": "eager step under torch DistributedDataParallel(find_unused_parameters=True), train_launch.py:30 as it is"}
         out.update({"images_per_s": ctx.world * B * args.steps / elapsed, "final_loss": float(last["err"].detach()),
                     "parameters": sum(p.numel() for p in net.parameters()),
                     "roofline": {"kernel": "whole training step (all kernels)", "bound": "mfma", "achieved": flops / ms / 1e9,
