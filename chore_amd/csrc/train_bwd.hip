@@ -505,6 +505,218 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
     if (a.part_bias && pair % nbc == 0 && tid < 64) a.part_bias[(size_t)share * a.Cout + co0 + tid] = bias_acc * yinv;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fp16 x 3 weight gradient with SPECIALISED WAVES (round 5, second version; wgrad64_x3_kernel above is the first).
+// wgrad64_x3_kernel runs its phases in turn -- split + LDS stores of a tile (1.9 us), then its MFMAs (4.6 us) -- on one wave per SIMD.
+// Here a workgroup is 8 waves, two per SIMD: waves 0-3 (consumers) hold the 64 x 64-channel accumulators and only read fragments and
+// issue MFMAs; waves 4-7 (producers) only move data: global loads of tile i + 2, GroupNorm + ReLU + hi / lo split of tile i + 1 into
+// the OTHER LDS buffer.  The matrix pipe and the vector ALU of a SIMD issue independently (conv_pc.hip's premise).  Two buffers of four
+// planes fit with 2 x 32-pixel tiles (2 x 64 KB); hand-over by one s_barrier per tile, which both roles reach the same number of
+// times: producers write buffer k % 2 before barrier k, consumers read it between barriers k and k + 1.
+// Same arithmetic as wgrad64_x3_kernel per tile; the tile is half as high, so a share's partial is a sum over twice as many tiles in the
+// same order of pixels -- the rounding of the fp32 accumulation is that of a different tile split, results equal to fp32 round-off.
+// ------------------------------------------------------------------------------------------------
+constexpr int WP_TH = 2;
+
+// LDS traffic of this wave done, then the workgroup barrier; vector-memory loads stay in flight across it (__syncthreads() would
+// wait for the producers' prefetched global loads at every tile)
+__device__ __forceinline__ void wp_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int TAPS>
+__global__ __launch_bounds__(512) void wgrad64_x3_pc_kernel(WgradArgs a) {
+    f16_saturate_mode();
+    constexpr int PAD = TAPS == 9 ? 1 : 0;
+    constexpr int AW = TW + 2 * PAD, AH = WP_TH + 2 * PAD, AROWS = AH * AW, YROWS = WP_TH * TW;
+    constexpr int NVX = (AROWS * 8 + 255) / 256, NVY = YROWS * 8 / 256;
+    constexpr int PLA = AROWS * W64_PITCH, PLY = YROWS * W64_PITCH;
+    constexpr int BUF = 2 * PLA + 2 * PLY;                   // one buffer: A hi, A lo, Y hi, Y lo
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int nbo = a.Cout / 64, nbc = a.Cin / 64, npairs = nbo * nbc;
+    int share, pair;
+    {
+        const int L = blockIdx.x;
+        if (a.S % 8 == 0) { const int xcd = L & 7, j = L >> 3; share = (j / npairs) * 8 + xcd; pair = j % npairs; }
+        else { share = L / npairs; pair = L % npairs; }
+    }
+    const int co0 = (pair / nbc) * 64, ci0 = (pair % nbc) * 64;
+    const int tiles_x = (a.W + TW - 1) / TW, tiles_y = (a.H + WP_TH - 1) / WP_TH;
+    const int tiles = a.B * tiles_x * tiles_y;
+    const int ntile = share < tiles ? (tiles - share + a.S - 1) / a.S : 0;      // tiles of this workgroup: share, share + S, ...
+    float ymul, yinv;
+    x3_in_scale(a.dy_amax, ymul, yinv);
+    float* red = (float*)smem;                                 // after the loop: [256 producer threads][8] bias partials
+
+    if (producer) {
+        // =========================== producers ===========================
+        const int ptid = tid & 255;
+        const bool use_gn = a.st != nullptr;
+        const float* X = (const float*)a.x;
+        const float* DY = (const float*)a.dy;
+        const int v = ptid & 7;                                // this thread's 8-channel slot of every row it stages
+        float sc[8], sh[8], bias8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; bias8[j] = 0.f; }
+        int cur_b = -1;
+        u32x4 vy[NVY][2], vx[NVX][2];
+        auto issue_loads = [&](int tile) {
+            const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+            const int ty0 = (tt / tiles_x) * WP_TH, tx0 = (tt % tiles_x) * TW;
+#pragma unroll
+            for (int q = 0; q < NVY; ++q) {
+                const int row = (ptid + 256 * q) >> 3;
+                const int y = min(ty0 + row / TW, a.H - 1), x = min(tx0 + row % TW, a.W - 1);
+                const u32x4* p = (const u32x4*)(DY + (((size_t)b * a.H + y) * a.W + x) * a.ys + co0 + v * 8);
+                vy[q][0] = p[0]; vy[q][1] = p[1];
+            }
+#pragma unroll
+            for (int q = 0; q < NVX; ++q) {
+                const int row = min(ptid + 256 * q, AROWS * 8 - 1) >> 3;
+                const int y = min(max(ty0 + row / AW - PAD, 0), a.H - 1), x = min(max(tx0 + row % AW - PAD, 0), a.W - 1);
+                const u32x4* p = (const u32x4*)(X + (((size_t)b * a.H + y) * a.W + x) * a.xs + ci0 + v * 8);
+                vx[q][0] = p[0]; vx[q][1] = p[1];
+            }
+        };
+        auto split8 = [](const float (&f)[8], u32x4& hi, u32x4& lo) {
+            tb_f16x8 hh, ll;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hh[j] = (_Float16)f[j]; ll[j] = (_Float16)(f[j] - (float)hh[j]); }
+            hi = __builtin_bit_cast(u32x4, hh);
+            lo = __builtin_bit_cast(u32x4, ll);
+        };
+        if (ntile > 0 && !(a.dbg & 4)) issue_loads(share);
+        for (int it = 0; it < ntile; ++it) {
+            const int tile = share + it * a.S;
+            const int b = tile / (tiles_x * tiles_y), tt = tile % (tiles_x * tiles_y);
+            const int ty0 = (tt / tiles_x) * WP_TH, tx0 = (tt % tiles_x) * TW;
+            char* imgA = smem + (it & 1) * BUF;
+            char* imgY = imgA + 2 * PLA;
+            if (use_gn && b != cur_b) {                        // the affine of this thread's 8 channels (a few times per workgroup)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + v * 8 + j, a.H * a.W, a.gamma, a.beta, sc[j], sh[j]);
+                cur_b = b;
+            }
+            if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int q = 0; q < NVY; ++q) {
+                const int row = (ptid + 256 * q) >> 3;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vy[q][0][j]) * ymul; f[4 + j] = __uint_as_float(vy[q][1][j]) * ymul; }
+                const bool out = ty0 + row / TW >= a.H || tx0 + row % TW >= a.W;
+                u32x4 hi, lo;
+                split8(f, hi, lo);
+                if (out) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
+                else if (a.part_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bias8[j] += f[j];
+                }
+                *(u32x4*)(imgY + row * W64_PITCH + v * 16) = hi;
+                *(u32x4*)(imgY + PLY + row * W64_PITCH + v * 16) = lo;
+            }
+#pragma unroll
+            for (int q = 0; q < NVX; ++q) {
+                const int i = ptid + 256 * q, row = i >> 3;
+                const int y = ty0 + row / AW - PAD, x = tx0 + row % AW - PAD;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vx[q][0][j]); f[4 + j] = __uint_as_float(vx[q][1][j]); }
+                if (use_gn) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], sc[j], sh[j]); f[j] = t > 0.f ? t : 0.f; }
+                }
+                u32x4 hi, lo;
+                split8(f, hi, lo);
+                if (y < 0 || y >= a.H || x < 0 || x >= a.W) { hi = u32x4{0u, 0u, 0u, 0u}; lo = hi; }
+                if (i < AROWS * 8) {
+                    *(u32x4*)(imgA + row * W64_PITCH + v * 16) = hi;
+                    *(u32x4*)(imgA + PLA + row * W64_PITCH + v * 16) = lo;
+                }
+            }
+            }
+            if (!(a.dbg & 4)) issue_loads(it + 1 < ntile ? tile + a.S : tile);      // in flight across the barrier and the next split
+            wp_barrier();                                   // barrier `it`: buffer it % 2 is complete
+        }
+        wp_barrier();                                       // the consumers have read the last buffer: the LDS is free
+        if (a.part_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[ptid * 8 + j] = bias8[j];
+        }
+    } else {
+        // =========================== consumers ===========================
+        const int cih = wid & 1, coh = wid >> 1;
+        f32x16 acc[TAPS];
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        const int h = lane >> 5, g = (lane >> 4) & 1, i16 = lane & 15;
+        const int lane_off = (8 * h + (i16 >> 2)) * W64_PITCH + (g * 16 + (i16 & 3) * 4) * 2;
+        auto frag = [&](const char* p) -> tb_f16x8 {
+            const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+            const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(tb_f16x8, vv);
+        };
+        for (int it = 0; it < ntile; ++it) {
+            wp_barrier();                                   // barrier `it`: buffer it % 2 is complete
+            const char* imgA = smem + (it & 1) * BUF;
+            const char* baseY = imgA + 2 * PLA + lane_off + coh * 64;
+            const char* baseA = imgA + lane_off + cih * 64;
+            if (a.dbg & 1) continue;
+#pragma unroll
+            for (int y = 0; y < WP_TH; ++y) {
+#pragma unroll
+                for (int xb = 0; xb < TW; xb += 16) {
+                    const tb_f16x8 fyh = frag(baseY + (y * TW + xb) * W64_PITCH), fyl = frag(baseY + PLY + (y * TW + xb) * W64_PITCH);
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t) {
+                        const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
+                        const char* pa = baseA + ((y + ky) * AW + xb + kx) * W64_PITCH;
+                        const tb_f16x8 fxh = frag(pa), fxl = frag(pa + PLA);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl, fxh, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxl, acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        wp_barrier();                                       // (pairs with the producers' final barrier)
+        const int col = lane & 31;
+        float* out = a.part + ((size_t)share * npairs + pair) * TAPS * 4096;
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                out[(size_t)t * 4096 + (coh * 32 + mfma32_row(r, h)) * 64 + cih * 32 + col] = acc[t][r] * yinv;
+    }
+    if (a.part_bias) {          // uniform.  dbias partial of this share: the producers' per-thread sums, added in thread order
+        wp_barrier();
+        if (pair % nbc == 0 && tid < 64) {
+            float sum = 0.f;
+            const int vv = tid >> 3, j = tid & 7;              // channel tid = slot vv, element j
+            for (int p = 0; p < 32; ++p) sum += red[(p * 8 + vv) * 8 + j];
+            a.part_bias[(size_t)share * a.Cout + co0 + tid] = sum * yinv;
+        }
+    }
+}
+
+static int wgrad64_x3_pc_shares(int B, int H, int W, int Cin, int Cout) {
+    const int tiles = B * ((W + TW - 1) / TW) * ((H + WP_TH - 1) / WP_TH);
+    const int pairs = (Cout / 64) * (Cin / 64);
+    int S = ((256 + pairs - 1) / pairs + 7) / 8 * 8;
+    if (S > tiles) S = tiles;
+    return S;
+}
+
 static int wgrad64_x3_shares(int B, int H, int W, int Cin, int Cout) {
     const int tiles = B * ((W + TW - 1) / TW) * ((H + WX_TH - 1) / WX_TH);
     const int pairs = (Cout / 64) * (Cin / 64);
@@ -831,8 +1043,8 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
     const int S = wgrad_shares(B, H, W, Cin, Cout);
     size_t n = (size_t)S * (Cout / 32) * (Cin / 32) * taps * 1024 + (size_t)S * Cout;
     if (wgrad_use64(CHORE_BF16, taps, Cin, Cout)) {       // the bf16 path of these shapes uses 64-channel tiles
-        const int Sb = wgrad64_shares(B, H, W, Cin, Cout), Sx = wgrad64_x3_shares(B, H, W, Cin, Cout);
-        const int S64 = Sb > Sx ? Sb : Sx;
+        const int Sb = wgrad64_shares(B, H, W, Cin, Cout), Sx = wgrad64_x3_shares(B, H, W, Cin, Cout), Sp = wgrad64_x3_pc_shares(B, H, W, Cin, Cout);
+        const int S64 = (Sb > Sx ? Sb : Sx) > Sp ? (Sb > Sx ? Sb : Sx) : Sp;
         const size_t n64 = (size_t)S64 * (Cout / 64) * (Cin / 64) * taps * 4096 + (size_t)S64 * Cout;
         if (n64 > n) n = n64;
     }
@@ -902,6 +1114,34 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
         a.S = x3 ? wgrad64_x3_shares(B, H, W, Cin, Cout) : wgrad64_shares(B, H, W, Cin, Cout);
         const int npairs = (Cout / 64) * (Cin / 64);
         a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
+        // which fp16 x 3 kernel: the specialised-wave one where it measured faster alone (profiles/r05_wgrad_x3.txt: the 1x1 layers
+        // 101 -> 85 us, 3x3 256->128 at 128^2 150 -> 131, 128->128 90 -> 82; the 64-channel layers and the 32^2 maps are 2 - 8 us
+        // SLOWER on it: twice the tiles, twice the barriers).  CHORE_WGRAD_X3_V1=1 / CHORE_WGRAD_X3_PC=1 force one of them.
+        static const bool x3_v1 = getenv("CHORE_WGRAD_X3_V1") != nullptr, x3_pc = getenv("CHORE_WGRAD_X3_PC") != nullptr;
+        const bool use_pc = x3_pc || (!x3_v1 && (taps == 1 || (Cin >= 128 && Cout >= 128 && (long)H * W >= 64 * 64)));
+        if (x3 && use_pc) {
+            a.S = wgrad64_x3_pc_shares(B, H, W, Cin, Cout);
+            a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
+            const size_t arows = taps == 9 ? (size_t)(WP_TH + 2) * PW : (size_t)WP_TH * TW;
+            const size_t smp = (size_t)2 * 2 * (arows + WP_TH * TW) * W64_PITCH;
+            bool& attrp = CHORE_ONCE_FLAG(h);
+            if (!attrp) {
+                CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_x3_pc_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((size_t)4 * ((WP_TH + 2) * PW + WP_TH * TW) * W64_PITCH)));
+                CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad64_x3_pc_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)((size_t)4 * (2 * WP_TH * TW) * W64_PITCH)));
+                attrp = true;
+            }
+            if (taps == 9) hipLaunchKernelGGL(wgrad64_x3_pc_kernel<9>, dim3(a.S * npairs), dim3(512), smp, s, a);
+            else hipLaunchKernelGGL(wgrad64_x3_pc_kernel<1>, dim3(a.S * npairs), dim3(512), smp, s, a);
+            CHORE_LAUNCH_CHECK(h, s);
+            if (defer) { defer->j[defer->n++] = {a.part, a.part_bias, dw, dbias, a.S, Cout, Cin, taps, ct}; return CHORE_OK; }
+            const size_t n = (size_t)Cout * Cin * taps;
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
+                               Cin, taps, dw, dbias, ct);
+            CHORE_LAUNCH_CHECK(h, s);
+            return CHORE_OK;
+        }
         if (x3) {
             const size_t smx = (size_t)2 * ((taps == 9 ? (WX_TH + 2) * PW : WX_TH * TW) + WX_TH * TW) * W64_PITCH + 64 * 2 * sizeof(float);
             bool& attrx = CHORE_ONCE_FLAG(h);

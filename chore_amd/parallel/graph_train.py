@@ -43,6 +43,8 @@ gradients equal the unsegmented step's bit for bit (tests/test_gpu_ddp_nccl.py).
 Side effect: `model.losses_on_host` is switched off (the reference returns the six separate losses as a CPU tensor, a host copy
 per step that cannot be recorded); `close()` restores it.
 """
+import os
+
 import torch
 
 
@@ -69,7 +71,6 @@ class GraphedTrainStep:
         # the learning rates as device tensors (see the module docstring)
         dev = next(model.parameters()).device
         self._lr = []
-        import os
         for g in ([] if os.environ.get("CHORE_GRAPH_FLOAT_LR") else optimizer.param_groups):      # (debug switch: keep the float rate)
             lr = g["lr"]
             t = lr if (torch.is_tensor(lr) and lr.device == dev) else torch.tensor(float(lr), dtype=torch.float32, device=dev)

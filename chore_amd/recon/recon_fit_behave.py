@@ -258,9 +258,11 @@ class ReconFitterBehave(ReconFitterBase):
             gens = [generator, copy.copy(generator)]
             gens[1].model = nets[1]
             prio = int(os.environ.get("CHORE_PIPE_PRIO", "0"))
+            # ONE worker thread for the fitter's lifetime (it owns a C handle of its own, chore_amd/_lib.py: a thread per call would
+            # leave a handle behind per call)
             state = self._pipe_state = (generator, nets, gens, [torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev, priority=prio)],
-                                        [False, False])
-        _, nets, gens, streams, warm = state            # warm[s]: slot s's inner steps are recorded (kept across calls with the slots)
+                                        [False, False], ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-prep"))
+        _, nets, gens, streams, warm, pool = state      # warm[s]: slot s's inner steps are recorded (kept across calls with the slots)
         if not self.reuse_graphs:
             warm[0] = warm[1] = False
         last_read = [None, None]        # event: the optimisation that last used the slot has been issued AND executed up to here
@@ -293,35 +295,34 @@ class ReconFitterBehave(ReconFitterBase):
             ready.record(main)
             return pool.submit(prepare, k, ready)
 
-        with ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-prep") as pool:
-            fut = submit(pool, 0)
-            for k, (i, data) in enumerate(todo):
-                prep, done = fut.result()
-                s = k % 2
-                fut = None
-                if k + 1 < len(todo):
-                    if not warm[s] and self.use_graphs:            # this optimisation records: nothing beside it
-                        main.wait_event(done)
-                        fitted = self.optimise_batch(prep, smpl_iters, object_iters)
-                        self._mark_read(last_read, s, main)
-                        warm[s] = True
-                        fut = submit(pool, k + 1)
-                        finish(i, data, fitted)
-                        continue
+        fut = submit(pool, 0)
+        for k, (i, data) in enumerate(todo):
+            prep, done = fut.result()
+            s = k % 2
+            fut = None
+            if k + 1 < len(todo):
+                if not warm[s] and self.use_graphs:            # this optimisation records: nothing beside it
+                    main.wait_event(done)
+                    fitted = self.optimise_batch(prep, smpl_iters, object_iters)
+                    self._mark_read(last_read, s, main)
+                    warm[s] = True
                     fut = submit(pool, k + 1)
-                th0 = time.perf_counter()
-                main.wait_event(done)
-                if dbg is not None:
-                    o0 = torch.cuda.Event(enable_timing=True)
-                    o0.record(main)
-                fitted = self.optimise_batch(prep, smpl_iters, object_iters)
-                self._mark_read(last_read, s, main)
-                if dbg is not None:
-                    o1 = torch.cuda.Event(enable_timing=True)
-                    o1.record(main)
-                    dbg.append(("opt", k, th0 - t_base, time.perf_counter() - t_base, o0, o1))
-                warm[s] = True
-                finish(i, data, fitted)
+                    finish(i, data, fitted)
+                    continue
+                fut = submit(pool, k + 1)
+            th0 = time.perf_counter()
+            main.wait_event(done)
+            if dbg is not None:
+                o0 = torch.cuda.Event(enable_timing=True)
+                o0.record(main)
+            fitted = self.optimise_batch(prep, smpl_iters, object_iters)
+            self._mark_read(last_read, s, main)
+            if dbg is not None:
+                o1 = torch.cuda.Event(enable_timing=True)
+                o1.record(main)
+                dbg.append(("opt", k, th0 - t_base, time.perf_counter() - t_base, o0, o1))
+            warm[s] = True
+            finish(i, data, fitted)
         if dbg:
             torch.cuda.synchronize()
             ref = [d for d in dbg if d[0] == "opt"][0][4]

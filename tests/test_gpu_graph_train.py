@@ -103,9 +103,9 @@ if not use_reducer:
     # load_state_dict() swaps the optimiser's state tensors: the recording is dropped and made again (not replayed on stale state)
     import copy
     opt.load_state_dict(copy.deepcopy(opt.state_dict()))      # (a checkpoint read back: new tensors)
-    n_rec = id(next(iter(step2._rec.values()))["ga"])
+    old_graph = next(iter(step2._rec.values()))["ga"]          # (a reference, not an id: a freed object's id can be handed out again)
     step2(**batches[0])
-    assert id(next(iter(step2._rec.values()))["ga"]) != n_rec
+    assert next(iter(step2._rec.values()))["ga"] is not old_graph
 print("graphed == eager over", STEPS, "steps (", STEPS - WARM, "replayed ),", len(ra[0][2]), "gradient tensors; losses", [round(r[0], 6) for r in rb])
 print("graph train ok")
 '''
