@@ -333,6 +333,33 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
 }
 
 
+typedef _Float16 tb_f16x8 __attribute__((ext_vector_type(8)));
+// Three taps of one kernel row from ONE set of transposing reads (fp16 / bf16 weight gradients, 3x3): the fragments of taps kx = 0, 1, 2
+// are 8-pixel windows starting at pixels 0, 1, 2 of the same channel -- 10 of 12 pixels shared.  Three ds_read_b64_tr_b16 (pixels 0-3,
+// 4-7, 8-11 of this lane's k half) give six dwords; window 0 = dwords 0-3, window 2 = dwords 1-4, window 1 = four 16-bit funnel
+// shifts.  6 reads instead of 3 x 4 per (kernel row, plane).  Used by wgrad64_x3_kernel (150 -> 141 us on the largest layer, 1 - 4 us on
+// the others); NOT by wgrad64_x3_pc_kernel, where it measured slower.
+struct TrWin { unsigned d[6]; };
+__device__ __forceinline__ TrWin tr_load3(const char* p) {
+    const tb_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const tb_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
+    const tb_s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * W64_PITCH));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b), uc = __builtin_bit_cast(u32x2_t, c);
+    TrWin w;
+    w.d[0] = ua[0]; w.d[1] = ua[1]; w.d[2] = ub[0]; w.d[3] = ub[1]; w.d[4] = uc[0]; w.d[5] = uc[1];
+    return w;
+}
+template <typename FR>
+__device__ __forceinline__ FR tr_window(const TrWin& w, int kx) {
+    u32x4 v;
+    if (kx == 0) v = u32x4{w.d[0], w.d[1], w.d[2], w.d[3]};
+    else if (kx == 2) v = u32x4{w.d[1], w.d[2], w.d[3], w.d[4]};
+    else v = u32x4{__builtin_amdgcn_alignbit(w.d[1], w.d[0], 16), __builtin_amdgcn_alignbit(w.d[2], w.d[1], 16),
+                   __builtin_amdgcn_alignbit(w.d[3], w.d[2], 16), __builtin_amdgcn_alignbit(w.d[4], w.d[3], 16)};
+    return __builtin_bit_cast(FR, v);
+}
+
 // ------------------------------------------------------------------------------------------------
 // fp16 x 3 weight gradient (CHORE_F16X3 training: fp32 tensors, fp32-grade result on the fp16 matrix cores).
 // The structure of wgrad64_kernel -- 64 output x 64 input channels x all taps per workgroup, wave (coh, cih) owns a 32 x 32
@@ -345,7 +372,6 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
 // an fp16 pair keeps 22 bits only above 2^-3 -- and the accumulators by its inverse at the end.
 // ------------------------------------------------------------------------------------------------
 constexpr int WX_TH = 4;
-typedef _Float16 tb_f16x8 __attribute__((ext_vector_type(8)));
 
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
@@ -481,14 +507,26 @@ __global__ __launch_bounds__(256) void wgrad64_x3_kernel(WgradArgs a) {
 #pragma unroll
             for (int xb = 0; xb < TW; xb += 16) {
                 const tb_f16x8 fyh = frag(baseY + (y * TW + xb) * W64_PITCH), fyl = frag(baseY + PLY + (y * TW + xb) * W64_PITCH);
+                if constexpr (TAPS == 9) {
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
-                    const char* pa = baseA + ((y + ky) * AW + xb + kx) * W64_PITCH;
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const char* pa = baseA + ((y + ky) * AW + xb) * W64_PITCH;
+                        const TrWin wh = tr_load3(pa), wl = tr_load3(pa + PLA);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const tb_f16x8 fxh = tr_window<tb_f16x8>(wh, kx), fxl = tr_window<tb_f16x8>(wl, kx);
+                            f32x16& ac = acc[ky * 3 + kx];
+                            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl, fxh, ac, 0, 0, 0);
+                            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxl, ac, 0, 0, 0);
+                            ac = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, ac, 0, 0, 0);
+                        }
+                    }
+                } else {
+                    const char* pa = baseA + (y * AW + xb) * W64_PITCH;
                     const tb_f16x8 fxh = frag(pa), fxl = frag(pa + PLA);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl, fxh, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxl, acc[t], 0, 0, 0);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, acc[t], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl, fxh, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxl, acc[0], 0, 0, 0);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh, fxh, acc[0], 0, 0, 0);
                 }
             }
         }
@@ -677,6 +715,9 @@ __global__ __launch_bounds__(512) void wgrad64_x3_pc_kernel(WgradArgs a) {
 #pragma unroll
                 for (int xb = 0; xb < TW; xb += 16) {
                     const tb_f16x8 fyh = frag(baseY + (y * TW + xb) * W64_PITCH), fyl = frag(baseY + PLY + (y * TW + xb) * W64_PITCH);
+                    // (one fragment read pair per tap: sharing the reads between the three taps of a kernel row -- tr_load3 / tr_window, what
+                    // wgrad64_x3_kernel does -- measured SLOWER here, 131 -> 137 us on the largest layer: the consumers are not bound by the
+                    // number of LDS reads, and the funnel shifts sit in front of their MFMAs)
 #pragma unroll
                     for (int t = 0; t < TAPS; ++t) {
                         const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
@@ -1118,7 +1159,7 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
         // 101 -> 85 us, 3x3 256->128 at 128^2 150 -> 131, 128->128 90 -> 82; the 64-channel layers and the 32^2 maps are 2 - 8 us
         // SLOWER on it: twice the tiles, twice the barriers).  CHORE_WGRAD_X3_V1=1 / CHORE_WGRAD_X3_PC=1 force one of them.
         static const bool x3_v1 = getenv("CHORE_WGRAD_X3_V1") != nullptr, x3_pc = getenv("CHORE_WGRAD_X3_PC") != nullptr;
-        const bool use_pc = x3_pc || (!x3_v1 && (taps == 1 || (Cin >= 128 && Cout >= 128 && (long)H * W >= 64 * 64)));
+        const bool use_pc = x3_pc || (!x3_v1 && (taps == 1 || (Cin >= 128 && Cout >= 128 && (long)H * W >= 128 * 128)));
         if (x3 && use_pc) {
             a.S = wgrad64_x3_pc_shares(B, H, W, Cin, Cout);
             a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
