@@ -208,6 +208,33 @@ constexpr int W64_PITCH = 160;                 // bytes per pixel row of the LDS
 typedef short tb_s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) tb_s16x4 lds_s16x4;
 
+// Three taps of one kernel row from ONE set of transposing reads (fp16 / bf16 weight gradients, 3x3): the fragments of taps kx = 0, 1, 2
+// are 8-pixel windows starting at pixels 0, 1, 2 of the same channel -- 10 of 12 pixels shared.  Three ds_read_b64_tr_b16 (pixels 0-3,
+// 4-7, 8-11 of this lane's k half) give six dwords; window 0 = dwords 0-3, window 2 = dwords 1-4, window 1 = four 16-bit funnel
+// shifts.  6 reads instead of 3 x 4 per (kernel row, plane).  Used by wgrad64_x3_kernel (150 -> 141 us on the largest layer, 1 - 4 us on
+// the others); NOT by wgrad64_x3_pc_kernel, where it measured slower.
+struct TrWin { unsigned d[6]; };
+__device__ __forceinline__ TrWin tr_load3(const char* p) {
+    const tb_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+    const tb_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
+    const tb_s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * W64_PITCH));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b), uc = __builtin_bit_cast(u32x2_t, c);
+    TrWin w;
+    w.d[0] = ua[0]; w.d[1] = ua[1]; w.d[2] = ub[0]; w.d[3] = ub[1]; w.d[4] = uc[0]; w.d[5] = uc[1];
+    return w;
+}
+template <typename FR>
+__device__ __forceinline__ FR tr_window(const TrWin& w, int kx) {
+    u32x4 v;
+    if (kx == 0) v = u32x4{w.d[0], w.d[1], w.d[2], w.d[3]};
+    else if (kx == 2) v = u32x4{w.d[1], w.d[2], w.d[3], w.d[4]};
+    else v = u32x4{__builtin_amdgcn_alignbit(w.d[1], w.d[0], 16), __builtin_amdgcn_alignbit(w.d[2], w.d[1], 16),
+                   __builtin_amdgcn_alignbit(w.d[3], w.d[2], 16), __builtin_amdgcn_alignbit(w.d[4], w.d[3], 16)};
+    return __builtin_bit_cast(FR, v);
+}
+
+
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
     constexpr int PAD = TAPS == 9 ? 1 : 0;
@@ -312,11 +339,17 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
 #pragma unroll
             for (int xb = 0; xb < TW; xb += 16) {
                 const tb_bf16x8 fy = frag(baseY + (y * TW + xb) * W64_PITCH);
+                if constexpr (TAPS == 9) {      // the three taps of a kernel row from one set of reads (tr_load3)
 #pragma unroll
-                for (int t = 0; t < TAPS; ++t) {
-                    const int ky = TAPS == 9 ? t / 3 : 0, kx = TAPS == 9 ? t % 3 : 0;
-                    const tb_bf16x8 fx = frag(baseA + ((y + ky) * AW + xb + kx) * W64_PITCH);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fx, acc[t], 0, 0, 0);
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const TrWin w = tr_load3(baseA + ((y + ky) * AW + xb) * W64_PITCH);
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, tr_window<tb_bf16x8>(w, kx), acc[ky * 3 + kx], 0, 0, 0);
+                    }
+                } else {
+                    const tb_bf16x8 fx = frag(baseA + (y * AW + xb) * W64_PITCH);
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy, fx, acc[0], 0, 0, 0);
                 }
             }
         }
@@ -334,32 +367,6 @@ __global__ __launch_bounds__(256) void wgrad64_kernel(WgradArgs a) {
 
 
 typedef _Float16 tb_f16x8 __attribute__((ext_vector_type(8)));
-// Three taps of one kernel row from ONE set of transposing reads (fp16 / bf16 weight gradients, 3x3): the fragments of taps kx = 0, 1, 2
-// are 8-pixel windows starting at pixels 0, 1, 2 of the same channel -- 10 of 12 pixels shared.  Three ds_read_b64_tr_b16 (pixels 0-3,
-// 4-7, 8-11 of this lane's k half) give six dwords; window 0 = dwords 0-3, window 2 = dwords 1-4, window 1 = four 16-bit funnel
-// shifts.  6 reads instead of 3 x 4 per (kernel row, plane).  Used by wgrad64_x3_kernel (150 -> 141 us on the largest layer, 1 - 4 us on
-// the others); NOT by wgrad64_x3_pc_kernel, where it measured slower.
-struct TrWin { unsigned d[6]; };
-__device__ __forceinline__ TrWin tr_load3(const char* p) {
-    const tb_s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
-    const tb_s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W64_PITCH));
-    const tb_s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 8 * W64_PITCH));
-    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    const u32x2_t ua = __builtin_bit_cast(u32x2_t, a), ub = __builtin_bit_cast(u32x2_t, b), uc = __builtin_bit_cast(u32x2_t, c);
-    TrWin w;
-    w.d[0] = ua[0]; w.d[1] = ua[1]; w.d[2] = ub[0]; w.d[3] = ub[1]; w.d[4] = uc[0]; w.d[5] = uc[1];
-    return w;
-}
-template <typename FR>
-__device__ __forceinline__ FR tr_window(const TrWin& w, int kx) {
-    u32x4 v;
-    if (kx == 0) v = u32x4{w.d[0], w.d[1], w.d[2], w.d[3]};
-    else if (kx == 2) v = u32x4{w.d[1], w.d[2], w.d[3], w.d[4]};
-    else v = u32x4{__builtin_amdgcn_alignbit(w.d[1], w.d[0], 16), __builtin_amdgcn_alignbit(w.d[2], w.d[1], 16),
-                   __builtin_amdgcn_alignbit(w.d[3], w.d[2], 16), __builtin_amdgcn_alignbit(w.d[4], w.d[3], 16)};
-    return __builtin_bit_cast(FR, v);
-}
-
 // ------------------------------------------------------------------------------------------------
 // fp16 x 3 weight gradient (CHORE_F16X3 training: fp32 tensors, fp32-grade result on the fp16 matrix cores).
 // The structure of wgrad64_kernel -- 64 output x 64 input channels x all taps per workgroup, wave (coh, cih) owns a 32 x 32
