@@ -693,11 +693,13 @@ def mode_fit(args, ctx):
                     fitter.batch_ends = []
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    fitter.fit_recon(opt, loader=Loader(batches), generator=gen, save=False, pipeline=pipe)
+                    # (fit_recon shards the loader's batches rank::world under torch.distributed: every batch world times, so that
+                    # each rank fits one copy of each)
+                    fitter.fit_recon(opt, loader=Loader([b for b in batches for _ in range(ctx.world)]), generator=gen, save=False, pipeline=pipe)
                     torch.cuda.synchronize()
                     marks.append((time.perf_counter() - t0) * 1e3)
                 ends = fitter.batch_ends
-                gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)]     # device time between consecutive batches' ends
+                gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)] or [float("nan")]     # device time between consecutive batches' ends
                 fitter.batch_ends = None
                 loop[name] = {"ms_per_batch": marks[2] / len(batches), "ms_per_frame": marks[2] / (len(batches) * B),
                               "steady_state_ms_per_batch_median": float(np.median(gaps)), "steady_state_ms_per_frame": float(np.median(gaps)) / B,
