@@ -193,6 +193,14 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        # Rehearsal of the N > 1 code path on a ONE-GPU box (no multi-GPU box was ever available to the builder): every rank on device 0
+        # and gloo moving the device tensors (RCCL refuses two ranks on one device).  Timings of such a run mean nothing; what it
+        # exercises is the launch, the sharding, the segmented reducer with a real second rank, the gathers and the line's schema.
+        rehearsal = bool(os.environ.get("CHORE_BENCH_REHEARSAL"))
+        if rehearsal:
+            self.local, backend = 0, "gloo"
+            import faulthandler
+            faulthandler.dump_traceback_later(int(os.environ.get("CHORE_BENCH_REHEARSAL_DUMP_S", "600")), repeat=True)     # where a hung rank is
         if self.world != gpus:
             raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}")
         self.cuda = torch.cuda.is_available()
@@ -794,6 +802,13 @@ def train_grad_error(mode, dev):
             "against": "the reference's CPU autograd gradients of the same batch (tests/golden/train_grads.npz)"}
 
 
+def _stage(ctx, what):
+    """progress marks of every rank on stderr (rehearsals of the N > 1 path only)"""
+    if os.environ.get("CHORE_BENCH_REHEARSAL"):
+        mem = torch.cuda.memory_allocated() / 2 ** 30 if ctx.cuda else 0.0
+        print("[rank %d] %s (%.1f GiB allocated)" % (ctx.rank, what, mem), file=sys.stderr, flush=True)
+
+
 def mode_train(args, ctx):
     from chore_amd.model import CHORE
     from chore_amd.utils import synth
@@ -883,8 +898,11 @@ def mode_train(args, ctx):
         primary, eager_primary = (make_graphed(None), step_plain) if graphed else (step_plain, None)
     if graphed:
         args.warmup = max(args.warmup, 4)      # two eager calls, the recording, one replay: all before the timed region
+    _stage(ctx, "train: primary")
     elapsed = ctx.timed(primary, args.steps, args.warmup)
+    _stage(ctx, "train: eager")
     eager_elapsed = ctx.timed(eager_primary, args.steps, 2) if eager_primary is not None else None
+    _stage(ctx, "train: variants")
     nosync = other = None
     variants = {}
     if have_group and reducer_kind == "arena" and graphed:
@@ -894,6 +912,7 @@ def mode_train(args, ctx):
                          ("segmented reduce_scatter + all_gather under the backward",
                           lambda: FlatGradReducer(net, segments=chore_segments(net), collective="rs_ag"))):
             try:
+                _stage(ctx, "train: variant " + name)
                 red = mk()
                 gs = GraphedTrainStep(net, optim, reducer=red, warmup=2)
                 tv = ctx.timed(lambda: gs(**batch), args.steps, 4)
@@ -902,6 +921,7 @@ def mode_train(args, ctx):
                 del gs, red
             except Exception as e:
                 variants[name] = {"error": repr(e)[:200]}
+                _stage(ctx, "train: variant FAILED " + repr(e)[:200])
             torch.cuda.empty_cache()
     if have_group and reducer_kind == "arena":
         # the same steps without any gradient reduction, and with the reference's wrap: what the collective costs either way
@@ -1001,7 +1021,9 @@ def mode_train(args, ctx):
 def mode_all(args, ctx):
     """the query line with the fit and training records inside (what the driver's one command measures)"""
     import copy
+    _stage(ctx, "all: query")
     out = mode_query(args, ctx)
+    _stage(ctx, "all: query done")
     subs = {}
     # training first: after the fit (a dozen capture streams, a few dozen live hipGraphs in the process) the two streams of the
     # ConvBlock backward no longer overlap and the same training step measures 25.0 ms instead of 22.7 (scripts/bench_order_probe.py;
@@ -1016,6 +1038,7 @@ def mode_all(args, ctx):
             setattr(a, k, v)
         if ctx.cuda:
             torch.cuda.empty_cache()
+        _stage(ctx, "all: " + name)
         subs[name] = fn(a, ctx)
     again = ctx.requery() if getattr(ctx, "requery", None) else None
     if ctx.rank == 0:

@@ -137,9 +137,10 @@ class FlatGradReducer:
     def all_reduce(self):
         """the collective half: the arena summed over the ranks in `chunks` pieces, then scaled to the mean"""
         if self.world > 1 or dist.is_initialized():
-            works = [dist.all_reduce(c, group=self.group, async_op=True) for c in self.chunks]
-            for w in works:
-                w.wait()
+            # one after the other, each a stream-ordered call (on RCCL the collectives of one communicator run in issue order on its
+            # stream whichever way they are issued)
+            for c in self.chunks:
+                dist.all_reduce(c, group=self.group)
             if self.average and self.world > 1:
                 self.arena.mul_(1.0 / self.world)
 
