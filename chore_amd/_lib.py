@@ -35,6 +35,9 @@ SIGNATURES = {
     "chore_create": (c_int, [POINTER(c_void_p), c_int]),
     "chore_destroy": (c_int, [c_void_p]),
     "chore_last_error": (c_char_p, [c_void_p]),
+    "chore_cu_count": (c_int, [c_void_p]),
+    "chore_stream_create_cu_mask": (c_int, [c_void_p, POINTER(ctypes.c_uint32), c_int, POINTER(c_void_p)]),
+    "chore_stream_destroy": (c_int, [c_void_p, c_void_p]),
     "chore_heads_arena_bytes": (c_size_t, [c_int]),
     "chore_heads_pack": (c_int, [c_void_p, POINTER(WeightDesc), c_int, c_int, c_void_p, c_void_p]),
     "chore_query_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -110,7 +113,9 @@ SIGNATURES = {
     "chore_fit_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_float,
                                     c_float, c_float, c_void_p, c_void_p]),
     "chore_fit_adam_step_acc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+                                        c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_int, c_void_p]),
+    "chore_fit_weighted_sum_step": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "chore_fit_weighted_sum": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "chore_fit_weighted_sum_bwd": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "chore_fit_smpl_terms_fwd": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
@@ -235,6 +240,23 @@ def check(rc: int, h: c_void_p, what: str):
     if rc != 0:
         msg = lib.chore_last_error(h)
         raise ChoreError(f"{what} failed with {rc}: {msg.decode() if msg else ''}")
+
+
+def cu_masked_stream(device_index: int, n_cus: int):
+    """a torch stream whose kernels run on n_cus of the device's compute units, the same number in every XCD
+    (chore_stream_create_cu_mask; mask bit i = CU i / 8 of XCD i % 8).  The stream lives as long as the process."""
+    import torch
+    h = handle(device_index)
+    total = lib.chore_cu_count(h)
+    if not 0 < n_cus <= total:
+        raise ChoreError(f"cu_masked_stream: {n_cus} of {total} compute units")
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cus):
+        mask[i // 32] |= 1 << (i % 32)
+    st = c_void_p()
+    check(lib.chore_stream_create_cu_mask(h, mask, words, ctypes.byref(st)), h, "chore_stream_create_cu_mask")
+    return torch.cuda.ExternalStream(st.value, device=torch.device("cuda", device_index))
 
 
 def profile_enable(device_index: int, on: bool):

@@ -62,6 +62,36 @@ int chore_destroy(chore_handle* h) {
 
 const char* chore_last_error(const chore_handle* h) { return h ? h->err.c_str() : g_noh_err.c_str(); }
 
+// A stream whose kernels run on a SUBSET of the compute units (the hardware queue carries the mask).  A conv_pc / query
+// workgroup owns its CU (8 waves x 256 registers, > 80 KB of LDS): two streams time-share CUs, and a chain of small kernels
+// beside a stream of such workgroups waits for a CU to drain before each of its launches.  Masking the LARGE stream off a few
+// CUs per XCD keeps those free for the other.  Mask bit i = CU (i / n_xcd) of XCD (i % n_xcd) (the driver deals the bits round
+// robin over the XCDs), so "the first k bits" = k / 8 CUs of every XCD on this part.
+int chore_cu_count(chore_handle* h) {
+    if (!h) return -1;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, h->device) != hipSuccess) return -1;
+    return p.multiProcessorCount;
+}
+int chore_stream_create_cu_mask(chore_handle* h, const uint32_t* mask, int n_words, chore_stream_t* out) {
+    CHORE_ENTER(h);
+    if (!mask || n_words <= 0 || !out) CHORE_FAIL(h, CHORE_EINVAL, "chore_stream_create_cu_mask: bad argument");
+    bool any = false;
+    for (int i = 0; i < n_words; ++i) any |= mask[i] != 0;
+    if (!any) CHORE_FAIL(h, CHORE_EINVAL, "chore_stream_create_cu_mask: empty mask");
+    hipStream_t s = nullptr;
+    CHORE_HIP_CHECK(h, hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, mask));
+    *out = (chore_stream_t)s;
+    return CHORE_OK;
+}
+int chore_stream_destroy(chore_handle* h, chore_stream_t stream) {
+    CHORE_ENTER(h);
+    if (!stream) CHORE_FAIL(h, CHORE_EINVAL, "chore_stream_destroy: null stream");
+    CHORE_HIP_CHECK(h, hipStreamSynchronize((hipStream_t)stream));
+    CHORE_HIP_CHECK(h, hipStreamDestroy((hipStream_t)stream));
+    return CHORE_OK;
+}
+
 size_t chore_heads_arena_bytes(int dtype) {
     (void)dtype;  // one arena for every mode: the fp32 MFMA fragments, then the fp16 x 3 fragments (heads_x3.h)
     return heads_arena_bytes();

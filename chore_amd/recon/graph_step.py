@@ -15,6 +15,7 @@ stepper (same formulas evaluated on the device).
 """
 import ctypes
 import os
+import threading
 
 import torch
 from torch import optim
@@ -78,10 +79,11 @@ class FusedAdam:
                                                 torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step")
 
 
-    def step_acc(self, stop, leaves, new_grads):
+    def step_acc(self, stop, leaves, new_grads, counted=False):
         """Adam with autograd's accumulation folded into the launch (chore_fit_adam_step_acc): leaves = the parameters of
         this optimiser followed by the leaves that only accumulate; new_grads[i] = this step's gradient of leaves[i]
-        (torch.autograd.grad; None = the loss does not reach it).  Equals  leaf.grad += new  for every leaf, then step()."""
+        (torch.autograd.grad; None = the loss does not reach it).  Equals  leaf.grad += new  for every leaf, then step().
+        counted: the step counter already includes this step (the fused sum + rule launch advanced it)."""
         state = {id(p): (m, v) for p, m, v in zip(self.params, self.m, self.v)}
         rows = []
         for leaf, g in zip(leaves, new_grads):
@@ -121,7 +123,7 @@ class FusedAdam:
         dev = self.params[0].device
         h = _lib.handle(dev.index or 0)
         _lib.check(_lib.lib.chore_fit_adam_step_acc(h, pp, aa, gg, mm, vv, nn, cc, ss, n, self.step_t.data_ptr(), self.lr, self.betas[0],
-                                                    self.betas[1], self.eps, stop.data_ptr(),
+                                                    self.betas[1], self.eps, stop.data_ptr(), 1 if counted else 0,
                                                     torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_adam_step_acc")
 
 
@@ -155,9 +157,57 @@ class _WeightedSum(torch.autograd.Function):
         return (None, None) + tuple(grads[k] for k in range(ctx.n))
 
 
+class _WeightedSumStep(torch.autograd.Function):
+    """the same sum inside a stepper: one launch also writes the sum's gradients for the stepper's own upstream gradient (its
+    `seed`) and runs the stop rule on the sum (chore_fit_weighted_sum_step).  backward() launches nothing when it is handed
+    that very seed; any other upstream gradient takes the stand-alone backward launch."""
+
+    @staticmethod
+    def forward(ctx, denom, coeffs, st, *losses):
+        dev = denom.device
+        h = _lib.handle(dev.index or 0)
+        n = len(losses)
+        out = torch.empty((), device=dev)
+        grads = torch.empty(n, device=dev)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in losses])
+        cs = (ctypes.c_float * n)(*coeffs)
+        _lib.check(_lib.lib.chore_fit_weighted_sum_step(
+            h, ptrs, cs, n, denom.data_ptr(), out.data_ptr(), st.seed.data_ptr(), grads.data_ptr(), st.prev.data_ptr(),
+            st.stop.data_ptr(), st.frozen.data_ptr(), st.armed.data_ptr(), float(st.tol), st.loss.data_ptr(),
+            st.opt.step_t.data_ptr(), torch.cuda.current_stream(dev).cuda_stream), h, "chore_fit_weighted_sum_step")
+        ctx.save_for_backward(denom)
+        ctx.cs, ctx.n, ctx.grads, ctx.seed_ptr = cs, n, grads, st.seed.data_ptr()
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        grads = ctx.grads
+        if g.data_ptr() != ctx.seed_ptr or g.dtype != torch.float32:
+            (denom,) = ctx.saved_tensors
+            dev = denom.device
+            h = _lib.handle(dev.index or 0)
+            g = g.contiguous().float()
+            grads = torch.empty(ctx.n, device=dev)
+            _lib.check(_lib.lib.chore_fit_weighted_sum_bwd(h, ctx.cs, ctx.n, denom.data_ptr(), g.data_ptr(), grads.data_ptr(),
+                                                           torch.cuda.current_stream(dev).cuda_stream), h,
+                       "chore_fit_weighted_sum_bwd")
+        return (None, None, None) + tuple(grads[k] for k in range(ctx.n))
+
+
+# The stepper whose loss is being formed on this host thread and wants its stop rule inside the sum's launch (EagerStep._one);
+# weighted_sum takes the request (at most once per step) and says so.
+_step_request = threading.local()
+
+
 def weighted_sum(losses, coeffs, denom):
     if os.environ.get("CHORE_FIT_TORCH_SUM"):
         return torch.stack([c * v / denom for c, v in zip(coeffs, losses)]).sum()
+    st = getattr(_step_request, "stepper", None)
+    if st is not None and denom is st.denom:
+        _step_request.stepper = None
+        out = _WeightedSumStep.apply(denom, tuple(coeffs), st, *losses)
+        _step_request.taken = out
+        return out
     return _WeightedSum.apply(denom, tuple(coeffs), *losses)
 
 
@@ -183,8 +233,10 @@ class _OnePlusDecay:
 
 class EagerStep:
     def __init__(self, params, lr, loss_fn, tol, prev, betas=(0.9, 0.999), state=(), opt=None, release=None,
-                 capturable=False, carry=()):
-        """opt: continue with an existing optimiser (a phase that only changes the loss, recon_fit_behave.py:252-254);
+                 capturable=False, carry=(), fuse_rule=False):
+        """fuse_rule: loss_fn returns what weighted_sum() returned, untouched -- the stop rule then runs inside that launch
+        (a loss_fn that post-processes the sum must leave this off: the rule would have tested the wrong value; _one raises);
+        opt: continue with an existing optimiser (a phase that only changes the loss, recon_fit_behave.py:252-254);
         capturable: evaluate Adam's bias corrections on the device like the graph stepper does (bit-comparable runs);
         carry: parameters this phase does not step but whose .grad keeps accumulating (every leaf the loss reaches does in
         the reference, and a later phase's new Adam starts from those sums, recon_fit_behave.py:243-259)"""
@@ -193,6 +245,7 @@ class EagerStep:
         self.opt = opt if opt is not None else self._make_opt(lr, betas, capturable)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
         self.release = release
+        self.fuse_rule = bool(fuse_rule)
         self._init_flags(self.params[0].device)
 
     def _make_opt(self, lr, betas, capturable):
@@ -210,6 +263,7 @@ class EagerStep:
         self.denom = torch.ones((), device=dev)           # 1 + decay
         self.armed = torch.zeros((), dtype=torch.bool, device=dev)   # the early-stop rule is live in this outer iteration
         self.stop = torch.zeros((), dtype=torch.bool, device=dev)    # latched: the reference has returned
+        self.frozen = torch.zeros((), dtype=torch.bool, device=dev)  # `stop` as it was before the current step's test (fused rule)
         self.loss = torch.zeros((), device=dev)
         self.seed = torch.ones((), device=dev)            # d loss / d loss: handed to backward() (it fills a fresh one per call otherwise)
 
@@ -218,6 +272,7 @@ class EagerStep:
         """make a kept stepper (recon_fit_behave._FitSlot) equal to a newly built one: flags cleared, the optimiser's state zeroed
         unless it continues another stepper's (reset_opt=False).  Only steppers on a FusedAdam are kept."""
         self.stop.fill_(False)
+        self.frozen.fill_(False)
         self.armed.fill_(False)
         self.loss.zero_()
         self.denom.fill_(1.0)
@@ -247,8 +302,19 @@ class EagerStep:
         # the remaining inner steps still run -- as no-ops: once `stop` is latched every later step leaves the
         # parameters and the previous loss as they were.
         if isinstance(self.opt, FusedAdam):
-            # two launches: Adam on all tensors (the latched flag freezes the parameters), then the stop rule + step counter
-            loss = self.loss_fn(_OnePlusDecay(self.denom))
+            # two launches: Adam on all tensors (the latched flag freezes the parameters), then the stop rule + step counter --
+            # or, with fuse_rule, the rule inside the launch that sums the loss terms (before Adam, which then reads `frozen`)
+            fuse = self.fuse_rule and not os.environ.get("CHORE_FIT_BACKWARD_ACCUMULATE")
+            _step_request.stepper, _step_request.taken = (self if fuse else None), None
+            try:
+                loss = self.loss_fn(_OnePlusDecay(self.denom))
+            finally:
+                _step_request.stepper = None
+                taken, _step_request.taken = getattr(_step_request, "taken", None), None
+            if taken is not None and taken is not loss:
+                raise RuntimeError("fit step: the stop rule ran inside weighted_sum() on a value that is not the step's loss "
+                                   "(loss_fn changed the sum): build the stepper with fuse_rule=False")
+            fused = taken is not None
             seed = self.seed if loss.dtype == self.seed.dtype and loss.dim() == 0 else None
             if os.environ.get("CHORE_FIT_BACKWARD_ACCUMULATE"):        # A/B switch: .backward() + one add launch per leaf
                 loss.backward(seed)
@@ -263,7 +329,9 @@ class EagerStep:
                     self._check_leaves(loss, leaves)
                     self._leaves_checked = True
                 grads = torch.autograd.grad(loss, leaves, seed, allow_unused=True)
-                self.opt.step_acc(self.stop, leaves, grads)
+                self.opt.step_acc(self.frozen if fused else self.stop, leaves, grads, counted=fused)
+            if fused:
+                return
             lv = loss.detach()
             if lv.dtype != torch.float32:
                 lv = lv.float()
@@ -323,7 +391,7 @@ class GraphedStep(EagerStep):
     noise index) -- they are snapshotted around the warm-up runs, which must not leave a trace in the fit."""
 
     def __init__(self, params, lr, loss_fn, tol, prev, betas=(0.9, 0.999), state=(), opt=None, release=None,
-                 capturable=True, warmup=2, carry=()):
+                 capturable=True, warmup=2, carry=(), fuse_rule=False):
         """release: drops every reference to autograd graphs of earlier steps (cached predictions, concatenated
         parameters).  The gradient accumulators of the parameters live as long as such a graph does and stay bound
         to the stream they were created on; recording needs them re-created on the capture stream."""
@@ -336,8 +404,9 @@ class GraphedStep(EagerStep):
                 p.grad = torch.zeros_like(p)   # replaced by a graph-private tensor and overwritten on every replay)
         self.opt = opt if opt is not None else self._make_opt(lr, betas, True)
         self.loss_fn, self.tol, self.prev = loss_fn, tol, prev
+        self.fuse_rule = bool(fuse_rule)
         self._init_flags(dev)
-        mutable = [p.data for p in self.params] + [p.grad for p in self.params + carry] + [self.prev, self.stop, self.loss]
+        mutable = [p.data for p in self.params] + [p.grad for p in self.params + carry] + [self.prev, self.stop, self.frozen, self.loss]
         mutable += list(state)
         mutable += self._opt_state_tensors()   # a continued Adam (torch's creates its state lazily; see _restore)
         snap = [t.clone() for t in mutable]

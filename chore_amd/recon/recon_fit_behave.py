@@ -66,7 +66,10 @@ class ReconFitterBehave(ReconFitterBase):
     timer = None          # a list: per outer iteration (start event, end event, number of inner steps, phase name) is appended
     adam_capturable = False   # eager steps with Adam's scalars evaluated on the device (what the graph does)
 
+    fuse_stop_rule = True      # the steps' loss is sum_dict's result as it comes: the stop rule rides in that launch (graph_step)
+
     def _stepper(self, *a, **k):
+        k.setdefault("fuse_rule", self.fuse_stop_rule and not os.environ.get("CHORE_FIT_SPLIT_RULE"))
         if self.use_graphs:
             return GraphedStep(*a, **k)
         return EagerStep(*a, capturable=self.adam_capturable, **k)
@@ -179,7 +182,26 @@ class ReconFitterBehave(ReconFitterBase):
                                 obj_s=obj_s.detach()))
         use_pipe = self.pipeline if pipeline is None else pipeline
         if use_pipe and len(todo) > 1 and torch.device(self.device).type == "cuda":
-            self._fit_pipelined(todo, generator, finish)
+            import sys
+            sw = os.environ.get("CHORE_PIPE_SWITCH_US")
+            old_sw = sys.getswitchinterval()
+            if sw:
+                sys.setswitchinterval(float(sw) * 1e-6)
+            try:
+                if os.environ.get("CHORE_PIPE_OWN_STREAM"):
+                    dev = torch.device(self.device)
+                    cur = torch.cuda.current_stream(dev)
+                    st = self.__dict__.get("_pipe_main")
+                    if st is None:
+                        st = self._pipe_main = torch.cuda.Stream(dev)
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        self._fit_pipelined(todo, generator, finish)
+                    cur.wait_stream(st)
+                else:
+                    self._fit_pipelined(todo, generator, finish)
+            finally:
+                sys.setswitchinterval(old_sw)
         else:
             for i, data in todo:
                 # (index only when per-batch generators are on: a subclass's fit_batch(data, generator) keeps working)
@@ -260,7 +282,15 @@ class ReconFitterBehave(ReconFitterBase):
             prio = int(os.environ.get("CHORE_PIPE_PRIO", "0"))
             # ONE worker thread for the fitter's lifetime (it owns a C handle of its own, chore_amd/_lib.py: a thread per call would
             # leave a handle behind per call)
-            state = self._pipe_state = (generator, nets, gens, [torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev, priority=prio)],
+            # CHORE_PIPE_CUS=n: the preparation streams run on n of the compute units (the same share of every XCD), the rest stay
+            # free for the optimisation's small kernels whatever the preparation has in flight (chore_stream_create_cu_mask)
+            cus = int(os.environ.get("CHORE_PIPE_CUS", "0"))
+            if cus > 0:
+                from chore_amd import _lib
+                prep_streams = [_lib.cu_masked_stream(dev.index or 0, cus) for _ in range(2)]
+            else:
+                prep_streams = [torch.cuda.Stream(dev, priority=prio), torch.cuda.Stream(dev, priority=prio)]
+            state = self._pipe_state = (generator, nets, gens, prep_streams,
                                         [False, False], ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-prep"))
         _, nets, gens, streams, warm, pool = state      # warm[s]: slot s's inner steps are recorded (kept across calls with the slots)
         if not self.reuse_graphs:

@@ -70,6 +70,15 @@ int chore_create(chore_handle** out, int device_ordinal);
 int chore_destroy(chore_handle* h);
 const char* chore_last_error(const chore_handle* h);
 
+/* Streams restricted to a subset of the compute units (no reference counterpart: the reference's loader loop,
+ * recon/recon_fit_behave.py:41-76, is serial; this serves the pipelined loop of ReconFitterBehave.fit_recon, where the
+ * preparation of batch k+1 must leave CUs free for the small kernels of batch k's optimisation).
+ * mask: n_words x 32 bits, bit i = one CU (dealt round robin over the XCDs); chore_cu_count = CUs of the handle's device.
+ * The stream is a plain hipStream_t: hand it to any entry point, destroy it with chore_stream_destroy (waits for it). */
+int chore_cu_count(chore_handle* h);
+int chore_stream_create_cu_mask(chore_handle* h, const uint32_t* mask, int n_words, chore_stream_t* out);
+int chore_stream_destroy(chore_handle* h, chore_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Per-point MLP heads + fused query  (replaces CHORE.query, model/chore.py:107-154:
  * camera.project_points model/camera.py:44-88, index()/grid_sample model/geometry.py:4-14 twice,
@@ -543,7 +552,9 @@ int chore_fit_adam_step(chore_handle* h, float* const* p, const float* const* g,
  * multi-frame batch, lib_smpl/wrapper_pytorch.py's SMPLPyTorchWrapperBatchSplitParams); g, gnew, m, v stay dense.  nt <= 16. */
 int chore_fit_adam_step_acc(chore_handle* h, float* const* p, float* const* g, const float* const* gnew, float* const* m,
                             float* const* v, const int* n, const int* cols, const int* pstride, int nt, const float* step,
-                            float lr, float beta1, float beta2, float eps, const uint8_t* stop, chore_stream_t stream);
+                            float lr, float beta1, float beta2, float eps, const uint8_t* stop, int step_counted,
+                            chore_stream_t stream);   /* step_counted != 0: `step` already counts this step (see
+                                                         chore_fit_weighted_sum_step) */
 int chore_fit_stop_rule(chore_handle* h, const float* loss, float* prev, uint8_t* stop, const uint8_t* armed, float tol,
                         float* loss_out, float* step, chore_stream_t stream);
 /* the weighting of the fit's loss dictionary (recon_fit_behave.py:339-358): out = sum_k coeff[k] * loss[k] / denom over
@@ -552,6 +563,14 @@ int chore_fit_weighted_sum(chore_handle* h, const float* const* losses, const fl
                            float* out, chore_stream_t stream);
 int chore_fit_weighted_sum_bwd(chore_handle* h, const float* coeffs, int n, const float* denom, const float* g, float* grads,
                                chore_stream_t stream);
+/* The three single-thread launches of a step as one: chore_fit_weighted_sum, its backward for the upstream gradient *seed
+ * (the step's d loss / d loss), and -- when prev != NULL -- chore_fit_stop_rule on the sum (recon_fit_behave.py:143-160,
+ * 270-287).  The rule runs BEFORE the step's Adam launch here: `frozen` receives the stop flag as earlier steps left it
+ * (hand THAT to chore_fit_adam_step_acc as `stop`: the reference applies the update of the step that meets the rule), and
+ * `step` is advanced here (step_counted = 1 for the Adam launch). */
+int chore_fit_weighted_sum_step(chore_handle* h, const float* const* losses, const float* coeffs, int n, const float* denom,
+                                float* out, const float* seed, float* grads, float* prev, uint8_t* stop, uint8_t* frozen,
+                                const uint8_t* armed, float tol, float* loss_out, float* step, chore_stream_t stream);
 
 /* The small loss terms of forward_smpl (recon_fit_behave.py:293-337) in one launch each way.  pose (B,156) SMPL-H
  * axis-angle, pose_init (B,69) = the initial pose[3:72], J (B,R,3) landmarks whose first 25 rows are the body-25 keypoints

@@ -411,6 +411,49 @@ def test_fused_adam_step_equals_torch_adam():
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
 
 
+def test_stop_rule_inside_the_sum_launch_equals_the_separate_launches():
+    """chore_fit_weighted_sum_step (sum of the loss terms + its backward for the stepper's seed + the stop rule, one launch,
+    the rule BEFORE the step's Adam) against the three separate launches (rule after Adam): 30 steps with the rule firing
+    in between -- losses, flags, previous loss, step counter, parameters and accumulated gradients bit for bit, eager and as a
+    hipGraph replay; a loss_fn that changes the sum is refused."""
+    from chore_amd.recon import graph_step as gs
+    shapes = [(2, 72), (2, 10), (2, 3), (2, 3, 3), (2,)]
+    coeffs = [1.0, 0.5, 2.0, 0.25, 3.0, 1.0]
+    res = {}
+    for mode in ("split", "fused", "fused graph"):
+        torch.manual_seed(12)
+        params = [torch.randn(s, device="cuda").requires_grad_(True) for s in shapes]
+        targets = [torch.randn(s, device="cuda") for s in shapes]
+        five = torch.tensor(5.0, device="cuda")
+        gate = torch.ones((), device="cuda")          # 0 for a few steps: the loss stalls, the rule fires
+        prev = torch.tensor(300.0, device="cuda")
+
+        def loss_fn(decay):
+            terms = [((p - t) ** 2).sum() * gate for p, t in zip(params, targets)] + [five]
+            return gs.weighted_sum(terms, coeffs, 1 + decay)
+        cls = gs.GraphedStep if mode == "fused graph" else gs.EagerStep
+        st = cls(params, 0.02, loss_fn, 0.001, prev, capturable=True, fuse_rule=mode != "split")
+        trace, k = [], 0
+        for it in range(6):
+            st.begin_outer(it, armed=it >= 2, zero=True)
+            for _ in range(5):
+                k += 1
+                gate.fill_(0.0 if 12 <= k <= 14 else 1.0)
+                st.step()
+                trace.append((float(st.loss), bool(st.stop), float(st.prev), float(st.opt.step_t)))
+        res[mode] = (trace, [p.detach().clone() for p in params], [p.grad.clone() for p in params])
+    assert any(t[1] for t in res["split"][0]) and not res["split"][0][10][1]
+    for mode in ("fused", "fused graph"):
+        assert res[mode][0] == res["split"][0], mode
+        for a, b in zip(res[mode][1] + res[mode][2], res["split"][1] + res["split"][2]):
+            assert torch.equal(a, b), mode
+    params = [torch.randn(3, device="cuda").requires_grad_(True)]
+    st = gs.EagerStep(params, 0.02, lambda decay: 2.0 * gs.weighted_sum([(params[0] ** 2).sum()], [1.0], 1 + decay), 0.001,
+                      torch.tensor(300.0, device="cuda"), capturable=True, fuse_rule=True)
+    with pytest.raises(RuntimeError, match="fuse_rule=False"):
+        st.step()
+
+
 def test_fused_adam_on_column_slices_of_a_batch_equals_torch_adam():
     """the split SMPL parameters of a multi-frame batch are column slices of the wrapper's storage (b[:, :2], p[:, 3:66], ...:
     non-contiguous for B > 1, lib_smpl/wrapper_pytorch.py from_smpl): the accumulate-in-Adam launch updates them in place
