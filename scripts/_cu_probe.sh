@@ -1,13 +1,15 @@
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_fit.py tests/test_gpu_fit_chain.py tests/test_gpu_fit_stress.py -x -q -m gpu > gpurun_out/fit_tests.txt 2>&1
-tail -15 gpurun_out/fit_tests.txt
-for v in 0 1; do
-  if [ $v = 1 ]; then export CHORE_FIT_SPLIT_RULE=1; fi
-  timeout 300 python bench.py --mode fit --steps 3 --warmup 1 > gpurun_out/fit_rule_$v.json 2> gpurun_out/fit_rule_$v.err
-  python - <<PY
+CHORE_BENCH_RECORDS_DEADLINE_S=15 timeout 300 python bench.py > gpurun_out/bench_dog.json 2> gpurun_out/bench_dog.err; echo "rc=$?"
+python - <<PY
 import json
-for l in open("gpurun_out/fit_rule_$v.json"):
-    if l.startswith("{"):
-        d=json.loads(l); ll=d["loader_loop"]; print("split=$v", "iter ms", round(d["value"],4), "chain", round(d["chain_ms_median"],1), {k:round(v["median_ms_per_iter"],4) for k,v in d["per_phase"].items()}, "serial", round(ll["serial"]["steady_state_ms_per_frame"],1), "pipelined", round(ll["pipelined"]["steady_state_ms_per_frame"],1), ll["pipelined"]["gaps_ms"])
+d=json.loads([l for l in open("gpurun_out/bench_dog.json") if l.startswith("{")][-1])
+print("dog:", d["value"], d.get("records_aborted"), [k for k in ("train","fit","fit_fp16_fields") if k in d])
 PY
-done
+date +%s > /tmp/t0
+timeout 600 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; echo "rc=$?"
+echo "seconds: $(( $(date +%s) - $(cat /tmp/t0) ))"
+python - <<PY
+import json
+d=json.loads([l for l in open("gpurun_out/bench_full.json") if l.startswith("{")][-1])
+print("full:", d["value"], d["ms_per_step"], d.get("records_aborted"), d["train"]["value"], d["train"]["ms_per_step"], d["fit"]["value"], d["fit"]["loader_loop"]["pipelined"]["steady_state_ms_per_frame"], d["fit_fp16_fields"]["value"])
+PY
