@@ -757,6 +757,196 @@ __global__ __launch_bounds__(512) void wgrad64_x3_pc_kernel(WgradArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// fp16 x 3 weight gradient of the 1 x 1 layers with 128 x 128-channel workgroup tiles (round 5, third version).
+// A 1 x 1 layer has one product per staged element and tap where the 3 x 3 layers have nine: on 64 x 64 tiles wgrad64_x3_pc_kernel
+// spends its time in the PRODUCERS (85 us alone on 256 -> 256 at 128^2; 54 without the split + LDS stores, 80 without the MFMAs:
+// profiles/r05_wgrad_x3.txt) and every element of x and dy is loaded, normalised and split by FOUR workgroups (one per tile of the
+// other operand's channels).  Here a workgroup owns 128 output x 128 input channels: each element is staged by two workgroups, each
+// staged element feeds four times the MFMAs, and each consumer wave holds a 64 x 64 block (2 x 2 accumulators).  Tiles are 32
+// consecutive pixels of the flattened (B, H, W) index (a 1 x 1 layer has no neighbourhood; H W % 32 == 0, so a tile lies in one
+// image); LDS rows are 320 bytes (256 + 64: the four rows a transposing read touches tile the 64 banks), two buffers of four planes
+// = 80 KB.  Roles, hand-over and arithmetic per product as in wgrad64_x3_pc_kernel; the partial sums are [share][pair][128][128].
+// ------------------------------------------------------------------------------------------------
+constexpr int W128_PITCH = 320, W128_PX = 32;
+
+__global__ __launch_bounds__(512) void wgrad128_x3_pc_kernel(WgradArgs a) {
+    f16_saturate_mode();
+    constexpr int CT = 128, SLOTS = CT / 8;                     // 8-channel slots per pixel row
+    constexpr int NV = W128_PX * SLOTS / 256;                   // (pixel, 8 channels) units per producer thread, tile and operand
+    constexpr int PL = W128_PX * W128_PITCH;                    // one plane of a buffer
+    constexpr int BUF = 4 * PL;                                 // A hi, A lo, Y hi, Y lo
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wid >= 4;
+    const int nbo = a.Cout / CT, nbc = a.Cin / CT, npairs = nbo * nbc;
+    int share, pair;
+    {
+        const int L = blockIdx.x;
+        if (a.S % 8 == 0) { const int xcd = L & 7, j = L >> 3; share = (j / npairs) * 8 + xcd; pair = j % npairs; }
+        else { share = L / npairs; pair = L % npairs; }
+    }
+    const int co0 = (pair / nbc) * CT, ci0 = (pair % nbc) * CT;
+    const int HW = a.H * a.W;
+    const int tiles = (int)(a.npix / W128_PX);
+    const int ntile = share < tiles ? (tiles - share + a.S - 1) / a.S : 0;
+    float ymul, yinv;
+    x3_in_scale(a.dy_amax, ymul, yinv);
+    float* red = (float*)smem;                                  // after the loop: [256 producer threads][8] bias partials
+
+    if (producer) {
+        const int ptid = tid & 255;
+        const bool use_gn = a.st != nullptr;
+        const float* X = (const float*)a.x;
+        const float* DY = (const float*)a.dy;
+        const int v = ptid & (SLOTS - 1), prow = ptid / SLOTS;  // this thread's 8-channel slot; its pixel rows: prow + 16 q
+        float sc[8], sh[8], bias8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { sc[j] = 1.f; sh[j] = 0.f; bias8[j] = 0.f; }
+        int cur_b = -1;
+        u32x4 vy[NV][2], vx[NV][2];
+        auto issue_loads = [&](int tile) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const size_t pix = (size_t)tile * W128_PX + prow + (256 / SLOTS) * q;
+                const u32x4* py = (const u32x4*)(DY + pix * a.ys + co0 + v * 8);
+                vy[q][0] = py[0]; vy[q][1] = py[1];
+                const u32x4* px = (const u32x4*)(X + pix * a.xs + ci0 + v * 8);
+                vx[q][0] = px[0]; vx[q][1] = px[1];
+            }
+        };
+        auto split8 = [](const float (&f)[8], u32x4& hi, u32x4& lo) {
+            tb_f16x8 hh, ll;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { hh[j] = (_Float16)f[j]; ll[j] = (_Float16)(f[j] - (float)hh[j]); }
+            hi = __builtin_bit_cast(u32x4, hh);
+            lo = __builtin_bit_cast(u32x4, ll);
+        };
+        if (ntile > 0 && !(a.dbg & 4)) issue_loads(share);
+        for (int it = 0; it < ntile; ++it) {
+            const int tile = share + it * a.S;
+            const int b = (int)(((size_t)tile * W128_PX) / HW);
+            char* imgA = smem + (it & 1) * BUF;
+            char* imgY = imgA + 2 * PL;
+            if (use_gn && b != cur_b) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gn_scale_shift(a.st, a.B, b, a.Cin, ci0 + v * 8 + j, HW, a.gamma, a.beta, sc[j], sh[j]);
+                cur_b = b;
+            }
+            if (!(a.dbg & 2)) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                const int row = prow + (256 / SLOTS) * q;
+                float f[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vy[q][0][j]) * ymul; f[4 + j] = __uint_as_float(vy[q][1][j]) * ymul; }
+                u32x4 hi, lo;
+                split8(f, hi, lo);
+                if (a.part_bias) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bias8[j] += f[j];
+                }
+                *(u32x4*)(imgY + row * W128_PITCH + v * 16) = hi;
+                *(u32x4*)(imgY + PL + row * W128_PITCH + v * 16) = lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { f[j] = __uint_as_float(vx[q][0][j]); f[4 + j] = __uint_as_float(vx[q][1][j]); }
+                if (use_gn) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const float t = fmaf(f[j], sc[j], sh[j]); f[j] = t > 0.f ? t : 0.f; }
+                }
+                split8(f, hi, lo);
+                *(u32x4*)(imgA + row * W128_PITCH + v * 16) = hi;
+                *(u32x4*)(imgA + PL + row * W128_PITCH + v * 16) = lo;
+            }
+            }
+            if (!(a.dbg & 4)) issue_loads(it + 1 < ntile ? tile + a.S : tile);      // in flight across the barrier and the next split
+            wp_barrier();                                       // barrier `it`: buffer it % 2 is complete
+        }
+        wp_barrier();                                           // the consumers have read the last buffer: the LDS is free
+        if (a.part_bias) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) red[ptid * 8 + j] = bias8[j];
+        }
+    } else {
+        const int cih = wid & 1, coh = wid >> 1;                // this wave's 64 x 64 block of the tile
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+        const int h = lane >> 5, g = (lane >> 4) & 1, i16 = lane & 15;
+        const int lane_off = (8 * h + (i16 >> 2)) * W128_PITCH + (g * 16 + (i16 & 3) * 4) * 2;
+        auto frag = [&](const char* p) -> tb_f16x8 {
+            const tb_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+            const tb_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * W128_PITCH));
+            typedef short s16x8 __attribute__((ext_vector_type(8)));
+            const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(tb_f16x8, vv);
+        };
+        for (int it = 0; it < ntile; ++it) {
+            wp_barrier();                                       // barrier `it`: buffer it % 2 is complete
+            const char* imgA = smem + (it & 1) * BUF;
+            const char* baseY = imgA + 2 * PL + lane_off + coh * 128;
+            const char* baseA = imgA + lane_off + cih * 128;
+            if (a.dbg & 1) continue;
+#pragma unroll
+            for (int xb = 0; xb < W128_PX; xb += 16) {
+                tb_f16x8 fyh[2], fyl[2], fxh[2], fxl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    fyh[m] = frag(baseY + xb * W128_PITCH + m * 64);
+                    fyl[m] = frag(baseY + PL + xb * W128_PITCH + m * 64);
+                    fxh[m] = frag(baseA + xb * W128_PITCH + m * 64);
+                    fxl[m] = frag(baseA + PL + xb * W128_PITCH + m * 64);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {           // small terms first, all three into the same accumulator
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyl[m], fxh[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh[m], fxl[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fyh[m], fxh[n], acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+        wp_barrier();                                           // (pairs with the producers' final barrier)
+        const int col = lane & 31;
+        float* out = a.part + ((size_t)share * npairs + pair) * (CT * CT);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    out[(coh * 64 + m * 32 + mfma32_row(r, h)) * CT + cih * 64 + n * 32 + col] = acc[m][n][r] * yinv;
+    }
+    if (a.part_bias) {          // uniform.  dbias partial of this share: the producers' per-thread sums, added in thread order
+        wp_barrier();
+        if (pair % nbc == 0 && tid < CT) {
+            float sum = 0.f;
+            const int vv = tid >> 3, j = tid & 7;               // channel tid = slot vv, element j
+            for (int p = 0; p < 256 / SLOTS; ++p) sum += red[(p * SLOTS + vv) * 8 + j];
+            a.part_bias[(size_t)share * a.Cout + co0 + tid] = sum * yinv;
+        }
+    }
+}
+
+static bool wgrad128_ok(int taps, int B, int H, int W, int Cin, int Cout) {
+    static const bool off = getenv("CHORE_WGRAD_NO128") != nullptr;
+    return !off && taps == 1 && Cin % 128 == 0 && Cout % 128 == 0 && ((long)H * W) % W128_PX == 0 && (long)B * H * W >= 8 * W128_PX;
+}
+static int wgrad128_shares(int B, int H, int W, int Cin, int Cout) {
+    const int tiles = (int)((long)B * H * W / W128_PX);
+    const int pairs = (Cout / 128) * (Cin / 128);
+    static const int wgs = getenv("CHORE_WGRAD128_WGS") ? atoi(getenv("CHORE_WGRAD128_WGS")) : 256;      // workgroups to aim for (A/B)
+    int S = ((wgs + pairs - 1) / pairs + 7) / 8 * 8;
+    if (S > tiles) S = tiles;
+    return S;
+}
+
 static int wgrad64_x3_pc_shares(int B, int H, int W, int Cin, int Cout) {
     const int tiles = B * ((W + TW - 1) / TW) * ((H + WP_TH - 1) / WP_TH);
     const int pairs = (Cout / 64) * (Cin / 64);
@@ -1096,6 +1286,11 @@ size_t chore_conv2d_wgrad_workspace_bytes(int taps, int B, int H, int W, int Cin
         const size_t n64 = (size_t)S64 * (Cout / 64) * (Cin / 64) * taps * 4096 + (size_t)S64 * Cout;
         if (n64 > n) n = n64;
     }
+    if (wgrad128_ok(taps, B, H, W, Cin, Cout)) {
+        const int S128 = wgrad128_shares(B, H, W, Cin, Cout);
+        const size_t n128 = (size_t)S128 * (Cout / 128) * (Cin / 128) * 16384 + (size_t)S128 * Cout;
+        if (n128 > n) n = n128;
+    }
     return n * sizeof(float);
 }
 
@@ -1167,6 +1362,26 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
         // SLOWER on it: twice the tiles, twice the barriers).  CHORE_WGRAD_X3_V1=1 / CHORE_WGRAD_X3_PC=1 force one of them.
         static const bool x3_v1 = getenv("CHORE_WGRAD_X3_V1") != nullptr, x3_pc = getenv("CHORE_WGRAD_X3_PC") != nullptr;
         const bool use_pc = x3_pc || (!x3_v1 && (taps == 1 || (Cin >= 128 && Cout >= 128 && (long)H * W >= 128 * 128)));
+        if (x3 && !x3_v1 && !x3_pc && wgrad128_ok(taps, B, H, W, Cin, Cout)) {      // the 1 x 1 layers: 128 x 128-channel tiles
+            ct = 128;
+            a.S = wgrad128_shares(B, H, W, Cin, Cout);
+            const int np128 = (Cout / 128) * (Cin / 128);
+            a.part_bias = dbias ? a.part + (size_t)a.S * np128 * 16384 : nullptr;
+            const size_t sm128 = (size_t)2 * 4 * W128_PX * W128_PITCH;
+            bool& attr128 = CHORE_ONCE_FLAG(h);
+            if (!attr128) {
+                CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)wgrad128_x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm128));
+                attr128 = true;
+            }
+            hipLaunchKernelGGL(wgrad128_x3_pc_kernel, dim3(a.S * np128), dim3(512), sm128, s, a);
+            CHORE_LAUNCH_CHECK(h, s);
+            if (defer) { defer->j[defer->n++] = {a.part, a.part_bias, dw, dbias, a.S, Cout, Cin, taps, ct}; return CHORE_OK; }
+            const size_t n = (size_t)Cout * Cin * taps;
+            hipLaunchKernelGGL(wgrad_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.part, a.part_bias, a.S, Cout,
+                               Cin, taps, dw, dbias, ct);
+            CHORE_LAUNCH_CHECK(h, s);
+            return CHORE_OK;
+        }
         if (x3 && use_pc) {
             a.S = wgrad64_x3_pc_shares(B, H, W, Cin, Cout);
             a.part_bias = dbias ? a.part + (size_t)a.S * npairs * taps * 4096 : nullptr;
