@@ -333,6 +333,7 @@ def mode_query(args, ctx):
                         step()
                 torch.cuda.current_stream(dev).wait_stream(side)
                 torch.cuda.synchronize()
+                _drain()
                 for k in range(max(1, args.in_flight)):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, stream=torch.cuda.Stream(dev)):     # own capture stream = own encoder workspace
@@ -445,6 +446,7 @@ def mode_query(args, ctx):
                                      "field_err": field_errors(net2.get_preds())["all"]}
                 try:        # the same step as ONE hipGraph replay (what `single_in_flight_ms_per_step` is for the headline mode)
                     torch.cuda.synchronize()
+                    _drain()
                     g2 = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g2):
                         step2()
@@ -486,6 +488,7 @@ def mode_query(args, ctx):
                     fn()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
+            _drain()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
@@ -802,9 +805,15 @@ def train_grad_error(mode, dev):
             "against": "the reference's CPU autograd gradients of the same batch (tests/golden/train_grads.npz)"}
 
 
+def _drain():
+    """before a recording: no collective left in the process group's watchdog list (chore_amd.parallel.drain_collectives)"""
+    from chore_amd.parallel import drain_collectives
+    drain_collectives()
+
+
 def _stage(ctx, what):
     """progress marks of every rank on stderr (rehearsals of the N > 1 path only)"""
-    if os.environ.get("CHORE_BENCH_REHEARSAL"):
+    if os.environ.get("CHORE_BENCH_REHEARSAL") or os.environ.get("CHORE_BENCH_STAGES"):
         mem = torch.cuda.memory_allocated() / 2 ** 30 if ctx.cuda else 0.0
         print("[rank %d] %s (%.1f GiB allocated)" % (ctx.rank, what, mem), file=sys.stderr, flush=True)
 

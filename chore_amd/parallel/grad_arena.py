@@ -31,6 +31,8 @@ CHORE: the 4 MB of the stem, the first three ConvBlocks and the heads, against 1
 gathered: SURVEY 8e's sketch; over 7 xGMI links per GPU both halves are direct sends) instead of one all_reduce per segment --
 the same sums; which one is faster at 13.6 MB per segment is for the first multi-GPU run to say.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -137,10 +139,10 @@ class FlatGradReducer:
     def all_reduce(self):
         """the collective half: the arena summed over the ranks in `chunks` pieces, then scaled to the mean"""
         if self.world > 1 or dist.is_initialized():
-            # one after the other, each a stream-ordered call (on RCCL the collectives of one communicator run in issue order on its
-            # stream whichever way they are issued)
-            for c in self.chunks:
-                dist.all_reduce(c, group=self.group)
+            # (all issued, then waited for: on RCCL the collectives of one communicator run in issue order on its stream either way)
+            works = [dist.all_reduce(c, group=self.group, async_op=True) for c in self.chunks]
+            for w in works:
+                w.wait()
             if self.average and self.world > 1:
                 self.arena.mul_(1.0 / self.world)
 

@@ -48,6 +48,32 @@ import os
 import torch
 
 
+def drain_collectives(*groups):
+    """Before a hipGraph recording in a process that has issued collectives: none of them may still sit in its process group's
+    watchdog list.  The watchdog thread polls the end events of the works it holds (every 100 ms, until it has seen each one
+    finished); with works of the eager warm-up steps still listed when a capture started, the process died about once in eight
+    starts with `watchdog thread terminated with exception: HIP error: operation not permitted on an event last recorded in a
+    capturing stream` (scripts/probes/graph_record_watchdog.py: 2 of 12 starts; 0 of 40 with the list drained first).  torch's own
+    capture_begin waits for this in the global capture mode; GraphedTrainStep records thread-local (other threads of the process
+    may touch events), so the wait is done here -- and, as a second line, before the package's other recordings too.
+    Call with the device idle (torch.cuda.synchronize()): the wait is for the watchdog's next pass, not for the GPU."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    todo = {}
+    for g in (dist.group.WORLD,) + groups:
+        if g is not None:
+            todo[id(g)] = g
+    for g in todo.values():
+        try:
+            if dist.get_backend(g) != "nccl":
+                continue                      # gloo works carry no device events
+            g._wait_for_pending_works()
+        except Exception:
+            import time
+            time.sleep(0.4)                   # (an older torch without the call: four passes of the watchdog)
+
+
 class GraphedTrainStep:
     def __init__(self, model, optimizer, reducer=None, warmup=3, max_recordings=2):
         """model: CHORE (or a wrapper with the same call surface) returning (loss, separate losses); optimizer: a torch
@@ -176,6 +202,7 @@ class GraphedTrainStep:
         split = self.reducer is not None and (self.reducer.world > 1 or torch.distributed.is_initialized())
         ga = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        drain_collectives(getattr(self.reducer, "group", None))
         # a process group's watchdog thread polls events while we record: only THIS thread's calls belong to the recording
         mode = dict(capture_error_mode="thread_local") if torch.distributed.is_initialized() else {}
         if split and self._segmented():

@@ -422,6 +422,10 @@ class GraphedStep(EagerStep):
                 self._one()
             self._restore(mutable, snap, known)
         cur.wait_stream(side)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():      # frame-sharded fit: see drain_collectives
+            from ..parallel import drain_collectives
+            torch.cuda.synchronize(dev)
+            drain_collectives()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, stream=side):
             self._one()

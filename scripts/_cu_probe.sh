@@ -1,5 +1,11 @@
-for f in "" "1,256,256,128:4256;1,128,256,128:4256"; do
-  CHORE_PC_FORCE="$f" timeout 300 python scripts/conv_layer_ab.py fp16x3 2>&1 | tail -1 | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('force=$f', {k:v['us'] for k,v in d.items() if k.startswith('1x1')})"
+mkdir -p gpurun_out
+ok=0; bad=0
+for i in $(seq 1 10); do
+  timeout 120 python scripts/probes/graph_record_watchdog.py flat > /tmp/o.txt 2> /tmp/e.txt
+  if [ $? = 0 ]; then ok=$((ok+1)); else bad=$((bad+1)); grep -m1 "Error\|error" /tmp/e.txt | cut -c1-200; fi
 done
-CHORE_PC_FORCE="1,256,256,128:4256;1,128,256,128:4256" timeout 600 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_config2.py -x -q -m gpu 2>&1 | tail -3
+echo "reproducer: ok=$ok bad=$bad"
+for i in 1 2 3; do
+  timeout 600 python bench.py > gpurun_out/r05_bench_$i.json 2> gpurun_out/r05_bench_$i.err; echo "bench $i rc=$?"
+done
+timeout 900 python -m pytest tests/test_gpu_graph_train.py tests/test_gpu_ddp_nccl.py tests/test_gpu_ddp.py tests/test_gpu_ddp_trainstep.py tests/test_gpu_fit_chain.py -x -q -m gpu 2>&1 | tail -3
