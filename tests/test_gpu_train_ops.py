@@ -47,6 +47,7 @@ def check(a, b, dtype, what):
     (3, 64, 128, True, False, (5, 64, 64)),    # ... more tiles than shares
     (1, 128, 256, True, False, (2, 20, 44)),   # ... 1x1, ragged
     (1, 256, 256, False, True, (2, 32, 64)),   # ... 1x1 plain with bias
+    (1, 128, 256, True, True, (3, 16, 32)),    # 1x1 on 128 x 128-channel tiles (fp16 x 3), GroupNorm recomputed, three images, bias
 ])
 def test_conv_gn_layer(dtype, k, cin, cout, gn, bias, shape):
     from chore_amd import ops
