@@ -65,13 +65,13 @@ def drain_collectives(*groups):
         if g is not None:
             todo[id(g)] = g
     for g in todo.values():
+        # (no test on the backend's NAME first: a group made with "cpu:gloo,cuda:nccl" -- bench.py's -- reports that string)
         try:
-            if dist.get_backend(g) != "nccl":
-                continue                      # gloo works carry no device events
-            g._wait_for_pending_works()
+            g._wait_for_pending_works()       # the group's device backend; raises for a gloo-only group, whose works carry no device events
         except Exception:
-            import time
-            time.sleep(0.4)                   # (an older torch without the call: four passes of the watchdog)
+            if "nccl" in str(dist.get_backend(g)).lower():
+                import time
+                time.sleep(0.4)               # (an older torch without the call: four passes of the watchdog)
 
 
 class GraphedTrainStep:

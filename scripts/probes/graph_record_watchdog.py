@@ -1,6 +1,7 @@
 """Reproducer loop for: 'Process group watchdog thread terminated with exception: HIP error: operation not permitted on an event last
 recorded in a capturing stream' during the first recorded training steps of a process with a one-rank RCCL group.
-    python scripts/probes/graph_record_watchdog.py [flat|segmented]      (exit code 0 = six steps ran)"""
+    python scripts/probes/graph_record_watchdog.py [flat|segmented] [nccl|mixed]      (exit code 0 = six steps ran;
+mixed = a group made with "cpu:gloo,cuda:nccl" like bench.py's, whose get_backend() is that string)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
@@ -9,7 +10,11 @@ import torch.distributed as dist
 
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+if len(sys.argv) > 2 and sys.argv[2] == "mixed":
+    torch.cuda.set_device(0)
+    dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+else:
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from bench import chore_opt                                   # noqa: E402
 from chore_amd.model import CHORE                             # noqa: E402
 from chore_amd.utils import synth                             # noqa: E402
@@ -34,7 +39,7 @@ batch = dict(images=t(synth.synth_images(B, 512, 512, seed=0)), points=t(synth.s
 layout = sys.argv[1] if len(sys.argv) > 1 else "flat"
 red = FlatGradReducer(net) if layout == "flat" else FlatGradReducer(net, segments=chore_segments(net))
 g = GraphedTrainStep(net, optim, reducer=red, warmup=2)
-dist.barrier()
+dist.all_reduce(torch.zeros(1, device=dev))
 for i in range(6):
     loss, _ = g(**batch)
 torch.cuda.synchronize()

@@ -136,12 +136,13 @@ def test_recorded_step_after_eager_collectives_survives_the_watchdog():
     works of the eager warm-up steps listed killed the process about once in eight starts (`operation not permitted on an event
     last recorded in a capturing stream`).  GraphedTrainStep drains the list first
     (chore_amd.parallel.drain_collectives).  The reproducer -- a one-rank RCCL group, two eager steps, the recording, three
-    replays at the full configs[3] size -- is started four times; every start must finish."""
+    replays at the full configs[3] size -- is started four times (a plain "nccl" group and the "cpu:gloo,cuda:nccl" group of
+    bench.py, flat and segmented reducer); every start must finish."""
     import subprocess
     probe = os.path.join(REPO, "scripts", "probes", "graph_record_watchdog.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for start in range(4):
         env["MASTER_PORT"] = str(29700 + (os.getpid() + start) % 200)
-        r = subprocess.run([sys.executable, probe, "flat" if start % 2 == 0 else "segmented"], cwd=REPO, env=env, capture_output=True,
+        r = subprocess.run([sys.executable, probe, "flat" if start % 2 == 0 else "segmented", "nccl" if start < 2 else "mixed"], cwd=REPO, env=env, capture_output=True,
                            text=True, timeout=300)
         assert r.returncode == 0 and r.stdout.strip().startswith("ok"), (start, r.returncode, r.stderr[-600:])
