@@ -534,6 +534,9 @@ def mode_query(args, ctx):
         tpath = os.path.join(REPO, "profiles", "pmc_traffic_%s.json" % args.dtype)
         if os.path.exists(tpath):
             traffic = {k: v["bytes_per_launch"] for k, v in json.load(open(tpath)).items()}
+            # (rocprofv3 prints conv_pc_kernel's last template argument -- SC, the scaled-operand instantiation of the training
+            # data gradients; the library's own profile classes, which name `dom` below, do not carry it)
+            traffic.update({k[:-len(", false>")] + ">": v for k, v in traffic.items() if k.startswith("conv_pc_kernel<") and k.endswith(", false>")})
         # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
         # 32-point tiles when 64-point tiles would not fill the CUs)
         x3 = args.dtype in ("fp16x3", "bf16", "fp16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)
