@@ -697,7 +697,7 @@ def mode_fit(args, ctx):
     if fitter.reuse_graphs and not args.eager:
         fitter.smpl_iters, fitter.object_iters, fitter.batch_seed = SMPL_ITERS, OBJECT_ITERS, 1234
         batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(6)]
-        for name, pipe in (("serial", False), ("pipelined", True)):
+        for name, pipe in (("serial", False), ("pipelined", True), ("chains", "chains")):
             marks = []
 
             class Loader(list):
@@ -715,8 +715,14 @@ def mode_fit(args, ctx):
                 ends = fitter.batch_ends
                 gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)] or [float("nan")]     # device time between consecutive batches' ends
                 fitter.batch_ends = None
+                span = ends[1].elapsed_time(ends[-1]) / max(1, len(ends) - 2) if len(ends) > 2 else float("nan")
+                # steady state: the median gap between consecutive batches' ends -- for the chains mode, where two batches run side by
+                # side and end in pairs (gaps alternate between long and short or negative), the span from the second batch's end to the
+                # last batch's end over the batches in between
+                steady = span if name == "chains" else float(np.median(gaps))
                 loop[name] = {"ms_per_batch": marks[2] / len(batches), "ms_per_frame": marks[2] / (len(batches) * B),
-                              "steady_state_ms_per_batch_median": float(np.median(gaps)), "steady_state_ms_per_frame": float(np.median(gaps)) / B,
+                              "steady_state_ms_per_batch_span": span, "steady_state_ms_per_frame_span": span / B,
+                              "steady_state_ms_per_batch_median": float(np.median(gaps)), "steady_state_ms_per_frame": steady / B,
                               "gaps_ms": [round(g, 1) for g in gaps],
                               "first_pass_ms_per_batch": marks[0] / len(batches), "batches": len(batches)}
             except Exception as e:
@@ -756,7 +762,9 @@ def mode_fit(args, ctx):
                     "loader_loop": dict(loop, note="fit_recon over 6 consecutive loader batches of the same shapes (recordings kept), wall time "
                                                    "per batch of the second pass; pipelined = batch k+1's encoder + point clouds + SMPL-H "
                                                    "initialisation on a second stream / host thread while batch k is optimised, results equal to "
-                                                   "the serial loop bit for bit (tests/test_gpu_fit_chain.py)"),
+                                                   "the serial loop bit for bit (tests/test_gpu_fit_chain.py); chains = the whole chains of two batches side by side, each "
+                                                   "on its own stream and host thread, same results; *_span = device time from the second batch's end to the last "
+                                                   "batch's end / batches in between"),
                     "per_phase_note": "SURVEY 8(d) metric 2: median device ms per Adam iteration per phase over all outer iterations "
                                       "of all timed chains ('global' / 'smpl all pose' / 'kpts' = optimize_smpl; 'object only' / "
                                       "'sil' / 'joint' = optimize_smpl_object, joint incl. contact + collision terms)",

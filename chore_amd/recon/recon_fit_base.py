@@ -8,6 +8,7 @@ the same.  Heavy steps run in libchore_hip.so: the field queries (chore_query_fw
 reductions over (B,N) tensors expressed with torch ops on the device.
 """
 import os
+import threading
 import pickle as pkl
 
 import numpy as np
@@ -42,6 +43,16 @@ def write_ply(path, verts, faces=None):
             rec = np.zeros(len(faces), np.dtype([("n", "u1"), ("v", "<i4", (3,))]))
             rec["n"], rec["v"] = 3, np.asarray(faces)
             f.write(rec.tobytes())
+
+
+# The CPU random stream the optimisation of the batch fitted by THIS host thread draws from (the SO(3) perturbations): None = the
+# process-wide generator, like the reference; fit_recon with `batch_seed` gives every batch a generator of its own, so that
+# batches fitted side by side (recon_fit_behave._fit_concurrent) draw what they draw in the serial loop.
+_BATCH_RNG = threading.local()
+
+
+def cpu_generator():
+    return getattr(_BATCH_RNG, "gen", None)
 
 
 class _SO3Fn(torch.autograd.Function):
@@ -386,7 +397,7 @@ class ReconFitterBase:
         if no_rand:
             return ReconFitterBase.project_so3(rot)
         if noise is None:
-            noise = torch.rand(rot.shape[0], 3, 3)
+            noise = torch.rand(rot.shape[0], 3, 3, generator=cpu_generator())
         return ReconFitterBase.project_so3(rot + 1e-4 * noise.to(rot.device))
 
     @staticmethod

@@ -25,7 +25,66 @@ import torch.nn.functional as F
 from ..lib_smpl.const import SMPL_POSE_PRAMS_NUM
 from . import fit_terms
 from .graph_step import EagerStep, FusedAdam, GraphedStep
-from .recon_fit_base import RECON_PATH, ReconFitterBase  # noqa: F401  (recon_fit_coco.py:15 imports RECON_PATH from here)
+from .recon_fit_base import _BATCH_RNG, RECON_PATH, ReconFitterBase, cpu_generator  # noqa: F401  (recon_fit_coco.py:15 imports RECON_PATH from here)
+
+
+
+class _CaptureGate:
+    """Mutual exclusion between a hipGraph RECORDING and everything else the fitter's host threads do (fit_recon with
+    pipeline="chains": two chains issued by two threads).  A capture in the global mode does not tolerate another thread's
+    allocations, synchronisations or event queries; a thread that is about to record therefore waits until every other
+    participant has parked at a checkpoint (the top of an outer iteration) or left, records alone, and lets them go on.
+    Kernels the others have already issued keep running: only their HOST threads pause."""
+
+    def __init__(self):
+        import threading
+        self.cv = threading.Condition()
+        self.active = self.parked = 0
+        self.recording = False
+
+    def enter(self):
+        with self.cv:
+            while self.recording:
+                self.cv.wait()
+            self.active += 1
+
+    def leave(self):
+        with self.cv:
+            self.active -= 1
+            self.cv.notify_all()
+
+    def checkpoint(self):
+        if not self.recording:              # (unlocked read: a recorder that raises the flag just now is seen at the next checkpoint)
+            return
+        with self.cv:
+            self.parked += 1
+            self.cv.notify_all()
+            while self.recording:
+                self.cv.wait()
+            self.parked -= 1
+
+    def exclusive(self):
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            with self.cv:
+                while self.recording:       # another participant records: park like at a checkpoint, then take the turn
+                    self.parked += 1
+                    self.cv.notify_all()
+                    while self.recording:
+                        self.cv.wait()
+                    self.parked -= 1
+                self.recording = True
+                while self.parked < self.active - 1:
+                    self.cv.wait()
+            try:
+                yield
+            finally:
+                with self.cv:
+                    self.recording = False
+                    self.cv.notify_all()
+        return cm()
 
 
 class _FitSlot:
@@ -71,7 +130,13 @@ class ReconFitterBehave(ReconFitterBase):
     def _stepper(self, *a, **k):
         k.setdefault("fuse_rule", self.fuse_stop_rule and not os.environ.get("CHORE_FIT_SPLIT_RULE"))
         if self.use_graphs:
-            return GraphedStep(*a, **k)
+            gate = self.__dict__.get("_gate")
+            if gate is None:
+                return GraphedStep(*a, **k)
+            with gate.exclusive():             # two chains side by side (_fit_concurrent): a recording runs alone
+                st = GraphedStep(*a, **k)
+                torch.cuda.current_stream(torch.device(self.device)).synchronize()      # the recording's own work is done before the others resume
+                return st
         return EagerStep(*a, capturable=self.adam_capturable, **k)
 
     def _slot(self, *key):
@@ -109,6 +174,9 @@ class ReconFitterBehave(ReconFitterBase):
 
     def _inner(self, st, n, phase=None):
         """the inner steps of one outer iteration"""
+        gate = self.__dict__.get("_gate")
+        if gate is not None:
+            gate.checkpoint()
         if self.timer is None:
             for _ in range(n):
                 st.step()
@@ -198,6 +266,8 @@ class ReconFitterBehave(ReconFitterBase):
                     with torch.cuda.stream(st):
                         self._fit_pipelined(todo, generator, finish)
                     cur.wait_stream(st)
+                elif use_pipe == "chains":
+                    self._fit_concurrent(todo, generator, finish)
                 else:
                     self._fit_pipelined(todo, generator, finish)
             finally:
@@ -235,10 +305,22 @@ class ReconFitterBehave(ReconFitterBase):
         gens = self._batch_generators(index)
         kw = {} if gens is None else {"generators": gens}      # (the reference's signature when the global streams are used)
         pc_generated = generator.generate_pclouds_batch(data, num_points=5000, num_steps=10, mute=True, **kw)
-        return dict(data=data, pc=pc_generated, model=generator.model, smplfit=self.prep_smplfit(data, generator, pc_generated))
+        opt_gen = None
+        if gens is not None:                   # the optimisation's CPU draws (SO(3) perturbations): a third stream of the batch's own
+            opt_gen = torch.Generator()
+            opt_gen.manual_seed(int(self.batch_seed) + 2 * int(index) + 1000003)
+        return dict(data=data, pc=pc_generated, model=generator.model, smplfit=self.prep_smplfit(data, generator, pc_generated),
+                    opt_gen=opt_gen)
 
     def optimise_batch(self, prep, smpl_iters=None, object_iters=None):
         """the second half (:58-74): optimize_smpl -> object initialisation -> optimize_smpl_object"""
+        _BATCH_RNG.gen = prep.get("opt_gen")
+        try:
+            return self._optimise_batch(prep, smpl_iters, object_iters)
+        finally:
+            _BATCH_RNG.gen = None
+
+    def _optimise_batch(self, prep, smpl_iters, object_iters):
         data, pc_generated = prep["data"], prep["pc"]
         batch_size = data["images"].shape[0]
         (betas_dict, body_kpts, human_parts, human_points, human_t, obj_points, part_colors, part_labels, query_dict,
@@ -359,6 +441,76 @@ class ReconFitterBehave(ReconFitterBase):
             for kind, k, h0, h1, e0, e1 in sorted(dbg, key=lambda d: d[2]):
                 print("[pipe] %-4s batch %d  host %7.1f .. %7.1f ms   device %7.1f .. %7.1f ms (relative to the first timed optimisation's start)"
                       % (kind, k, h0 * 1e3, h1 * 1e3, ref.elapsed_time(e0), ref.elapsed_time(e1)), file=__import__("sys").stderr)
+
+    def _fit_concurrent(self, todo, generator, finish, smpl_iters=None, object_iters=None):
+        """pipeline="chains": the WHOLE chains of two batches side by side, each on its slot's stream, issued by its slot's host
+        thread (the slots of _fit_pipelined: a view of the network, its maps and kept recordings each).  The optimisation of one
+        frame is a chain of ~10 000 small dependent launches that leaves most of the chip idle (0.25 ms per iteration at one
+        frame, 0.073 per frame in a batch of eight): a second chain beside it costs little.  Results per batch do not depend on
+        what runs beside it (own generators, own slot, deterministic kernels): equal to the serial loop bit for bit, like
+        _fit_pipelined.  Slot s takes the batches s, s + 2, ... in order.  A chain that has to RECORD inner steps (a slot's first
+        batch, a new shape later in the loader, recordings dropped by the slot cap) does so alone: the other host thread parks
+        at its next outer iteration, the caller's thread does not run `finish` meanwhile (_CaptureGate) -- a capture does not
+        tolerate another thread's allocations or synchronisations.  `finish` is called by the calling thread in loader order."""
+        import copy
+        from concurrent.futures import ThreadPoolExecutor
+        if self.batch_seed is None:
+            self.batch_seed = 0
+        dev = torch.device(self.device)
+        main = torch.cuda.current_stream(dev)
+        state = self.__dict__.get("_chain_state")
+        if state is None or state["generator"] is not generator or state["nets"][0] is not generator.model:
+            nets = [generator.model, copy.copy(generator.model)]
+            gens = [generator, copy.copy(generator)]
+            gens[1].model = nets[1]
+            state = self._chain_state = dict(generator=generator, nets=nets, gens=gens, streams=[torch.cuda.Stream(dev), torch.cuda.Stream(dev)],
+                                             pools=[ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-chain%d" % k) for k in range(2)])
+        gens, streams, pools = state["gens"], state["streams"], state["pools"]
+        timing = self.batch_ends is not None
+        gate = self._gate = _CaptureGate()     # recordings (a slot's first batch, a new shape later on) run alone: see _stepper / _inner
+
+        def chain(k, ready):
+            i, data = todo[k]
+            s = k % 2
+            torch.cuda.set_device(dev)
+            gate.enter()
+            try:
+                with torch.cuda.stream(streams[s]):
+                    streams[s].wait_event(ready)                   # the loader's tensors, issued on the caller's stream
+                    fitted = self.optimise_batch(self.prepare_batch(data, gens[s], index=i), smpl_iters, object_iters)
+                    done = torch.cuda.Event(enable_timing=timing)
+                    done.record(streams[s])
+            finally:
+                gate.leave()
+            return fitted, done
+
+        try:
+            futs = []
+            for k in range(len(todo)):                             # each slot's executor runs its batches in order
+                ready = torch.cuda.Event()
+                ready.record(main)
+                futs.append(pools[k % 2].submit(chain, k, ready))
+            for k, fut in enumerate(futs):
+                fitted, done = fut.result()
+                gate.enter()                                       # `finish` synchronises (results to the host): not during a recording
+                try:
+                    main.wait_event(done)
+                    for t in fitted:                               # made on the slot's stream, read on the caller's from here on
+                        for u in ((t.pose, t.betas, t.trans) if hasattr(t, "pose") else (t,)):
+                            if torch.is_tensor(u) and u.is_cuda:
+                                u.record_stream(main)
+                    if timing:
+                        self.batch_ends.append(done)
+                    finish(todo[k][0], todo[k][1], fitted)
+                finally:
+                    gate.leave()
+        finally:
+            for fut in futs:                                       # (an exception above: let the chains end before the gate goes)
+                try:
+                    fut.result()
+                except Exception:
+                    pass
+            self._gate = None
 
     batch_ends = None     # a list: one timing event per finished batch of fit_recon (serial or pipelined) is appended
 
@@ -663,9 +815,10 @@ class ReconFitterBehave(ReconFitterBase):
         # device (consecutive torch.rand calls continue one stream: n calls = one call of n times the size).
         B = obj_R.shape[0]
         n_obj = obj_iter * steps_per_iter
-        noise_obj = torch.rand(n_obj, B, 3, 3)
-        noise_rot = torch.rand(B, 3, 3) if sil_iter > 0 else None
-        noise = torch.cat([noise_obj, torch.rand((n_outer - obj_iter) * steps_per_iter, B, 3, 3)]).to(self.device)
+        rng = cpu_generator()                  # the batch's own stream under fit_recon(batch_seed=...), else the process-wide one
+        noise_obj = torch.rand(n_obj, B, 3, 3, generator=rng)
+        noise_rot = torch.rand(B, 3, 3, generator=rng) if sil_iter > 0 else None
+        noise = torch.cat([noise_obj, torch.rand((n_outer - obj_iter) * steps_per_iter, B, 3, 3, generator=rng)]).to(self.device)
         k = torch.zeros(1, dtype=torch.long, device=self.device)
         if slot is not None:
             noise, k = slot.bind("noise", noise), slot.bind("k", k)

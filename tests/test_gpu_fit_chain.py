@@ -493,7 +493,8 @@ def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
     other).  Five different loader batches through the whole chain (silhouette, contact and collision terms, hipGraph-replayed
     inner iterations kept across batches), pipelined and serial with the same `batch_seed`: every fitted parameter of every batch
     EQUAL -- the pipelined batches read the right maps (two alternating map sets), wait for the right events, and draw the
-    same random numbers."""
+    same random numbers.  pipeline="chains": the whole chains of two batches side by side, each issued by its slot's host thread
+    (the optimisation's CPU draws come from the batch's own generator then, like the point clouds')."""
     import copy
     import bench
     from chore_amd.model import CHORE
@@ -505,7 +506,7 @@ def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
     o = copy.copy(opt)
     o.compute_dtype = "fp16x3"
     res = {}
-    for pipe in (False, True):
+    for pipe in (False, True, "chains"):
         net = CHORE(o).to(dev).eval()
         synth.load_synth_weights(net, seed=0)
         fitter = ReconFitterBehave(None, device=dev, obj_name="synthetic", outpath=None, args=o, assets=SyntheticAssets(0))
@@ -522,8 +523,9 @@ def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
         res[pipe] = [{k: v.detach().cpu().clone() for k, v in r.items() if torch.is_tensor(v)} for r in out]
         if pipe:
             assert len(fitter._slots) == 4         # (smpl, object) x two map sets, each recorded once
-    for k, (a, b) in enumerate(zip(res[False], res[True])):
-        for name in a:
-            assert torch.isfinite(b[name]).all(), (k, name)
-            assert torch.equal(a[name], b[name]), (k, name, float((a[name] - b[name]).abs().max()))
+    for mode in (True, "chains"):
+        for k, (a, b) in enumerate(zip(res[False], res[mode])):
+            for name in a:
+                assert torch.isfinite(b[name]).all(), (mode, k, name)
+                assert torch.equal(a[name], b[name]), (mode, k, name, float((a[name] - b[name]).abs().max()))
     assert not torch.equal(res[True][0]["obj_t"], res[True][1]["obj_t"])      # different batches, different fits
