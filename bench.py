@@ -691,12 +691,12 @@ def mode_fit(args, ctx):
                       "samples": len(v), "iterations": len(v) * SMPL_ITERS["steps_per_iter"]} for ph, v in by_phase.items()}
     chain_wall = [sum(c.values()) for c in chains]
     fitted = gather_fitted(result, B * ctx.world, rank, ctx.world, device=dev)
-    # ---- the loop over loader batches (recon_fit_behave.py:41-76), serial and pipelined (round 5): 6 consecutive batches through
-    # fit_recon; per-frame wall time of batches 2 .. 5 (the first two record the inner steps of the two map sets) ----
+    # ---- the loop over loader batches (recon_fit_behave.py:41-76): serial, batch k+1 prepared ahead, whole chains side by side
+    # (round 5).  12 consecutive batches through fit_recon, three passes each (recordings, allocator warm-up, timed) ----
     loop = {}
     if fitter.reuse_graphs and not args.eager:
         fitter.smpl_iters, fitter.object_iters, fitter.batch_seed = SMPL_ITERS, OBJECT_ITERS, 1234
-        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(6)]
+        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(int(os.environ.get("CHORE_BENCH_LOOP_BATCHES", "12")))]
         for name, pipe in (("serial", False), ("pipelined", True), ("chains", "chains")):
             marks = []
 
@@ -715,7 +715,10 @@ def mode_fit(args, ctx):
                 ends = fitter.batch_ends
                 gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)] or [float("nan")]     # device time between consecutive batches' ends
                 fitter.batch_ends = None
-                span = ends[1].elapsed_time(ends[-1]) / max(1, len(ends) - 2) if len(ends) > 2 else float("nan")
+                # (ends in time order: side by side, batches do not end in loader order; the first wave -- one batch per chain -- is left out)
+                skip = fitter.chains if name == "chains" else 1
+                tt = sorted(ends[0].elapsed_time(e) for e in ends)
+                span = (tt[-1] - tt[skip]) / (len(tt) - 1 - skip) if len(tt) > skip + 1 else float("nan")
                 # steady state: the median gap between consecutive batches' ends -- for the chains mode, where two batches run side by
                 # side and end in pairs (gaps alternate between long and short or negative), the span from the second batch's end to the
                 # last batch's end over the batches in between
@@ -759,12 +762,12 @@ def mode_fit(args, ctx):
                     "chain_ms_median": float(np.median(chain_wall)), "chain_ms_all": [round(c, 2) for c in chain_wall],
                     "chain_stage_ms_median": {k: float(np.median([c.get(k, 0.0) for c in chains])) for k in per_step},
                     "per_phase": per_phase,
-                    "loader_loop": dict(loop, note="fit_recon over 6 consecutive loader batches of the same shapes (recordings kept), wall time "
+                    "loader_loop": dict(loop, note="fit_recon over 12 consecutive loader batches of the same shapes (recordings kept), wall time "
                                                    "per batch of the second pass; pipelined = batch k+1's encoder + point clouds + SMPL-H "
                                                    "initialisation on a second stream / host thread while batch k is optimised, results equal to "
                                                    "the serial loop bit for bit (tests/test_gpu_fit_chain.py); chains = the whole chains of two batches side by side, each "
-                                                   "on its own stream and host thread, same results; *_span = device time from the second batch's end to the last "
-                                                   "batch's end / batches in between"),
+                                                   "on its own stream and host thread, same results; *_span = device time from the end of the first wave of batches (one "
+                                                   "per chain; serial / pipelined: the second batch) to the last end / batches in between"),
                     "per_phase_note": "SURVEY 8(d) metric 2: median device ms per Adam iteration per phase over all outer iterations "
                                       "of all timed chains ('global' / 'smpl all pose' / 'kpts' = optimize_smpl; 'object only' / "
                                       "'sil' / 'joint' = optimize_smpl_object, joint incl. contact + collision terms)",

@@ -145,7 +145,7 @@ class ReconFitterBehave(ReconFitterBase):
             return None
         slots = self.__dict__.setdefault("_slots", {})
         if key not in slots:
-            if len(slots) >= 8:          # shapes keep changing: do not hoard graphs
+            if len(slots) >= 16:         # shapes keep changing: do not hoard graphs
                 slots.clear()
             slots[key] = _FitSlot()
         return slots[key]
@@ -284,7 +284,9 @@ class ReconFitterBehave(ReconFitterBase):
     # Every batch's point-cloud random numbers from generators of its own (seed = batch_seed + the batch's index in the loader):
     # None = the process-wide streams, like the reference (serial loop only -- two threads drawing from one stream have no order).
     batch_seed = None
-    pipeline = False      # fit_recon: prepare batch k+1 on a second stream / host thread while batch k is optimised
+    pipeline = False      # fit_recon: True = prepare batch k+1 on a second stream / host thread while batch k is optimised;
+                          # "chains" = the whole chains of `chains` batches side by side (_fit_concurrent)
+    chains = 3            # (one frame per batch: 2 -> 60 ms per frame, 3 -> 49, 4 -> 49: the host threads are the limit from three on)
     smpl_iters = None     # fit_recon / fit_batch: keyword arguments of optimize_smpl / optimize_smpl_object other than the
     object_iters = None   # reference's (benchmarks and tests with shorter schedules)
 
@@ -443,12 +445,12 @@ class ReconFitterBehave(ReconFitterBase):
                       % (kind, k, h0 * 1e3, h1 * 1e3, ref.elapsed_time(e0), ref.elapsed_time(e1)), file=__import__("sys").stderr)
 
     def _fit_concurrent(self, todo, generator, finish, smpl_iters=None, object_iters=None):
-        """pipeline="chains": the WHOLE chains of two batches side by side, each on its slot's stream, issued by its slot's host
-        thread (the slots of _fit_pipelined: a view of the network, its maps and kept recordings each).  The optimisation of one
+        """pipeline="chains": the WHOLE chains of `self.chains` (3) batches side by side, each on its slot's stream, issued by its
+        slot's host thread (slots as in _fit_pipelined: a view of the network, its maps and kept recordings each).  The optimisation of one
         frame is a chain of ~10 000 small dependent launches that leaves most of the chip idle (0.25 ms per iteration at one
         frame, 0.073 per frame in a batch of eight): a second chain beside it costs little.  Results per batch do not depend on
         what runs beside it (own generators, own slot, deterministic kernels): equal to the serial loop bit for bit, like
-        _fit_pipelined.  Slot s takes the batches s, s + 2, ... in order.  A chain that has to RECORD inner steps (a slot's first
+        _fit_pipelined.  Slot s takes the batches s, s + chains, ... in order.  A chain that has to RECORD inner steps (a slot's first
         batch, a new shape later in the loader, recordings dropped by the slot cap) does so alone: the other host thread parks
         at its next outer iteration, the caller's thread does not run `finish` meanwhile (_CaptureGate) -- a capture does not
         tolerate another thread's allocations or synchronisations.  `finish` is called by the calling thread in loader order."""
@@ -458,20 +460,22 @@ class ReconFitterBehave(ReconFitterBase):
             self.batch_seed = 0
         dev = torch.device(self.device)
         main = torch.cuda.current_stream(dev)
+        nch = max(2, int(os.environ.get("CHORE_FIT_CHAINS", self.chains)))
         state = self.__dict__.get("_chain_state")
-        if state is None or state["generator"] is not generator or state["nets"][0] is not generator.model:
-            nets = [generator.model, copy.copy(generator.model)]
-            gens = [generator, copy.copy(generator)]
-            gens[1].model = nets[1]
-            state = self._chain_state = dict(generator=generator, nets=nets, gens=gens, streams=[torch.cuda.Stream(dev), torch.cuda.Stream(dev)],
-                                             pools=[ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-chain%d" % k) for k in range(2)])
+        if state is None or state["generator"] is not generator or state["nets"][0] is not generator.model or len(state["nets"]) != nch:
+            nets = [generator.model] + [copy.copy(generator.model) for _ in range(nch - 1)]
+            gens = [generator] + [copy.copy(generator) for _ in range(nch - 1)]
+            for g_, n_ in zip(gens[1:], nets[1:]):
+                g_.model = n_
+            state = self._chain_state = dict(generator=generator, nets=nets, gens=gens, streams=[torch.cuda.Stream(dev) for _ in range(nch)],
+                                             pools=[ThreadPoolExecutor(max_workers=1, thread_name_prefix="chore-chain%d" % k) for k in range(nch)])
         gens, streams, pools = state["gens"], state["streams"], state["pools"]
         timing = self.batch_ends is not None
         gate = self._gate = _CaptureGate()     # recordings (a slot's first batch, a new shape later on) run alone: see _stepper / _inner
 
         def chain(k, ready):
             i, data = todo[k]
-            s = k % 2
+            s = k % nch
             torch.cuda.set_device(dev)
             gate.enter()
             try:
@@ -489,7 +493,7 @@ class ReconFitterBehave(ReconFitterBase):
             for k in range(len(todo)):                             # each slot's executor runs its batches in order
                 ready = torch.cuda.Event()
                 ready.record(main)
-                futs.append(pools[k % 2].submit(chain, k, ready))
+                futs.append(pools[k % nch].submit(chain, k, ready))
             for k, fut in enumerate(futs):
                 fitted, done = fut.result()
                 gate.enter()                                       # `finish` synchronises (results to the host): not during a recording

@@ -522,7 +522,7 @@ def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
         assert [r["index"] for r in out] == list(range(5))
         res[pipe] = [{k: v.detach().cpu().clone() for k, v in r.items() if torch.is_tensor(v)} for r in out]
         if pipe:
-            assert len(fitter._slots) == 4         # (smpl, object) x two map sets, each recorded once
+            assert len(fitter._slots) == 2 * (2 if pipe is True else fitter.chains)         # (smpl, object) x the map sets, each recorded once
     for mode in (True, "chains"):
         for k, (a, b) in enumerate(zip(res[False], res[mode])):
             for name in a:
