@@ -696,7 +696,7 @@ def mode_fit(args, ctx):
     loop = {}
     if fitter.reuse_graphs and not args.eager:
         fitter.smpl_iters, fitter.object_iters, fitter.batch_seed = SMPL_ITERS, OBJECT_ITERS, 1234
-        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(int(os.environ.get("CHORE_BENCH_LOOP_BATCHES", "12")))]
+        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(int(os.environ.get("CHORE_BENCH_LOOP_BATCHES", "12" if B == 1 else "9")))]
         for name, pipe in (("serial", False), ("pipelined", True), ("chains", "chains")):
             marks = []
 
@@ -762,7 +762,7 @@ def mode_fit(args, ctx):
                     "chain_ms_median": float(np.median(chain_wall)), "chain_ms_all": [round(c, 2) for c in chain_wall],
                     "chain_stage_ms_median": {k: float(np.median([c.get(k, 0.0) for c in chains])) for k in per_step},
                     "per_phase": per_phase,
-                    "loader_loop": dict(loop, note="fit_recon over 12 consecutive loader batches of the same shapes (recordings kept), wall time "
+                    "loader_loop": dict(loop, note="fit_recon over 12 (one frame per batch) / 9 consecutive loader batches of the same shapes (recordings kept), wall time "
                                                    "per batch of the second pass; pipelined = batch k+1's encoder + point clouds + SMPL-H "
                                                    "initialisation on a second stream / host thread while batch k is optimised, results equal to "
                                                    "the serial loop bit for bit (tests/test_gpu_fit_chain.py); chains = the whole chains of two batches side by side, each "
