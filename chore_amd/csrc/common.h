@@ -21,6 +21,7 @@ struct chore_handle {
     // weight gradients of a ConvBlock beside its data-gradient chain (convblock.hip); created on first use
     hipStream_t side = nullptr;
     hipEvent_t side_ev[8] = {};
+    int cu_count = 0;          // hipDeviceAttributeMultiprocessorCount of `device`, read on first use (conv_rw.hip)
     int lds_per_cu = 0;        // hipDeviceAttributeMaxSharedMemoryPerMultiprocessor of `device`, read on first use (conv_pc.hip)
 };
 

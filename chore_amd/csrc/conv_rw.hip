@@ -1,0 +1,320 @@
+// conv_rw.hip -- 1x1 convolution of the fp16 x 3 mode with REGISTER-RESIDENT WEIGHTS (the 1x1 layers of the stack tail,
+// model/HGFilters.py:128-142,167-183: conv_last / l / the merged bl + al.l, and ConvBlock's downsample, model/net_util.py:364-371).
+// Same arithmetic, same ConvArgs contract and the same packed weights as conv_pc_kernel<x3_t, 1, ...>.
+//
+// Why (round 5, profiles/r05_conv_rw.txt).  A 1x1 layer has K = Cin <= 256: on conv_pc_kernel a 256-pixel tile is ONE pass
+// load -> split -> 16 k-steps of MFMAs -> store, every workgroup of the launch in the same phase at the same time, so HBM idles
+// while the matrix pipe works and the other way round: 256 -> 256 at 128^2 took 61 us for 134 MB of compulsory traffic (22 us
+// at the 6 TB/s the part reaches) and 17 us of MFMAs -- the phases add up.  The whole weight matrix of such a layer is small:
+// hi + lo fp16 planes of 32 output channels x 256 input channels are 32 KB = 128 registers of a wave.  So here
+//   * a workgroup is 8 waves, wave w keeps the fragments of ITS 32 output channels (all K) in registers for the whole launch;
+//   * the workgroup is persistent over a contiguous run of 32-pixel blocks of one image (1x1: the map is a list of pixels);
+//   * per block: every thread loads its 8-channel units of the NEXT block (global -> registers), the block's fp16 hi / lo
+//     planes are read from LDS as MFMA A fragments by all eight waves, the accumulators leave straight from registers
+//     (a lane holds one channel of 16 pixels: a store instruction writes two full 128-byte lines), GroupNorm statistics of
+//     the outputs are kept per lane and reduced once at the end;
+//   * the two waves of a SIMD run the block's work in OPPOSITE order -- the early wave stages the next block (GroupNorm +
+//     ReLU + split: vector ALU) and then issues its MFMAs, the late wave the other way round -- so that one wave's vector
+//     arithmetic and stores run beside the other's matrix instructions; one s_barrier per block.
+//   Input read once, output written once, loads of block i + 1 (i + 2 for the early waves) in flight under block i's MFMAs.
+#include "conv_common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+
+using namespace conv_detail;
+
+namespace {
+
+__device__ __forceinline__ void wg_barrier() {
+    // LDS traffic of this wave done, then the workgroup barrier; vector-memory loads and stores stay in flight across it
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// KC input channels, WN = Cout / 32 channel blocks; the 8 waves are WN channel blocks x WM pixel blocks of 32
+template <int KC, int WN> struct RGeo {
+    static constexpr int WM = 8 / WN, MPX = 32 * WM;               // pixels per block
+    static constexpr int NKG = KC / 16;                            // MFMA k-groups
+    static constexpr int PLANE = KC * 2;                           // bytes of one fp16 plane of a pixel
+    static constexpr int ROWB = 2 * PLANE + 16;                    // LDS row of a pixel: hi plane, lo plane, pad (odd number of 16-byte slots)
+    static constexpr int ABUF = MPX * ROWB;
+    static constexpr int UPP = KC / 8;                             // 8-channel units per pixel
+    static constexpr int NV = MPX * UPP / 512;                     // units per thread and block
+    static constexpr size_t smem_bytes() { return (size_t)2 * ABUF + (size_t)KC * 8 + (size_t)8 * 4 * 32 * 4; }
+    static_assert(WN * WM == 8 && NV >= 1 && NV * 512 == MPX * UPP, "conv_rw geometry");
+};
+
+template <int KC, int WN, bool RES>
+__global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int wg_per_img) {
+    f16_saturate_mode();
+    using G = RGeo<KC, WN>;
+    constexpr int WM = G::WM, MPX = G::MPX, NKG = G::NKG, PLANE = G::PLANE, ROWB = G::ROWB, ABUF = G::ABUF, UPP = G::UPP, NV = G::NV;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* abuf = smem;                                       // [2][MPX][ROWB]
+    float* ss_lds = (float*)(smem + 2 * ABUF);               // [KC][2] GroupNorm scale, shift
+    float* red = ss_lds + 2 * KC;                            // [8 waves][4 kinds][32]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wid % WN, wm = wid / WN;
+    const int b = blockIdx.x / wg_per_img, wgi = blockIdx.x % wg_per_img;
+    const int HW = a.H * a.W;
+    const int nblk = (HW + MPX - 1) / MPX;
+    const int b0 = wgi * bpw;
+    const int n_it = (b0 + bpw <= nblk ? bpw : nblk - b0);   // >= 1 by construction of the grid
+    const bool use_gn = a.in_st != nullptr;
+    const float* in_b = (const float*)a.in.p + (size_t)b * HW * a.in.cs + a.in.co;
+
+    // ---- staging: unit u = tid + 512 j of a block = (pixel u / UPP, 8 channels (u % UPP) * 8) ----
+    auto issue_loads = [&](u32x4 (&r)[NV][2], int blk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int u = tid + 512 * j, p = u / UPP, g = u % UPP;
+            const int pix = blk * MPX + p;
+            const u32x4* q = (const u32x4*)(in_b + (size_t)(pix < HW ? pix : 0) * a.in.cs + g * 8);
+            r[j][0] = q[0];
+            r[j][1] = q[1];
+        }
+    };
+    auto stage = [&](const u32x4 (&r)[NV][2], int blk, char* dstb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int u = tid + 512 * j, p = u / UPP, g = u % UPP;
+            const int pix = blk * MPX + p;
+            float sc[8], sh[8];
+            if (use_gn) {
+                const f32x4* q = (const f32x4*)(ss_lds + g * 16);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 t = q[k];
+                    sc[2 * k] = t[0]; sh[2 * k] = t[1]; sc[2 * k + 1] = t[2]; sh[2 * k + 1] = t[3];
+                }
+            }
+            u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
+            if (pix < HW) xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo);
+            char* d = dstb + p * ROWB + g * 16;
+            *(u32x4*)d = hi;
+            *(u32x4*)(d + PLANE) = lo;
+        }
+    };
+
+    // ---- prologue: block 0 on its way, this wave's weight fragments into registers, the GroupNorm table ----
+    u32x4 setA[NV][2], setB[NV][2];
+    issue_loads(setA, b0);
+    u32x4 bh[NKG], bl[NKG];
+    {
+        const u32x4* wv = (const u32x4*)a.wpk + (size_t)wn * 64 + lane;
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+            bh[kg] = wv[(size_t)kg * WN * 64];
+            bl[kg] = wv[(size_t)(NKG + kg) * WN * 64];       // the lo plane follows the complete hi plane
+        }
+    }
+    for (int ci = tid; ci < KC; ci += 512) {
+        float sc = 1.f, sh = 0.f;
+        if (use_gn) gn_scale_shift(a.in_st, a.B, b, KC, ci, HW, a.gamma, a.beta, sc, sh);
+        ss_lds[2 * ci] = sc;
+        ss_lds[2 * ci + 1] = sh;
+    }
+    wg_barrier();
+    stage(setA, b0, abuf);
+    const bool early = wid >= 4;                             // the second wave of every SIMD
+    if (early) issue_loads(setA, b0 + 1);                    // (past the end: pixel 0 again, never used)
+    wg_barrier();
+
+    // ---- per-wave output coordinates: lane = channel (lane & 31) of 16 pixels ----
+    const int half = lane >> 5, ch = wn * 32 + (lane & 31);
+    const float ASCALE = 1.0f / (float)(1 << X3_WSHIFT);
+    const float bias = a.bias ? a.bias[ch] : 0.f;
+    const size_t img = (size_t)b * HW;
+    float* out_p = (float*)a.out.p + img * a.out.cs + a.out.co + ch;
+    float* raw_p = a.raw.p ? (float*)a.raw.p + img * a.raw.cs + a.raw.co + ch : nullptr;
+    const float* res_p = RES ? (const float*)a.res.p + img * a.res.cs + a.res.co + ch : nullptr;
+    const bool want_stats = a.st_raw || a.st_out;
+    float sr = 0.f, qr = 0.f, so = 0.f, qo = 0.f;
+    const char* a_rd = abuf + ((wm * 32) + (lane & 31)) * ROWB + half * 16;
+
+    // one block: MFMAs on LDS buffer (i & 1), then the accumulators leave
+    constexpr int NACC = (RES && KC > 128) ? 1 : 2;         // accumulators that take turns over the k-groups (register budget: 256)
+    f32x16 acc[NACC];
+    float rq[16];
+    auto matmul = [&](int i) __attribute__((always_inline)) {
+        const int blk = b0 + i;
+        const char* ap = a_rd + (i & 1) * ABUF;
+        const int pix0 = blk * MPX + wm * 32 + 4 * half;     // this lane's pixel of accumulator register r: pix0 + (r & 3) + 8 (r >> 2)
+        const bool full = (blk + 1) * MPX <= HW;             // wave-uniform: no pixel of the block is past the image
+        if constexpr (RES) {
+            const float* rb = res_p + (size_t)pix0 * a.res.cs;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                rq[r] = (full || pix0 + rr < HW) ? rb[rr * a.res.cs] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NACC; ++q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+#pragma unroll
+        for (int kg = 0; kg < NKG; ++kg) {
+            const f16x8_t ah = __builtin_bit_cast(f16x8_t, *(const u32x4*)(ap + kg * 32));
+            const f16x8_t al = __builtin_bit_cast(f16x8_t, *(const u32x4*)(ap + PLANE + kg * 32));
+            const f16x8_t wh = __builtin_bit_cast(f16x8_t, bh[kg]), wl = __builtin_bit_cast(f16x8_t, bl[kg]);
+            f32x16& c = acc[kg % NACC];                      // small terms first
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, c, 0, 0, 0);
+        }
+    };
+    auto leave = [&](int i) __attribute__((always_inline)) {
+        const int blk = b0 + i;
+        const int pix0 = blk * MPX + wm * 32 + 4 * half;
+        const bool full = (blk + 1) * MPX <= HW;
+        float* ob = out_p + (size_t)pix0 * a.out.cs;
+        float* rwb = raw_p ? raw_p + (size_t)pix0 * a.raw.cs : nullptr;
+        auto value = [&](int r) __attribute__((always_inline)) -> float {
+            float v = acc[0][r];
+            if constexpr (NACC == 2) v += acc[1][r];
+            return v * ASCALE + bias;
+        };
+        if (full && !rwb) {          // the common case: no masks, no second tensor
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float v = value(r);
+                if constexpr (RES) v += rq[r];
+                ob[rr * a.out.cs] = v;
+                so += v; qo += v * v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2);
+                float v = value(r);
+                if (pix0 + rr < HW) {
+                    if (rwb) {
+                        rwb[rr * a.raw.cs] = v;
+                        sr += v; qr += v * v;
+                    }
+                    if constexpr (RES) v += rq[r];
+                    ob[rr * a.out.cs] = v;
+                    so += v; qo += v * v;
+                }
+            }
+        }
+    };
+
+    // iteration i with `cur` / `nxt` the two register sets (they swap roles every iteration)
+    auto body = [&](auto early_c, int i, u32x4 (&cur)[NV][2], u32x4 (&nxt)[NV][2]) __attribute__((always_inline)) {
+        constexpr bool EARLY = decltype(early_c)::value;
+        const bool more = i + 1 < n_it;
+        if constexpr (EARLY) {
+            issue_loads(nxt, b0 + i + 2);                    // used in iteration i + 1 (or never)
+            __builtin_amdgcn_sched_barrier(0);               // the loads leave first: they fly under everything below
+            if (more) stage(cur, b0 + i + 1, abuf + ((i + 1) & 1) * ABUF);
+            matmul(i);
+            leave(i);
+        } else {
+            issue_loads(nxt, b0 + i + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            matmul(i);
+            if (more) stage(nxt, b0 + i + 1, abuf + ((i + 1) & 1) * ABUF);   // before the stores: it waits for loads only
+            leave(i);
+        }
+        wg_barrier();
+    };
+    if (early) {
+#pragma unroll 1
+        for (int i = 0; i < n_it; i += 2) {
+            body(std::true_type{}, i, setA, setB);
+            if (i + 1 < n_it) body(std::true_type{}, i + 1, setB, setA);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < n_it; i += 2) {
+            body(std::false_type{}, i, setA, setB);
+            if (i + 1 < n_it) body(std::false_type{}, i + 1, setB, setA);
+        }
+    }
+
+    if (want_stats) {   // uniform over the grid
+        // lane = channel: the two halves of a wave hold the same 32 channels (different pixels), the WM waves of a channel block too
+        sr += __shfl_xor(sr, 32, 64); qr += __shfl_xor(qr, 32, 64); so += __shfl_xor(so, 32, 64); qo += __shfl_xor(qo, 32, 64);
+        if (lane < 32) {
+            float* p = red + wid * 128 + lane;
+            p[0] = sr; p[32] = qr; p[64] = so; p[96] = qo;
+        }
+        wg_barrier();
+        if (tid < 32 * WN) {
+            // thread = channel; t[kind]: kinds 0 / 1 = sum / sum of squares of `raw`, 2 / 3 of `out`; fixed order over the pixel blocks
+            const int nb = tid >> 5, c = tid & 31;
+            float t[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k] = 0.f;
+#pragma unroll
+                for (int m = 0; m < WM; ++m) t[k] += red[(m * WN + nb) * 128 + k * 32 + c];
+            }
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                GroupStat* st = k ? a.st_out : a.st_raw;
+                if (!st) continue;
+                const int gs = (k ? a.st_out_C : a.st_raw_C) / GN_GROUPS, co = k ? a.st_out_co : a.st_raw_co;
+                const float s1 = group_lane_sum(t[2 * k], gs), s2 = group_lane_sum(t[2 * k + 1], gs);
+                GroupStat* o = st + (size_t)b * GN_GROUPS + (co + tid) / gs;
+                if (tid % gs == 0) stat_add(&o->sum, act_hi_cells(a.B), s1);
+                if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells(a.B), s2);
+            }
+        }
+    }
+}
+
+template <int KC, int WN, bool RES>
+int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+    using G = RGeo<KC, WN>;
+    const size_t smem = G::smem_bytes();
+    bool& attr = CHORE_ONCE_FLAG(h);
+    if (!attr) {
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_rw_kernel<KC, WN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr = true;
+    }
+    if (h->cu_count <= 0) {
+        CHORE_HIP_CHECK(h, hipDeviceGetAttribute(&h->cu_count, hipDeviceAttributeMultiprocessorCount, h->device));
+        if (h->cu_count <= 0) h->cu_count = 256;
+    }
+    // one persistent workgroup per CU: every image's blocks are dealt to cu / B workgroups in contiguous runs
+    const int nblk = (a.H * a.W + G::MPX - 1) / G::MPX;
+    int wpi = h->cu_count / a.B;
+    if (wpi < 1) wpi = 1;
+    if (wpi > nblk) wpi = nblk;
+    const int bpw = (nblk + wpi - 1) / wpi;
+    wpi = (nblk + bpw - 1) / bpw;
+    hipLaunchKernelGGL((conv_rw_kernel<KC, WN, RES>), dim3((unsigned)(wpi * a.B)), dim3(512), smem, s, a, bpw, wpi);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+}  // namespace
+
+// CHORE_CONV_RW=0: the 1x1 layers stay on conv_pc_kernel (A/B runs)
+bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a) {
+    static const bool off = getenv("CHORE_CONV_RW") && atoi(getenv("CHORE_CONV_RW")) == 0;
+    if (off || dtype != CHORE_F16X3 || taps != 1 || a.in_amax || a.res2.p) return false;
+    const int k = a.in.C, n = a.Cout;
+    return (k == 256 && n == 256) || (k == 128 && n == 256) || (k == 64 && n == 128);
+}
+
+int launch_conv_rw(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+    const int k = a.in.C, n = a.Cout;
+    const bool res = a.res.p != nullptr;
+#define RW_CASE(KC, WN) \
+    if (k == KC && n == 32 * WN) return res ? launch_rw_t<KC, WN, true>(h, a, s) : launch_rw_t<KC, WN, false>(h, a, s)
+    RW_CASE(256, 8);
+    RW_CASE(128, 8);
+    RW_CASE(64, 4);
+#undef RW_CASE
+    CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: no kernel for Cin=%d Cout=%d", k, n);
+}
