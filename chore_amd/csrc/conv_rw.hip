@@ -13,16 +13,24 @@
 //     planes are read from LDS as MFMA A fragments by all eight waves, the accumulators leave straight from registers
 //     (a lane holds one channel of 16 pixels: a store instruction writes two full 128-byte lines), GroupNorm statistics of
 //     the outputs are kept per lane and reduced once at the end;
-//   * the two waves of a SIMD run the block's work in OPPOSITE order -- the early wave stages the next block (GroupNorm +
-//     ReLU + split: vector ALU) and then issues its MFMAs, the late wave the other way round -- so that one wave's vector
-//     arithmetic and stores run beside the other's matrix instructions; one s_barrier per block.
-//   Input read once, output written once, loads of block i + 1 (i + 2 for the early waves) in flight under block i's MFMAs.
+//   * one s_barrier per block; the next block's loads are issued before the block's MFMAs and staged (GroupNorm + ReLU +
+//     split) after them.
+//   Input read once, output written once, loads of block i + 1 in flight under block i's MFMAs.
 #include "conv_common.h"
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
 using namespace conv_detail;
+
+// kernel experiments (scripts/build_variant.sh <name> conv_rw.hip -D...): CHORE_RW_STAMPS=1 -- wall-clock stamps of every phase of
+// the workgroup in the middle of the grid (wave 0 and wave 4), printed by the launcher for the first launches of each tiling
+#ifndef CHORE_RW_STAMPS
+#define CHORE_RW_STAMPS 0
+#endif
+#if CHORE_RW_STAMPS
+__device__ unsigned long long g_rw_stamps[2][64];
+#endif
 
 namespace {
 
@@ -47,7 +55,7 @@ template <int KC, int WN> struct RGeo {
     static_assert(WN * WM == 8 && NV >= 1 && NV * 512 == MPX * UPP, "conv_rw geometry");
 };
 
-template <int KC, int WN, bool RES>
+template <int KC, int WN, bool RES, bool SC>
 __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int wg_per_img) {
     f16_saturate_mode();
     using G = RGeo<KC, WN>;
@@ -60,12 +68,22 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wid % WN, wm = wid / WN;
+#if CHORE_RW_STAMPS
+    auto stamp = [&](int k) { if (blockIdx.x == gridDim.x / 2 && (tid == 0 || tid == 256) && k < 64) g_rw_stamps[tid ? 1 : 0][k] = wall_clock64(); };
+#else
+    auto stamp = [&](int) {};
+#endif
+    stamp(0);
     const int b = blockIdx.x / wg_per_img, wgi = blockIdx.x % wg_per_img;
     const int HW = a.H * a.W;
     const int nblk = (HW + MPX - 1) / MPX;
     const int b0 = wgi * bpw;
     const int n_it = (b0 + bpw <= nblk ? bpw : nblk - b0);   // >= 1 by construction of the grid
     const bool use_gn = a.in_st != nullptr;
+    // SC: the input is a gradient whose range comes in ConvArgs::in_amax (the data-gradient convolutions of fp16 x 3 training):
+    // operand times a power of two before the split, accumulators times its inverse (enc_common.h, x3_in_scale)
+    float in_mul = 1.f, in_inv = 1.f;
+    if constexpr (SC) x3_in_scale(a.in_amax, in_mul, in_inv);
     const float* in_b = (const float*)a.in.p + (size_t)b * HW * a.in.cs + a.in.co;
 
     // ---- staging: unit u = tid + 512 j of a block = (pixel u / UPP, 8 channels (u % UPP) * 8) ----
@@ -79,22 +97,19 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
             r[j][1] = q[1];
         }
     };
+    // (512 is a multiple of UPP: every unit of a thread covers the SAME 8 channels, their GroupNorm affine lives in registers)
+    static_assert(512 % UPP == 0, "a thread's units share their channels");
+    float sc[8], sh[8];
     auto stage = [&](const u32x4 (&r)[NV][2], int blk, char* dstb) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int u = tid + 512 * j, p = u / UPP, g = u % UPP;
             const int pix = blk * MPX + p;
-            float sc[8], sh[8];
-            if (use_gn) {
-                const f32x4* q = (const f32x4*)(ss_lds + g * 16);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 t = q[k];
-                    sc[2 * k] = t[0]; sh[2 * k] = t[1]; sc[2 * k + 1] = t[2]; sh[2 * k + 1] = t[3];
-                }
-            }
             u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
-            if (pix < HW) xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo);
+            if (pix < HW) {
+                if constexpr (SC) xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo, in_mul);
+                else xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo);
+            }
             char* d = dstb + p * ROWB + g * 16;
             *(u32x4*)d = hi;
             *(u32x4*)(d + PLANE) = lo;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     };
 
     // ---- prologue: block 0 on its way, this wave's weight fragments into registers, the GroupNorm table ----
-    u32x4 setA[NV][2], setB[NV][2];
+    u32x4 setA[NV][2];
     issue_loads(setA, b0);
     u32x4 bh[NKG], bl[NKG];
     {
@@ -119,15 +134,24 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
         ss_lds[2 * ci] = sc;
         ss_lds[2 * ci + 1] = sh;
     }
+    stamp(1);
     wg_barrier();
+    stamp(2);
+    {
+        const f32x4* q = (const f32x4*)(ss_lds + (tid % UPP) * 16);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 t = q[k];
+            sc[2 * k] = t[0]; sh[2 * k] = t[1]; sc[2 * k + 1] = t[2]; sh[2 * k + 1] = t[3];
+        }
+    }
     stage(setA, b0, abuf);
-    const bool early = wid >= 4;                             // the second wave of every SIMD
-    if (early) issue_loads(setA, b0 + 1);                    // (past the end: pixel 0 again, never used)
     wg_barrier();
+    stamp(3);
 
     // ---- per-wave output coordinates: lane = channel (lane & 31) of 16 pixels ----
     const int half = lane >> 5, ch = wn * 32 + (lane & 31);
-    const float ASCALE = 1.0f / (float)(1 << X3_WSHIFT);
+    const float ASCALE = (SC ? in_inv : 1.0f) / (float)(1 << X3_WSHIFT);
     const float bias = a.bias ? a.bias[ch] : 0.f;
     const size_t img = (size_t)b * HW;
     float* out_p = (float*)a.out.p + img * a.out.cs + a.out.co + ch;
@@ -138,7 +162,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     const char* a_rd = abuf + ((wm * 32) + (lane & 31)) * ROWB + half * 16;
 
     // one block: MFMAs on LDS buffer (i & 1), then the accumulators leave
-    constexpr int NACC = (RES && KC > 128) ? 1 : 2;         // accumulators that take turns over the k-groups (register budget: 256)
+    constexpr int NACC = 2;                                  // accumulators that take turns over the k-groups
     f32x16 acc[NACC];
     float rq[16];
     auto matmul = [&](int i) __attribute__((always_inline)) {
@@ -178,7 +202,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
         auto value = [&](int r) __attribute__((always_inline)) -> float {
             float v = acc[0][r];
             if constexpr (NACC == 2) v += acc[1][r];
-            return v * ASCALE + bias;
+            return fmaf(v, ASCALE, bias);                    // (ASCALE is a power of two: the same value as v * ASCALE + bias)
         };
         if (full && !rwb) {          // the common case: no masks, no second tensor
 #pragma unroll
@@ -187,7 +211,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
                 float v = value(r);
                 if constexpr (RES) v += rq[r];
                 ob[rr * a.out.cs] = v;
-                so += v; qo += v * v;
+                so += v; qo = fmaf(v, v, qo);
             }
         } else {
 #pragma unroll
@@ -207,37 +231,24 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
         }
     };
 
-    // iteration i with `cur` / `nxt` the two register sets (they swap roles every iteration)
-    auto body = [&](auto early_c, int i, u32x4 (&cur)[NV][2], u32x4 (&nxt)[NV][2]) __attribute__((always_inline)) {
-        constexpr bool EARLY = decltype(early_c)::value;
+    // iteration i: block i + 1's loads leave first and fly under block i's MFMAs
+    // (tried: the two waves of a SIMD in opposite orders -- stage, MFMAs, leave against MFMAs, stage, leave, with a second register
+    // set for the early wave's loads: no faster, 40.6 against 42.3 us; LDS progress counts and three buffers instead of the
+    // barrier, so that the waves drift apart: no faster either, profiles/r05_conv_rw.txt)
+#pragma unroll 1
+    for (int i = 0; i < n_it; ++i) {
         const bool more = i + 1 < n_it;
-        if constexpr (EARLY) {
-            issue_loads(nxt, b0 + i + 2);                    // used in iteration i + 1 (or never)
-            __builtin_amdgcn_sched_barrier(0);               // the loads leave first: they fly under everything below
-            if (more) stage(cur, b0 + i + 1, abuf + ((i + 1) & 1) * ABUF);
-            matmul(i);
-            leave(i);
-        } else {
-            issue_loads(nxt, b0 + i + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            matmul(i);
-            if (more) stage(nxt, b0 + i + 1, abuf + ((i + 1) & 1) * ABUF);   // before the stores: it waits for loads only
-            leave(i);
-        }
+        issue_loads(setA, b0 + i + 1);                       // (past the end: pixel 0 again, never used)
+        __builtin_amdgcn_sched_barrier(0);
+        stamp(4 + 5 * i);
+        matmul(i);
+        stamp(5 + 5 * i);
+        if (more) stage(setA, b0 + i + 1, abuf + ((i + 1) & 1) * ABUF);   // before the stores: it waits for loads only
+        stamp(6 + 5 * i);
+        leave(i);
+        stamp(7 + 5 * i);
         wg_barrier();
-    };
-    if (early) {
-#pragma unroll 1
-        for (int i = 0; i < n_it; i += 2) {
-            body(std::true_type{}, i, setA, setB);
-            if (i + 1 < n_it) body(std::true_type{}, i + 1, setB, setA);
-        }
-    } else {
-#pragma unroll 1
-        for (int i = 0; i < n_it; i += 2) {
-            body(std::false_type{}, i, setA, setB);
-            if (i + 1 < n_it) body(std::false_type{}, i + 1, setB, setA);
-        }
+        stamp(8 + 5 * i);
     }
 
     if (want_stats) {   // uniform over the grid
@@ -272,13 +283,13 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     }
 }
 
-template <int KC, int WN, bool RES>
+template <int KC, int WN, bool RES, bool SC = false>
 int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     using G = RGeo<KC, WN>;
     const size_t smem = G::smem_bytes();
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_rw_kernel<KC, WN, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_rw_kernel<KC, WN, RES, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
     if (h->cu_count <= 0) {
@@ -292,24 +303,51 @@ int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     if (wpi > nblk) wpi = nblk;
     const int bpw = (nblk + wpi - 1) / wpi;
     wpi = (nblk + bpw - 1) / bpw;
-    hipLaunchKernelGGL((conv_rw_kernel<KC, WN, RES>), dim3((unsigned)(wpi * a.B)), dim3(512), smem, s, a, bpw, wpi);
+    hipLaunchKernelGGL((conv_rw_kernel<KC, WN, RES, SC>), dim3((unsigned)(wpi * a.B)), dim3(512), smem, s, a, bpw, wpi);
     CHORE_LAUNCH_CHECK(h, s);
+#if CHORE_RW_STAMPS
+    {
+        static int shown = 0;
+        if (shown < 40 && (++shown % 10 == 0)) {
+            unsigned long long t[2][64];
+            CHORE_HIP_CHECK(h, hipStreamSynchronize(s));
+            CHORE_HIP_CHECK(h, hipMemcpyFromSymbol(t, HIP_SYMBOL(g_rw_stamps), sizeof(t)));
+            for (int w = 0; w < 2; ++w) {
+                fprintf(stderr, "[rw stamps KC=%d WN=%d bpw=%d] wave %d (%s), us since entry: setup %.2f bar %.2f block0 %.2f |", KC, WN, bpw, 4 * w,
+                        "loads matmul stage leave barrier",
+                        (t[w][1] - t[w][0]) * 0.01, (t[w][2] - t[w][0]) * 0.01, (t[w][3] - t[w][0]) * 0.01);
+                for (int i = 0; i < bpw && 8 + 5 * i < 64; ++i)
+                    fprintf(stderr, " [%d] %.2f %.2f %.2f %.2f %.2f |", i, (t[w][4 + 5 * i] - t[w][0]) * 0.01, (t[w][5 + 5 * i] - t[w][0]) * 0.01,
+                            (t[w][6 + 5 * i] - t[w][0]) * 0.01, (t[w][7 + 5 * i] - t[w][0]) * 0.01, (t[w][8 + 5 * i] - t[w][0]) * 0.01);
+                fprintf(stderr, "\n");
+            }
+        }
+    }
+#endif
     return CHORE_OK;
 }
 
 }  // namespace
 
 // CHORE_CONV_RW=0: the 1x1 layers stay on conv_pc_kernel (A/B runs)
-bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a) {
+bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input) {
     static const bool off = getenv("CHORE_CONV_RW") && atoi(getenv("CHORE_CONV_RW")) == 0;
-    if (off || dtype != CHORE_F16X3 || taps != 1 || a.in_amax || a.res2.p) return false;
-    const int k = a.in.C, n = a.Cout;
-    return (k == 256 && n == 256) || (k == 128 && n == 256) || (k == 64 && n == 128);
+    if (off || dtype != CHORE_F16X3 || taps != 1) return false;
+    if (scaled_input) return Cin == 256 && Cout == 256;     // data gradients of training: the stack tail's layers
+    return (Cin == 256 && Cout == 256) || (Cin == 128 && Cout == 256) || (Cin == 64 && Cout == 128);
+}
+bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a) {
+    if (a.res2.p) return false;
+    return conv_rw_covers(dtype, taps, a.in.C, a.Cout, a.in_amax != nullptr);
 }
 
 int launch_conv_rw(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     const int k = a.in.C, n = a.Cout;
     const bool res = a.res.p != nullptr;
+    if (a.in_amax) {
+        if (k == 256 && n == 256) return res ? launch_rw_t<256, 8, true, true>(h, a, s) : launch_rw_t<256, 8, false, true>(h, a, s);
+        CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: no data-gradient kernel for Cin=%d Cout=%d", k, n);
+    }
 #define RW_CASE(KC, WN) \
     if (k == KC && n == 32 * WN) return res ? launch_rw_t<KC, WN, true>(h, a, s) : launch_rw_t<KC, WN, false>(h, a, s)
     RW_CASE(256, 8);

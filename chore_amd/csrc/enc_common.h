@@ -255,6 +255,7 @@ PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout,
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
 // 1x1 layers of the fp16 x 3 mode with register-resident weights (conv_rw.hip): persistent workgroups over runs of pixel blocks
+bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input);   // by shape (scaled_input: ConvArgs::in_amax set)
 bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a);
 int launch_conv_rw(chore_handle* h, const ConvArgs& a, hipStream_t s);
 // persistent specialised-wave convolution (conv_pp.hip): workgroups loop over tpw tiles, the producers drain a tile's epilogue

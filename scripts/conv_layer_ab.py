@@ -1,6 +1,6 @@
 """every convolution layer shape of the encoder at B = 4 x 512^2, one at a time through chore_conv2d_fwd (GroupNorm + ReLU fused,
 statistics in the epilogue): median us per launch over 50 hipGraph-free back-to-back launches (events around 20 launches x 5).
-usage: python scripts/conv_layer_ab.py bf16|fp16x3   (kernel choice by environment: CHORE_CONV_LDS_BF16=1, CHORE_CONV_LDS=1, ...)"""
+usage: python scripts/conv_layer_ab.py bf16|fp16x3 [1x1|3x3]   (kernel choice by environment: CHORE_CONV_LDS_BF16=1, CHORE_CONV_LDS=1, ...)"""
 import json
 import sys
 
@@ -21,6 +21,8 @@ LAYERS = [(9, 64, 64, 256), (9, 64, 32, 256), (9, 32, 32, 256), (1, 64, 128, 256
           (9, 256, 128, 128), (1, 256, 256, 128),
           (9, 256, 128, 64), (9, 128, 64, 64), (9, 64, 64, 64),
           (9, 256, 128, 32), (9, 128, 64, 32), (9, 64, 64, 32)]
+if len(sys.argv) > 2:      # e.g. "1x1": only the layers whose label starts with it
+    LAYERS = [l for l in LAYERS if ("%dx%d" % ((3, 3) if l[0] == 9 else (1, 1))).startswith(sys.argv[2])]
 out = {}
 stream = torch.cuda.current_stream().cuda_stream
 for taps, cin, cout, H in LAYERS:
