@@ -615,7 +615,9 @@ struct EncCache {
 // own streams.  The idea: a launch of specialised-wave workgroups (one per CU) lasts as long as ONE workgroup lives, whether
 // it has 256 workgroups or 64, so the chains of half batches could overlap.  Measured (B = 4, fp16x3): G = 1 5.6 ms, G = 2
 // 6.9 ms, G = 4 10.7 ms per step with only 2.6 ms of host time at G = 2 -- the device does not run the chains side by side
-// (six and more streams share the hardware queues).  Off by default; kept as a switch.
+// (six and more streams share the hardware queues).  Off by default; kept as a switch.  Round 5, with hipGraph replays: two
+// recordings of a HALF batch side by side take 2 x 2.72 ms for the four images, one recording of the whole batch 5.31 ms (same
+// box): splitting the batch does not pay under replay either.
 int enc_groups(int B) {
     static const int want = getenv("CHORE_ENC_GROUPS") ? atoi(getenv("CHORE_ENC_GROUPS")) : 1;
     int g = want < 1 ? 1 : (want > MAX_GROUPS ? MAX_GROUPS : want);
@@ -765,6 +767,13 @@ int chore_encode_fwd(chore_handle* h, const chore_encoder_cfg* cfg, const float*
     for (int i = 0; i < n_stack_out; ++i)
         if (!feat_out[i]) CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: null feat_out[%d]", i);
     const int G = enc_groups(B), Bg = B / G;
+    if (G > 1) {   // CHORE_ENC_GROUPS (an experiment switch, off by default): its fork / join of the groups' chains crashes this
+                   // runtime's hipStreamEndCapture (round 5) -- refuse a recording instead
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        CHORE_HIP_CHECK(h, hipStreamIsCapturing((hipStream_t)stream, &cs));
+        if (cs != hipStreamCaptureStatusNone)
+            CHORE_FAIL(h, CHORE_EINVAL, "chore_encode_fwd: CHORE_ENC_GROUPS=%d cannot be recorded into a hipGraph (eager launches only)", G);
+    }
     Program* P = get_program(h, *cfg, Bg, H, W, dtype, n_stack_out, normx != nullptr);
     const size_t ws_group = align_up(P->ws_bytes, 256);
     if (workspace_bytes < (size_t)G * ws_group)
