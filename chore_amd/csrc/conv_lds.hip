@@ -570,8 +570,8 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
     if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
-    // fp16 x 3, 1x1: weights resident in registers, persistent workgroups (conv_rw.hip; 256 -> 256 at 128^2: 61 -> ~30 us)
-    if (conv_rw_eligible(dtype, taps, a_in) && conv_use_pc()) return launch_conv_rw(h, a_in, s);
+    // 1x1 (every 16-bit-operand mode): weights resident in registers, persistent workgroups (conv_rw.hip; fp16 x 3 256 -> 256 at 128^2: 64 -> 39 us)
+    if (conv_rw_eligible(dtype, taps, a_in) && conv_use_pc()) return launch_conv_rw(h, dtype, a_in, s);
     // CHORE_CONV_PP=1: the persistent variant (conv_pp.hip) where a layer has at least two tiles per CU.  Measured slower than
     // conv_pc_kernel on every layer of the encoder (profiles/r04_conv_pp.txt): opt-in, for A/B runs and tests.
     static const bool use_pp = getenv("CHORE_CONV_PP") != nullptr;

@@ -43,11 +43,11 @@ __device__ __forceinline__ void wg_barrier() {
 }
 
 // KC input channels, WN = Cout / 32 channel blocks; the 8 waves are WN channel blocks x WM pixel blocks of 32
-template <int KC, int WN> struct RGeo {
+template <int KC, int WN, int APL = 2> struct RGeo {   // APL: fp16 planes of a staged pixel (fp16 x 3: hi + lo; fp16 / bf16 tensors: one)
     static constexpr int WM = 8 / WN, MPX = 32 * WM;               // pixels per block
     static constexpr int NKG = KC / 16;                            // MFMA k-groups
     static constexpr int PLANE = KC * 2;                           // bytes of one fp16 plane of a pixel
-    static constexpr int ROWB = 2 * PLANE + 16;                    // LDS row of a pixel: hi plane, lo plane, pad (odd number of 16-byte slots)
+    static constexpr int ROWB = APL * PLANE + 16;                  // LDS row of a pixel: hi plane [, lo plane], pad (odd number of 16-byte slots)
     static constexpr int ABUF = MPX * ROWB;
     static constexpr int UPP = KC / 8;                             // 8-channel units per pixel
     static constexpr int NV = MPX * UPP / 512;                     // units per thread and block
@@ -55,10 +55,19 @@ template <int KC, int WN> struct RGeo {
     static_assert(WN * WM == 8 && NV >= 1 && NV * 512 == MPX * UPP, "conv_rw geometry");
 };
 
-template <int KC, int WN, bool RES, bool SC>
+// T = x3_t: fp32 tensors, activations split into fp16 hi + lo while they are staged, three MFMAs per product;
+// T = h16_t ("fp16 fields"): fp16 tensors, one activation plane, two MFMAs per product (a * w_lo, a * w_hi);
+// T = bf16_t: bf16 tensors, one activation and one weight plane, one v_mfma_f32_32x32x16_bf16 per product
+template <typename T, int KC, int WN, bool RES, bool SC>
 __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int wg_per_img) {
-    f16_saturate_mode();
-    using G = RGeo<KC, WN>;
+    constexpr bool X3 = IS_X3<T>, BF = std::is_same<T, bf16_t>::value, H16 = IS_H16<T>;
+    static_assert(X3 || BF || H16, "conv_rw_kernel: fp16 x 3, fp16 or bf16 operands");
+    static_assert(!SC || X3, "the operand scale belongs to the fp16 x 3 data gradients");
+    if constexpr (!BF) f16_saturate_mode();
+    using ST = typename std::conditional<X3, float, unsigned short>::type;     // element type in memory
+    constexpr int LVI = X3 ? 2 : 1;                     // 16-byte loads per 8 channels
+    constexpr int APL = X3 ? 2 : 1, WPL = BF ? 1 : 2;   // activation / weight planes
+    using G = RGeo<KC, WN, APL>;
     constexpr int WM = G::WM, MPX = G::MPX, NKG = G::NKG, PLANE = G::PLANE, ROWB = G::ROWB, ABUF = G::ABUF, UPP = G::UPP, NV = G::NV;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* abuf = smem;                                       // [2][MPX][ROWB]
@@ -84,48 +93,75 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     // operand times a power of two before the split, accumulators times its inverse (enc_common.h, x3_in_scale)
     float in_mul = 1.f, in_inv = 1.f;
     if constexpr (SC) x3_in_scale(a.in_amax, in_mul, in_inv);
-    const float* in_b = (const float*)a.in.p + (size_t)b * HW * a.in.cs + a.in.co;
+    const ST* in_b = (const ST*)a.in.p + (size_t)b * HW * a.in.cs + a.in.co;
 
     // ---- staging: unit u = tid + 512 j of a block = (pixel u / UPP, 8 channels (u % UPP) * 8) ----
-    auto issue_loads = [&](u32x4 (&r)[NV][2], int blk) __attribute__((always_inline)) {
+    auto issue_loads = [&](u32x4 (&r)[NV][LVI], int blk) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int u = tid + 512 * j, p = u / UPP, g = u % UPP;
             const int pix = blk * MPX + p;
             const u32x4* q = (const u32x4*)(in_b + (size_t)(pix < HW ? pix : 0) * a.in.cs + g * 8);
-            r[j][0] = q[0];
-            r[j][1] = q[1];
+#pragma unroll
+            for (int k = 0; k < LVI; ++k) r[j][k] = q[k];
         }
     };
     // (512 is a multiple of UPP: every unit of a thread covers the SAME 8 channels, their GroupNorm affine lives in registers)
     static_assert(512 % UPP == 0, "a thread's units share their channels");
     float sc[8], sh[8];
-    auto stage = [&](const u32x4 (&r)[NV][2], int blk, char* dstb) __attribute__((always_inline)) {
+    auto stage = [&](const u32x4 (&r)[NV][LVI], int blk, char* dstb) __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int u = tid + 512 * j, p = u / UPP, g = u % UPP;
             const int pix = blk * MPX + p;
             u32x4 hi = {0u, 0u, 0u, 0u}, lo = {0u, 0u, 0u, 0u};
-            if (pix < HW) {
-                if constexpr (SC) xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo, in_mul);
-                else xform_x3(r[j][0], r[j][1], sc, sh, use_gn, hi, lo);
-            }
             char* d = dstb + p * ROWB + g * 16;
-            *(u32x4*)d = hi;
-            *(u32x4*)(d + PLANE) = lo;
+            if constexpr (X3) {
+                if (pix < HW) {
+                    if constexpr (SC) xform_x3(r[j][0], r[j][LVI - 1], sc, sh, use_gn, hi, lo, in_mul);
+                    else xform_x3(r[j][0], r[j][LVI - 1], sc, sh, use_gn, hi, lo);
+                }
+                *(u32x4*)d = hi;
+                *(u32x4*)(d + PLANE) = lo;
+            } else {
+                if (pix < HW) {
+                    if (use_gn) {   // relu(x * scale + shift) in fp32, rounded to the 16-bit type once (as conv_pc_kernel's staging)
+                        if constexpr (BF) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                float x0 = fmaf(__uint_as_float(r[j][0][k] << 16), sc[2 * k], sh[2 * k]);
+                                float x1 = fmaf(__uint_as_float(r[j][0][k] & 0xffff0000u), sc[2 * k + 1], sh[2 * k + 1]);
+                                x0 = x0 > 0.f ? x0 : 0.f;
+                                x1 = x1 > 0.f ? x1 : 0.f;
+                                hi[k] = pack2bf(x0, x1);
+                            }
+                        } else {
+                            const f16x8_t x = __builtin_bit_cast(f16x8_t, r[j][0]);
+                            f16x8_t y;
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) {
+                                const float t = fmaf((float)x[k], sc[k], sh[k]);
+                                y[k] = (_Float16)(t > 0.f ? t : 0.f);
+                            }
+                            hi = __builtin_bit_cast(u32x4, y);
+                        }
+                    } else hi = r[j][0];
+                }
+                *(u32x4*)d = hi;
+            }
         }
     };
 
     // ---- prologue: block 0 on its way, this wave's weight fragments into registers, the GroupNorm table ----
-    u32x4 setA[NV][2];
+    u32x4 setA[NV][LVI];
     issue_loads(setA, b0);
-    u32x4 bh[NKG], bl[NKG];
+    u32x4 bh[NKG], bl[WPL == 2 ? NKG : 1];
     {
         const u32x4* wv = (const u32x4*)a.wpk + (size_t)wn * 64 + lane;
 #pragma unroll
         for (int kg = 0; kg < NKG; ++kg) {
             bh[kg] = wv[(size_t)kg * WN * 64];
-            bl[kg] = wv[(size_t)(NKG + kg) * WN * 64];       // the lo plane follows the complete hi plane
+            if constexpr (WPL == 2) bl[kg] = wv[(size_t)(NKG + kg) * WN * 64];       // the lo plane follows the complete hi plane
         }
     }
     for (int ci = tid; ci < KC; ci += 512) {
@@ -151,12 +187,23 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
 
     // ---- per-wave output coordinates: lane = channel (lane & 31) of 16 pixels ----
     const int half = lane >> 5, ch = wn * 32 + (lane & 31);
-    const float ASCALE = (SC ? in_inv : 1.0f) / (float)(1 << X3_WSHIFT);
+    const float ASCALE = BF ? 1.0f : (SC ? in_inv : 1.0f) / (float)(1 << X3_WSHIFT);   // undoes the weight scaling of the fp16 packing
     const float bias = a.bias ? a.bias[ch] : 0.f;
     const size_t img = (size_t)b * HW;
-    float* out_p = (float*)a.out.p + img * a.out.cs + a.out.co + ch;
-    float* raw_p = a.raw.p ? (float*)a.raw.p + img * a.raw.cs + a.raw.co + ch : nullptr;
-    const float* res_p = RES ? (const float*)a.res.p + img * a.res.cs + a.res.co + ch : nullptr;
+    ST* out_p = (ST*)a.out.p + img * a.out.cs + a.out.co + ch;
+    ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + ch : nullptr;
+    const ST* res_p = RES ? (const ST*)a.res.p + img * a.res.cs + a.res.co + ch : nullptr;
+    // one element <-> float; put() stores the value rounded to the tensor's type and returns it as stored (what the statistics see)
+    auto get = [&](const ST* q) __attribute__((always_inline)) -> float {
+        if constexpr (X3) return *q;
+        else if constexpr (BF) return __uint_as_float((unsigned)*q << 16);
+        else return (float)__builtin_bit_cast(_Float16, *q);
+    };
+    auto put = [&](ST* q, float v) __attribute__((always_inline)) -> float {
+        if constexpr (X3) { *q = v; return v; }
+        else if constexpr (BF) { const unsigned short u = (unsigned short)(pack2bf(v, v) & 0xffffu); *q = u; return __uint_as_float((unsigned)u << 16); }
+        else { const _Float16 hh = (_Float16)v; *q = __builtin_bit_cast(unsigned short, hh); return (float)hh; }
+    };
     const bool want_stats = a.st_raw || a.st_out;
     float sr = 0.f, qr = 0.f, so = 0.f, qo = 0.f;
     const char* a_rd = abuf + ((wm * 32) + (lane & 31)) * ROWB + half * 16;
@@ -171,11 +218,11 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
         const int pix0 = blk * MPX + wm * 32 + 4 * half;     // this lane's pixel of accumulator register r: pix0 + (r & 3) + 8 (r >> 2)
         const bool full = (blk + 1) * MPX <= HW;             // wave-uniform: no pixel of the block is past the image
         if constexpr (RES) {
-            const float* rb = res_p + (size_t)pix0 * a.res.cs;
+            const ST* rb = res_p + (size_t)pix0 * a.res.cs;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2);
-                rq[r] = (full || pix0 + rr < HW) ? rb[rr * a.res.cs] : 0.f;
+                rq[r] = (full || pix0 + rr < HW) ? get(rb + rr * a.res.cs) : 0.f;
             }
         }
 #pragma unroll
@@ -184,21 +231,28 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
             for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
 #pragma unroll
         for (int kg = 0; kg < NKG; ++kg) {
-            const f16x8_t ah = __builtin_bit_cast(f16x8_t, *(const u32x4*)(ap + kg * 32));
-            const f16x8_t al = __builtin_bit_cast(f16x8_t, *(const u32x4*)(ap + PLANE + kg * 32));
-            const f16x8_t wh = __builtin_bit_cast(f16x8_t, bh[kg]), wl = __builtin_bit_cast(f16x8_t, bl[kg]);
-            f32x16& c = acc[kg % NACC];                      // small terms first
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, c, 0, 0, 0);
+            const u32x4 av = *(const u32x4*)(ap + kg * 32);
+            f32x16& c = acc[kg % NACC];
+            if constexpr (BF) {
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), __builtin_bit_cast(bf16x8_t, bh[kg]), c, 0, 0, 0);
+            } else {
+                const f16x8_t ah = __builtin_bit_cast(f16x8_t, av);
+                const f16x8_t wh = __builtin_bit_cast(f16x8_t, bh[kg]), wl = __builtin_bit_cast(f16x8_t, bl[kg]);
+                if constexpr (X3) {                          // small terms first
+                    const f16x8_t al = __builtin_bit_cast(f16x8_t, *(const u32x4*)(ap + PLANE + kg * 32));
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, wh, c, 0, 0, 0);
+                }
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, wh, c, 0, 0, 0);
+            }
         }
     };
     auto leave = [&](int i) __attribute__((always_inline)) {
         const int blk = b0 + i;
         const int pix0 = blk * MPX + wm * 32 + 4 * half;
         const bool full = (blk + 1) * MPX <= HW;
-        float* ob = out_p + (size_t)pix0 * a.out.cs;
-        float* rwb = raw_p ? raw_p + (size_t)pix0 * a.raw.cs : nullptr;
+        ST* ob = out_p + (size_t)pix0 * a.out.cs;
+        ST* rwb = raw_p ? raw_p + (size_t)pix0 * a.raw.cs : nullptr;
         auto value = [&](int r) __attribute__((always_inline)) -> float {
             float v = acc[0][r];
             if constexpr (NACC == 2) v += acc[1][r];
@@ -210,7 +264,7 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
                 const int rr = (r & 3) + 8 * (r >> 2);
                 float v = value(r);
                 if constexpr (RES) v += rq[r];
-                ob[rr * a.out.cs] = v;
+                v = put(ob + rr * a.out.cs, v);
                 so += v; qo = fmaf(v, v, qo);
             }
         } else {
@@ -220,11 +274,11 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
                 float v = value(r);
                 if (pix0 + rr < HW) {
                     if (rwb) {
-                        rwb[rr * a.raw.cs] = v;
-                        sr += v; qr += v * v;
+                        const float g = put(rwb + rr * a.raw.cs, v);
+                        sr += g; qr += g * g;
                     }
                     if constexpr (RES) v += rq[r];
-                    ob[rr * a.out.cs] = v;
+                    v = put(ob + rr * a.out.cs, v);
                     so += v; qo += v * v;
                 }
             }
@@ -283,13 +337,13 @@ __global__ __launch_bounds__(512) void conv_rw_kernel(ConvArgs a, int bpw, int w
     }
 }
 
-template <int KC, int WN, bool RES, bool SC = false>
+template <typename T, int KC, int WN, bool RES, bool SC = false>
 int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
-    using G = RGeo<KC, WN>;
+    using G = RGeo<KC, WN, IS_X3<T> ? 2 : 1>;
     const size_t smem = G::smem_bytes();
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_rw_kernel<KC, WN, RES, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_rw_kernel<T, KC, WN, RES, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr = true;
     }
     if (h->cu_count <= 0) {
@@ -303,7 +357,7 @@ int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     if (wpi > nblk) wpi = nblk;
     const int bpw = (nblk + wpi - 1) / wpi;
     wpi = (nblk + bpw - 1) / bpw;
-    hipLaunchKernelGGL((conv_rw_kernel<KC, WN, RES, SC>), dim3((unsigned)(wpi * a.B)), dim3(512), smem, s, a, bpw, wpi);
+    hipLaunchKernelGGL((conv_rw_kernel<T, KC, WN, RES, SC>), dim3((unsigned)(wpi * a.B)), dim3(512), smem, s, a, bpw, wpi);
     CHORE_LAUNCH_CHECK(h, s);
 #if CHORE_RW_STAMPS
     {
@@ -332,8 +386,16 @@ int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 // CHORE_CONV_RW=0: the 1x1 layers stay on conv_pc_kernel (A/B runs)
 bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input) {
     static const bool off = getenv("CHORE_CONV_RW") && atoi(getenv("CHORE_CONV_RW")) == 0;
-    if (off || dtype != CHORE_F16X3 || taps != 1) return false;
-    if (scaled_input) return Cin == 256 && Cout == 256;     // data gradients of training: the stack tail's layers
+    // CHORE_CONV_RW_X3ONLY=1: the fp16 instantiation off (A/B against conv_pc_kernel in that mode).  bf16 is OPT-IN
+    // (CHORE_CONV_RW_BF16=1): alone the layers are faster (256 -> 256 at 128^2 24.8 against 36.2 us on conv_lds_kernel), inside the
+    // encoder they are not (12 launches: 0.399 against 0.376 ms per step; whole bf16 step 3.28 against 3.25 ms, profiles/r05_conv_rw.txt):
+    // conv_lds_kernel's many small workgroups hide a cold start (weights, statistics, instructions) that one persistent workgroup
+    // per CU pays in full on a 20 us kernel.
+    static const bool x3only = getenv("CHORE_CONV_RW_X3ONLY") != nullptr, bf16_on = getenv("CHORE_CONV_RW_BF16") != nullptr;
+    if (off || taps != 1 || (dtype != CHORE_F16X3 && dtype != CHORE_F16 && dtype != CHORE_BF16)) return false;
+    if (dtype == CHORE_F16 && x3only) return false;
+    if (dtype == CHORE_BF16 && !bf16_on) return false;
+    if (scaled_input) return dtype == CHORE_F16X3 && Cin == 256 && Cout == 256;     // data gradients of fp16 x 3 training: the stack tail's layers
     return (Cin == 256 && Cout == 256) || (Cin == 128 && Cout == 256) || (Cin == 64 && Cout == 128);
 }
 bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a) {
@@ -341,18 +403,28 @@ bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a) {
     return conv_rw_covers(dtype, taps, a.in.C, a.Cout, a.in_amax != nullptr);
 }
 
-int launch_conv_rw(chore_handle* h, const ConvArgs& a, hipStream_t s) {
+template <typename T>
+static int launch_conv_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     const int k = a.in.C, n = a.Cout;
     const bool res = a.res.p != nullptr;
-    if (a.in_amax) {
-        if (k == 256 && n == 256) return res ? launch_rw_t<256, 8, true, true>(h, a, s) : launch_rw_t<256, 8, false, true>(h, a, s);
-        CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: no data-gradient kernel for Cin=%d Cout=%d", k, n);
+    if constexpr (IS_X3<T>) {
+        if (a.in_amax) {
+            if (k == 256 && n == 256) return res ? launch_rw_t<T, 256, 8, true, true>(h, a, s) : launch_rw_t<T, 256, 8, false, true>(h, a, s);
+            CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: no data-gradient kernel for Cin=%d Cout=%d", k, n);
+        }
     }
 #define RW_CASE(KC, WN) \
-    if (k == KC && n == 32 * WN) return res ? launch_rw_t<KC, WN, true>(h, a, s) : launch_rw_t<KC, WN, false>(h, a, s)
+    if (k == KC && n == 32 * WN) return res ? launch_rw_t<T, KC, WN, true>(h, a, s) : launch_rw_t<T, KC, WN, false>(h, a, s)
     RW_CASE(256, 8);
     RW_CASE(128, 8);
     RW_CASE(64, 4);
 #undef RW_CASE
     CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: no kernel for Cin=%d Cout=%d", k, n);
+}
+
+int launch_conv_rw(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s) {
+    if (dtype == CHORE_F16) return launch_conv_rw_t<h16_t>(h, a, s);
+    if (dtype == CHORE_BF16) return launch_conv_rw_t<bf16_t>(h, a, s);
+    if (dtype == CHORE_F16X3) return launch_conv_rw_t<x3_t>(h, a, s);
+    CHORE_FAIL(h, CHORE_EINVAL, "conv_rw: dtype %d not covered", dtype);
 }

@@ -254,10 +254,10 @@ struct PcPlan { int th, nt, tps, nslot; };
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
-// 1x1 layers of the fp16 x 3 mode with register-resident weights (conv_rw.hip): persistent workgroups over runs of pixel blocks
+// 1x1 layers (fp16 x 3, fp16, bf16) with register-resident weights (conv_rw.hip): persistent workgroups over runs of pixel blocks
 bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input);   // by shape (scaled_input: ConvArgs::in_amax set)
 bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a);
-int launch_conv_rw(chore_handle* h, const ConvArgs& a, hipStream_t s);
+int launch_conv_rw(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s);
 // persistent specialised-wave convolution (conv_pp.hip): workgroups loop over tpw tiles, the producers drain a tile's epilogue
 // while the consumers run the next tile; th = 0: not covered (fewer than two tiles per CU, or no tiling whose image fits)
 struct PpPlan { int th, nt, tps, nslot, tpw; };
