@@ -139,12 +139,27 @@ class FlatGradReducer:
     def all_reduce(self):
         """the collective half: the arena summed over the ranks in `chunks` pieces, then scaled to the mean"""
         if self.world > 1 or dist.is_initialized():
-            # (all issued, then waited for: on RCCL the collectives of one communicator run in issue order on its stream either way)
-            works = [dist.all_reduce(c, group=self.group, async_op=True) for c in self.chunks]
-            for w in works:
-                w.wait()
+            if self._stream_ordered():
+                # RCCL: the collectives of one communicator run in issue order on its stream -- all issued, then waited for
+                works = [dist.all_reduce(c, group=self.group, async_op=True) for c in self.chunks]
+                for w in works:
+                    w.wait()
+            else:
+                # gloo (CPU tests, bench.py's one-GPU rehearsal of the N > 1 path): its worker threads run several outstanding
+                # collectives side by side, and with device tensors of two ranks on ONE GPU four outstanding all_reduces never
+                # finished (the rehearsal hung here, 10 min, both ranks in wait()): one at a time
+                for c in self.chunks:
+                    dist.all_reduce(c, group=self.group, async_op=True).wait()
             if self.average and self.world > 1:
                 self.arena.mul_(1.0 / self.world)
+
+    def _stream_ordered(self):
+        """True when the group's collectives on the arena's device are RCCL's (stream-ordered); False for gloo"""
+        try:
+            b = str(dist.get_backend(self.group))
+        except Exception:
+            return False
+        return self.arena.is_cuda and "nccl" in b
 
     # ---- the collective under the backward (segments) -------------------------------------------------------------------------
     @torch.no_grad()
@@ -163,6 +178,8 @@ class FlatGradReducer:
             self._works.append((w1, segment, shard))
         else:
             self._works.append((dist.all_reduce(c, group=self.group, async_op=True), None, None))
+        if not self._stream_ordered():
+            self._works[-1][0].wait()       # gloo: one collective outstanding at a time (see all_reduce)
 
     @torch.no_grad()
     def finish(self):
