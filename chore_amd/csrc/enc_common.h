@@ -306,8 +306,9 @@ int conv2d_bwd_weight_impl(chore_handle* h, int dtype, int taps, const void* x, 
                            const unsigned* dy_amax = nullptr);
 int launch_wgrad_finish_multi(chore_handle* h, const WgradFinishJobs& jobs, hipStream_t s);
 // y = relu(groupnorm(x)) with the affine derived from `st` (stem bn1 -> tmpx)
+// st_out: the statistics of y accumulated in the same launch (zeroed cells)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
-                         const float* beta, const View& y, int B, int HW, hipStream_t s);
+                         const float* beta, const View& y, int B, int HW, hipStream_t s, GroupStat* st_out = nullptr);
 int launch_avgpool2(chore_handle* h, int dtype, const View& x, const View& y, int B, int H, int W, GroupStat* st, hipStream_t s);
 // y = a + bicubic_up2(low)   (low is (B,H,W,C), a and y are (B,2H,2W,C); y may alias a)
 int launch_upadd(chore_handle* h, int dtype, const View& a, const View& low, const View& y, int B, int H, int W,

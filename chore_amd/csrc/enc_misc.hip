@@ -213,18 +213,23 @@ int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, Gr
 // ------------------------------------------------------------------------------------------------
 // elementwise: y = relu(groupnorm(x)); grid (blocks per image, B); the affine is derived per block
 // ------------------------------------------------------------------------------------------------
-template <typename T>
+// STATS: the statistics of y (the values as stored) in the same pass -- tmpx is the input of a ConvBlock whose GroupNorm needs
+// them (round 5: was a gn_stats_kernel pass over tmpx).  A thread's vectors all cover the same four channels (the grid stride is
+// a multiple of C / 4), so its sums are per channel; the workgroup adds them up in a fixed order as gn_stats_kernel does.
+template <typename T, bool STATS>
 __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict__ x, int xcs, int xco,
                                                             const GroupStat* __restrict__ st,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, T* __restrict__ y,
-                                                            int ycs, int yco, int C, int HW) {
+                                                            int ycs, int yco, int C, int HW, GroupStat* __restrict__ st_out) {
     __shared__ float ss[512];
+    __shared__ float red[STATS ? 2 : 1][STATS ? 1024 : 1];
     const int b = blockIdx.y, tid = threadIdx.x;
     if (tid < C) gn_scale_shift(st, (int)gridDim.y, b, C, tid, HW, gamma, beta, ss[2 * tid], ss[2 * tid + 1]);
     __syncthreads();
     const int tpr = C / 4;
     const size_t total4 = (size_t)HW * tpr;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f}, sq = {0.f, 0.f, 0.f, 0.f};
     for (size_t i = (size_t)blockIdx.x * 256 + tid; i < total4; i += (size_t)gridDim.x * 256) {
         const int cv = (int)(i % tpr);
         const size_t p = (size_t)b * HW + i / tpr;
@@ -235,26 +240,52 @@ __global__ __launch_bounds__(256) void gn_apply_relu_kernel(const T* __restrict_
             const float t = fmaf(v[j], ss[2 * (cv * 4 + j)], ss[2 * (cv * 4 + j) + 1]);
             r[j] = t > 0.f ? t : 0.f;
         }
-        Vec4<T>::st(y + p * ycs + yco + cv * 4, r);
+        if constexpr (STATS) {
+            const f32x4 w = Vec4<T>::st_round(y + p * ycs + yco + cv * 4, r);
+            sum += w;
+            sq += w * w;
+        } else Vec4<T>::st(y + p * ycs + yco + cv * 4, r);
+    }
+    if constexpr (STATS) {
+        const int cv = tid % tpr, pl = tid / tpr, P = 256 / tpr;      // (256 and the grid stride are multiples of tpr: cv is the thread's)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            red[0][pl * C + cv * 4 + j] = sum[j];
+            red[1][pl * C + cv * 4 + j] = sq[j];
+        }
+        __syncthreads();
+        if (tid < C) {
+            float a = 0.f, q = 0.f;
+            for (int i = 0; i < P; ++i) { a += red[0][i * C + tid]; q += red[1][i * C + tid]; }
+            const int gs = C / GN_GROUPS;
+            a = group_lane_sum(a, gs);
+            q = group_lane_sum(q, gs);
+            GroupStat* o = st_out + (size_t)b * GN_GROUPS + tid / gs;
+            if (tid % gs == 0) stat_add(&o->sum, act_hi_cells((int)gridDim.y), a);
+            if (tid % gs == (gs > 1 ? 1 : 0)) stat_add(&o->sq, act_hi_cells((int)gridDim.y), q);
+        }
     }
 }
 
+// st_out: zeroed statistics cells of y, accumulated in the same launch (C a multiple of 32 with 256 % (C / 4) == 0: 32 ... 256 in
+// powers of two)
 int launch_gn_apply_relu(chore_handle* h, int dtype, const View& x, const GroupStat* st, const float* gamma,
-                         const float* beta, const View& y, int B, int HW, hipStream_t s) {
+                         const float* beta, const View& y, int B, int HW, hipStream_t s, GroupStat* st_out) {
     if (x.C > 256 || x.C % GN_GROUPS) CHORE_FAIL(h, CHORE_EINVAL, "gn: unsupported C=%d", x.C);
     const size_t total4 = (size_t)HW * (x.C / 4);
     int blocks = (int)((total4 + 255) / 256);
     if (blocks > 1024) blocks = 1024;
+    if (st_out) {
+        if (256 % (x.C / 4)) CHORE_FAIL(h, CHORE_EINVAL, "gn_apply_relu with statistics: unsupported C=%d", x.C);
+        if (blocks > 256) blocks = 256;       // 256 x 2 x C / 32 atomics per image, as gn_stats_kernel's at most 256 slices
+    }
     dim3 grid(blocks, B);
-    if (dtype == CHORE_F16)
-        hipLaunchKernelGGL(gn_apply_relu_kernel<h16_t>, grid, dim3(256), 0, s, (const h16_t*)x.p, x.cs, x.co, st, gamma,
-                           beta, (h16_t*)y.p, y.cs, y.co, x.C, HW);
-    else if (dtype == CHORE_F32)
-        hipLaunchKernelGGL(gn_apply_relu_kernel<float>, grid, dim3(256), 0, s, (const float*)x.p, x.cs, x.co, st, gamma,
-                           beta, (float*)y.p, y.cs, y.co, x.C, HW);
-    else
-        hipLaunchKernelGGL(gn_apply_relu_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x.p, x.cs, x.co, st,
-                           gamma, beta, (bf16_t*)y.p, y.cs, y.co, x.C, HW);
+#define GN_APPLY(T, ST) hipLaunchKernelGGL((gn_apply_relu_kernel<T, ST>), grid, dim3(256), 0, s, (const T*)x.p, x.cs, x.co, st, gamma, beta, \
+                                            (T*)y.p, y.cs, y.co, x.C, HW, st_out)
+    if (dtype == CHORE_F16) { if (st_out) GN_APPLY(h16_t, true); else GN_APPLY(h16_t, false); }
+    else if (dtype == CHORE_F32) { if (st_out) GN_APPLY(float, true); else GN_APPLY(float, false); }
+    else { if (st_out) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
+#undef GN_APPLY
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

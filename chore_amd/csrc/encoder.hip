@@ -523,13 +523,17 @@ struct Builder {
             ensure_stats(c1);
             const WEntry ge = w(p + "bn1.weight"), bte = w(p + "bn1.bias");
             const Buf c1b = c1;
+            // tmpx's own statistics (the next ConvBlock's GroupNorm needs them) ride in this launch (round 5: was a gn_stats pass)
+            static const bool fold = getenv("CHORE_ENC_NO_TMPX_STATS_FOLD") == nullptr;
+            if (fold) new_stats(tmpx);
+            const Buf tb = tmpx;
             cur_label = "gn_apply_relu bn1";
             cur_class = K_GN_APPLY; cur_flops = 0.0; cur_bytes = 2.0 * B * H2 * W2 * 64 * es();
             push([=](RunCtx& r) {
                 if (r.rc) return;
                 r.rc = launch_gn_apply_relu(r.h, sdt(r.dtype), view(r, c1b), (const GroupStat*)(r.stats + c1b.st_off),
                                             (const float*)(r.arena + ge.off), (const float*)(r.arena + bte.off),
-                                            view(r, tmpx), Bn, H2 * W2, r.s);
+                                            view(r, tb), Bn, H2 * W2, r.s, fold ? (GroupStat*)(r.stats + tb.st_off) : nullptr);
             });
         }
         release(c1);
