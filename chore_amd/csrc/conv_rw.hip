@@ -1,6 +1,6 @@
-// conv_rw.hip -- 1x1 convolution of the fp16 x 3 mode with REGISTER-RESIDENT WEIGHTS (the 1x1 layers of the stack tail,
+// conv_rw.hip -- 1x1 convolution (fp16 x 3, fp16 and bf16 operands) with REGISTER-RESIDENT WEIGHTS (the 1x1 layers of the stack tail,
 // model/HGFilters.py:128-142,167-183: conv_last / l / the merged bl + al.l, and ConvBlock's downsample, model/net_util.py:364-371).
-// Same arithmetic, same ConvArgs contract and the same packed weights as conv_pc_kernel<x3_t, 1, ...>.
+// Same arithmetic, same ConvArgs contract and the same packed weights as conv_pc_kernel<T, 1, ...>.
 //
 // Why (round 5, profiles/r05_conv_rw.txt).  A 1x1 layer has K = Cin <= 256: on conv_pc_kernel a 256-pixel tile is ONE pass
 // load -> split -> 16 k-steps of MFMAs -> store, every workgroup of the launch in the same phase at the same time, so HBM idles
@@ -16,6 +16,8 @@
 //   * one s_barrier per block; the next block's loads are issued before the block's MFMAs and staged (GroupNorm + ReLU +
 //     split) after them.
 //   Input read once, output written once, loads of block i + 1 in flight under block i's MFMAs.
+// What bounds it (measured, profiles/r05_conv_rw.txt): instruction issue -- the vector-ALU work of the split and the epilogue does not
+// overlap the MFMAs of the SIMD's other wave; a block takes MFMAs + staging + stores.
 #include "conv_common.h"
 #include <cstdio>
 #include <cstdlib>
