@@ -11,8 +11,11 @@
 //   * waves 0-3 (consumers) only read fragments from LDS and issue MFMAs;
 //   * waves 4-7 (producers) only move data: activations global -> registers -> GroupNorm + ReLU (+ fp16 hi / lo split)
 //     -> the OTHER patch buffer, the next K-step's weight fragments -> the OTHER ring slot, residual rows -> registers.
-//   The matrix pipe and the vector ALU of a SIMD are separate issue ports, so the producer's arithmetic runs beside the
-//   consumer's MFMAs.  One s_barrier per K-step (raw: the producers' global loads stay in flight across it).
+//   The matrix pipe and the vector ALU of a SIMD are separate issue ports, so the producer's arithmetic was expected to run beside
+//   the consumer's MFMAs.  (Round 5, profiles/r05_mfma_issue_probe.txt: it does NOT -- a wave that streams MFMAs keeps the SIMD's
+//   issue to itself and the producer advances only while the consumer is stalled; the K loop's 57-60 cycles per MFMA are the sum of
+//   both.  The fix is the staging work inside the MFMA-issuing wave's own instruction stream: DESIGN.md section 8.)
+//   One s_barrier per K-step (raw: the producers' global loads stay in flight across it).
 //   * tile = TH x 32 pixels x NT channels with TH = 8 or 4: the 4-row tile doubles the workgroup count on the 64^2 maps.
 //   * epilogue: the accumulators go through an LDS image of the whole tile, then ALL 512 threads add the residuals
 //     (fetched during the last chunk), store 16-byte vectors and reduce the GroupNorm statistics in a fixed order.
