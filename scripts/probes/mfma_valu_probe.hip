@@ -20,6 +20,7 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, unsigned l
     const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 64 * 1040 / 4; i += 512) ((float*)lds)[i] = in[i & 4095];
     __syncthreads();
+    // variant bit 2 / 3: the matrix wave idles after every MFMA (s_nop / s_sleep) instead of waiting in the issue stage
     // variant bit 0: the OTHER role runs at s_setprio 3 (the matrix role at 0); bit 1: the matrix role on the YOUNGER waves 4-7
     const bool mrole = (variant & 2) ? wid >= 4 : wid < 4;
     if (!mrole && (variant & 1)) __builtin_amdgcn_s_setprio(3);
@@ -40,7 +41,13 @@ __global__ __launch_bounds__(512) void k(const float* in, float* out, unsigned l
 #pragma unroll 1
         for (int it = 0; it < m_iters; ++it) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i * 2) & 3], acc[i], 0, 0, 0);
+            for (int i = 0; i < 8; ++i) {
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i & 3], b[(i * 2) & 3], acc[i], 0, 0, 0);
+                if (variant & 4) {      // do not wait IN the issue stage for the pipe: 3 x 8 idle cycles of this wave after every MFMA
+                    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+                }
+                if (variant & 8) __builtin_amdgcn_s_sleep(0);
+            }
         }
         for (int i = 0; i < 8; ++i)
             for (int r = 0; r < 16; ++r) s += acc[i][r];
@@ -148,8 +155,8 @@ int main() {
     const int M = 4000;                     // 32 000 MFMAs per wave: ~1 M cycles at 32 cycles each
     const char* vn[4] = {"matrix role on waves 0-3 (older), no priorities", "... the other role at s_setprio 3", "matrix role on waves 4-7 (younger), no priorities",
                          "... the other role at s_setprio 3"};
-    for (int variant = 0; variant < 4; ++variant) {
-        printf("-- %s\n", vn[variant]);
+    for (int variant : {0, 1, 2, 3, 4, 8}) {
+        printf("-- %s\n", variant < 4 ? vn[variant] : (variant == 4 ? "matrix role on waves 0-3, every MFMA followed by 3 x s_nop 7" : "matrix role on waves 0-3, every MFMA followed by s_sleep 0"));
         run<0>("v_fma_f32", din, dout, dt, M, 8000, variant);
         run<1>("v_pk_fma_f32", din, dout, dt, M, 8000, variant);
         run<2>("ds_read_b128", din, dout, dt, M, 4000, variant);
