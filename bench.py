@@ -777,7 +777,7 @@ def mode_fit(args, ctx):
     loop = {}
     if fitter.reuse_graphs and not args.eager:
         fitter.smpl_iters, fitter.object_iters, fitter.batch_seed = SMPL_ITERS, OBJECT_ITERS, 1234
-        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(int(os.environ.get("CHORE_BENCH_LOOP_BATCHES", "12" if B == 1 else "9")))]
+        batches = [fit_batch_inputs(B, 100 + rank * 16 + k, dev) for k in range(int(os.environ.get("CHORE_BENCH_LOOP_BATCHES", "24" if B == 1 else "12")))]
         for name, pipe in (("serial", False), ("pipelined", True), ("chains", "chains")):
             marks = []
 
@@ -794,21 +794,19 @@ def mode_fit(args, ctx):
                     torch.cuda.synchronize()
                     marks.append((time.perf_counter() - t0) * 1e3)
                 ends = fitter.batch_ends
-                gaps = [ends[j].elapsed_time(ends[j + 1]) for j in range(1, len(ends) - 1)] or [float("nan")]     # device time between consecutive batches' ends
                 fitter.batch_ends = None
-                # (ends in time order: side by side, batches do not end in loader order; the first wave -- one batch per chain -- is left out)
-                skip = fitter.chains if name == "chains" else 1
+                # Steady state = device time from the end of the first wave of batches (one per chain side by side; serial /
+                # pipelined: the first batch) to the last batch's end, over the batches that ended in between.  The ends are put in
+                # time order first (side by side, batches do not end in loader order), so the span is never negative; nothing is
+                # derived from gaps between individual ends (interleaved chains end in bunches: round 5's medians were negative).
+                wave = fitter.chains if name == "chains" else 1
                 tt = sorted(ends[0].elapsed_time(e) for e in ends)
-                span = (tt[-1] - tt[skip]) / (len(tt) - 1 - skip) if len(tt) > skip + 1 else float("nan")
-                # steady state: the median gap between consecutive batches' ends -- for the chains mode, where two batches run side by
-                # side and end in pairs (gaps alternate between long and short or negative), the span from the second batch's end to the
-                # last batch's end over the batches in between
-                steady = span if name == "chains" else float(np.median(gaps))
+                span = (tt[-1] - tt[wave - 1]) / (len(tt) - wave) if len(tt) > wave else float("nan")
+                assert not (span < 0), (name, tt)
                 loop[name] = {"ms_per_batch": marks[2] / len(batches), "ms_per_frame": marks[2] / (len(batches) * B),
-                              "steady_state_ms_per_batch_span": span, "steady_state_ms_per_frame_span": span / B,
-                              "steady_state_ms_per_batch_median": float(np.median(gaps)), "steady_state_ms_per_frame": steady / B,
-                              "gaps_ms": [round(g, 1) for g in gaps],
-                              "first_pass_ms_per_batch": marks[0] / len(batches), "batches": len(batches)}
+                              "steady_state_ms_per_batch": span, "steady_state_ms_per_frame": span / B,
+                              "batches_in_span": len(tt) - wave, "first_pass_ms_per_batch": marks[0] / len(batches),
+                              "batches": len(batches)}
             except Exception as e:
                 loop[name] = {"error": repr(e)[:300]}
                 torch.cuda.synchronize()
@@ -843,12 +841,12 @@ def mode_fit(args, ctx):
                     "chain_ms_median": float(np.median(chain_wall)), "chain_ms_all": [round(c, 2) for c in chain_wall],
                     "chain_stage_ms_median": {k: float(np.median([c.get(k, 0.0) for c in chains])) for k in per_step},
                     "per_phase": per_phase,
-                    "loader_loop": dict(loop, note="fit_recon over 12 (one frame per batch) / 9 consecutive loader batches of the same shapes (recordings kept), wall time "
-                                                   "per batch of the second pass; pipelined = batch k+1's encoder + point clouds + SMPL-H "
+                    "loader_loop": dict(loop, note="fit_recon over 24 (one frame per batch) / 12 (eight) consecutive loader batches of the same shapes (recordings kept), three "
+                                                   "passes (recordings; allocator warm-up; timed): ms_per_batch = wall time of the THIRD pass / batches; pipelined = batch k+1's encoder + point clouds + SMPL-H "
                                                    "initialisation on a second stream / host thread while batch k is optimised, results equal to "
-                                                   "the serial loop bit for bit (tests/test_gpu_fit_chain.py); chains = the whole chains of two batches side by side, each "
-                                                   "on its own stream and host thread, same results; *_span = device time from the end of the first wave of batches (one "
-                                                   "per chain; serial / pipelined: the second batch) to the last end / batches in between"),
+                                                   "the serial loop bit for bit (tests/test_gpu_fit_chain.py); chains = the whole chains of `ReconFitterBehave.chains` (3) batches side by side, each "
+                                                   "on its own stream and host thread, same results; steady_state_* = device time from the end of the first wave of batches (one "
+                                                   "per chain; serial / pipelined: the first batch) to the last end / batches that ended in between"),
                     "per_phase_note": "SURVEY 8(d) metric 2: median device ms per Adam iteration per phase over all outer iterations "
                                       "of all timed chains ('global' / 'smpl all pose' / 'kpts' = optimize_smpl; 'object only' / "
                                       "'sil' / 'joint' = optimize_smpl_object, joint incl. contact + collision terms)",

@@ -32,7 +32,10 @@ def _side_stream(dev):
 # the fp16 matrix cores with hi / lo split operands (csrc/conv_pc.hip, train_bwd.hip wgrad64_x3_kernel).  The tensor dtype cannot
 # tell this mode from the exact-fp32 one, so it is a switch the forward pass sets (`with ops.x3_convs():`); every node remembers
 # the dtype word of its forward for its backward, which runs outside the `with`.
-_X3 = False
+# The switch is per host thread: two threads running training forwards in different modes must not see each other's.
+import threading as _threading
+
+_X3 = _threading.local()
 
 
 class x3_convs:
@@ -40,19 +43,18 @@ class x3_convs:
         self.on = bool(on)
 
     def __enter__(self):
-        global _X3
-        self.prev, _X3 = _X3, self.on
+        self.prev = getattr(_X3, "on", False)
+        _X3.on = self.on
         return self
 
     def __exit__(self, *exc):
-        global _X3
-        _X3 = self.prev
+        _X3.on = self.prev
         return False
 
 
 def _conv_dt(dt):
     """dtype word of the convolution entry points for a tensor of element type dt"""
-    return _lib.F16X3 if (_X3 and dt == _lib.F32) else dt
+    return _lib.F16X3 if (getattr(_X3, "on", False) and dt == _lib.F32) else dt
 
 
 def _absmax(t, dev, h, stream):

@@ -120,11 +120,30 @@ class GraphedTrainStep:
                 g["lr"] = t
 
     def _hyper_key(self):
+        """what the live recordings depend on besides the batch: the optimiser's scalars and the addresses of its state.  Runs
+        on every replayed step, so it must not touch the device: a tensor-valued entry (a scheduler built after this object
+        stores `initial_lr` as a device tensor; tensor betas) is keyed by (address, version), never by repr(), which would
+        copy it to the host and wait for the stream; the walk over the ~1.4 k state tensors is redone only when the state's
+        size or its first / last tensor changed."""
         opt = self.optimizer
-        groups = tuple(tuple((k, repr(v)) for k, v in sorted(g.items()) if k not in ("params", "lr")) for g in opt.param_groups)
-        state = tuple((id(p), tuple((k, v.data_ptr()) for k, v in sorted(opt.state[p].items()) if torch.is_tensor(v)))
-                      for g in opt.param_groups for p in g["params"] if p in opt.state)
-        return groups, state
+
+        def key(v):
+            return ("tensor", v.data_ptr(), v._version) if torch.is_tensor(v) else repr(v)
+        groups = tuple(tuple((k, key(v)) for k, v in sorted(g.items()) if k not in ("params", "lr")) for g in opt.param_groups)
+        st = opt.state
+        sig = (len(st),)
+        if st:
+            ends = []
+            for g in (opt.param_groups[0], opt.param_groups[-1]):
+                for p in (g["params"][0], g["params"][-1]):
+                    ends.append(tuple(v.data_ptr() for v in st[p].values() if torch.is_tensor(v)) if p in st else None)
+            sig = (len(st), tuple(ends))
+        cached = self.__dict__.get("_state_key")
+        if cached is None or cached[0] != sig:
+            state = tuple((id(p), tuple((k, v.data_ptr()) for k, v in sorted(st[p].items()) if torch.is_tensor(v)))
+                          for g in opt.param_groups for p in g["params"] if p in st)
+            cached = self._state_key = (sig, state)
+        return groups, cached[1]
 
     # ---- the step, as the eager sequence --------------------------------------------------------------------------------
     def _zero(self):

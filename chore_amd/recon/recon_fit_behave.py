@@ -256,6 +256,8 @@ class ReconFitterBehave(ReconFitterBase):
             if sw:
                 sys.setswitchinterval(float(sw) * 1e-6)
             try:
+                if self.batch_seed is None:            # two host threads cannot share the process-wide random streams
+                    self._pipe_seed = int(torch.initial_seed() % (1 << 31))
                 if os.environ.get("CHORE_PIPE_OWN_STREAM"):
                     dev = torch.device(self.device)
                     cur = torch.cuda.current_stream(dev)
@@ -271,6 +273,7 @@ class ReconFitterBehave(ReconFitterBase):
                 else:
                     self._fit_pipelined(todo, generator, finish)
             finally:
+                self._pipe_seed = None
                 sys.setswitchinterval(old_sw)
         else:
             for i, data in todo:
@@ -290,13 +293,20 @@ class ReconFitterBehave(ReconFitterBase):
     smpl_iters = None     # fit_recon / fit_batch: keyword arguments of optimize_smpl / optimize_smpl_object other than the
     object_iters = None   # reference's (benchmarks and tests with shorter schedules)
 
+    _pipe_seed = None     # the per-batch seed of a pipelined fit_recon call when `batch_seed` is None (from torch.initial_seed(),
+                          # for that call only: a later serial call draws from the process-wide streams again, like the reference)
+
+    def _seed(self):
+        return self.batch_seed if self.batch_seed is not None else self._pipe_seed
+
     def _batch_generators(self, index):
-        if self.batch_seed is None or index is None:
+        seed = self._seed()
+        if seed is None or index is None:
             return None
         dev = torch.device(self.device)
         cpu_g, dev_g = torch.Generator(), torch.Generator(device=dev)
-        cpu_g.manual_seed(int(self.batch_seed) + 2 * int(index))
-        dev_g.manual_seed(int(self.batch_seed) + 2 * int(index) + 1)
+        cpu_g.manual_seed(int(seed) + 2 * int(index))
+        dev_g.manual_seed(int(seed) + 2 * int(index) + 1)
         return cpu_g, dev_g
 
     def prepare_batch(self, data, generator, index=None):
@@ -310,7 +320,7 @@ class ReconFitterBehave(ReconFitterBase):
         opt_gen = None
         if gens is not None:                   # the optimisation's CPU draws (SO(3) perturbations): a third stream of the batch's own
             opt_gen = torch.Generator()
-            opt_gen.manual_seed(int(self.batch_seed) + 2 * int(index) + 1000003)
+            opt_gen.manual_seed(int(self._seed()) + 2 * int(index) + 1000003)
         return dict(data=data, pc=pc_generated, model=generator.model, smplfit=self.prep_smplfit(data, generator, pc_generated),
                     opt_gen=opt_gen)
 
@@ -353,8 +363,8 @@ class ReconFitterBehave(ReconFitterBase):
         issued: a capture does not tolerate another thread's allocations."""
         import copy
         from concurrent.futures import ThreadPoolExecutor
-        if self.batch_seed is None:
-            self.batch_seed = 0
+        if self._seed() is None:
+            self._pipe_seed = int(torch.initial_seed() % (1 << 31))
         dev = torch.device(self.device)
         main = torch.cuda.current_stream(dev)
         state = self.__dict__.get("_pipe_state")
@@ -385,7 +395,19 @@ class ReconFitterBehave(ReconFitterBase):
         dbg = [] if os.environ.get("CHORE_PIPE_DEBUG") else None
         t_base = time.perf_counter()
 
+        # A recording the `warm` bookkeeping does not foresee (a new shape later in the loader, recordings dropped at the slot cap,
+        # maps at new addresses) must still run alone: the worker holds the gate while it prepares, the calling thread records
+        # through _stepper's gate.exclusive(), which waits until the worker has left and keeps it out until the recording is done.
+        gate = self._gate = _CaptureGate()
+
         def prepare(k, ready):
+            gate.enter()
+            try:
+                return prepare_(k, ready)
+            finally:
+                gate.leave()
+
+        def prepare_(k, ready):
             i, data = todo[k]
             s = k % 2
             torch.cuda.set_device(dev)
@@ -409,6 +431,21 @@ class ReconFitterBehave(ReconFitterBase):
             ready.record(main)
             return pool.submit(prepare, k, ready)
 
+        gate.enter()
+        try:
+            self._fit_pipelined_loop(todo, submit, pool, warm, main, last_read, finish, smpl_iters, object_iters, dbg, t_base)
+        finally:
+            gate.leave()
+            self._gate = None
+        if dbg:
+            torch.cuda.synchronize()
+            ref = [d for d in dbg if d[0] == "opt"][0][4]
+            for kind, k, h0, h1, e0, e1 in sorted(dbg, key=lambda d: d[2]):
+                print("[pipe] %-4s batch %d  host %7.1f .. %7.1f ms   device %7.1f .. %7.1f ms (relative to the first timed optimisation's start)"
+                      % (kind, k, h0 * 1e3, h1 * 1e3, ref.elapsed_time(e0), ref.elapsed_time(e1)), file=__import__("sys").stderr)
+
+    def _fit_pipelined_loop(self, todo, submit, pool, warm, main, last_read, finish, smpl_iters, object_iters, dbg, t_base):
+        import time
         fut = submit(pool, 0)
         for k, (i, data) in enumerate(todo):
             prep, done = fut.result()
@@ -437,12 +474,6 @@ class ReconFitterBehave(ReconFitterBase):
                 dbg.append(("opt", k, th0 - t_base, time.perf_counter() - t_base, o0, o1))
             warm[s] = True
             finish(i, data, fitted)
-        if dbg:
-            torch.cuda.synchronize()
-            ref = [d for d in dbg if d[0] == "opt"][0][4]
-            for kind, k, h0, h1, e0, e1 in sorted(dbg, key=lambda d: d[2]):
-                print("[pipe] %-4s batch %d  host %7.1f .. %7.1f ms   device %7.1f .. %7.1f ms (relative to the first timed optimisation's start)"
-                      % (kind, k, h0 * 1e3, h1 * 1e3, ref.elapsed_time(e0), ref.elapsed_time(e1)), file=__import__("sys").stderr)
 
     def _fit_concurrent(self, todo, generator, finish, smpl_iters=None, object_iters=None):
         """pipeline="chains": the WHOLE chains of `self.chains` (3) batches side by side, each on its slot's stream, issued by its
@@ -456,8 +487,8 @@ class ReconFitterBehave(ReconFitterBase):
         tolerate another thread's allocations or synchronisations.  `finish` is called by the calling thread in loader order."""
         import copy
         from concurrent.futures import ThreadPoolExecutor
-        if self.batch_seed is None:
-            self.batch_seed = 0
+        if self._seed() is None:
+            self._pipe_seed = int(torch.initial_seed() % (1 << 31))
         dev = torch.device(self.device)
         main = torch.cuda.current_stream(dev)
         nch = max(2, int(os.environ.get("CHORE_FIT_CHAINS", self.chains)))

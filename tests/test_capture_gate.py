@@ -58,3 +58,43 @@ def test_a_recording_runs_alone_and_everybody_resumes():
         assert before[1 - k] == after[1 - k], ("the other participant moved during a recording", k, before, after)
     assert progress == [400, 400]
     assert gate.active == 0 and gate.parked == 0 and not gate.recording
+
+
+def test_pipelined_pattern_a_recording_waits_for_the_preparing_worker():
+    """fit_recon(pipeline=True) (_fit_pipelined): the worker thread holds the gate while it prepares a batch and never parks;
+    the calling thread stays entered for the whole loop and records through exclusive() -- which must wait until the worker has
+    left and keep its next preparation out until the recording is over"""
+    gate = _CaptureGate()
+    preparing = threading.Event()
+    overlap = []
+    errors = []
+
+    def prepare():
+        try:
+            gate.enter()
+            try:
+                preparing.set()
+                time.sleep(0.01)
+                preparing.clear()
+            finally:
+                gate.leave()
+        except Exception as e:      # pragma: no cover
+            errors.append(e)
+
+    gate.enter()
+    for _ in range(20):
+        t = threading.Thread(target=prepare)
+        t.start()
+        time.sleep(0.002)               # the worker is in the middle of its preparation
+        with gate.exclusive():
+            overlap.append(preparing.is_set())
+            t2 = threading.Thread(target=prepare)       # the next preparation is submitted during the recording
+            t2.start()
+            time.sleep(0.005)
+            overlap.append(preparing.is_set())
+        t.join(timeout=10)
+        t2.join(timeout=10)
+        assert not t.is_alive() and not t2.is_alive()
+    gate.leave()
+    assert not errors and not any(overlap)
+    assert gate.active == 0 and gate.parked == 0 and not gate.recording

@@ -1,7 +1,7 @@
 """GPU: the PER-GPU workloads of BASELINE configs[3] and [4] at their full sizes on one GPU (the multi-GPU part -- DDP's
 all-reduce, the final gather -- is covered by the 2-rank tests; no multi-GPU box exists for the tests).
 
-  configs[3]  DDP training: batch 4 x 512x512 images, 20 000 points per image, 5 stacks, bf16 -- one full training step
+  configs[3]  DDP training: batch 4 x 512x512 images, 20 000 points per image, 5 stacks, bf16 and fp16x3 -- one full training step
               (forward, backward to all 475 trained tensors, Adam) with finite loss / gradients and a loss that moves
   configs[4]  frame-sharded fitting: 8 frames per GPU fitted as one batch, every inner iteration a hipGraph replay --
               the whole fit_recon chain (point clouds, SMPL-H init, both optimisation loops with silhouette, contact and
@@ -16,11 +16,14 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def test_config3_training_step_at_full_per_gpu_size(opt):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16x3"])
+def test_config3_training_step_at_full_per_gpu_size(opt, dtype):
+    """fp16x3 is the mode bench.py's training record times (the reference's fp32 training precision, trainer/trainer.py:76-131,
+    on the fp16 matrix cores with split operands); bf16 the faster one"""
     from chore_amd.model import CHORE
     from chore_amd.utils import synth
     o = copy.copy(opt)
-    o.compute_dtype = "bf16"
+    o.compute_dtype = dtype
     net = CHORE(o).cuda()
     synth.load_synth_weights(net, seed=0)
     net.train(True)

@@ -47,11 +47,12 @@ def _steps(model, net, batches, record, reducer=None):
     return {n: p.detach().clone() for n, p in net.named_parameters()}
 
 
-def _worker(rank, port, out_path):
+def _worker(rank, port, out_path, dtype="bf16"):
     sys.path.insert(0, REPO)
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import torch.distributed as dist
-    from test_gpu_ddp_trainstep import _make
+    from test_gpu_ddp_trainstep import _make as _make_dt
+    _make = lambda r: _make_dt(r, dtype)      # noqa: E731
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(0)
@@ -117,10 +118,11 @@ def _worker(rank, port, out_path):
     dist.destroy_process_group()
 
 
-def test_ddp_over_rccl_equals_the_plain_step_bit_for_bit(tmp_path):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16x3"])
+def test_ddp_over_rccl_equals_the_plain_step_bit_for_bit(tmp_path, dtype):
     import torch.multiprocessing as mp
     out = str(tmp_path / "nccl_step.npz")
-    mp.spawn(_worker, args=(29611, out), nprocs=1, join=True)
+    mp.spawn(_worker, args=(29611 + (dtype == "fp16x3"), out, dtype), nprocs=1, join=True)
     r = np.load(out)
     print("RCCL DDP vs plain: tensors checked", int(r["n_checked"]), "differing", int(r["n_diff"]), "worst", float(r["worst"]),
           "parameters differing after", STEPS, "steps:", int(r["n_par_diff"]), str(r["first"][0]))

@@ -46,12 +46,12 @@ def _make(rank, dtype="bf16"):
     return net, batch
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, dtype="bf16"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    net, batch = _make(rank)
+    net, batch = _make(rank, dtype)
     model = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], find_unused_parameters=True)
     optimizer = torch.optim.Adam(model.parameters(), lr=1e-4)
     # ---- Trainer.train_step, line by line ----
@@ -71,14 +71,15 @@ def _worker(rank, world, port, out_path):
     dist.destroy_process_group()
 
 
-def test_trainer_train_step_through_ddp_at_config3_size(tmp_path):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16x3"])
+def test_trainer_train_step_through_ddp_at_config3_size(tmp_path, dtype):
     import torch.multiprocessing as mp
     out = str(tmp_path / "ddp_step.npz")
-    mp.spawn(_worker, args=(2, 29583, out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29583 + (dtype == "fp16x3"), out, dtype), nprocs=2, join=True)
     got = np.load(out)
     per_rank = []
     for r in range(2):
-        net, batch = _make(r)
+        net, batch = _make(r, dtype)
         net.train(True)
         error, _ = net(**batch)
         error.backward()

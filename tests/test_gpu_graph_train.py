@@ -19,7 +19,9 @@ import sys
 import numpy as np
 import torch
 sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
-from test_gpu_ddp_trainstep import _make
+from test_gpu_ddp_trainstep import _make as _make_dt
+DTYPE = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+_make = lambda rank: _make_dt(rank, DTYPE)
 from chore_amd.parallel import FlatGradReducer, GraphedTrainStep, chore_segments
 use_reducer = sys.argv[2] in ("arena", "segmented", "segmented_rs_ag")
 segmented = sys.argv[2].startswith("segmented")
@@ -107,15 +109,18 @@ if not use_reducer:
     step2(**batches[0])
     assert next(iter(step2._rec.values()))["ga"] is not old_graph
 print("graphed == eager over", STEPS, "steps (", STEPS - WARM, "replayed ),", len(ra[0][2]), "gradient tensors; losses", [round(r[0], 6) for r in rb])
-print("graph train ok")
+print("graph train ok", DTYPE)
 '''
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16x3"])
 @pytest.mark.parametrize("reducer", ["none", "arena", "segmented", "segmented_rs_ag"])
-def test_replayed_training_steps_equal_eager_steps_bit_for_bit(tmp_path, reducer):
+def test_replayed_training_steps_equal_eager_steps_bit_for_bit(tmp_path, reducer, dtype):
+    """fp16x3 (the mode bench.py's training record replays) carries range-tracked operand scales (enc_common.h x3_in_scale,
+    dy_amax): device state a replay or a segmented backward must read and write exactly like the eager step"""
     script = tmp_path / "graph_train.py"
     script.write_text(CHILD)
-    out = subprocess.run([sys.executable, str(script), REPO, reducer], capture_output=True, text=True, timeout=1500)
+    out = subprocess.run([sys.executable, str(script), REPO, reducer, dtype], capture_output=True, text=True, timeout=1500)
     print(out.stdout[-800:])
     assert out.returncode == 0 and "graph train ok" in out.stdout, (out.stdout[-1500:], out.stderr[-3000:])
 
