@@ -254,6 +254,9 @@ struct PcPlan { int th, nt, tps, nslot; };
 PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
+// the same tilings with the staging work inside the MFMA-issuing waves (conv_mw.hip, round 6): four waves, one per SIMD, no producers
+bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a);
+int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 // 1x1 layers (fp16 x 3, fp16, bf16) with register-resident weights (conv_rw.hip): persistent workgroups over runs of pixel blocks
 bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input);   // by shape (scaled_input: ConvArgs::in_amax set)
 bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a);

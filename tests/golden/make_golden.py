@@ -1042,6 +1042,93 @@ def gen_fullbody_crop():
                         no_keypoints=np.array([c[3] for c in cases]), regressor_seed=np.int64(0))
 
 
+def gen_sil_project():
+    """The silhouette term up to the rasteriser, from the reference's own code:
+      * recon/obj_pose_roi.py SilLossROI: to_original_bbox (:106-116), compute_K_roi (:118-136), cvt_masks (:138-151),
+        compute_edges / prepare_dist_trans (:92-104), apply_transformation (:173-176), compute_offscreen_loss (:178-199) --
+        the class is imported with the viewers / detectron2 / neural_renderer package stubbed (they are not on this path) and
+        instantiated with __new__ (its constructor needs detectron2's BitMasks and .cuda());
+      * external/neural_renderer/neural_renderer/projection.py and vertices_to_faces.py, loaded from their files (pure torch;
+        the package's __init__ imports the CUDA rasteriser, rasterize.py:261-262, which cannot load here);
+      * recon/bbox.py make_bbox_square.
+    Only `torch.cuda.FloatTensor` (compute_K_roi's constructor call) is pointed at torch.FloatTensor: there is no GPU here."""
+    import importlib.util
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        _install_stub_finder()
+        from recon.obj_pose_roi import SilLossROI
+        from recon.bbox import make_bbox_square
+
+        def load(name):
+            spec = importlib.util.spec_from_file_location("nmr_" + name, os.path.join(REF, "external/neural_renderer/neural_renderer", name + ".py"))
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+            return m
+        nmr_projection = load("projection").projection
+        nmr_v2f = load("vertices_to_faces").vertices_to_faces
+    finally:
+        os.chdir(cwd)
+    rs = np.random.RandomState(77)
+    B, S, V, Fn = 3, 64, 40, 60
+    # ---- ROI camera: object boxes (xywh, network-input pixels) -> square boxes -> original-image boxes -> intrinsics ----
+    boxes_xywh = np.array([[200.0, 150.0, 90.0, 140.0], [30.5, 300.25, 210.0, 80.0], [400.0, 410.0, 64.0, 64.0]])
+    crop_centers = np.array([[1000.0, 700.0], [850.5, 640.25], [1200.0, 900.0]], np.float32)
+    squares = make_bbox_square(boxes_xywh, 0.3)
+    scale = 1200 / 512.
+    old_ft = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    try:
+        bbox_orig = np.stack([SilLossROI.to_original_bbox(b, scale, c) for b, c in zip(squares, crop_centers)])
+        K = torch.cat([SilLossROI.compute_K_roi(b) for b in bbox_orig], 0)
+    finally:
+        torch.cuda.FloatTensor = old_ft
+    # ---- masks: keep mask, reference edges, their distance transform ----
+    sil = SilLossROI.__new__(SilLossROI)
+    torch.nn.Module.__init__(sil)
+    sil.pool = torch.nn.MaxPool2d(kernel_size=7, stride=1, padding=3)
+    yy, xx = np.mgrid[0:S, 0:S]
+    obj_crop = np.stack([((xx - 30 - 3 * b) ** 2 + (yy - 34 + 2 * b) ** 2) < (12 + 2 * b) ** 2 for b in range(B)]).astype(np.float32)
+    ps_crop = np.stack([(xx < 10 + 6 * b) | ((yy > 50) & (xx > 40)) for b in range(B)]).astype(np.float32)
+    # (0 / 1 valued, like the boolean crops detectron2's BitMasks.crop_and_resize hands the reference, obj_pose_roi.py:44-49)
+    keep, refs = [], []
+    for ps, obj in zip(torch.from_numpy(ps_crop), torch.from_numpy(obj_crop)):
+        keep.append(sil.cvt_masks(ps, obj).clone().float())
+        refs.append((obj > 0).clone().float())
+    sil.prepare_dist_trans(refs)
+    image_ref = torch.stack(refs, 0)
+    ref_edges = sil.compute_edges(image_ref)
+    # ---- placement + projection + triangle list ----
+    verts = (rs.standard_normal((V, 3)) * 0.25).astype(np.float32)
+    faces = np.stack([rs.choice(V, 3, replace=False) for _ in range(Fn)]).astype(np.int64)
+    sil.register_buffer("vertices", torch.from_numpy(verts).repeat(B, 1, 1))
+    q, _ = np.linalg.qr(rs.standard_normal((B, 3, 3)))
+    q[:, :, 0] *= np.sign(np.linalg.det(q))[:, None]
+    R = torch.from_numpy(q.astype(np.float32))
+    obj_t = torch.from_numpy(np.array([[0.05, -0.03, 2.0], [-0.4, 0.3, 2.6], [0.9, 0.1, 1.4]], np.float32))
+    obj_s = torch.from_numpy(np.array([1.0, 1.3, 0.8], np.float32))
+    placed = sil.apply_transformation(R, obj_t, obj_s)
+    cam_R, cam_t = torch.eye(3).unsqueeze(0), torch.zeros(1, 3)
+    dist = torch.zeros(1, 5)
+    proj = nmr_projection(placed, K, cam_R, cam_t, dist, 1)
+    f = torch.from_numpy(faces).repeat(B, 1, 1)
+    f2 = torch.cat((f, f[:, :, list(reversed(range(f.shape[-1])))]), dim=1)          # renderer.py:126-127 fill_back
+    tri = nmr_v2f(proj, f2)
+
+    class Rend:
+        pass
+    sil.renderer = Rend()
+    sil.renderer.K, sil.renderer.R, sil.renderer.t, sil.renderer.dist_coeffs, sil.renderer.orig_size, sil.renderer.far = K, cam_R, cam_t, dist, 1, 100
+    import recon.obj_pose_roi as ropr
+    ropr.nr.projection = nmr_projection          # the stubbed package's attribute -> the real function, for compute_offscreen_loss
+    offscreen = sil.compute_offscreen_loss(placed)
+    np.savez_compressed(os.path.join(HERE, "sil_project.npz"), boxes_xywh=boxes_xywh, crop_centers=crop_centers, squares=squares,
+                        bbox_orig=bbox_orig, K=K.numpy(), obj_crop=obj_crop, ps_crop=ps_crop,
+                        keep_mask=torch.stack(keep, 0).numpy(), image_ref=image_ref.numpy(), ref_edges=ref_edges.numpy(),
+                        edt_ref_edge=sil.edt_ref_edge.numpy(), verts=verts, faces=faces, R=R.numpy(), obj_t=obj_t.numpy(),
+                        obj_s=obj_s.numpy(), placed=placed.numpy(), proj=proj.numpy(), tri=tri.numpy(), offscreen=offscreen.numpy())
+
+
 def main():
     """no arguments: everything; otherwise the named generators (e.g. `make_golden.py config2 fit`)"""
     torch.manual_seed(0)
@@ -1053,6 +1140,8 @@ def main():
         return gen_coco()
     if todo == ["fullbody_crop"]:
         return gen_fullbody_crop()
+    if todo == ["sil_project"]:
+        return gen_sil_project()
     net = ref_model(seed=0)
     if todo:
         for name in todo:
@@ -1079,6 +1168,7 @@ def main():
     gen_eval()
     gen_coco()
     gen_fullbody_crop()
+    gen_sil_project()
     for f in sorted(os.listdir(HERE)):
         print(f, os.path.getsize(os.path.join(HERE, f)))
 

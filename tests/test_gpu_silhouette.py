@@ -180,3 +180,30 @@ def test_placed_triangles_operator_equals_tensor_expressions():
     (ref * g).sum().backward()
     for a, b, n in ((R.grad, R2.grad, "R"), (t.grad, t2.grad, "t"), (s.grad, s2.grad, "s")):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()), (n, float((a - b).abs().max()), float(b.abs().max()))
+
+
+def test_placement_projection_kernel_against_the_reference():
+    """chore_sil_project_fwd (object placement + camera projection + the doubled triangle list, one launch) against the
+    reference's own code: tests/golden/sil_project.npz holds what recon/obj_pose_roi.py apply_transformation and
+    neural_renderer's projection.py + vertices_to_faces.py (fill_back faces, renderer.py:126-127) computed on CPU for the same
+    pose, template and ROI intrinsics (written by make_golden.py gen_sil_project); and SilLossROI built from
+    the fixture's crops carries the reference's keep mask / edge distance transform on the device."""
+    import os
+    from chore_amd.recon.obj_pose_roi import SilLossROI, _PlacedTrianglesFn
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sil_project.npz"))
+    sil = SilLossROI.from_crops(g["obj_crop"], g["ps_crop"], g["K"], g["verts"], g["faces"])
+    R, t, s = (torch.from_numpy(g[k]).cuda() for k in ("R", "obj_t", "obj_s"))
+    tri = _PlacedTrianglesFn.apply(R, t, s, sil.vertices, sil.faces32, sil.K, sil.R, sil.t, sil.adj_off, sil.adj).cpu().numpy()
+    ref = g["tri"]
+    assert tri.shape == ref.shape
+    # x / (z + eps), the K row products and the affine map to [-1, 1] are a handful of fp32 operations per coordinate
+    assert np.abs(tri - ref).max() <= 4e-6 * np.abs(ref).max(), np.abs(tri - ref).max()
+    assert np.array_equal(tri[..., 2], ref[..., 2]) or np.abs(tri[..., 2] - ref[..., 2]).max() <= 1e-6      # depth = placed z
+    assert np.array_equal(sil.keep_mask.cpu().numpy(), g["keep_mask"])
+    np.testing.assert_allclose(sil.edt_ref_edge.cpu().numpy(), g["edt_ref_edge"], rtol=1e-6)
+    # and the rendering of that triangle list is the restatement's rendering of the REFERENCE's projected vertices
+    loss_dict, image, edges, image_ref, edt = sil(R, t, s)
+    img_o, _ = osil.render_silhouettes(g["proj"], np.stack([g["faces"]] * 3), sil.rend_size)
+    got = image.cpu().numpy()
+    assert (got != g["keep_mask"] * img_o).mean() < 2e-3          # (pixel centres within 4e-6 of an edge may flip)
+    assert img_o.sum() > 50

@@ -57,3 +57,45 @@ def test_forward_properties():
     p = osil.projection(np.array([[[0.0, 0.0, 3.0]]], np.float32), K, np.eye(3, dtype=np.float32)[None],
                         np.zeros((1, 1, 3), np.float32), orig_size=1.0)
     np.testing.assert_allclose(p[0, 0], [0.0, 0.0, 3.0], atol=1e-6)
+
+
+def _fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sil_project.npz"))
+
+
+def test_projection_and_triangle_list_against_the_reference():
+    """tests/golden/sil_project.npz is written by the reference's own neural_renderer/projection.py and vertices_to_faces.py
+    (make_golden.py gen_sil_project): the restatement's projection and fill_back + vertices_to_faces reproduce them"""
+    g = _fixture()
+    pv = osil.projection(g["placed"], g["K"], np.eye(3, dtype=np.float32)[None], np.zeros((1, 1, 3), np.float32))
+    assert np.abs(pv - g["proj"]).max() <= 2e-6 * np.abs(g["proj"]).max()
+    B = g["placed"].shape[0]
+    tri = osil.vertices_to_faces(g["proj"], osil.fill_back(np.stack([g["faces"]] * B)))
+    assert np.array_equal(tri, g["tri"])
+
+
+def test_roi_camera_and_masks_host_logic_against_the_reference():
+    """the host side of SilLossROI (chore_amd/recon/obj_pose_roi.py) on CPU tensors -- square box, box in the original image, ROI
+    intrinsics, keep mask, reference edges and their distance transform, placement, off-screen penalty -- against what the
+    reference's recon/obj_pose_roi.py:92-199 and recon/bbox.py:25-46 computed for the same inputs"""
+    import torch
+    from chore_amd.recon.obj_pose_roi import SilLossROI, make_bbox_square
+    g = _fixture()
+    sq = make_bbox_square(g["boxes_xywh"], 0.3)
+    np.testing.assert_allclose(sq, g["squares"], rtol=0, atol=1e-12)
+    orig = np.stack([SilLossROI.to_original_bbox(b, 1200 / 512., c) for b, c in zip(sq, g["crop_centers"])])
+    np.testing.assert_allclose(orig, g["bbox_orig"], rtol=0, atol=1e-9)
+    K = torch.cat([SilLossROI.compute_K_roi(b) for b in orig], 0).numpy()
+    assert np.array_equal(K, g["K"])
+    sil = SilLossROI.from_crops(g["obj_crop"], g["ps_crop"], g["K"], g["verts"], g["faces"], device="cpu")
+    assert np.array_equal(sil.keep_mask.numpy(), g["keep_mask"])
+    assert np.array_equal(sil.image_ref.numpy(), g["image_ref"])
+    assert np.array_equal(sil.compute_edges(sil.image_ref).numpy(), g["ref_edges"])
+    np.testing.assert_allclose(sil.edt_ref_edge.numpy(), g["edt_ref_edge"], rtol=1e-6, atol=0)
+    assert 0 < g["keep_mask"].mean() < 1 and g["ref_edges"].sum() > 0
+    placed = sil.apply_transformation(torch.from_numpy(g["R"]), torch.from_numpy(g["obj_t"]), torch.from_numpy(g["obj_s"]))
+    assert np.abs(placed.numpy() - g["placed"]).max() <= 1e-6
+    off = sil.compute_offscreen_loss(torch.from_numpy(g["placed"]))
+    np.testing.assert_allclose(off.numpy(), g["offscreen"], rtol=1e-5, atol=1e-6)
+    assert (g["offscreen"] > 0).any()
