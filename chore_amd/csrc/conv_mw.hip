@@ -26,6 +26,12 @@
 
 using namespace conv_detail;
 
+// kernel experiments (scripts/build_variant.sh mwN conv_mw.hip -DMW_DBG=N): 1 no weight staging, 2 no patch staging, 4 no MFMAs,
+// 8 no fragment reads, 16 no barriers inside the K loop, 32 no epilogue -- results are wrong when set
+#ifndef MW_DBG
+#define MW_DBG 0
+#endif
+
 namespace {
 
 constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
@@ -63,6 +69,21 @@ __host__ __device__ constexpr int mw_next_use(int k, int j, int UP, int KROWS, i
     for (int d = UP; d < KROWS; d += UP)
         if (((k + d) % KROWS) * RPS + j < NVP) return k + d;
     return k + KROWS;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {      // one v_cvt_pk_f16_f32 (round to nearest even)
+    const f16x2_t h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+// y - (float)(half HI of the packed pair h): v_fma_mix_f32 reads the half in place -- one instruction for the cvt_f32_f16 + sub pair,
+// the same value (the product with 1.0 is exact, the sum is rounded once)
+template <int HI> __device__ __forceinline__ float sub_half(float y, unsigned h) {
+    float r;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y));
+    else asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y));
+    return r;
 }
 
 __device__ __forceinline__ void wg_barrier_mw() {
@@ -133,69 +154,62 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     //      rows for every chunk, so their offsets and LDS rows stay in registers
     const int tv = tid & 3;
     int toff[NVP];                                       // element offset of the row's pixel, -1: outside the image / past the list
-    int trow[NVP];                                       // LDS row (the spare row for slots past the list)
+    int trow[NVP];                                       // LDS row (the spare row for slots past the list and pixels outside the image)
 #pragma unroll
     for (int m = 0; m < NVP; ++m) {
         const int row = (tid >> 2) + (MWT / 4) * m;
         const int y = ty0 + row / PW - PAD, x = tx0 + row % PW - PAD;
         const bool ok = (row < ROWS) && (y >= 0) && (y < a.H) && (x >= 0) && (x < a.W);
         toff[m] = ok ? (y * a.W + x) * a.in.cs : -1;
-        trow[m] = row < ROWS ? row : ROWS;
+        trow[m] = ok ? row : ROWS;       // zero padding: the cells of pixels outside the image are cleared once (prologue) and never written
     }
     auto load_task = [&](u32x4 (&r)[LVI], int off, int c0) {
         const u32x4* p = (const u32x4*)(in_b + (off >= 0 ? off : 0) + c0 + tv * 8);
 #pragma unroll
         for (int k = 0; k < LVI; ++k) r[k] = p[k];
     };
-    auto load_ss = [&](float (&sc)[8], float (&sh)[8], int c0) {
-        if constexpr (GN) {   // (scale, shift) pairs of the 8 channels: 64 contiguous bytes
+    // ss_lds: per channel pair {scale 2p, scale 2p + 1, shift 2p, shift 2p + 1}: register pairs for v_pk_fma_f32
+    auto load_ss = [&](f32x2 (&sc)[4], f32x2 (&sh)[4], int c0) {
+        if constexpr (GN) {
             const f32x4* q = (const f32x4*)(ss_lds + (c0 + tv * 8) * 2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const f32x4 t = q[j];
-                sc[2 * j] = t[0]; sh[2 * j] = t[1]; sc[2 * j + 1] = t[2]; sh[2 * j + 1] = t[3];
+                sc[j] = f32x2{t[0], t[1]};
+                sh[j] = f32x2{t[2], t[3]};
             }
         }
     };
     // one staging task: 8 channels of one patch row -> GroupNorm + ReLU -> fp16 hi / lo (or the 16-bit type) -> LDS.  Branch-free.
-    auto put_task = [&](const u32x4 (&r)[LVI], int off, const float (&sc)[8], const float (&sh)[8], int row, int pbuf) {
+    auto put_task = [&](const u32x4 (&r)[LVI], int off, const f32x2 (&sc)[4], const f32x2 (&sh)[4], int row, int pbuf) {
         const bool ok = off >= 0;
         char* d = patch + pbuf * PATCHB + row * RB + tv * 16;
-        const u32x4 z = {0u, 0u, 0u, 0u};
         if constexpr (X3) {
-            float t[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { t[j] = __uint_as_float(r[0][j]); t[4 + j] = __uint_as_float(r[LVI - 1][j]); }
-            if constexpr (GN) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float y = fmaf(t[j], sc[j], sh[j]);
-                    t[j] = y > 0.f ? y : 0.f;
-                }
-            } else if constexpr (SC) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) t[j] *= in_mul;
-            }
-            f16x8_t h, l;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                h[j] = (_Float16)t[j];
-                l[j] = (_Float16)(t[j] - (float)h[j]);
-            }
-            const u32x4 hi = __builtin_bit_cast(u32x4, h), lo = __builtin_bit_cast(u32x4, l);
             u32x4 oh, ol;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { oh[j] = ok ? hi[j] : 0u; ol[j] = ok ? lo[j] : 0u; }
+            for (int j = 0; j < 4; ++j) {        // channels 2 j, 2 j + 1
+                f32x2 t = {__uint_as_float(r[j >> 1][2 * (j & 1)]), __uint_as_float(r[j >> 1][2 * (j & 1) + 1])};
+                if constexpr (GN) {
+                    t = __builtin_elementwise_fma(t, sc[j], sh[j]);     // v_pk_fma_f32: x * scale + shift, one rounding (as fmaf)
+                    t[0] = t[0] > 0.f ? t[0] : 0.f;
+                    t[1] = t[1] > 0.f ? t[1] : 0.f;
+                } else if constexpr (SC) {
+                    t *= in_mul;
+                }
+                oh[j] = cvt_pk_f16(t[0], t[1]);
+                ol[j] = cvt_pk_f16(sub_half<0>(t[0], oh[j]), sub_half<1>(t[1], oh[j]));
+            }
             *(u32x4*)d = oh;
             *(u32x4*)(d + 64) = ol;
+            (void)ok;
         } else {
             u32x4 hi = r[0];
             if constexpr (GN) {   // relu(x * scale + shift) in fp32, rounded to the 16-bit type once
                 if constexpr (BF) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        float x0 = fmaf(__uint_as_float(r[0][j] << 16), sc[2 * j], sh[2 * j]);
-                        float x1 = fmaf(__uint_as_float(r[0][j] & 0xffff0000u), sc[2 * j + 1], sh[2 * j + 1]);
+                        float x0 = fmaf(__uint_as_float(r[0][j] << 16), sc[j][0], sh[j][0]);
+                        float x1 = fmaf(__uint_as_float(r[0][j] & 0xffff0000u), sc[j][1], sh[j][1]);
                         x0 = x0 > 0.f ? x0 : 0.f;
                         x1 = x1 > 0.f ? x1 : 0.f;
                         hi[j] = pack2bf(x0, x1);
@@ -205,16 +219,14 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                     f16x8_t y;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float t = fmaf((float)x[j], sc[j], sh[j]);
+                        const float t = fmaf((float)x[j], sc[j >> 1][j & 1], sh[j >> 1][j & 1]);
                         y[j] = (_Float16)(t > 0.f ? t : 0.f);
                     }
                     hi = __builtin_bit_cast(u32x4, y);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) hi[j] = ok ? hi[j] : 0u;
             *(u32x4*)d = hi;
-            (void)z;
+            (void)ok;
         }
     };
 
@@ -253,11 +265,25 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
         for (int ci = tid; ci < Cin; ci += MWT) {
             float sc = 1.f, sh = 0.f;
             if constexpr (GN) gn_scale_shift(a.in_st, a.B, b, Cin, ci, a.H * a.W, a.gamma, a.beta, sc, sh);
-            ss_lds[2 * ci] = sc;
-            ss_lds[2 * ci + 1] = sh;
+            ss_lds[4 * (ci >> 1) + (ci & 1)] = sc;
+            ss_lds[4 * (ci >> 1) + 2 + (ci & 1)] = sh;
+        }
+        // zero padding: the patch cells of pixels outside the image, both buffers, once
+#pragma unroll
+        for (int m = 0; m < NVP; ++m) {
+            const int row = (tid >> 2) + (MWT / 4) * m;
+            if (toff[m] < 0 && row < ROWS) {
+                const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int pbuf = 0; pbuf < 2; ++pbuf) {
+                    char* d = patch + pbuf * PATCHB + row * RB + tv * 16;
+                    *(u32x4*)d = z;
+                    if constexpr (X3) *(u32x4*)(d + 64) = z;
+                }
+            }
         }
         wg_barrier_mw();
-        float sc[8], sh[8];
+        f32x2 sc[4], sh[4];
         load_ss(sc, sh, c00);
 #pragma unroll
         for (int m = 0; m < NVP; ++m) put_task(p0[m], toff[m], sc, sh, trow[m], 0);
@@ -323,6 +349,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
         const char* ar = a_ptr + pbuf * PATCHB + ((TPS == 3) ? (krow * PW) * RB : ((TPS == 1 && TAPS == 9) ? ((krow / 3) * PW + krow % 3) * RB : 0));
         const int t = ks / KGC, kg = ks % KGC;
         const int ky = (TPS == 9) ? t / 3 : 0, kx = (TPS == 9) ? t % 3 : t;
+        if constexpr ((MW_DBG & 8) != 0) return;
 #pragma unroll
         for (int q = 0; q < NBW; ++q) bf[fs][q] = *(const u32x4*)(bs + ((t * KGC + kg) * (NT / 32) + q) * 1024);
         if constexpr (X3) {
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     auto chunk_body = [&](int c, auto stage_t, auto last_t) {
         constexpr bool STAGE = decltype(stage_t)::value, LASTC = decltype(last_t)::value;
         const int pb = c & 1;
-        float sc[8], sh[8];
+        f32x2 sc[4], sh[4];
         int c1 = 0, c2 = 0;
         if constexpr (STAGE) {
             c1 = chunk_of(c + 1) * CC;                                   // the chunk being staged
@@ -372,14 +399,14 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                 // ---- this k-step's slice of the staging work ----
 #pragma unroll
                 for (int j = 0; j < SBV; ++j) {
-                    if ((j * NKS) / SBV != ks) continue;
+                    if ((j * NKS) / SBV != ks || (MW_DBG & 1)) continue;
                     *(u32x4*)(bst + wslot * SBYTES + (tid + j * MWT) * 16) = wset[j];
                     wset[j] = wnext[woff[j]];
                 }
                 if constexpr (STAGE) {
 #pragma unroll
                     for (int j = 0; j < RPS; ++j) {
-                        if (((2 * j + 1) * NKS) / (2 * RPS) != ks || task_of(k, j) >= NVP) continue;
+                        if (((2 * j + 1) * NKS) / (2 * RPS) != ks || task_of(k, j) >= NVP || (MW_DBG & 2)) continue;
                         const int m = task_of(k, j);
                         put_task(pset[k % UP][j], toff[m], sc, sh, trow[m], pb ^ 1);
                         // the task this set holds next (at least UP K-steps from now)
@@ -388,6 +415,10 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                     }
                 }
                 // ---- the MFMAs: the three terms of a product go to the same accumulator in a fixed order (small terms first) ----
+                if constexpr ((MW_DBG & 4) != 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 if constexpr (X3) {
 #pragma unroll
                     for (int m = 0; m < MB; ++m)
@@ -429,7 +460,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            wg_barrier_mw();
+            if constexpr ((MW_DBG & 16) == 0) wg_barrier_mw();
             if (!CROSS && !lastk) {
                 load_frag(0, k + 1 < KROWS ? pb : pb ^ 1, (k + 1) % KROWS, nslot, 0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -446,6 +477,10 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     // (the last K-step's barrier: all fragment reads done -- the patch buffers and the ring are dead)
 
     // ---------------- epilogue: accumulators -> LDS image of the tile -> all threads store ----------------
+    if constexpr ((MW_DBG & 32) != 0) {
+        if (a.dbg == 12345) a.bias = (const float*)&acc[0][0];     // (never true: keeps the accumulators alive)
+        return;
+    }
     float* scr = (float*)smem;                                 // [TH * 32 pixels][SCR_LD]
 #pragma unroll
     for (int q = 0; q < NBW; ++q) {
@@ -463,9 +498,10 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
     using ET = typename std::conditional<X3, float, typename std::conditional<BF, bf16_t, h16_t>::type>::type;       // store8 / load8 element tag
     const bool want_stats = a.st_raw || a.st_out;
-    float sr[8], qr[8], so[8], qo[8];
+    // statistics partials as register pairs (v_pk_add_f32 / v_pk_fma_f32): sum and sum of squares of what is stored
+    f32x2 sr[4], qr[4], so[4], qo[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { sr[e] = qr[e] = so[e] = qo[e] = 0.f; }
+    for (int e = 0; e < 4; ++e) { sr[e] = qr[e] = so[e] = qo[e] = f32x2{0.f, 0.f}; }
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         const int p = (tid + MWT * j) / G8;                    // pixel of the tile
@@ -484,7 +520,11 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                 store8<ET>((ET*)(raw_p + pix * a.raw.cs), g);
                 if (want_stats) {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) { sr[e] += g[e]; qr[e] += g[e] * g[e]; }
+                    for (int e = 0; e < 4; ++e) {
+                        const f32x2 v = {g[2 * e], g[2 * e + 1]};
+                        sr[e] += v;
+                        qr[e] = __builtin_elementwise_fma(v, v, qr[e]);
+                    }
                 }
             }
             if (res_p) {
@@ -502,7 +542,11 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
             store8<ET>((ET*)(out_p + pix * a.out.cs), f);
             if (want_stats) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { so[e] += f[e]; qo[e] += f[e] * f[e]; }
+                for (int e = 0; e < 4; ++e) {
+                    const f32x2 v = {f[2 * e], f[2 * e + 1]};
+                    so[e] += v;
+                    qo[e] = __builtin_elementwise_fma(v, v, qo[e]);
+                }
             }
         }
     }
@@ -518,10 +562,11 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
         float* red = part + NROW * RL;                         // [NSEG][RL]
         {
             float* pr = part + (tid / G8) * RL + g8 * 8;
-            *(f32x4*)(pr) = f32x4{sr[0], sr[1], sr[2], sr[3]};           *(f32x4*)(pr + 4) = f32x4{sr[4], sr[5], sr[6], sr[7]};
-            *(f32x4*)(pr + NT) = f32x4{qr[0], qr[1], qr[2], qr[3]};      *(f32x4*)(pr + NT + 4) = f32x4{qr[4], qr[5], qr[6], qr[7]};
-            *(f32x4*)(pr + 2 * NT) = f32x4{so[0], so[1], so[2], so[3]};  *(f32x4*)(pr + 2 * NT + 4) = f32x4{so[4], so[5], so[6], so[7]};
-            *(f32x4*)(pr + 3 * NT) = f32x4{qo[0], qo[1], qo[2], qo[3]};  *(f32x4*)(pr + 3 * NT + 4) = f32x4{qo[4], qo[5], qo[6], qo[7]};
+            auto park = [&](float* q, const f32x2 (&v)[4]) {
+                *(f32x4*)q = f32x4{v[0][0], v[0][1], v[1][0], v[1][1]};
+                *(f32x4*)(q + 4) = f32x4{v[2][0], v[2][1], v[3][0], v[3][1]};
+            };
+            park(pr, sr); park(pr + NT, qr); park(pr + 2 * NT, so); park(pr + 3 * NT, qo);
         }
         wg_barrier_mw();
         for (int cs = tid; cs < NSEG * RL; cs += MWT) {
@@ -578,8 +623,8 @@ int launch_mw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Which tilings of conv_pc_plan this kernel takes over.  CHORE_CONV_MW=0: none (A/B against conv_pc_kernel); CHORE_CONV_MW=all:
-// every tiling it has; default: the tilings where it measured faster (profiles/r06_conv_layer_ab.txt)
+// Which tilings of conv_pc_plan this kernel takes over: every 3x3 tiling of the fp16 x 3 mode (it measured faster or equal on every
+// layer of the encoder, profiles/r06_conv_layer_ab.txt).  CHORE_CONV_MW=0: none (A/B against conv_pc_kernel)
 bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a) {
     static const char* env = getenv("CHORE_CONV_MW");
     if (env && env[0] == '0') return false;
@@ -588,9 +633,7 @@ bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a) {
     if (a.in_st != nullptr && a.in_amax != nullptr) return false;
     const int key = (p.th * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
     const bool has = key == 812813 || key == 806432 || key == 803232 || key == 406432 || key == 403292;
-    if (!has) return false;
-    if (env && !strcmp(env, "all")) return true;
-    return key == 812813;
+    return has;
 }
 
 int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {

@@ -23,6 +23,9 @@ LAYERS = [(9, 64, 64, 256), (9, 64, 32, 256), (9, 32, 32, 256), (1, 64, 128, 256
           (9, 256, 128, 32), (9, 128, 64, 32), (9, 64, 64, 32)]
 if len(sys.argv) > 2:      # e.g. "1x1": only the layers whose label starts with it
     LAYERS = [l for l in LAYERS if ("%dx%d" % ((3, 3) if l[0] == 9 else (1, 1))).startswith(sys.argv[2])]
+import os  # noqa: E402
+if os.environ.get("CONV_AB_ONLY"):         # e.g. "256->128 @128": only the layers whose label contains it
+    LAYERS = [l for l in LAYERS if os.environ["CONV_AB_ONLY"] in "%d->%d @%d" % (l[1], l[2], l[3])]
 out = {}
 stream = torch.cuda.current_stream().cuda_stream
 for taps, cin, cout, H in LAYERS:
