@@ -618,6 +618,8 @@ def mode_query(args, ctx):
             # (rocprofv3 prints conv_pc_kernel's last template argument -- SC, the scaled-operand instantiation of the training
             # data gradients; the library's own profile classes, which name `dom` below, do not carry it)
             traffic.update({k[:-len(", false>")] + ">": v for k, v in traffic.items() if k.startswith("conv_pc_kernel<") and k.endswith(", false>")})
+            # (conv_mw_kernel's last two template arguments: GN = true, SC = false in the inference step)
+            traffic.update({k[:-len(", true, false>")] + ">": v for k, v in traffic.items() if k.startswith("conv_mw_kernel<") and k.endswith(", true, false>")})
         # rocprofv3 name of the forward query kernel this size runs (csrc/query_fwd.hip: eight-wave variant for large queries,
         # 32-point tiles when 64-point tiles would not fill the CUs)
         x3 = args.dtype in ("fp16x3", "bf16", "fp16")        # heads on the fp16 matrix cores with split operands (fp32 mode: native fp32 MFMA)

@@ -593,8 +593,11 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     const bool bf16_pc = dtype == CHORE_BF16 && !bf16_lds &&
                          (bf16_pc_all || (taps == 9 && a_in.in.C <= 128 && (long)a_in.H * a_in.W <= 128 * 128));
     if ((dtype == CHORE_F16X3 || bf16_pc) && !a_in.res2.p && conv_use_pc()) {
+        if (conv_mw_on(dtype, taps)) {
+            const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+            if (mp.th && conv_mw_covers(dtype, taps, mp, a_in)) return launch_conv_mw(h, dtype, taps, mp, a_in, s);
+        }
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
-        if (pp.th && conv_mw_covers(dtype, taps, pp, a_in)) return launch_conv_mw(h, dtype, taps, pp, a_in, s);
         if (pp.th) return launch_conv_pc(h, dtype, taps, pp, a_in, s);
     }
     ConvArgs a = a_in;

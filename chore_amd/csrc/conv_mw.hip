@@ -625,14 +625,30 @@ int launch_mw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 
 // Which tilings of conv_pc_plan this kernel takes over: every 3x3 tiling of the fp16 x 3 mode (it measured faster or equal on every
 // layer of the encoder, profiles/r06_conv_layer_ab.txt).  CHORE_CONV_MW=0: none (A/B against conv_pc_kernel)
-bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a) {
+bool conv_mw_on(int dtype, int taps) {
     static const char* env = getenv("CHORE_CONV_MW");
     if (env && env[0] == '0') return false;
-    if (dtype != CHORE_F16X3 || taps != 9 || a.res2.p) return false;
+    return dtype == CHORE_F16X3 && taps == 9;
+}
+// The tiling for a layer: conv_pc_plan's, except where a tile of all output channels over fewer rows fills the chip -- 128 output
+// channels on maps with fewer than 256 eight-row tiles (64^2 at B = 4): conv_pc_plan gives four 32-channel workgroups per 8 x 32
+// pixels, each staging the same 256-channel patch for a quarter of the MFMAs; 2 x 32 pixels x 128 channels stages 0.4 of that
+// patch once (profiles/r06_conv_layer_ab.txt)
+PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+    PcPlan p = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
+    static const bool no2 = getenv("CHORE_CONV_MW_NO_TH2") != nullptr;
+    if (!no2 && p.th && taps == 9 && Cout % 128 == 0 && p.nt < 128 && H % 2 == 0) {
+        const long tiles2 = (long)B * (H / 2) * ((W + 31) / 32) * (Cout / 128);
+        if (tiles2 >= 256) { p.th = 2; p.nt = 128; p.tps = 1; p.nslot = 3; }
+    }
+    return p;
+}
+bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a) {
+    if (!conv_mw_on(dtype, taps) || a.res2.p) return false;
     if (a.in_st == nullptr && a.in_amax == nullptr) return false;      // instantiated: GroupNorm-fused forward, scaled data gradient
     if (a.in_st != nullptr && a.in_amax != nullptr) return false;
     const int key = (p.th * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
-    const bool has = key == 812813 || key == 806432 || key == 803232 || key == 406432 || key == 403292;
+    const bool has = key == 812813 || key == 806432 || key == 803232 || key == 406432 || key == 403292 || key == 212813;
     return has;
 }
 
@@ -644,6 +660,7 @@ int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const 
                          : launch_mw_t<x3_t, 9, TH, NT, TPS, NSLOT, true, false>(h, a, s)
     switch (key) {
         MW_CASE(8, 128, 1, 3);
+        MW_CASE(2, 128, 1, 3);
         MW_CASE(8, 64, 3, 2);
         MW_CASE(8, 32, 3, 2);
         MW_CASE(4, 64, 3, 2);
