@@ -630,14 +630,14 @@ bool conv_mw_on(int dtype, int taps) {
     if (env && env[0] == '0') return false;
     return dtype == CHORE_F16X3 && taps == 9;
 }
-// The tiling for a layer: conv_pc_plan's, except where a tile of all output channels over fewer rows fills the chip -- 128 output
-// channels on maps with fewer than 256 eight-row tiles (64^2 at B = 4): conv_pc_plan gives four 32-channel workgroups per 8 x 32
-// pixels, each staging the same 256-channel patch for a quarter of the MFMAs; 2 x 32 pixels x 128 channels stages 0.4 of that
-// patch once (profiles/r06_conv_layer_ab.txt)
+// The tiling for a layer: conv_pc_plan's.  CHORE_CONV_MW_TH2=1 (experiment, measured equal: 256 -> 128 at 64^2, B = 4, 41.5 - 42.4 us
+// against 40.6 - 42.4, profiles/r06_conv_layer_ab.txt): 128 output channels on maps with fewer than 256 eight-row tiles as
+// 2 x 32 pixels x 128 channels (0.4 of the 256-channel patch staged once) instead of four 32-channel workgroups per 8 x 32 pixels
+// that each stage the whole patch -- the staging is not what bounds that layer
 PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
     PcPlan p = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
-    static const bool no2 = getenv("CHORE_CONV_MW_NO_TH2") != nullptr;
-    if (!no2 && p.th && taps == 9 && Cout % 128 == 0 && p.nt < 128 && H % 2 == 0) {
+    static const bool th2 = getenv("CHORE_CONV_MW_TH2") != nullptr;
+    if (th2 && p.th && taps == 9 && Cout % 128 == 0 && p.nt < 128 && H % 2 == 0) {
         const long tiles2 = (long)B * (H / 2) * ((W + 31) / 32) * (Cout / 128);
         if (tiles2 >= 256) { p.th = 2; p.nt = 128; p.tps = 1; p.nslot = 3; }
     }

@@ -82,7 +82,7 @@ def stat_values(cells):
 
 
 def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
-    a = run(tmp_path, LAYERS, "layers_mw", {"CHORE_CONV_MW": "all"})
+    a = run(tmp_path, LAYERS, "layers_mw", {"CHORE_CONV_MW": "all", "CHORE_CONV_MW_TH2": "1"})
     b = run(tmp_path, LAYERS, "layers_pc", {"CHORE_CONV_MW": "0"})
     n = len([k for k in a if k.startswith("y")])
     assert n == 12 and set(a) == set(b)
@@ -90,7 +90,7 @@ def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
         ya, yb = a["y%d" % i], b["y%d" % i]
         assert np.isfinite(ya).all() and np.abs(ya).max() > 0.1
         if i == 6:
-            # 256 -> 128 at 64^2, B = 4: conv_mw_plan tiles it 2 x 32 pixels x 128 channels (conv_pc_plan: 8 x 32 x 32); the order
+            # 256 -> 128 at 64^2, B = 4: with CHORE_CONV_MW_TH2 conv_mw_plan tiles it 2 x 32 pixels x 128 channels (conv_pc_plan: 8 x 32 x 32); the order
             # in which a tile walks the 32-channel chunks depends on the tile's index, so the sums differ in their rounding
             assert np.abs(ya - yb).max() <= 2e-6 * np.abs(yb).max(), np.abs(ya - yb).max()
             assert not np.array_equal(ya, yb)
