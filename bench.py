@@ -321,7 +321,8 @@ def slim_line(out, text=160):
         line["roofline"] = _pick(out["roofline"], _ROOF_KEYS, text)
     if "cpu_baseline" in out:
         line["cpu_baseline"] = _pick(out["cpu_baseline"], _CPU_KEYS, text)
-    for k in ("single_in_flight_ms_per_step", "query_ms", "encode_ms", "query_fwd_bwd_points_per_s", "query_only_points_per_s"):
+    for k in ("single_in_flight_ms_per_step", "query_ms", "encode_ms", "query_fwd_bwd_points_per_s", "query_only_points_per_s",
+              "surface_step_points_per_s"):
         if k in out:
             line[k] = _clip(out[k], text)
     for name in ("train", "fit", "fit_fp16_fields"):
@@ -557,6 +558,18 @@ def mode_query(args, ctx):
     e1.record()
     torch.cuda.synchronize()
     fb_ms = e0.elapsed_time(e1) / 10
+    # the same step as the generator issues it (Generator.approx_surface: CHORE.surface_step = chore_gen_surface_step_fused -- the
+    # distance head's forward, its clamp mask, the backward to the points and the projection in ONE launch; None in the fp32-MFMA mode)
+    surf_ms = None
+    with torch.no_grad():
+        if net.surface_step(points, cc, 0, 2.0) is not None:
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                net.surface_step(points, cc, 0, 2.0)
+            e1.record()
+            torch.cuda.synchronize()
+            surf_ms = e0.elapsed_time(e1) / 10
 
     # SURVEY 8(d) metric 1: points/s = B * N / MEDIAN latency over >= 100 hipGraph replays, (i) query forward, (ii) forward +
     # backward to the points (the generator's step), (iii) the encoder; the whole step as one graph beside them
@@ -680,6 +693,7 @@ def mode_query(args, ctx):
                     "pipelined_outputs_equal_eager": pipe_ok,
                     "query_only_points_per_s": B * N / qry_ms * 1e3,
                     "query_fwd_bwd_points_per_s": B * N / fb_ms * 1e3, "query_fwd_bwd_ms": fb_ms,
+                    "surface_step_ms": surf_ms, "surface_step_points_per_s": (B * N / surf_ms * 1e3) if surf_ms else None,
                     "encode_tflops": B * ENCODER_FLOP_PER_IMAGE_EVAL / enc_ms / 1e9,
                     "encode_flop_per_image": ENCODER_FLOP_PER_IMAGE_EVAL, "graph_replay": graph_replay, "kernels": kernels})
         if ctx.world == 1 and not args.no_cpu_baseline:

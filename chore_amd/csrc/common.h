@@ -191,6 +191,7 @@ struct QueryArgs {
     // surface step only (chore_gen_surface_step_fused): distance channel and clamp of generator.py:50-79; dpoints = the moved points
     int surf_k = 0;
     float surf_thr = 0.f;
+    int one_head = 0;       // backward with exactly one upstream gradient (query_bwd.hip, ONE): the head that has it
 };
 
 // ints per image and map of the scatter's binned point lists: up to 64 chunks of CH points (CH = ceil(N / 64) rounded up to a

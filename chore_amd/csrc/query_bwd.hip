@@ -102,13 +102,18 @@ __device__ __forceinline__ void load_masks(unsigned (&m)[4], const float* base, 
 // last lane writes the moved point  p - normalize(grad) * min(df_k, thr)  instead of the gradient.  Bit for bit what
 // chore_query_fwd -> chore_gen_clamp_mask -> chore_query_bwd_points -> chore_gen_surface_step produce, without the second
 // gather and the forward pass the backward recomputes anyway.
-template <typename T, bool TRAIN, int NCB = 2, bool STAGED = false, int NW = 4, bool X3 = false, bool SURF = false>
+template <typename T, bool TRAIN, int NCB_ = 2, bool STAGED = false, int NW = 4, bool X3 = false, bool SURF = false, bool ONE = false>
 __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) {
     static_assert(!STAGED || TRAIN, "STAGED is a training mode");
     static_assert(!SURF || (X3 && !TRAIN && NW == 4), "the surface step exists for the fp16 x 3 recompute kernels");
     static_assert(!X3 || !TRAIN || STAGED, "fp16 x 3 training reads the staged forward");
-    static_assert(NW == 4 || (NW == 8 && NCB == 1), "eight waves = two column blocks of one 32-point block each");
-    constexpr int PTS = 32 * NCB * (NW / 4), NT_ = NW * 64;
+    static_assert(NW == 4 || (NW == 8 && NCB_ == 1), "eight waves = two column blocks of one 32-point block each");
+    static_assert(!ONE || (X3 && !TRAIN && NW == 4 && NCB_ == 2), "the one-head variant: fp16 x 3 recompute kernel, 64-point tiles");
+    // ONE (round 6): exactly one head has an upstream gradient (the surface step: the distance head; a fit phase that hands over one
+    // gradient: QueryArgs::one_head).  Instead of one busy wave and three that only gather and reduce, the head's chain runs on TWO
+    // waves, one 32-point column block each (waves 0 / 1 sit on different SIMDs); same products, same order per element.
+    constexpr int PTS = 32 * NCB_ * (NW / 4), NT_ = NW * 64;
+    constexpr int NCB = ONE ? 1 : NCB_;              // column blocks per WAVE
     static_assert(!TRAIN || PTS == 64, "the training staging is written for 64-point tiles");
     if constexpr (X3) f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -133,7 +138,8 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     }
 
     const float* arena = (const float*)a.arena;
-    const int head = wid & 3, pt0 = (wid >> 2) * 32 * NCB;     // this wave's head and first point of its column blocks
+    const int head = ONE ? (SURF ? 0 : a.one_head) : (wid & 3);         // this wave's head and first point of its column blocks
+    const int pt0 = ONE ? (wid & 1) * 32 : (wid >> 2) * 32 * NCB;
     const int odim = head_out_dim(head);
     const size_t row0 = (size_t)b * a.N + n0;                    // first point of the tile in the [B*N] staging rows
     const size_t plane = (size_t)a.B * a.N * HEAD_HID;           // one (layer, head) plane of tH / tdZ
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
     // A head without an upstream gradient contributes exact zeros: its wave skips the GEMM chain and the weight traffic that
     // goes with it (1.3 MB of fragments per tile and head) and only keeps the barriers.  The generator's projection steps
     // and most fit phases hand over one or two of the four gradients.
-    const bool active = TRAIN || (SURF ? head == 0 : a.g[head] != nullptr);
+    const bool active = ONE ? wid < 2 : (TRAIN || (SURF ? head == 0 : a.g[head] != nullptr));
     // ---- forward recompute, keep ReLU sign bits only (STAGED: read them back) ----
     unsigned m1[4], m2[4], m3[4];
     f32x16 u[4][NCB], v[4][NCB];
@@ -335,8 +341,8 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
         // block rb goes to buffer rb & 1: the barrier below separates its writes from its reduction, and the reduction of
         // block rb - 1 (other buffer) from the writes of block rb + 1 -- one barrier per block instead of two, and a wave
         // multiplies its next block while the others still add
-        if (active || rb < 2) {
-            float* P = sm.P[rb & 1][head];
+        if (ONE ? active : (active || rb < 2)) {
+            float* P = sm.P[rb & 1][ONE ? 0 : head];       // (ONE: both waves write slot 0, their own columns)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma32_row(r, half);
@@ -350,7 +356,8 @@ __global__ __launch_bounds__(NW * 64, 1) void query_bwd_f32_kernel(QueryArgs a) 
             const int idx = e * NT_ + tid;  // row-major [row][pt]
             const int row = idx / PTS, pt = idx % PTS;
             const float (*Pb)[32 * PTS] = sm.P[rb & 1];
-            const float s = ((Pb[0][idx] + Pb[1][idx]) + Pb[2][idx]) + Pb[3][idx];
+            // (ONE: the other heads' exact zeros are added as constants: the same bits, sign of zero included)
+            const float s = ONE ? ((Pb[0][idx] + 0.f) + 0.f) + 0.f : ((Pb[0][idx] + Pb[1][idx]) + Pb[2][idx]) + Pb[3][idx];
             const int k = rb * 32 + row;
             if (k < QF_KPAD) sm.X[pt * XS + k] = s;
         }
@@ -480,23 +487,28 @@ static bool x3_bwd_prefers_small(int B, int N) {
     return r32 * 455 < r64 * 825;
 }
 
-template <typename T, int NCB>
+static bool query_one_head() { static const bool off = getenv("CHORE_QUERY_NO_ONE_HEAD") != nullptr; return !off; }   // A/B switch
+
+template <typename T, int NCB, bool SURF = true, bool ONE = false>
 static int launch_query_surf_n(chore_handle* h, const QueryArgs& a, hipStream_t s) {
     bool& attr_set = CHORE_ONCE_FLAG(h);
     constexpr int PTS = 32 * NCB;
     const size_t smem = sizeof(QueryBwdSmemT<PTS>);
     if (!attr_set) {
-        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, false, NCB, false, 4, true, true>,
+        CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)query_bwd_f32_kernel<T, false, NCB, false, 4, true, SURF, ONE>,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
         attr_set = true;
     }
     dim3 grid((a.N + PTS - 1) / PTS, a.B);
-    hipLaunchKernelGGL((query_bwd_f32_kernel<T, false, NCB, false, 4, true, true>), grid, dim3(256), smem, s, a);
+    hipLaunchKernelGGL((query_bwd_f32_kernel<T, false, NCB, false, 4, true, SURF, ONE>), grid, dim3(256), smem, s, a);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }
 template <typename T>
 static int launch_query_surf_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    // 64-point tiles with the chain on two waves wherever 64-point tiles fill the CUs (the 32-point rule of the backward was
+    // measured on the one-wave chain); 32-point tiles for the small queries
+    if (query_one_head() && !query_small_tiles(a.B, a.N)) return launch_query_surf_n<T, 2, true, true>(h, a, s);
     return (query_small_tiles(a.B, a.N) || x3_bwd_prefers_small(a.B, a.N)) ? launch_query_surf_n<T, 1>(h, a, s)
                                                                               : launch_query_surf_n<T, 2>(h, a, s);     // as the backward
 }
@@ -525,6 +537,17 @@ static bool query_w4() { static const bool v = getenv("CHORE_QUERY_W4") != nullp
 
 template <typename T, bool TRAIN, bool X3 = false>
 static int launch_query_bwd_t(chore_handle* h, const QueryArgs& a, hipStream_t s) {
+    if constexpr (!TRAIN && X3) {
+        // one upstream gradient (the generator's steps, most fit phases): the head's chain on two waves of a 64-point tile
+        int live = 0, which = 0;
+        for (int i = 0; i < HEAD_NUM; ++i)
+            if (a.g[i]) { ++live; which = i; }
+        if (live == 1 && query_one_head() && !query_small_tiles(a.B, a.N)) {
+            QueryArgs b = a;
+            b.one_head = which;
+            return launch_query_surf_n<T, 2, false, true>(h, b, s);
+        }
+    }
     if constexpr (!TRAIN) {
         static const bool x3_small = getenv("CHORE_QUERY_X3_BWD_SMALL") != nullptr;
         if (query_small_tiles(a.B, a.N) || (X3 && (x3_small || x3_bwd_prefers_small(a.B, a.N))))

@@ -481,7 +481,9 @@ class CHORE(nn.Module):
         from query_df / query_grad_points."""
         dtype = _QDT[self.compute_dtype]
         fwd_dtype = self._fwd_dtype(dtype)
-        if not (fwd_dtype == _lib.F16X3 or (fwd_dtype & _lib.HEADS_X3)) or os.environ.get("CHORE_GEN_FOUR_LAUNCHES"):
+        # (fp16 maps are always read by the split-operand heads, capi.hip query_x3: until round 6 this test left the fp16-fields mode
+        # -- BASELINE configs[4] -- on the four launches per step)
+        if not (fwd_dtype in (_lib.F16X3, _lib.F16) or (fwd_dtype & _lib.HEADS_X3)) or os.environ.get("CHORE_GEN_FOUR_LAUNCHES"):
             return None
         if not self.im_feat_list:
             raise RuntimeError("call filter(images) before surface_step()")

@@ -146,7 +146,7 @@ def test_approx_surface_direct_path_equals_autograd_path(gen, name, monkeypatch)
     assert float((got.detach() - ref.detach()).abs().max()) <= 1e-6 * float(step)
 
 
-@pytest.mark.parametrize("mode,name", [("bf16", "human"), ("fp16x3", "object")])
+@pytest.mark.parametrize("mode,name", [("bf16", "human"), ("fp16x3", "object"), ("fp16", "human")])
 def test_fused_surface_step_equals_the_four_launches(opt, mode, name, monkeypatch):
     """chore_gen_surface_step_fused (forward of the distance head, its own upstream gradient, backward, projection in the
     backward-to-points kernel) against chore_query_fwd -> chore_gen_clamp_mask -> chore_query_bwd_points ->
@@ -174,3 +174,52 @@ def test_fused_surface_step_equals_the_four_launches(opt, mode, name, monkeypatc
         assert torch.equal(got.detach(), ref.detach())
         for a, b in zip(got_preds, ref_preds):
             assert torch.equal(a, b)
+
+
+ONE_HEAD_DUMP = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {repo!r}); sys.path.insert(0, {repo!r} + "/tests")
+from bench import chore_opt
+from chore_amd.model import CHORE
+from chore_amd.recon.generator import Generator
+from chore_amd.utils import synth
+out = {{}}
+torch.manual_seed(11)
+for mode in ("fp16x3", "fp16", "bf16"):
+    net = CHORE(chore_opt(mode)).cuda().eval(); synth.load_synth_weights(net, 0)
+    gen = Generator(net, None, threshold=2.0, filter_val=0.004, device=torch.device("cuda"))
+    B, N = 2, 20000
+    with torch.no_grad():
+        net.filter(torch.from_numpy(synth.synth_images(B, 128, 128, 0)).cuda())
+    q = {{"crop_center": torch.tensor([synth.CROP_CENTER] * B).cuda()}}
+    pts = gen.init_samples(N, B)
+    s, preds = gen.approx_surface(net, pts.clone(), 4, q, "object")
+    out[mode + "_surf"] = s.detach().cpu().numpy()
+    g = torch.randn(B, 14, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(3))
+    out[mode + "_gparts"] = net.query_grad_points(pts, q["crop_center"], g_parts=g).cpu().numpy()     # one gradient, not the distance head's
+np.savez({path!r}, **out)
+"""
+
+
+def test_one_head_two_wave_backward_equals_the_one_wave_chain(tmp_path):
+    """round 6: with exactly one upstream gradient (the surface step; a backward with only g_parts) the head's chain runs on two
+    waves, a 32-point column block each (csrc/query_bwd.hip ONE), instead of one wave with three idle beside it.  Same products
+    in the same order per element: the moved points after 4 steps and a parts-only gradient are EQUAL BIT FOR BIT to the
+    one-wave kernels (CHORE_QUERY_NO_ONE_HEAD=1), in the fp16x3, fp16-fields and bf16 modes."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for tag, env in (("one", {}), ("old", {"CHORE_QUERY_NO_ONE_HEAD": "1"})):
+        path = str(tmp_path / ("one_head_%s.npz" % tag))
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", ONE_HEAD_DUMP.format(repo=repo, path=path)], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(dict(np.load(path)))
+    a, b = res
+    assert set(a) == set(b) and len(a) == 6
+    for k in a:
+        assert np.isfinite(a[k]).all() and np.abs(a[k]).max() > 0
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), (k, np.abs(a[k] - b[k]).max())
