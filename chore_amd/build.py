@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libchore_hip.so")
 OBJ_DIR = os.path.join(CSRC, "build")
-SOURCES = ["capi.hip", "query_fwd.hip", "query_bwd.hip", "query_scatter.hip", "encoder.hip", "conv_lds.hip", "conv_pc.hip", "conv_mw.hip", "conv_pp.hip", "conv_rw.hip", "conv_small.hip", "enc_misc.hip", "smpl_lbs.hip", "so3.hip", "contact.hip", "silhouette.hip", "collision.hip", "generator.hip", "eval_metrics.hip", "ops.hip", "train_bwd.hip", "convblock.hip", "train_loss.hip", "fit_step.hip", "fit_terms.hip", "heads_wgrad.hip", "image_prep.hip"]
+SOURCES = ["capi.hip", "query_fwd.hip", "query_bwd.hip", "query_scatter.hip", "encoder.hip", "conv_lds.hip", "conv_pc.hip", "conv_mw.hip", "conv_rw.hip", "conv_small.hip", "enc_misc.hip", "smpl_lbs.hip", "so3.hip", "contact.hip", "silhouette.hip", "collision.hip", "generator.hip", "eval_metrics.hip", "ops.hip", "train_bwd.hip", "convblock.hip", "train_loss.hip", "fit_step.hip", "fit_terms.hip", "heads_wgrad.hip", "image_prep.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-Wno-unused-result", "-Wno-pass-failed"]

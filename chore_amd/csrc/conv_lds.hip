@@ -572,13 +572,6 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
     if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
     // 1x1 (every 16-bit-operand mode): weights resident in registers, persistent workgroups (conv_rw.hip; fp16 x 3 256 -> 256 at 128^2: 64 -> 39 us)
     if (conv_rw_eligible(dtype, taps, a_in) && conv_use_pc()) return launch_conv_rw(h, dtype, a_in, s);
-    // CHORE_CONV_PP=1: the persistent variant (conv_pp.hip) where a layer has at least two tiles per CU.  Measured slower than
-    // conv_pc_kernel on every layer of the encoder (profiles/r04_conv_pp.txt): opt-in, for A/B runs and tests.
-    static const bool use_pp = getenv("CHORE_CONV_PP") != nullptr;
-    if (use_pp && (dtype == CHORE_F16X3 || dtype == CHORE_F16) && !a_in.res2.p && !a_in.in_amax && conv_use_pc()) {
-        const PpPlan qq = conv_pp_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
-        if (qq.th) return launch_conv_pp(h, dtype, taps, qq, a_in, s);
-    }
     if (dtype == CHORE_F16) {   // fp16 tensors: the specialised-wave kernel is the only implementation
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
         if (!pp.th || a_in.res2.p) CHORE_FAIL(h, CHORE_EINVAL, "conv: layer not covered in the fp16 mode (Cin=%d Cout=%d)", a_in.in.C, a_in.Cout);

@@ -263,12 +263,6 @@ int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const 
 bool conv_rw_covers(int dtype, int taps, int Cin, int Cout, bool scaled_input);   // by shape (scaled_input: ConvArgs::in_amax set)
 bool conv_rw_eligible(int dtype, int taps, const ConvArgs& a);
 int launch_conv_rw(chore_handle* h, int dtype, const ConvArgs& a, hipStream_t s);
-// persistent specialised-wave convolution (conv_pp.hip): workgroups loop over tpw tiles, the producers drain a tile's epilogue
-// while the consumers run the next tile; th = 0: not covered (fewer than two tiles per CU, or no tiling whose image fits)
-struct PpPlan { int th, nt, tps, nslot, tpw; };
-PpPlan conv_pp_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int force = 0);
-int launch_conv_pp(chore_handle* h, int dtype, int taps, const PpPlan& p, const ConvArgs& a, hipStream_t s);
-
 int launch_conv(chore_handle* h, int dtype, int taps /*1|9*/, const ConvArgs& a, hipStream_t s);
 size_t packed_conv_bytes(int dtype, int taps, int Cin, int Cout);
 // up to MAXJ weight packs and one region to clear (16-byte multiples), one launch (conv_lds.hip)

@@ -119,37 +119,24 @@ int main(int argc, char** argv) {
         CK(hipEventCreate(&e1));
         const double gflop = 2.0 * sh.taps * sh.Cin * sh.Cout * (double)px * 1e-9;
         // variant 0 = conv_lds_kernel (or conv_small), then the forced tilings of conv_pc_kernel: th * 1000 + nt
-        // 1 = the tiling conv_pc_plan picks; negative = the persistent kernel (conv_pp.hip): -1 = the tiling conv_pp_plan picks
-        const int forces9[] = {0, 1, 8128, 8064, 8032, 4064, 4032, -1, -4128, -4064, -8032, -4032};
-        const int forces1[] = {0, 1, 8128, 8064, -1, -4128};
-        const int* forces = sh.taps == 9 ? forces9 : forces1;
-        const int nforce = getenv("CONV_BENCH_PP_ONLY") ? 0 : (sh.taps == 9 ? 12 : 6);
-        const bool pp_only = getenv("CONV_BENCH_PP_ONLY") != nullptr;
+        // 1 = the tiling conv_pc_plan picks  (the persistent kernel of round 4, conv_pp.hip, was removed in round 6: slower on every
+        // layer, profiles/r04_conv_pp.txt; `git show b66b39a:chore_amd/csrc/conv_pp.hip` has it)
+        const int forces9[] = {0, 1, 8128, 8064, 8032, 4064, 4032};
+        const int forces1[] = {0, 1, 8128, 8064};
         std::vector<float> ref_out(nout), ref_raw(px * sh.Cout), got(nout);
-        (void)pp_only;
-        const int ppf9[] = {0, 1, 8128, 8064, 8032, -1, -4128, -4064, -8032, -4032}, ppf1[] = {0, 1, -1, -4128};
-        const int* fl = pp_only ? (sh.taps == 9 ? ppf9 : ppf1) : forces;
-        const int nfl = pp_only ? (sh.taps == 9 ? 10 : 4) : nforce;
+        const int* fl = sh.taps == 9 ? forces9 : forces1;
+        const int nfl = sh.taps == 9 ? 7 : 4;
         for (int fi = 0; fi < nfl; ++fi) {
             const int force = fl[fi];
             PcPlan pp{0, 0, 0, 0};
-            PpPlan qq{0, 0, 0, 0, 0};
             int vw = wgs;
             if (force > 0) {
                 pp = conv_pc_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force == 1 ? 0 : force);
                 if (!pp.th || sh.Cout % pp.nt || sh.H % pp.th) continue;
                 vw = B * (sh.H / pp.th) * (sh.W / 32) * (sh.Cout / pp.nt);
-            } else if (force < 0) {
-                qq = conv_pp_plan(dtype, sh.taps, B, sh.H, sh.W, sh.Cin, sh.Cout, force == -1 ? 0 : -force);
-                if (!qq.th || sh.Cout % qq.nt || sh.H % qq.th) continue;
-                if (sh.taps == 1 && qq.nt != 128) continue;
-                if (sh.taps == 9 && !((qq.th == 4 && (qq.nt == 128 || qq.nt == 64 || qq.nt == 32)) || (qq.th == 8 && qq.nt == 32))) continue;
-                vw = (B * (sh.H / qq.th) * (sh.W / 32) * (sh.Cout / qq.nt) + qq.tpw - 1) / qq.tpw;
-                pp.th = qq.th; pp.nt = qq.nt; pp.tps = qq.tps; pp.nslot = qq.tpw;      // (for the label: the last field shows tiles per workgroup)
             }
             auto run = [&](int dbg) -> int {
                 a.dbg = dbg | (1 << 30);
-                if (force < 0) return launch_conv_pp(h, dtype, sh.taps, qq, a, s);
                 return force ? launch_conv_pc(h, dtype, sh.taps, pp, a, s) : launch_conv(h, dtype, sh.taps, a, s);
             };
             // correctness against variant 0 (same arithmetic, another summation order over the chunks)
@@ -173,7 +160,6 @@ int main(int argc, char** argv) {
             for (int i = 0; i < 400; ++i) run(0);   // clocks up before the first timed variant (it read 5 us high without)
             double full_us = 0;
             for (size_t di = 0; di < sizeof(dbgs) / sizeof(dbgs[0]); ++di) {
-                if (force < 0 && (dbgs[di] & (16 | 4096 | 8192))) { printf(" %13s", "-"); continue; }   // switches conv_pp does not have
                 for (int i = 0; i < 5; ++i)
                     if (run(dbgs[di])) { fprintf(stderr, "%s\n", h->err.c_str()); return 1; }
                 CK(hipEventRecord(e0, s));
