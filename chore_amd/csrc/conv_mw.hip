@@ -32,6 +32,17 @@ using namespace conv_detail;
 #define MW_DBG 0
 #endif
 
+// phase time stamps (scripts/build_variant.sh stamps conv_mw.hip -DMW_STAMPS=1; scripts/conv_mw_stamps.py): thread 0 of every workgroup
+#ifdef MW_STAMPS
+__device__ unsigned long long g_mw_stamps[2048 * 8];
+#define MWSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 2048) g_mw_stamps[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+extern "C" int chore_debug_mw_stamps(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mw_stamps), sizeof(unsigned long long) * (n < 2048 * 8 ? n : 2048 * 8));
+}
+#else
+#define MWSTAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int PTW = 32;          // tile width in pixels (one MFMA pixel block)
@@ -129,6 +140,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    MWSTAMP(0);
     float in_mul = 1.f, in_inv = 1.f;                    // operand scale of a gradient input (training's data-gradient convolutions)
     if constexpr (X3 && SC) x3_in_scale(a.in_amax, in_mul, in_inv);
     const int wn = wid % WAVES_N, wm = wid / WAVES_N;
@@ -249,6 +261,23 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
 
     // ---------------- prologue: chunk 0's patch and the first NSLOT - 1 K-steps of weights ----------------
     {
+        // The statistics of this thread's channel FIRST (Cin <= 256 = one channel per thread): they are L2 hits the GroupNorm table
+        // waits for, and the vector-memory counter retires in order -- requested after the patch loads they would be waited for
+        // behind twelve HBM round trips (the prologue is 4 - 6 us of every launch: profiles/r06_conv_mw_stamps.txt)
+        unsigned long long st_lo[2] = {0ull, 0ull};
+        long long st_hi[2] = {0ll, 0ll};
+        float gam = 1.f, bet = 0.f;
+        const int gs_in = Cin / GN_GROUPS;
+        if constexpr (GN) {
+            if (tid < Cin) {
+                const GroupStat* g = a.in_st + (size_t)b * GN_GROUPS + tid / gs_in;
+                const size_t hc = act_hi_cells(a.B);
+                st_lo[0] = g->sum.lo; st_hi[0] = (&g->sum)[hc].hi;
+                st_lo[1] = g->sq.lo;  st_hi[1] = (&g->sq)[hc].hi;
+                gam = a.gamma[tid]; bet = a.beta[tid];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
         u32x4 p0[NVP][LVI];
         const int c00 = chunk_of(0) * CC;
 #pragma unroll
@@ -262,11 +291,26 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
 #pragma unroll
             for (int j = 0; j < SBV; ++j) wpro[u][j] = wb[woff[j]];
         }
-        for (int ci = tid; ci < Cin; ci += MWT) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < Cin) {       // the arithmetic of gn_scale_shift / stat_read (enc_common.h) on the values requested above
             float sc = 1.f, sh = 0.f;
-            if constexpr (GN) gn_scale_shift(a.in_st, a.B, b, Cin, ci, a.H * a.W, a.gamma, a.beta, sc, sh);
-            ss_lds[4 * (ci >> 1) + (ci & 1)] = sc;
-            ss_lds[4 * (ci >> 1) + 2 + (ci & 1)] = sh;
+            if constexpr (GN) {
+                double t[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const long long top = st_hi[k] + (long long)(st_lo[k] >> 32);
+                    t[k] = ((double)top * 0x1p32 + (double)(st_lo[k] & 0xffffffffull)) * 0x1p-40;
+                }
+                const double n = (double)(a.H * a.W) * gs_in;
+                const double mean = t[0] / n;
+                double var = t[1] / n - mean * mean;
+                if (var < 0.0) var = 0.0;
+                const float rstd = 1.0f / sqrtf((float)var + 1e-5f);
+                sc = rstd * gam;
+                sh = bet - (float)mean * sc;
+            }
+            ss_lds[4 * (tid >> 1) + (tid & 1)] = sc;
+            ss_lds[4 * (tid >> 1) + 2 + (tid & 1)] = sh;
         }
         // zero padding: the patch cells of pixels outside the image, both buffers, once
 #pragma unroll
@@ -366,6 +410,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     constexpr int NRD = (X3 ? 2 : 1) * MB + WPL * NBW, NMF = (X3 ? 3 : WPL) * MB * NBW;     // LDS reads / MFMAs of one k-step
     int slot = 0;
     wg_barrier_mw();   // chunk 0 and the first K-steps are in LDS
+    MWSTAMP(1);
     load_frag(0, 0, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 
@@ -477,6 +522,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
     // (the last K-step's barrier: all fragment reads done -- the patch buffers and the ring are dead)
 
     // ---------------- epilogue: accumulators -> LDS image of the tile -> all threads store ----------------
+    MWSTAMP(2);
     if constexpr ((MW_DBG & 32) != 0) {
         if (a.dbg == 12345) a.bias = (const float*)&acc[0][0];     // (never true: keeps the accumulators alive)
         return;
@@ -493,6 +539,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
                 scr[((wm * MB + m) * PTW + mfma32_row(r, half)) * SCR_LD + ch] = acc[m][q][r] * ASCALE + bias;
     }
     wg_barrier_mw();
+    MWSTAMP(3);
 
     ST* out_p = (ST*)a.out.p + img * a.out.cs + a.out.co + nv;
     ST* raw_p = a.raw.p ? (ST*)a.raw.p + img * a.raw.cs + a.raw.co + nv : nullptr;
@@ -551,6 +598,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
         }
     }
 
+    MWSTAMP(4);
     if (want_stats) {   // uniform over the grid
         // 256 threads x (4 sums x 8 channels) -> per-channel totals through LDS, in a fixed order: every thread parks its 32 partial
         // sums as a row segment of part[thread / G8][kind * NT + channel]; the columns are added up by all threads (a column per
@@ -597,6 +645,7 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
             }
         }
     }
+    MWSTAMP(5);
 }
 
 template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT, bool GN, bool SC>
