@@ -569,6 +569,10 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
+    if (conv_mw_on(dtype, taps) && conv_mw_fill() < 256 && !a_in.res2.p) {      // the small maps on dense conv_mw tiles (conv_mw_plan)
+        const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+        if (mp.th && conv_mw_covers(dtype, taps, mp, a_in)) return launch_conv_mw(h, dtype, taps, mp, a_in, s);
+    }
     if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
     // 1x1 (every 16-bit-operand mode): weights resident in registers, persistent workgroups (conv_rw.hip; fp16 x 3 256 -> 256 at 128^2: 64 -> 39 us)
     if (conv_rw_eligible(dtype, taps, a_in) && conv_use_pc()) return launch_conv_rw(h, dtype, a_in, s);

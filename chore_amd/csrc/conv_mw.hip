@@ -58,7 +58,9 @@ template <int TAPS, int TH_, int NT_, int TPS_, int NSLOT_, bool X3_, int WPL_> 
     static constexpr int NB = NT / 32;
     static constexpr int SB1 = TPS * KGC * NB * 1024;               // bytes of one operand plane of a K-step's weights
     static constexpr int SBYTES = WPL_ * SB1;
-    static constexpr int NBW = NT >= 64 ? 2 : 1;                    // channel blocks per wave
+    // channel blocks per wave: two where a wave then still has a pixel block of its own (a two-row tile of 64 channels splits into
+    // 2 x 2 single blocks)
+    static constexpr int NBW = NT >= 128 ? 2 : (NT == 64 ? (TH_ >= 4 ? 2 : 1) : 1);
     static constexpr int WAVES_N = NB / NBW, WAVES_M = 4 / WAVES_N, MB = TH / WAVES_M;
     static constexpr int SCR_LD = NT + 4;                           // epilogue image: floats per pixel
     static constexpr int G8 = NT / 8;                               // 8-channel groups per pixel
@@ -651,12 +653,22 @@ __global__ __launch_bounds__(MWT, 1) void conv_mw_kernel(ConvArgs a) {
 template <typename T, int TAPS, int TH, int NT, int TPS, int NSLOT, bool GN, bool SC>
 int launch_mw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     using G = MGeo<TAPS, TH, NT, TPS, NSLOT, IS_X3<T>, std::is_same<T, bf16_t>::value ? 1 : 2>;
-    const size_t smem = G::smem_bytes(a.in.C);
+    size_t smem = G::smem_bytes(a.in.C);
     if (h->lds_per_cu <= 0) {
         CHORE_HIP_CHECK(h, hipDeviceGetAttribute(&h->lds_per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, h->device));
         if (h->lds_per_cu <= 0) h->lds_per_cu = 160 * 1024;
     }
     if (smem > (size_t)h->lds_per_cu) CHORE_FAIL(h, CHORE_EINVAL, "conv_mw: %zu bytes of LDS, the CU has %d", smem, h->lds_per_cu);
+    // The workgroup takes ALL of the CU's LDS, whatever its tiling needs: no other workgroup that uses LDS -- of this kernel or of any
+    // other -- shares the CU with it.  Round 6 measured why (scripts/pipe_stress.py, profiles/r06_pipe_stress.txt): with the small
+    // tilings (2 x 32 x 64: 64 KB) requesting what they need, or half the CU + 1 KB like conv_pc_kernel, a fit that runs on another
+    // stream BESIDE an encoder pass came out with different bits in 10 - 20 % of the batches (the fit's kernels, not the
+    // convolution: the encoder's maps were equal); 128 KB: 1 of 128; 160 KB: 0 of 128.  conv_pc_kernel never shared a CU either
+    // (8 waves x 256 registers).  What exactly goes wrong when LDS-using workgroups of other kernels sit beside these four
+    // 1-wave-per-SIMD MFMA waves is NOT understood; the cost of the exclusion is nil inside the kernel.
+    static const size_t lds_min_env = getenv("CHORE_CONV_MW_LDS_MIN") ? (size_t)atol(getenv("CHORE_CONV_MW_LDS_MIN")) : 0;   // experiments
+    const size_t lds_min = lds_min_env ? lds_min_env : (size_t)h->lds_per_cu;
+    if (smem < lds_min) smem = lds_min;
     bool& attr = CHORE_ONCE_FLAG(h);
     if (!attr) {
         CHORE_HIP_CHECK(h, hipFuncSetAttribute((const void*)conv_mw_kernel<T, TAPS, TH, NT, TPS, NSLOT, GN, SC>,
@@ -674,6 +686,10 @@ int launch_mw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 
 // Which tilings of conv_pc_plan this kernel takes over: every 3x3 tiling of the fp16 x 3 mode (it measured faster or equal on every
 // layer of the encoder, profiles/r06_conv_layer_ab.txt).  CHORE_CONV_MW=0: none (A/B against conv_pc_kernel)
+int conv_mw_fill() {
+    static const int v = getenv("CHORE_CONV_MW_FILL") ? atoi(getenv("CHORE_CONV_MW_FILL")) : 128;
+    return v > 0 ? v : 256;
+}
 bool conv_mw_on(int dtype, int taps) {
     static const char* env = getenv("CHORE_CONV_MW");
     if (env && env[0] == '0') return false;
@@ -690,15 +706,37 @@ PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout)
         const long tiles2 = (long)B * (H / 2) * ((W + 31) / 32) * (Cout / 128);
         if (tiles2 >= 256) { p.th = 2; p.nt = 128; p.tps = 1; p.nslot = 3; }
     }
+    // A layer too small to give every CU a full tile (the 64^2 and 32^2 maps at B = 4) takes the WIDEST tile that still yields
+    // CHORE_CONV_MW_FILL workgroups (default 128 = half the CUs) instead of the narrowest that yields 256 -- fewer, denser workgroups:
+    // the same launch time on half of the CUs, the other half free for the other step in flight (two in flight 4.24 -> 3.99 ms, one
+    // at a time 5.03 -> 5.06; 64: 4.03 / 5.47; profiles/r06_conv_fill.txt).  Also takes the 32^2 maps over from conv_small_kernel.
+    // CHORE_CONV_MW_FILL=256: a tile per CU as conv_pc_plan has it.
+    const int fill = conv_mw_fill();
+    if (fill < 256 && taps == 9 && conv_mw_on(dtype, taps) && Cin % 32 == 0 && W % 32 == 0) {
+        const long px8 = (long)B * ((H + 7) / 8) * (W / 32);
+        if (px8 * (Cout / 32) < 256 || !p.th || (p.th == 4 && p.nt == 32) || (p.th == 8 && p.nt == 32 && px8 * (Cout / 32) < 512)) {
+            static const int cand[][4] = {{8, 128, 1, 3}, {4, 128, 1, 3}, {2, 128, 1, 3}, {8, 64, 3, 2}, {4, 64, 3, 2}, {2, 64, 1, 3},
+                                          {8, 32, 3, 2}, {4, 32, 9, 2}};
+            static const char* skip = getenv("CHORE_CONV_MW_SKIP");      // experiments: "th*1000+nt[,...]" tilings left out
+            for (const auto& c : cand) {
+                if (Cout % c[1] || H % c[0]) continue;
+                if (skip) { char key[16]; snprintf(key, sizeof key, "%d", c[0] * 1000 + c[1]); if (strstr(skip, key)) continue; }
+                const long wgs = (long)B * (H / c[0]) * (W / 32) * (Cout / c[1]);
+                if (wgs >= fill) { p.th = c[0]; p.nt = c[1]; p.tps = c[2]; p.nslot = c[3]; break; }
+            }
+        }
+    }
     return p;
+}
+bool conv_mw_has(const PcPlan& p) {
+    const int key = (p.th * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
+    return key == 812813 || key == 806432 || key == 803232 || key == 406432 || key == 403292 || key == 212813 || key == 412813 || key == 206413;
 }
 bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a) {
     if (!conv_mw_on(dtype, taps) || a.res2.p) return false;
     if (a.in_st == nullptr && a.in_amax == nullptr) return false;      // instantiated: GroupNorm-fused forward, scaled data gradient
     if (a.in_st != nullptr && a.in_amax != nullptr) return false;
-    const int key = (p.th * 1000 + p.nt) * 100 + p.tps * 10 + p.nslot;
-    const bool has = key == 812813 || key == 806432 || key == 803232 || key == 406432 || key == 403292 || key == 212813;
-    return has;
+    return conv_mw_has(p);
 }
 
 int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s) {
@@ -709,7 +747,9 @@ int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const 
                          : launch_mw_t<x3_t, 9, TH, NT, TPS, NSLOT, true, false>(h, a, s)
     switch (key) {
         MW_CASE(8, 128, 1, 3);
+        MW_CASE(4, 128, 1, 3);
         MW_CASE(2, 128, 1, 3);
+        MW_CASE(2, 64, 1, 3);
         MW_CASE(8, 64, 3, 2);
         MW_CASE(8, 32, 3, 2);
         MW_CASE(4, 64, 3, 2);

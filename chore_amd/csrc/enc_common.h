@@ -255,8 +255,10 @@ PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout,
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
 // the same tilings with the staging work inside the MFMA-issuing waves (conv_mw.hip, round 6): four waves, one per SIMD, no producers
+int conv_mw_fill();                     // CHORE_CONV_MW_FILL: minimum workgroups a tiling must yield (default 256 = a tile per CU)
 bool conv_mw_on(int dtype, int taps);   // by mode: fp16 x 3, 3x3, not switched off (CHORE_CONV_MW=0)
 PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // conv_pc_plan's tiling, or one only this kernel has
+bool conv_mw_has(const PcPlan& p);      // an instantiation for this tiling exists
 bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a);
 int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 // 1x1 layers (fp16 x 3, fp16, bf16) with register-resident weights (conv_rw.hip): persistent workgroups over runs of pixel blocks

@@ -174,7 +174,7 @@ struct RunCtx {
 
 // one class per kernel instantiation, named like the kernel in a rocprofv3 trace so that bench.py's live
 // hipEvent numbers can be checked against profiles/*_kernel_stats.csv line by line
-enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_PC_FIRST = K_CONV_FIRST + 11, K_RW = K_PC_FIRST + 7, K_MW_FIRST = K_RW + 1, K_NUM = K_MW_FIRST + 6 };
+enum KClass { K_STEM = 0, K_GN_STATS, K_GN_APPLY, K_POOL, K_UPADD, K_CONV_FIRST, K_PC_FIRST = K_CONV_FIRST + 11, K_RW = K_PC_FIRST + 7, K_MW_FIRST = K_RW + 1, K_NUM = K_MW_FIRST + 8 };
 const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_apply_relu_kernel", "map_stats_kernel<T,C,PoolOp>",
                                          "map_stats_kernel<T,C,UpAddOp>", "conv_lds_kernel<T,9,128,3>", "conv_lds_kernel<T,9,64,3>",
                                          "conv_lds_kernel<T,9,32,3>", "conv_lds_kernel<T,9,64,9>",
@@ -185,7 +185,8 @@ const char* const kclass_names[K_NUM] = {"stem_kernel", "gn_stats_kernel", "gn_a
                                          "conv_pc_kernel<T,9,8,32,3,2>", "conv_pc_kernel<T,9,4,64,3,2>", "conv_pc_kernel<T,9,4,32,9,2>",
                                          "conv_pc_kernel<T,1,8,128,1,2>", "conv_pc_kernel<T,1,8,64,1,2>", "conv_rw_kernel<KC,WN,RES,SC>",
                                          "conv_mw_kernel<T,9,8,128,1,3>", "conv_mw_kernel<T,9,8,64,3,2>", "conv_mw_kernel<T,9,8,32,3,2>",
-                                         "conv_mw_kernel<T,9,4,64,3,2>", "conv_mw_kernel<T,9,4,32,9,2>", "conv_mw_kernel<T,9,2,128,1,3>"};
+                                         "conv_mw_kernel<T,9,4,64,3,2>", "conv_mw_kernel<T,9,4,32,9,2>", "conv_mw_kernel<T,9,2,128,1,3>",
+                                         "conv_mw_kernel<T,9,4,128,1,3>", "conv_mw_kernel<T,9,2,64,1,3>"};
 inline int conv_class(const ConvPlan& p, int taps) {
     if (p.tps == 0) return K_CONV_FIRST + 8 + (p.small_cin == 64 ? 0 : (p.small_cin == 128 ? 1 : 2));
     const int ni = p.nt == 128 ? 0 : (p.nt == 64 ? 1 : 2);
@@ -195,16 +196,21 @@ inline int conv_class(const ConvPlan& p, int taps) {
 }
 // class of the kernel launch_conv will pick for a layer (the specialised-wave kernel where it covers the layer)
 inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+    if (conv_mw_on(dtype, taps)) {   // as launch_conv: conv_mw_kernel's own tiling first (it also takes the small maps, CHORE_CONV_MW_FILL)
+        const PcPlan mp = conv_mw_plan(dtype, taps, B, H, W, Cin, Cout);
+        if (mp.th && conv_mw_has(mp) && (conv_mw_fill() < 256 || !conv_small_eligible(dtype, taps, H, W, Cin, Cout))) {
+            if (mp.th == 8) return K_MW_FIRST + (mp.nt == 128 ? 0 : (mp.nt == 64 ? 1 : 2));
+            if (mp.th == 4) return K_MW_FIRST + (mp.nt == 128 ? 6 : (mp.nt == 64 ? 3 : 4));
+            return K_MW_FIRST + (mp.nt == 128 ? 5 : 7);
+        }
+    }
     if (conv_rw_covers(dtype, taps, Cin, Cout, false) && conv_use_pc() && !conv_small_eligible(dtype, taps, H, W, Cin, Cout)) return K_RW;
     if ((dtype == CHORE_F16 || (dtype == CHORE_F16X3 && conv_use_pc())) && !conv_small_eligible(dtype, taps, H, W, Cin, Cout)) {
         const PcPlan pp = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
         if (pp.th) {
             if (taps == 1) return K_PC_FIRST + (pp.nt == 128 ? 5 : 6);
-            // (the encoder's 3x3 layers all carry a fused GroupNorm and one residual at most: what conv_mw_covers asks of the launch)
-            const int first = conv_mw_on(dtype, taps) ? K_MW_FIRST : K_PC_FIRST;
-            if (conv_mw_on(dtype, taps) && conv_mw_plan(dtype, taps, B, H, W, Cin, Cout).th == 2) return K_MW_FIRST + 5;
-            if (pp.th == 8) return first + (pp.nt == 128 ? 0 : (pp.nt == 64 ? 1 : 2));
-            return first + (pp.nt == 64 ? 3 : 4);
+            if (pp.th == 8) return K_PC_FIRST + (pp.nt == 128 ? 0 : (pp.nt == 64 ? 1 : 2));
+            return K_PC_FIRST + (pp.nt == 64 ? 3 : 4);
         }
     }
     return conv_class(conv_plan(dtype, taps, B, H, W, Cin, Cout), taps);

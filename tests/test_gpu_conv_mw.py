@@ -3,7 +3,8 @@ inside the MFMA-issuing waves -- against conv_pc_kernel, the specialised-wave ke
 
 The kernel choice is an environment switch the library reads once per process (CHORE_CONV_MW=0: conv_pc_kernel everywhere, =all:
 conv_mw_kernel on every tiling it has), so each variant runs in a process of its own and the results are compared here:
-  * single layers through chore_conv2d_fwd at every tiling (8 x 32 x 128 / 64 / 32, 4 x 32 x 64 / 32), whole and ragged maps: the two
+  * single layers through chore_conv2d_fwd at every tiling conv_pc_plan has (8 x 32 x 128 / 64 / 32, 4 x 32 x 64 / 32; CHORE_CONV_MW_FILL=256
+    keeps conv_mw_plan on them), whole and ragged maps: the two
     kernels add the same products to the same accumulators in the same order, so the OUTPUT must be equal BIT FOR BIT; the GroupNorm
     statistics of the output are reduced from different partial sums (256 instead of 512 threads): equal to fp32 summation order;
   * the whole encoder (every stack's feature map, tmpx, normx), residual and raw-copy paths included: the statistics' last bits move
@@ -82,8 +83,9 @@ def stat_values(cells):
 
 
 def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
-    a = run(tmp_path, LAYERS, "layers_mw", {"CHORE_CONV_MW": "all", "CHORE_CONV_MW_TH2": "1"})
+    a = run(tmp_path, LAYERS, "layers_mw", {"CHORE_CONV_MW": "all", "CHORE_CONV_MW_TH2": "1", "CHORE_CONV_MW_FILL": "256"})
     b = run(tmp_path, LAYERS, "layers_pc", {"CHORE_CONV_MW": "0"})
+    c = run(tmp_path, LAYERS, "layers_mw_default", {})            # the default tilings (CHORE_CONV_MW_FILL = 128: dense tiles on small maps)
     n = len([k for k in a if k.startswith("y")])
     assert n == 12 and set(a) == set(b)
     for i in range(n):
@@ -100,6 +102,15 @@ def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
         assert np.abs(sa - sb).max() <= 2e-6 * np.abs(sb).max(), (i, np.abs(sa - sb).max(), np.abs(sb).max())
     # the switch did something: at least one layer's statistics differ in their last bits
     assert any(not np.array_equal(a["s%d" % i], b["s%d" % i]) for i in range(n))
+    # default tilings: where conv_mw_plan picks another tile the chunk order differs, hence the rounding; same values otherwise
+    other = 0
+    for i in range(n):
+        yc, yb = c["y%d" % i], b["y%d" % i]
+        assert np.abs(yc - yb).max() <= 2e-6 * np.abs(yb).max(), (i, np.abs(yc - yb).max())
+        sc, sb = stat_values(c["s%d" % i]), stat_values(b["s%d" % i])
+        assert np.abs(sc - sb).max() <= 2e-6 * np.abs(sb).max(), i
+        other += int(not np.array_equal(yc, yb))
+    assert other >= 3                # the 64^2 maps at B = 4 and the 128-channel layer at B = 2 run on other tiles
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 80, 112), (4, 512, 512)])

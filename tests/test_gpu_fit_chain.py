@@ -529,3 +529,19 @@ def test_pipelined_fit_recon_equals_the_serial_loop_bit_for_bit(opt):
                 assert torch.isfinite(b[name]).all(), (mode, k, name)
                 assert torch.equal(a[name], b[name]), (mode, k, name, float((a[name] - b[name]).abs().max()))
     assert not torch.equal(res[True][0]["obj_t"], res[True][1]["obj_t"])      # different batches, different fits
+
+
+def test_pipelined_fit_beside_encoder_passes_stays_bit_equal_over_many_batches():
+    """round 6: four pipelined fit_recon runs of 12 one-frame batches in ONE process against the serial loop (scripts/pipe_stress.py):
+    the maps, the point clouds, the SMPL-H initialisation, optimize_smpl's result and the fitted pose of every batch EQUAL.  The
+    five-batch test above passed while this failed in 10 - 20 % of the batches from the fourth run on, when conv_mw_kernel's small
+    tilings let LDS-using workgroups of the fit's kernels share CUs with the encoder's (csrc/conv_mw.hip launch_mw_t: the workgroup
+    now takes the CU's whole LDS)."""
+    import os
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(repo, "scripts", "pipe_stress.py"), "12", "4"], capture_output=True, text=True,
+                       timeout=900, cwd=repo)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "mismatching (round, batch) pairs: 0 of 48" in r.stdout, r.stdout[-1500:]
