@@ -569,8 +569,8 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
         if (c % GN_GROUPS || gs > 8 || (gs & (gs - 1)))
             CHORE_FAIL(h, CHORE_EINVAL, "conv: GroupNorm over %d channels unsupported (group size must be 1, 2, 4 or 8)", c);
     }
-    if (conv_mw_on(dtype, taps) && conv_mw_fill() < 256 && !a_in.res2.p) {      // the small maps on dense conv_mw tiles (conv_mw_plan)
-        const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+    if (conv_mw_on(dtype, taps) && conv_mw_fill(a_in.fill) < 256 && !a_in.res2.p) {      // the small maps on dense conv_mw tiles (conv_mw_plan)
+        const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout, a_in.fill);
         if (mp.th && conv_mw_covers(dtype, taps, mp, a_in)) return launch_conv_mw(h, dtype, taps, mp, a_in, s);
     }
     if (conv_small_eligible(dtype, taps, a_in.H, a_in.W, a_in.in.C, a_in.Cout)) return launch_conv_small(h, dtype, a_in, s);
@@ -591,7 +591,7 @@ int launch_conv(chore_handle* h, int dtype, int taps, const ConvArgs& a_in, hipS
                          (bf16_pc_all || (taps == 9 && a_in.in.C <= 128 && (long)a_in.H * a_in.W <= 128 * 128));
     if ((dtype == CHORE_F16X3 || bf16_pc) && !a_in.res2.p && conv_use_pc()) {
         if (conv_mw_on(dtype, taps)) {
-            const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);
+            const PcPlan mp = conv_mw_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout, a_in.fill);
             if (mp.th && conv_mw_covers(dtype, taps, mp, a_in)) return launch_conv_mw(h, dtype, taps, mp, a_in, s);
         }
         const PcPlan pp = conv_pc_plan(dtype, taps, a_in.B, a_in.H, a_in.W, a_in.in.C, a_in.Cout);

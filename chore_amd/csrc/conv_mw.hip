@@ -686,8 +686,9 @@ int launch_mw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
 
 // Which tilings of conv_pc_plan this kernel takes over: every 3x3 tiling of the fp16 x 3 mode (it measured faster or equal on every
 // layer of the encoder, profiles/r06_conv_layer_ab.txt).  CHORE_CONV_MW=0: none (A/B against conv_pc_kernel)
-int conv_mw_fill() {
-    static const int v = getenv("CHORE_CONV_MW_FILL") ? atoi(getenv("CHORE_CONV_MW_FILL")) : 128;
+int conv_mw_fill(int asked) {
+    static const int env = getenv("CHORE_CONV_MW_FILL") ? atoi(getenv("CHORE_CONV_MW_FILL")) : 0;
+    const int v = env > 0 ? env : asked;
     return v > 0 ? v : 256;
 }
 bool conv_mw_on(int dtype, int taps) {
@@ -699,7 +700,7 @@ bool conv_mw_on(int dtype, int taps) {
 // against 40.6 - 42.4, profiles/r06_conv_layer_ab.txt): 128 output channels on maps with fewer than 256 eight-row tiles as
 // 2 x 32 pixels x 128 channels (0.4 of the 256-channel patch staged once) instead of four 32-channel workgroups per 8 x 32 pixels
 // that each stage the whole patch -- the staging is not what bounds that layer
-PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
+PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int fill_asked) {
     PcPlan p = conv_pc_plan(dtype, taps, B, H, W, Cin, Cout);
     static const bool th2 = getenv("CHORE_CONV_MW_TH2") != nullptr;
     if (th2 && p.th && taps == 9 && Cout % 128 == 0 && p.nt < 128 && H % 2 == 0) {
@@ -707,11 +708,11 @@ PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout)
         if (tiles2 >= 256) { p.th = 2; p.nt = 128; p.tps = 1; p.nslot = 3; }
     }
     // A layer too small to give every CU a full tile (the 64^2 and 32^2 maps at B = 4) takes the WIDEST tile that still yields
-    // CHORE_CONV_MW_FILL workgroups (default 128 = half the CUs) instead of the narrowest that yields 256 -- fewer, denser workgroups:
+    // `fill` workgroups (ConvArgs::fill; the inference encoder asks for 128 = half the CUs) instead of the narrowest that yields 256 -- fewer, denser workgroups:
     // the same launch time on half of the CUs, the other half free for the other step in flight (two in flight 4.24 -> 3.99 ms, one
     // at a time 5.03 -> 5.06; 64: 4.03 / 5.47; profiles/r06_conv_fill.txt).  Also takes the 32^2 maps over from conv_small_kernel.
     // CHORE_CONV_MW_FILL=256: a tile per CU as conv_pc_plan has it.
-    const int fill = conv_mw_fill();
+    const int fill = conv_mw_fill(fill_asked);
     if (fill < 256 && taps == 9 && conv_mw_on(dtype, taps) && Cin % 32 == 0 && W % 32 == 0) {
         const long px8 = (long)B * ((H + 7) / 8) * (W / 32);
         if (px8 * (Cout / 32) < 256 || !p.th || (p.th == 4 && p.nt == 32) || (p.th == 8 && p.nt == 32 && px8 * (Cout / 32) < 512)) {

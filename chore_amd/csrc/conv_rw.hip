@@ -354,7 +354,11 @@ int launch_rw_t(chore_handle* h, const ConvArgs& a, hipStream_t s) {
     }
     // one persistent workgroup per CU: every image's blocks are dealt to cu / B workgroups in contiguous runs
     const int nblk = (a.H * a.W + G::MPX - 1) / G::MPX;
-    int wpi = h->cu_count / a.B;
+    // ... on THREE QUARTERS of the CUs (CHORE_CONV_RW_CUS=n: n): these layers are bound by HBM, 192 workgroups move the bytes as fast
+    // as 256 (one step at a time 4.99 -> 4.86 ms) and the other step in flight gets a quarter of the chip for its MFMA-bound
+    // convolutions meanwhile (two in flight 4.01 -> 3.87 ms; 224 / 160 / 128: 3.91 / 3.86 / 3.90; profiles/r06_conv_fill.txt)
+    static const int cus_env = getenv("CHORE_CONV_RW_CUS") ? atoi(getenv("CHORE_CONV_RW_CUS")) : 0;
+    int wpi = (cus_env > 0 ? cus_env : (h->cu_count * 3) / 4) / a.B;
     if (wpi < 1) wpi = 1;
     if (wpi > nblk) wpi = nblk;
     const int bpw = (nblk + wpi - 1) / wpi;

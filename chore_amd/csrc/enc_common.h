@@ -190,6 +190,10 @@ struct ConvArgs {
     // kernel multiplies the operand by the power of two that brings the maximum to 2^13 .. 2^14 before the hi / lo split (fp16
     // keeps 22 bits of a pair only above 2^-3) and the accumulators by its inverse.  NULL: operand taken as is.
     const unsigned* in_amax = nullptr;
+    // minimum number of workgroups the tiling of a small layer must yield (conv_mw_plan): 0 = a tile per CU (256).  The inference
+    // encoder passes CONV_MW_FILL_INFER: half the CUs per launch, the other half for the other step in flight; training's operators
+    // leave 0 (measured: 29.15 against 29.55 ms per step with the dense tiles, profiles/r06_conv_fill.txt)
+    int fill = 0;
     unsigned long long* dbg_ticks = nullptr;   // CHORE_CONV_ABLATE builds: phase time stamps of workgroup 0 (conv_pc.hip)
     int dbg = 0;   // ablation bits for kernel experiments (CHORE_CONV_DBG): 1 no weight loads, 2 no patch
                    // prefetch, 4 no MFMA, 8 no epilogue -- results are wrong when set
@@ -255,9 +259,10 @@ PcPlan conv_pc_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout,
 int launch_conv_pc(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);
 bool conv_use_pc();
 // the same tilings with the staging work inside the MFMA-issuing waves (conv_mw.hip, round 6): four waves, one per SIMD, no producers
-int conv_mw_fill();                     // CHORE_CONV_MW_FILL: minimum workgroups a tiling must yield (default 256 = a tile per CU)
+constexpr int CONV_MW_FILL_INFER = 128;
+int conv_mw_fill(int asked);            // the `fill` a launch gets: CHORE_CONV_MW_FILL if set (every launch), else asked (0 -> 256)
 bool conv_mw_on(int dtype, int taps);   // by mode: fp16 x 3, 3x3, not switched off (CHORE_CONV_MW=0)
-PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout);   // conv_pc_plan's tiling, or one only this kernel has
+PcPlan conv_mw_plan(int dtype, int taps, int B, int H, int W, int Cin, int Cout, int fill);   // conv_pc_plan's tiling, or one only this kernel has
 bool conv_mw_has(const PcPlan& p);      // an instantiation for this tiling exists
 bool conv_mw_covers(int dtype, int taps, const PcPlan& p, const ConvArgs& a);
 int launch_conv_mw(chore_handle* h, int dtype, int taps, const PcPlan& p, const ConvArgs& a, hipStream_t s);

@@ -197,8 +197,8 @@ inline int conv_class(const ConvPlan& p, int taps) {
 // class of the kernel launch_conv will pick for a layer (the specialised-wave kernel where it covers the layer)
 inline int conv_class_of(int dtype, int taps, int B, int H, int W, int Cin, int Cout) {
     if (conv_mw_on(dtype, taps)) {   // as launch_conv: conv_mw_kernel's own tiling first (it also takes the small maps, CHORE_CONV_MW_FILL)
-        const PcPlan mp = conv_mw_plan(dtype, taps, B, H, W, Cin, Cout);
-        if (mp.th && conv_mw_has(mp) && (conv_mw_fill() < 256 || !conv_small_eligible(dtype, taps, H, W, Cin, Cout))) {
+        const PcPlan mp = conv_mw_plan(dtype, taps, B, H, W, Cin, Cout, CONV_MW_FILL_INFER);
+        if (mp.th && conv_mw_has(mp) && (conv_mw_fill(CONV_MW_FILL_INFER) < 256 || !conv_small_eligible(dtype, taps, H, W, Cin, Cout))) {
             if (mp.th == 8) return K_MW_FIRST + (mp.nt == 128 ? 0 : (mp.nt == 64 ? 1 : 2));
             if (mp.th == 4) return K_MW_FIRST + (mp.nt == 128 ? 6 : (mp.nt == 64 ? 3 : 4));
             return K_MW_FIRST + (mp.nt == 128 ? 5 : 7);
@@ -386,6 +386,7 @@ struct Builder {
         push([=](RunCtx& r) {
             if (r.rc) return;
             ConvArgs a{};
+            a.fill = CONV_MW_FILL_INFER;
             a.in = view(r, cs.in, 0, cs.in_C);
             if (use_gn) {
                 a.in_st = (const GroupStat*)(r.stats + cs.in.st_off);

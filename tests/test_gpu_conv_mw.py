@@ -85,7 +85,7 @@ def stat_values(cells):
 def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
     a = run(tmp_path, LAYERS, "layers_mw", {"CHORE_CONV_MW": "all", "CHORE_CONV_MW_TH2": "1", "CHORE_CONV_MW_FILL": "256"})
     b = run(tmp_path, LAYERS, "layers_pc", {"CHORE_CONV_MW": "0"})
-    c = run(tmp_path, LAYERS, "layers_mw_default", {})            # the default tilings (CHORE_CONV_MW_FILL = 128: dense tiles on small maps)
+    c = run(tmp_path, LAYERS, "layers_mw_dense", {"CHORE_CONV_MW_FILL": "128"})     # the inference encoder's tilings: dense tiles on small maps
     n = len([k for k in a if k.startswith("y")])
     assert n == 12 and set(a) == set(b)
     for i in range(n):
@@ -102,7 +102,7 @@ def test_layers_equal_conv_pc_bit_for_bit(tmp_path):
         assert np.abs(sa - sb).max() <= 2e-6 * np.abs(sb).max(), (i, np.abs(sa - sb).max(), np.abs(sb).max())
     # the switch did something: at least one layer's statistics differ in their last bits
     assert any(not np.array_equal(a["s%d" % i], b["s%d" % i]) for i in range(n))
-    # default tilings: where conv_mw_plan picks another tile the chunk order differs, hence the rounding; same values otherwise
+    # dense tilings (what the inference encoder asks for, ConvArgs::fill = 128): where conv_mw_plan picks another tile the chunk order differs, hence the rounding; same values otherwise
     other = 0
     for i in range(n):
         yc, yb = c["y%d" % i], b["y%d" % i]
