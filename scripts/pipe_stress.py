@@ -1,6 +1,6 @@
 """stress of fit_recon(pipeline=True) against the serial loop: N loader batches of one frame, per batch the checksums of what the
 preparation produced (last feature map, tmpx, both point clouds) and the fitted pose -- which stage differs first when the two loops
-disagree?   usage: pipe_stress.py [batches] [rounds]"""
+disagree?   usage: pipe_stress.py [batches] [rounds]      STRESS_CHAINS=1: fit_recon(pipeline="chains") instead; STRESS_EAGER=1: eager inner steps"""
 import copy, os, sys, torch
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, R + "/tests")
 import bench
@@ -25,8 +25,11 @@ def run(pipe):
     gen = Generator(net, None, threshold=2.0, sparse_thres=0.03, filter_val=1.0, device=dev)
     rec = {}
     orig = fitter.prepare_batch
+    import threading
+    cur = {}                      # batch index by preparing / optimising thread (chains: a thread per chain; pipelined: optimise_batch below)
     def prep(data, generator, index=None):
         out = orig(data, generator, index=index)
+        out["_index"] = index
         m = generator.model
         rec[index] = [m.im_feat_list[-1].double().sum(), m.tmpx.double().sum(), out["pc"]["human"]["points"].double().sum(),
                       out["pc"]["object"]["points"].double().sum()]
@@ -34,15 +37,20 @@ def run(pipe):
     fitter.prepare_batch = prep
     stage = {}
     o_smpl, o_obj = fitter.optimize_smpl, fitter.init_obj_fit_data
+    o_optb = fitter.optimise_batch
+    def optb(prep_, *a, **k):
+        cur[threading.get_ident()] = prep_["_index"]
+        return o_optb(prep_, *a, **k)
+    fitter.optimise_batch = optb
     def opt_smpl(smpl, betas_dict, **kw):
-        key = len(stage)
+        key = cur[threading.get_ident()]
         pre = [smpl.pose.detach().double().sum(), smpl.betas.detach().double().sum(), smpl.trans.detach().double().sum()]
         out = o_smpl(smpl, betas_dict, **kw)
         stage[key] = pre + [out[0].pose.detach().double().sum(), out[0].trans.detach().double().sum()]
         return out
     def init_obj(*a, **k):
         out = o_obj(*a, **k)
-        stage[len(stage) - 1] += [out[0].detach().double().sum(), out[2].detach().double().sum()]
+        stage[cur[threading.get_ident()]] += [out[0].detach().double().sum(), out[2].detach().double().sum()]
         return out
     fitter.optimize_smpl, fitter.init_obj_fit_data = opt_smpl, init_obj
     torch.manual_seed(3)
@@ -60,7 +68,7 @@ for r in range(ROUNDS):
             del _lib._handles[k]
     import threading
     print("round", r, "handles:", [k if isinstance(k, int) else hex(k[1] & 0xffffff) for k in __import__("chore_amd")._lib._handles], "threads", threading.active_count(), flush=True)
-    rec, pose = run(True)
+    rec, pose = run("chains" if os.environ.get("STRESS_CHAINS") else True)
     for k in range(NB):
         names = ("feat", "tmpx", "pc_human", "pc_object", "init_pose", "init_betas", "init_trans", "smpl_pose", "smpl_trans", "obj_R0", "obj_t0")
         d = [n for n, a, b in zip(names, ref_rec[k], rec[k]) if a != b]
