@@ -292,6 +292,12 @@ int launch_pack_conv(chore_handle* h, int dtype, int taps, int Cin, int Cout, co
 int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin, int H, int W,
                 const float* wk /*[Cin*49][64]*/, const float* bias, void* out /*(B,H/2,W/2,64)*/, hipStream_t s);
 int launch_pack_stem(chore_handle* h, int Cin, const float* w /*(64,Cin,7,7)*/, float* dst, hipStream_t s);
+// the stem on the matrix cores (fp16 x 3 mode, enc_misc.hip): fragment-ordered weights (stem_x3_bytes()) after the fp32 pack
+size_t stem_x3_bytes();
+bool stem_x3_on(int Cin);
+int launch_pack_stem_x3(chore_handle* h, int Cin, const float* w, void* dst, hipStream_t s);
+int launch_stem_x3(chore_handle* h, const float* images, int B, int Cin, int H, int W, const void* wfr, const float* bias, float* out,
+                   hipStream_t s);
 // statistics of a tensor no convolution produced (pooling / upsampling / stem outputs): one pass, atomics
 int launch_gn_stats(chore_handle* h, int dtype, const View& x, int B, int HW, GroupStat* st, hipStream_t s);
 // train_bwd.hip: the layer backward pieces with channel-strided gradients (what a ConvBlock's concat hands its convs)

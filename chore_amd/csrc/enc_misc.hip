@@ -8,6 +8,7 @@
 // All tensors NHWC; every thread moves 4 channels (16 B fp32 / 8 B bf16) so accesses coalesce.
 #include "enc_common.h"
 #include <type_traits>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // stem: conv 7x7 stride 2 pad 3, Cin(5) -> 64, + bias      (model/HGFilters.py:102,149)
@@ -133,6 +134,191 @@ int launch_stem(chore_handle* h, int dtype, const float* images, int B, int Cin,
         hipLaunchKernelGGL(stem_kernel<bf16_t>, grid, dim3(256), smem, s, images, B, Cin, H, W, wk, bias,
                            (bf16_t*)out);
     }
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// stem on the matrix cores (fp16 x 3 mode, round 6): the same 7x7 stride-2 convolution as a GEMM  out^T[64 channels][256 pixels] =
+// W[64][K] x im2col[K][256 pixels]  with K = Cin * 7 kernel rows of 8 (7 taps + a zero) = 18 k-steps of v_mfma_f32_32x32x16_f16 for the
+// released 5-channel input, three MFMAs per product on hi / lo split operands (enc_common.h).  The stem_kernel above is bound by the vector ALU (78 TFLOP/s of packed fp32
+// FMAs: 104 us per 4 x 512^2 images); here the FMAs are 192 MFMAs per wave and tile.
+//   * workgroup = 16 x 16 output pixels, 4 waves; wave w owns output rows 4 w .. 4 w + 3 as two 32-pixel column blocks (2 rows x 16);
+//   * A operand = weights (rows = channels): fragment-ordered [k-step][row block][plane][lane] by pack_stem_x3_kernel, streamed from
+//     the L2 three k-steps ahead (64 KB, the same for every workgroup);
+//   * B operand = pixels: the 8 consecutive k of lane (half, col) are one kernel row = 8 consecutive floats of a patch row (stride 40:
+//     8-byte aligned): four ds_read_b64, then the hi / lo split (v_cvt_pk_f16_f32, v_fma_mix_f32);
+//   * D fragment: lane = pixel, registers = 4 groups of 4 consecutive channels: 16-byte stores straight into the NHWC map.
+// The sum runs in another order than stem_kernel's (k-steps of 16, three terms per product) and each product carries 2^-22: the
+// fp32 mode keeps stem_kernel (its results equal the reference's to the last bits the oracle test asks for).
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 sx_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 sx_f16x2 __attribute__((ext_vector_type(2)));
+typedef float sx_f32x2 __attribute__((ext_vector_type(2)));
+// K order: k = (c * 7 + ky) * 8 + kx with kx padded 7 -> 8 (zero weight): the 8 consecutive k of a lane are 8 consecutive floats of one
+// patch row -- four 8-byte LDS reads instead of eight gathers through an offset table.  (c, ky) rows: Cin * 7 = 35 -> 18 k-steps of two.
+constexpr int SX_KS = 18, SX_PF = 3, SX_PS = 40;                   // SX_PS: patch row stride in floats (even: 8-byte aligned reads)
+constexpr size_t STEM_X3_BYTES = (size_t)SX_KS * 2 * 2 * 1024;     // [ks][rb][plane][lane] u32x4
+
+__global__ void pack_stem_x3_kernel(int Cin, const float* __restrict__ w /*(64,Cin,7,7)*/, u32x4* __restrict__ dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;            // (ks, rb, lane)
+    if (i >= SX_KS * 2 * 64) return;
+    const int lane = i & 63, rb = (i >> 6) & 1, ks = i >> 7;
+    const int n = rb * 32 + (lane & 31);
+    const int q = 2 * ks + (lane >> 5);                              // (c, ky) row of this half of the k-step
+    sx_f16x8 hh, ll;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool real = q < Cin * 7 && j < 7;
+        const float ws = (real ? w[((size_t)n * Cin * 7 + q) * 7 + j] : 0.f) * (float)(1 << X3_WSHIFT);
+        hh[j] = (_Float16)ws;
+        ll[j] = (_Float16)(ws - (float)hh[j]);
+    }
+    dst[((ks * 2 + rb) * 2 + 0) * 64 + lane] = __builtin_bit_cast(u32x4, hh);
+    dst[((ks * 2 + rb) * 2 + 1) * 64 + lane] = __builtin_bit_cast(u32x4, ll);
+}
+
+__device__ __forceinline__ unsigned sx_cvt_pk(float a, float b) {
+    const sx_f16x2 h = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, h);
+}
+template <int HI> __device__ __forceinline__ float sx_sub_half(float y, unsigned h) {      // y - float(half HI of h): v_fma_mix_f32
+    float r;
+    if constexpr (HI) asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y));
+    else asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(y));
+    return r;
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ img, int B, int H, int W,
+                                                      const u32x4* __restrict__ wfr, const float* __restrict__ bias,
+                                                      float* __restrict__ out) {
+    f16_saturate_mode();
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* patch = sm;                                   // [CIN][37][SX_PS] (+ a zero row for the k-step past the last (c, ky) row)
+    constexpr int PLANE = STEM_P * SX_PS;
+    const int OH = H / 2, OW = W / 2;
+    const int b = blockIdx.z, ty0 = blockIdx.y * STEM_T, tx0 = blockIdx.x * STEM_T;
+    const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    struct Frag { u32x4 h[2], l[2]; };
+    Frag ring[SX_PF];
+    auto load_frag = [&](Frag& f, int ks) {
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) { f.h[rb] = wfr[((ks * 2 + rb) * 2 + 0) * 64 + lane]; f.l[rb] = wfr[((ks * 2 + rb) * 2 + 1) * 64 + lane]; }
+    };
+#pragma unroll
+    for (int p = 0; p < SX_PF; ++p) load_frag(ring[p], p);           // in flight under the patch staging
+    const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
+    {   // the patch, a row per wave and load, all of a channel's rows in flight
+        const int x = ix0 + lane;
+        const bool xin = lane < STEM_P && x >= 0 && x < W;
+        constexpr int RPW = (STEM_P + 3) / 4;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            const float* plane = img + ((size_t)b * CIN + c) * H * W;
+            float v[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int ry = wv + 4 * i, y = iy0 + ry;
+                const bool ok = xin && ry < STEM_P && y >= 0 && y < H;
+                v[i] = plane[ok ? (size_t)y * W + x : 0];
+                v[i] = ok ? v[i] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int ry = wv + 4 * i;
+                if (lane < SX_PS && ry < STEM_P) patch[c * PLANE + ry * SX_PS + lane] = lane < STEM_P ? v[i] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    // this lane's two pixels (column block cb: row 4 wv + 2 cb + (col >> 4), column col & 15) and their patch origins
+    int pbase[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) pbase[cb] = (2 * (4 * wv + 2 * cb + (col >> 4))) * SX_PS + 2 * (col & 15);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+        f32x16 bf;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b4 = *(const f32x4*)(bias + rb * 32 + 8 * g + 4 * half);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bf[4 * g + e] = b4[e] * (float)(1 << X3_WSHIFT);
+        }
+        acc[rb][0] = bf; acc[rb][1] = bf;
+    }
+#pragma unroll
+    for (int ks = 0; ks < SX_KS; ++ks) {
+        // (c, ky) rows 2 ks (lower half of the wave) and 2 ks + 1 (upper half); past the last row: row 0 again (its weights are zero)
+        constexpr int NQ = CIN * 7;
+        const int q0 = 2 * ks < NQ ? 2 * ks : 0, q1 = 2 * ks + 1 < NQ ? 2 * ks + 1 : 0;
+        const int off0 = (q0 / 7) * PLANE + (q0 % 7) * SX_PS, off1 = (q1 / 7) * PLANE + (q1 % 7) * SX_PS;
+        const int off = half ? off1 : off0;
+        u32x4 bh[2], bl[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const sx_f32x2* src = (const sx_f32x2*)(patch + pbase[cb] + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const sx_f32x2 v = src[j];
+                bh[cb][j] = sx_cvt_pk(v[0], v[1]);
+                bl[cb][j] = sx_cvt_pk(sx_sub_half<0>(v[0], bh[cb][j]), sx_sub_half<1>(v[1], bh[cb][j]));
+            }
+        }
+        Frag& f = ring[ks % SX_PF];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const sx_f16x8 a0 = __builtin_bit_cast(sx_f16x8, f.h[rb]), a1 = __builtin_bit_cast(sx_f16x8, f.l[rb]);
+                const sx_f16x8 b0 = __builtin_bit_cast(sx_f16x8, bh[cb]), b1 = __builtin_bit_cast(sx_f16x8, bl[cb]);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[rb][cb], 0, 0, 0);   // small terms first
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[rb][cb], 0, 0, 0);
+                acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[rb][cb], 0, 0, 0);
+            }
+        if (ks + SX_PF < SX_KS) load_frag(f, ks + SX_PF);
+    }
+    const float inv = 1.0f / (float)(1 << X3_WSHIFT);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+        const int oy = ty0 + 4 * wv + 2 * cb + (col >> 4), ox = tx0 + (col & 15);
+        if (oy < OH && ox < OW) {
+            float* o = out + (((size_t)b * OH + oy) * OW + ox) * 64;
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {acc[rb][cb][4 * g] * inv, acc[rb][cb][4 * g + 1] * inv, acc[rb][cb][4 * g + 2] * inv, acc[rb][cb][4 * g + 3] * inv};
+                    *(f32x4*)(o + rb * 32 + 8 * g + 4 * half) = v;
+                }
+        }
+    }
+}
+
+size_t stem_x3_bytes() { return STEM_X3_BYTES; }
+int launch_pack_stem_x3(chore_handle* h, int Cin, const float* w, void* dst, hipStream_t s) {
+    if (Cin * 7 > 2 * SX_KS) CHORE_FAIL(h, CHORE_EINVAL, "stem (fp16 x 3): Cin * 7 > %d kernel rows", 2 * SX_KS);
+    hipLaunchKernelGGL(pack_stem_x3_kernel, dim3((SX_KS * 2 * 64 + 255) / 256), dim3(256), 0, s, Cin, w, (u32x4*)dst);
+    CHORE_LAUNCH_CHECK(h, s);
+    return CHORE_OK;
+}
+// the instantiated input widths: RGBM3 (5 channels: the released model), RGB (3), RGBM (4).  CHORE_STEM_VALU=1: the fp16 x 3 mode on
+// stem_kernel as before round 6 (A/B)
+bool stem_x3_on(int Cin) {
+    static const bool off = getenv("CHORE_STEM_VALU") != nullptr;
+    return !off && (Cin == 5 || Cin == 4 || Cin == 3);
+}
+int launch_stem_x3(chore_handle* h, const float* images, int B, int Cin, int H, int W, const void* wfr, const float* bias, float* out,
+                   hipStream_t s) {
+    const int OH = H / 2, OW = W / 2;
+    dim3 grid((OW + STEM_T - 1) / STEM_T, (OH + STEM_T - 1) / STEM_T, B);
+    const size_t smem = (size_t)Cin * STEM_P * SX_PS * sizeof(float);
+    if (Cin == 5) hipLaunchKernelGGL(stem_x3_kernel<5>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
+    else if (Cin == 4) hipLaunchKernelGGL(stem_x3_kernel<4>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
+    else if (Cin == 3) hipLaunchKernelGGL(stem_x3_kernel<3>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
+    else CHORE_FAIL(h, CHORE_EINVAL, "stem (fp16 x 3): Cin = %d not instantiated", Cin);
     CHORE_LAUNCH_CHECK(h, s);
     return CHORE_OK;
 }

@@ -69,7 +69,7 @@ void layout_hg(WLayout& L, int dtype, const std::string& n, int level) {
 WLayout make_layout(const chore_encoder_cfg& cfg, int dtype) {
     WLayout L;
     const std::string p = "image_filter.";
-    L.add(p + "conv1.weight", (size_t)cfg.in_channels * 49 * 64 * 4, 2, 49, cfg.in_channels, 64);
+    L.add(p + "conv1.weight", (size_t)cfg.in_channels * 49 * 64 * 4 + stem_x3_bytes(), 2, 49, cfg.in_channels, 64);   // fp32 pack, then the fp16 x 3 fragments
     L.add(p + "conv1.bias", 64 * 4, 1, 0, 0, 64);
     layout_gn(L, p + "bn1", 64);
     layout_block(L, dtype, p + "conv2", 64, 128);
@@ -526,8 +526,12 @@ struct Builder {
             cur_bytes = (double)B * H * W * Cin * 4 + (double)B * (H / 2) * (W / 2) * 64 * es();
             push([=](RunCtx& r) {
                 if (r.rc) return;
-                r.rc = launch_stem(r.h, sdt(r.dtype), r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
-                                   (const float*)(r.arena + be.off), ptr(r, c1), r.s);
+                if (r.dtype == CHORE_F16X3 && stem_x3_on(Cin))
+                    r.rc = launch_stem_x3(r.h, r.images, Bn, Cin, H, W, r.arena + we.off + (size_t)Cin * 49 * 64 * 4,
+                                          (const float*)(r.arena + be.off), (float*)ptr(r, c1), r.s);
+                else
+                    r.rc = launch_stem(r.h, sdt(r.dtype), r.images, Bn, Cin, H, W, (const float*)(r.arena + we.off),
+                                       (const float*)(r.arena + be.off), ptr(r, c1), r.s);
             });
         }
         Buf tmpx = external(100, H2, W2, 64);
@@ -753,6 +757,8 @@ int chore_encoder_pack(chore_handle* h, const chore_encoder_cfg* cfg, const chor
         } else {
             expect = (int64_t)64 * e.cin * 49;
             if (d->numel == expect) rc = launch_pack_stem(h, e.cin, (const float*)d->ptr, (float*)dst, s);
+            if (d->numel == expect && !rc && stem_x3_on(e.cin))
+                rc = launch_pack_stem_x3(h, e.cin, (const float*)d->ptr, dst + (size_t)e.cin * 49 * 64 * 4, s);
         }
         if (d->numel != expect)
             CHORE_FAIL(h, CHORE_ESTATE, "chore_encoder_pack: tensor '%s' has %lld elements, expected %lld", name.c_str(),
