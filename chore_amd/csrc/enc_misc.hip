@@ -189,16 +189,20 @@ template <int HI> __device__ __forceinline__ float sx_sub_half(float y, unsigned
     return r;
 }
 
+// tile = 16 rows x 32 pixels: wave w owns rows 4 w .. 4 w + 3, one 32-pixel column block per row (four blocks x two channel blocks =
+// eight accumulators).  (First version: 16 x 16 tiles, two column blocks per wave -- every wave streams all 72 KB of weight fragments
+// from the L2 whatever its pixel count, 295 MB per launch: 53 us.  Twice the pixels per fetch: profiles/r06_stem.txt.)
+constexpr int SX_TW = 32, SX_PW = 2 * SX_TW + 5, SX_PS2 = 72;      // patch columns (69) and row stride in floats (even, >= 69 + 3)
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ img, int B, int H, int W,
                                                       const u32x4* __restrict__ wfr, const float* __restrict__ bias,
                                                       float* __restrict__ out) {
     f16_saturate_mode();
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* patch = sm;                                   // [CIN][37][SX_PS] (+ a zero row for the k-step past the last (c, ky) row)
-    constexpr int PLANE = STEM_P * SX_PS;
+    float* patch = sm;                                   // [CIN][37][SX_PS2]
+    constexpr int PLANE = STEM_P * SX_PS2;
     const int OH = H / 2, OW = W / 2;
-    const int b = blockIdx.z, ty0 = blockIdx.y * STEM_T, tx0 = blockIdx.x * STEM_T;
+    const int b = blockIdx.z, ty0 = blockIdx.y * STEM_T, tx0 = blockIdx.x * SX_TW;
     const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, col = lane & 31;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     struct Frag { u32x4 h[2], l[2]; };
@@ -210,34 +214,35 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ 
 #pragma unroll
     for (int p = 0; p < SX_PF; ++p) load_frag(ring[p], p);           // in flight under the patch staging
     const int iy0 = 2 * ty0 - 3, ix0 = 2 * tx0 - 3;
-    {   // the patch, a row per wave and load, all of a channel's rows in flight
-        const int x = ix0 + lane;
-        const bool xin = lane < STEM_P && x >= 0 && x < W;
+    {   // the patch: a row (69 floats: lanes 0 .. 63, then lanes 0 .. 7 again, the last three of them padding) per wave and pass,
+        // all of a channel's rows in flight
         constexpr int RPW = (STEM_P + 3) / 4;
+        const int x0 = ix0 + lane, x1 = ix0 + 64 + lane;
+        const bool in0 = x0 >= 0 && x0 < W, in1 = lane < SX_PW - 64 && x1 >= 0 && x1 < W;
 #pragma unroll
         for (int c = 0; c < CIN; ++c) {
             const float* plane = img + ((size_t)b * CIN + c) * H * W;
-            float v[RPW];
+            float v0[RPW], v1[RPW];
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const int ry = wv + 4 * i, y = iy0 + ry;
-                const bool ok = xin && ry < STEM_P && y >= 0 && y < H;
-                v[i] = plane[ok ? (size_t)y * W + x : 0];
-                v[i] = ok ? v[i] : 0.f;
+                const bool yin = ry < STEM_P && y >= 0 && y < H;
+                const float a0 = plane[yin && in0 ? (size_t)y * W + x0 : 0], a1 = plane[yin && in1 ? (size_t)y * W + x1 : 0];
+                v0[i] = yin && in0 ? a0 : 0.f;
+                v1[i] = yin && in1 ? a1 : 0.f;
             }
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const int ry = wv + 4 * i;
-                if (lane < SX_PS && ry < STEM_P) patch[c * PLANE + ry * SX_PS + lane] = lane < STEM_P ? v[i] : 0.f;
+                if (ry < STEM_P) {
+                    patch[c * PLANE + ry * SX_PS2 + lane] = v0[i];
+                    if (lane < SX_PS2 - 64) patch[c * PLANE + ry * SX_PS2 + 64 + lane] = v1[i];
+                }
             }
         }
     }
     __syncthreads();
-    // this lane's two pixels (column block cb: row 4 wv + 2 cb + (col >> 4), column col & 15) and their patch origins
-    int pbase[2];
-#pragma unroll
-    for (int cb = 0; cb < 2; ++cb) pbase[cb] = (2 * (4 * wv + 2 * cb + (col >> 4))) * SX_PS + 2 * (col & 15);
-    f32x16 acc[2][2];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int rb = 0; rb < 2; ++rb) {
         f32x16 bf;
@@ -247,19 +252,21 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ 
 #pragma unroll
             for (int e = 0; e < 4; ++e) bf[4 * g + e] = b4[e] * (float)(1 << X3_WSHIFT);
         }
-        acc[rb][0] = bf; acc[rb][1] = bf;
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[rb][cb] = bf;
     }
+    const int pbase0 = (2 * (4 * wv)) * SX_PS2 + 2 * col;            // column block cb: row 4 wv + cb -> + cb * 2 * SX_PS2
 #pragma unroll
     for (int ks = 0; ks < SX_KS; ++ks) {
         // (c, ky) rows 2 ks (lower half of the wave) and 2 ks + 1 (upper half); past the last row: row 0 again (its weights are zero)
         constexpr int NQ = CIN * 7;
         const int q0 = 2 * ks < NQ ? 2 * ks : 0, q1 = 2 * ks + 1 < NQ ? 2 * ks + 1 : 0;
-        const int off0 = (q0 / 7) * PLANE + (q0 % 7) * SX_PS, off1 = (q1 / 7) * PLANE + (q1 % 7) * SX_PS;
-        const int off = half ? off1 : off0;
-        u32x4 bh[2], bl[2];
+        const int off0 = (q0 / 7) * PLANE + (q0 % 7) * SX_PS2, off1 = (q1 / 7) * PLANE + (q1 % 7) * SX_PS2;
+        const int off = pbase0 + (half ? off1 : off0);
+        u32x4 bh[4], bl[4];
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const sx_f32x2* src = (const sx_f32x2*)(patch + pbase[cb] + off);
+        for (int cb = 0; cb < 4; ++cb) {
+            const sx_f32x2* src = (const sx_f32x2*)(patch + off + cb * 2 * SX_PS2);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const sx_f32x2 v = src[j];
@@ -271,7 +278,7 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ 
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
+            for (int cb = 0; cb < 4; ++cb) {
                 const sx_f16x8 a0 = __builtin_bit_cast(sx_f16x8, f.h[rb]), a1 = __builtin_bit_cast(sx_f16x8, f.l[rb]);
                 const sx_f16x8 b0 = __builtin_bit_cast(sx_f16x8, bh[cb]), b1 = __builtin_bit_cast(sx_f16x8, bl[cb]);
                 acc[rb][cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[rb][cb], 0, 0, 0);   // small terms first
@@ -282,8 +289,8 @@ __global__ __launch_bounds__(256) void stem_x3_kernel(const float* __restrict__ 
     }
     const float inv = 1.0f / (float)(1 << X3_WSHIFT);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-        const int oy = ty0 + 4 * wv + 2 * cb + (col >> 4), ox = tx0 + (col & 15);
+    for (int cb = 0; cb < 4; ++cb) {
+        const int oy = ty0 + 4 * wv + cb, ox = tx0 + col;
         if (oy < OH && ox < OW) {
             float* o = out + (((size_t)b * OH + oy) * OW + ox) * 64;
 #pragma unroll
@@ -313,8 +320,15 @@ bool stem_x3_on(int Cin) {
 int launch_stem_x3(chore_handle* h, const float* images, int B, int Cin, int H, int W, const void* wfr, const float* bias, float* out,
                    hipStream_t s) {
     const int OH = H / 2, OW = W / 2;
-    dim3 grid((OW + STEM_T - 1) / STEM_T, (OH + STEM_T - 1) / STEM_T, B);
-    const size_t smem = (size_t)Cin * STEM_P * SX_PS * sizeof(float);
+    dim3 grid((OW + SX_TW - 1) / SX_TW, (OH + STEM_T - 1) / STEM_T, B);
+    const size_t smem = (size_t)Cin * STEM_P * SX_PS2 * sizeof(float);
+    bool& attr = CHORE_ONCE_FLAG(h);
+    if (!attr) {       // 53 KB for five channels
+        (void)hipFuncSetAttribute((const void*)stem_x3_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_x3_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute((const void*)stem_x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
     if (Cin == 5) hipLaunchKernelGGL(stem_x3_kernel<5>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
     else if (Cin == 4) hipLaunchKernelGGL(stem_x3_kernel<4>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
     else if (Cin == 3) hipLaunchKernelGGL(stem_x3_kernel<3>, grid, dim3(256), smem, s, images, B, H, W, (const u32x4*)wfr, bias, out);
